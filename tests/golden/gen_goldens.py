@@ -1,0 +1,220 @@
+"""Generate golden vectors by running the REAL reference on seeded inputs.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONPATH=/root/reference/src PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_goldens.py
+
+The reference is imported from where it lies (nothing is copied); torchvision and
+tensorboard are absent from the container, so empty in-memory module stubs are
+registered for them before the import -- none of the functions
+exercised here touches those modules.  Outputs: tests/golden/*.npz (inputs +
+expected outputs, data only).  Version skew: reference pins torch 2.5.1, this
+container runs the torch recorded in each file's ``meta``.
+"""
+import json
+import sys
+import types
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+
+for name in ["torchvision", "torchvision.transforms", "torchvision.transforms.functional", "torchvision.models"]:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+sys.modules["torchvision.models"].resnet34 = None
+sys.modules["torchvision.models"].ResNet34_Weights = None
+_tb = types.ModuleType("torch.utils.tensorboard")
+_tb.SummaryWriter = object
+sys.modules["torch.utils.tensorboard"] = _tb
+
+import sdnet.utils as RU  # noqa: E402  (the reference)
+from sdnet.data.dataset import CropDataset  # noqa: E402
+from sdnet.data.decoders import Decoder  # noqa: E402
+from sdnet.data.transforms import Encode  # noqa: E402
+from sdnet.model.loss import Loss  # noqa: E402
+from sdnet.model.network import Fpn, Head  # noqa: E402
+
+from oracle import sdnet_oracle as O  # noqa: E402  (only for the synthetic INPUT generator)
+
+META = json.dumps({"torch": torch.__version__, "numpy": np.__version__, "reference_pins": "torch 2.5.1"})
+
+
+def make_args(M, N, K, P, hm_loss_fn="mse", anchor_name="stem"):
+    labels = {f"label{i}": i for i in range(M)}
+    parts = {f"part{i}": i for i in range(N)}
+    return Namespace(labels=labels, parts=parts, _r_labels={v: k for k, v in labels.items()},
+                     _r_parts={v: k for k, v in parts.items()}, anchor_name=anchor_name, down_ratio=4.0,
+                     max_objects=K, max_parts=P, conf_threshold=0.5, decoder_dist_thresh=0.1, sigma_gauss=0.1,
+                     hm_loss_fn=hm_loss_fn, hm_weight=1.0, offset_weight=0.001, embedding_weight=0.001)
+
+
+def to_annotation(args, objs, name="img.png"):
+    out = []
+    for (label, x, y, parts) in objs:
+        kps = [RU.Keypoint(args._r_parts[k], px, py) for (k, px, py) in parts]
+        out.append(RU.Object(args._r_labels[label], RU.Keypoint(args.anchor_name, x, y), kps))
+    return RU.ImageAnnotation(name, out)
+
+
+def flat_scene(objs):
+    """(label,x,y,parts) list -> flat float64 arrays (data only)."""
+    o = np.array([[l, x, y, len(p)] for (l, x, y, p) in objs], np.float64).reshape(-1, 4)
+    p = np.array([[k, px, py] for (_, _, _, ps) in objs for (k, px, py) in ps], np.float64).reshape(-1, 3)
+    return o, p
+
+
+def annotation_to_arrays(args, ann):
+    """ImageAnnotation -> objs (n,4) [label_idx,x,y,score], parts (m,5) [obj,kind_idx,x,y,score] float64."""
+    objs, parts = [], []
+    for oi, obj in enumerate(ann.objects):
+        objs.append([args.labels[obj.name], obj.anchor.x, obj.anchor.y, obj.anchor.score])
+        for kp in obj.parts:
+            parts.append([oi, args.parts[kp.kind], kp.x, kp.y, kp.score])
+    return np.array(objs, np.float64).reshape(-1, 4), np.array(parts, np.float64).reshape(-1, 5)
+
+
+def check_margins(scores_sorted, what, rel_gap=4e-6):
+    """tie-free guard: consecutive positive scores must differ by >= ~32 fp32 ulps (relative),
+    so that 1-2 ulp differences between sigmoid implementations cannot reorder them."""
+    s = np.asarray(scores_sorted, np.float64)
+    pos = s[s > 0]
+    gaps = -np.diff(pos) / pos[1:]
+    assert (gaps > rel_gap).all(), f"{what}: near-tie in golden input (min relative gap {gaps.min()})"
+
+
+# --------------------------------------------------------------------------
+def gen_prims(rng):
+    out = {"meta": META}
+    x = (3.0 * rng.standard_normal((2, 3, 40, 56))).astype(np.float32)
+    x[0, 0, 5, 5] = 30.0; x[0, 0, 5, 7] = 31.0   # saturated -> clamp plateau (both survive: equal after clamp)
+    x[1, 2, 0, 0] = 9.0; x[1, 2, 39, 55] = 8.5    # borders / corners
+    t = torch.from_numpy(x)
+    sig = RU.clamped_sigmoid(t)
+    out["logits"] = x
+    out["sig"] = sig.numpy()
+    out["nms"] = RU.nms(sig).numpy()
+    # topk on a tie-free dense map (no NMS): random distinct values
+    d = rng.permutation(2 * 3 * 40 * 56).astype(np.float32).reshape(2, 3, 40, 56) / 16384.0
+    out["dense"] = d
+    for k in (2, 7, 40):  # k=1 trips the squeeze(-1) bug at utils.py:343
+        s, i, c, y, xx = RU.topk(torch.from_numpy(d), k=k)
+        out[f"topk{k}_score"] = s.numpy(); out[f"topk{k}_ind"] = i.numpy(); out[f"topk{k}_cls"] = c.numpy()
+        out[f"topk{k}_y"] = y.numpy(); out[f"topk{k}_x"] = xx.numpy()
+    feat = rng.standard_normal((2, 2, 40, 56)).astype(np.float32)
+    ind = rng.integers(0, 40 * 56, (2, 9))
+    out["feat"] = feat; out["gind"] = ind
+    out["gathered"] = RU.transpose_and_gather(torch.from_numpy(feat), torch.from_numpy(ind)).numpy()
+    v = (100 * rng.standard_normal((4, 5, 6, 2))).astype(np.float32)
+    out["hyp_in"] = v; out["hyp_out"] = RU.hypot(torch.from_numpy(v)).numpy()
+    Y, X = torch.meshgrid(torch.arange(32), torch.arange(48), indexing="ij")
+    out["gauss"] = RU.gaussian_2d(X, Y, 17, 5, 0.1 * 32 / 3).numpy()
+    np.savez_compressed(HERE / "prims.npz", **out)
+
+
+def gen_encode_decode(rng, tag, img, M, N, K, P, n_img, n_min, n_max, noise):
+    args = make_args(M, N, K, P)
+    enc_ref = Encode(args); dec_ref = Decoder(args)
+    out = {"meta": META, "cfg": np.array([img, img, M, N, K, P], np.int64), "noise": np.float64(noise)}
+    samples, heads = [], []
+    for n in range(n_img):
+        objs = O.synthetic_scene(rng, img, img, M, N, n_min, n_max)
+        if n == 1:
+            objs = objs[:1]                      # near-empty scene
+        if n == 2:
+            objs = []                            # empty scene
+        so, sp = flat_scene(objs)
+        out[f"scene{n}_objs"] = so; out[f"scene{n}_parts"] = sp
+        e = enc_ref(torch.zeros(3, img, img), to_annotation(args, objs))
+        for k in ["anchor_hm", "part_hm", "anchor_inds", "part_inds", "anchor_offsets", "part_offsets",
+                  "embeddings", "anchor_mask", "part_mask"]:
+            out[f"enc{n}_{k}"] = e[k].numpy()
+        samples.append(e)
+        enp = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in e.items()}
+        heads.append(O.head_from_targets(rng, enp, M, N, noise=noise))
+    head = np.stack(heads, 0)
+    out["head"] = head
+    th = torch.from_numpy(head)
+    outputs = {"anchor_hm": th[:, :M], "part_hm": th[:, M:M + N], "offsets": th[:, M + N:M + N + 2],
+               "embeddings": th[:, M + N + 2:]}
+    md = dec_ref(outputs, return_metadata=True)
+    names = ["score", "ind", "cls", "y", "x"]
+    for nm, v in zip(names, md["topk_anchor"]):
+        out[f"dec_anchor_{nm}"] = v.numpy()
+    for nm, v in zip(names, md["topk_kp"]):
+        out[f"dec_part_{nm}"] = v.numpy()
+    out["dec_embeddings"] = md["embeddings"].numpy()
+    for b in range(n_img):
+        check_margins(np.sort(RU.nms(md["anchor_hm_sig"])[b].numpy().ravel())[::-1][:K + 1], f"{tag} anchors img{b}")
+        check_margins(np.sort(RU.nms(md["part_hm_sig"])[b].numpy().ravel())[::-1][:P + 1], f"{tag} parts img{b}")
+        o, p = annotation_to_arrays(args, md["annotation"][b])
+        out[f"ann{b}_objs"] = o; out[f"ann{b}_parts"] = p
+        out[f"raw{b}"] = np.array([[args.parts[k.kind], k.x, k.y, k.score] for k in md["raw_parts"][b]],
+                                  np.float64).reshape(-1, 4)
+    # loss goldens on the same (head, collated targets), mse and focal, value + autograd grad
+    batch = CropDataset.collate_fn([dict(s, image=torch.zeros(1), annotation=None) for s in samples])
+    for fn in ("mse", "focal"):
+        largs = make_args(M, N, K, P, hm_loss_fn=fn)
+        lref = Loss(largs)
+        x = th.clone().requires_grad_(True)
+        od = {"anchor_hm": x[:, :M], "part_hm": x[:, M:M + N], "offsets": x[:, M + N:M + N + 2], "embeddings": x[:, M + N + 2:]}
+        val = lref(od, batch)
+        val.backward()
+        out[f"loss_{fn}"] = np.array([float(val), float(lref.stats.hm_loss), float(lref.stats.offset_loss),
+                                      float(lref.stats.embedding_loss)], np.float64)
+        out[f"lossgrad_{fn}"] = x.grad.numpy()
+    np.savez_compressed(HERE / f"{tag}.npz", **out)
+    print(tag, "objects per image:", [len(md["annotation"][b].objects) for b in range(n_img)])
+
+
+def gen_truncation(rng):
+    """K / P truncation quirk of Encode (transforms.py:157,186-191)."""
+    M, N, K, P, img = 2, 2, 4, 6, 128
+    args = make_args(M, N, K, P)
+    out = {"meta": META, "cfg": np.array([img, img, M, N, K, P], np.int64)}
+    cases = {
+        "many_objs": O.synthetic_scene(rng, img, img, M, N, 7, 7, 1, 1),       # > K objects
+        "many_parts": O.synthetic_scene(rng, img, img, M, N, 3, 3, 3, 3),      # parts hit P before objects run out
+        "exact_parts": O.synthetic_scene(rng, img, img, M, N, 4, 4, 2, 2)[:3] + O.synthetic_scene(rng, img, img, M, N, 1, 1, 1, 1),
+        "out_of_bounds": [(0, -5.0, 140.0, [(1, 300.0, -2.0)]), (1, 127.0, 127.0, [(0, 126.99, 0.0)])],
+    }
+    out["cases"] = np.array(list(cases))
+    for name, objs in cases.items():
+        so, sp = flat_scene(objs)
+        out[f"{name}_objs"] = so; out[f"{name}_parts"] = sp
+        e = Encode(args)(torch.zeros(3, img, img), to_annotation(args, objs))
+        for k in ["anchor_hm", "part_hm", "anchor_inds", "part_inds", "anchor_offsets", "part_offsets",
+                  "embeddings", "anchor_mask", "part_mask"]:
+            out[f"{name}_{k}"] = e[k].numpy()
+    np.savez_compressed(HERE / "encode_trunc.npz", **out)
+
+
+def gen_fpn_head(rng):
+    torch.manual_seed(1234)
+    fpn = Fpn(16, 8).train(); head = Head(8, 7)
+    x = torch.randn(2, 8, 6, 10); sc = torch.randn(2, 16, 12, 20)
+    y = fpn(x, sc)
+    out = {"meta": META, "x": x.numpy(), "shortcut": sc.numpy(), "fpn_out": y.detach().numpy(),
+           "head_out": head(y).detach().numpy()}
+    for k, v in fpn.state_dict().items():
+        out[f"fpn.{k}"] = v.numpy()
+    for k, v in head.state_dict().items():
+        out[f"head.{k}"] = v.numpy()
+    np.savez_compressed(HERE / "fpn_head.npz", **out)
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(20261003)
+    gen_prims(rng)
+    gen_encode_decode(rng, "scene_cfg512", 512, 2, 1, 20, 40, n_img=3, n_min=6, n_max=12, noise=0.05)
+    gen_encode_decode(rng, "scene_small256", 256, 3, 2, 12, 24, n_img=4, n_min=3, n_max=8, noise=0.2)
+    gen_truncation(rng)
+    gen_fpn_head(rng)
+    print("goldens written to", HERE)

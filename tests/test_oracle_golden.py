@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/sdnet_oracle.py) against golden vectors produced by the real
+reference (tests/golden/gen_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdnet_oracle as O
+from tests.helpers import ENC_KEYS, objects_to_arrays, scene_from_flat
+
+SCENES = ["scene_cfg512", "scene_small256"]
+
+
+def test_prims(golden_dir):
+    g = np.load(golden_dir / "prims.npz")
+    sig = O.clamped_sigmoid(g["logits"])
+    np.testing.assert_array_equal(sig, g["sig"])
+    np.testing.assert_array_equal(O.nms(g["sig"]), g["nms"])
+    # plateau: both saturated pixels survive; borders compete only with in-image neighbours
+    assert g["nms"][0, 0, 5, 5] > 0 and g["nms"][0, 0, 5, 7] > 0
+    assert g["nms"][1, 2, 0, 0] > 0 and g["nms"][1, 2, 39, 55] > 0
+    for k in (2, 7, 40):
+        s, i, c, y, x = O.topk(g["dense"], k)
+        np.testing.assert_array_equal(s, g[f"topk{k}_score"])
+        np.testing.assert_array_equal(i, g[f"topk{k}_ind"])
+        np.testing.assert_array_equal(c, g[f"topk{k}_cls"])
+        np.testing.assert_array_equal(y, g[f"topk{k}_y"])
+        np.testing.assert_array_equal(x, g[f"topk{k}_x"])
+    np.testing.assert_array_equal(O.transpose_and_gather(g["feat"], g["gind"]), g["gathered"])
+    np.testing.assert_array_equal(O.hypot(g["hyp_in"]), g["hyp_out"])
+    np.testing.assert_array_equal(O.gaussian_2d(32, 48, 17, 5, 0.1 * 32 / 3), g["gauss"])
+    assert g["gauss"][5, 17] == 1.0
+
+
+@pytest.mark.parametrize("tag", SCENES)
+def test_encode(golden_dir, tag):
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    n = 0
+    while f"scene{n}_objs" in g:
+        objs = scene_from_flat(g[f"scene{n}_objs"], g[f"scene{n}_parts"])
+        e = O.encode(W, H, objs, M, N, K, P, 4.0, 0.1)
+        for k in ENC_KEYS:
+            np.testing.assert_array_equal(e[k], g[f"enc{n}_{k}"], err_msg=f"{tag} img{n} {k}")
+            assert e[k].dtype == g[f"enc{n}_{k}"].dtype
+        n += 1
+    assert n >= 3
+
+
+def test_encode_truncation(golden_dir):
+    g = np.load(golden_dir / "encode_trunc.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    for name in g["cases"]:
+        objs = scene_from_flat(g[f"{name}_objs"], g[f"{name}_parts"])
+        e = O.encode(W, H, objs, M, N, K, P, 4.0, 0.1)
+        for k in ENC_KEYS:
+            np.testing.assert_array_equal(e[k], g[f"{name}_{k}"], err_msg=f"{name} {k}")
+
+
+@pytest.mark.parametrize("tag", SCENES)
+def test_decode(golden_dir, tag):
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    head = g["head"]
+    t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+    for grp, key_out, key_inds, key_sm, n in (("anchor", "anchor_out", "anchor_inds", "anchor_scores_masked", K),
+                                              ("part", "part_out", "part_inds", "part_scores_masked", P)):
+        gs = g[f"dec_{grp}_score"]          # masked scores (-1 where score <= conf)
+        np.testing.assert_array_equal(t[key_sm], gs)
+        pos = t[key_out][..., 2] > 0        # indices are defined by the reference only where score > 0
+        np.testing.assert_array_equal(t[key_inds][pos], g[f"dec_{grp}_ind"][pos])
+        np.testing.assert_array_equal(t[key_out][..., 3][pos], g[f"dec_{grp}_cls"][pos])
+        np.testing.assert_array_equal(t[key_out][..., 0][pos], g[f"dec_{grp}_x"][pos])
+        np.testing.assert_array_equal(t[key_out][..., 1][pos], g[f"dec_{grp}_y"][pos])
+        assert pos.sum() > 0
+    pos = t["part_out"][..., 2] > 0
+    np.testing.assert_array_equal(t["part_embeddings"][pos], g["dec_embeddings"][pos])
+    out_w, out_h = W // 4, H // 4
+    for b in range(head.shape[0]):
+        o, p = objects_to_arrays(O.assemble_objects(t, b, 0.5, 4.0, out_w, out_h))
+        np.testing.assert_array_equal(o, g[f"ann{b}_objs"])
+        np.testing.assert_array_equal(p, g[f"ann{b}_parts"])
+        r = np.array(O.raw_parts(t, b, 0.5, 4.0, out_w, out_h), np.float64).reshape(-1, 4)
+        np.testing.assert_array_equal(r, g[f"raw{b}"])
+
+
+@pytest.mark.parametrize("tag", SCENES)
+@pytest.mark.parametrize("fn", ["mse", "focal"])
+def test_loss(golden_dir, tag, fn):
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    n_img = g["head"].shape[0]
+    target = {k: np.stack([g[f"enc{n}_{k}"] for n in range(n_img)]) for k in ENC_KEYS}
+    r = O.loss(g["head"], target, M, N, hm_loss_fn=fn, want_grad=True)
+    ref = g[f"loss_{fn}"]
+    np.testing.assert_allclose([r["total"], r["hm"], r["offset"], r["embedding"]], ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["grad"], g[f"lossgrad_{fn}"], rtol=1e-5, atol=1e-9)
+
+
+def test_fpn_head(golden_dir):
+    g = np.load(golden_dir / "fpn_head.npz")
+    fpn = O._Fpn(16, 8).train(); head = O._Head(8, 7)
+    fpn.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fpn.")})
+    head.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("head.")})
+    y = fpn(torch.from_numpy(g["x"]), torch.from_numpy(g["shortcut"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["fpn_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(head(y).detach().numpy(), g["head_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_reference_network_schema():
+    """state_dict key schema of SURVEY.md A.3 (the 'adpater' spelling is load-bearing)."""
+    net = O.build_reference_network(2, 1)
+    sd = net.state_dict()
+    assert sd["adpater.0.weight"].shape == (64, 3, 7, 7)
+    assert sd["down2.0.downsample.0.weight"].shape == (128, 64, 1, 1)
+    assert sd["down4.2.conv2.weight"].shape == (512, 512, 3, 3)
+    assert sd["up1.weight"].shape == (128, 512, 1, 1) and sd["up1.bias"].shape == (128,)
+    assert sd["up4.lateral.weight"].shape == (128, 64, 1, 1)
+    assert sd["up3.conv.0.weight"].shape == (128, 128, 3, 3)
+    assert sd["head.conv.weight"].shape == (7, 128, 1, 1)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == 21_852_295 or abs(n_params - 21.852e6) < 2e3
+    with torch.no_grad():
+        y = net.eval()(torch.zeros(1, 3, 64, 64))
+    assert y.shape == (1, 7, 16, 16)
