@@ -1,0 +1,157 @@
+/*
+ * sdnet_hip.h -- C ABI of libsdnet_hip.so: the MI355X (gfx950) implementation of the SDNet
+ * hot path of laclouis5/StructureDetector.
+ *
+ * The reference has no FFI layer: this path sits behind plain Python classes
+ * (SURVEY.md 8b).  Each entry point below therefore cites the reference *Python* interface it
+ * replaces (paths relative to the reference repository root); INTEGRATION.md shows the ctypes
+ * stub a reference maintainer would add at each of those sites.
+ *
+ * Conventions
+ *   - plain pointers and sizes only, no torch / C++ types;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every call is
+ *     asynchronous with respect to the host and performs no allocation and no synchronisation;
+ *   - scratch memory comes from the caller: ask sd_*_workspace_bytes(), pass a device buffer;
+ *   - return value: 0 = ok, <0 = invalid argument (SD_ERR_*), >0 = hipError_t;
+ *     sd_last_error() returns a thread-local message for the last non-zero return;
+ *   - maps are fp32, rows contiguous (x stride 1, y stride w); batch / channel strides are
+ *     explicit (in elements) so that channel-slice views of the head output
+ *     (src/sdnet/model/network.py:77-84) are consumed without a copy.
+ */
+#ifndef SDNET_HIP_H
+#define SDNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_ERR_INVALID   (-1)   /* bad shape / null pointer / unsupported size */
+#define SD_ERR_WORKSPACE (-2)   /* workspace too small */
+#define SD_ERR_ALIGN     (-3)   /* pointer or stride not 16-byte aligned where required */
+
+#define SD_MAX_TOPK 1024        /* max_objects / max_parts upper bound supported by the select kernel */
+
+typedef void* sd_stream_t;
+
+int         sd_version(void);
+const char* sd_last_error(void);
+
+/* ---- tensor primitives: src/sdnet/utils/utils.py ------------------------------------------ */
+
+/* clamped_sigmoid, utils.py:355-361: y = clamp(sigmoid(x), 1e-6, 1-1e-6); n contiguous floats. */
+int sd_clamped_sigmoid(const float* x, float* y, int64_t n, sd_stream_t stream);
+
+/* nms, utils.py:441-443: out = (hm == maxpool5x5(hm)) * hm, -inf padding.  in strided
+ * (sb, sc), out contiguous (B,C,h,w).  apply_sigmoid != 0 fuses clamped_sigmoid first. */
+int sd_nms5(const float* hm, int64_t sb, int64_t sc, float* out, int B, int C, int h, int w,
+            int apply_sigmoid, sd_stream_t stream);
+
+/* topk, utils.py:447-467 on an arbitrary (B,C,h,w) score map (no sigmoid, no NMS): global top-k
+ * over the class-major flattened map; order: score desc, class asc, flat index asc.
+ * Outputs (B,k): score f32, ind i64, cls f32, ys f32, xs f32. */
+size_t sd_topk_workspace_bytes(int B, int C, int h, int w, int k);
+int sd_topk(const float* scores, int64_t sb, int64_t sc, int B, int C, int h, int w, int k,
+            float* out_score, int64_t* out_ind, float* out_cls, float* out_ys, float* out_xs,
+            void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* transpose_and_gather, utils.py:347-351: feat (B,C,h*w) strided, ind (B,n) i64 -> out (B,n,C). */
+int sd_transpose_and_gather(const float* feat, int64_t sb, int64_t sc, int B, int C, int64_t hw,
+                            const int64_t* ind, int n, float* out, sd_stream_t stream);
+
+/* hypot, utils.py:422-437: out[i] = sqrt(fl(fl(x0*x0) + fl(x1*x1))) over n pairs (no FMA). */
+int sd_hypot(const float* in_pairs, float* out, int64_t n, sd_stream_t stream);
+
+/* ---- decoder: src/sdnet/data/decoders.py:29-179 ------------------------------------------- */
+
+/* D1-D3 (decoders.py:44-48 / 60-64): clamped sigmoid + 5x5 NMS + top-k of one heatmap group,
+ * fused (logits are read once).  Same outputs as sd_topk. */
+size_t sd_decode_peaks_workspace_bytes(int B, int C, int h, int w, int k);
+int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, int h, int w, int k,
+                    float* out_score, int64_t* out_ind, float* out_cls, float* out_ys, float* out_xs,
+                    void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* Whole device stage of Decoder.__call__ (decoders.py:41-100) in two launches (+1 memset node):
+ * peaks of the anchor group (M maps, top K) and of the part group (N maps, top P), offset /
+ * embedding gather, refinement, masking, K x P association.
+ * `packed` receives B*(6K+11P) 4-byte words, structure-of-arrays over the batch:
+ *   anchor_out   f32 (B,K,4)  x, y, raw score, label           decoders.py:55-57
+ *   part_out     f32 (B,P,6)  x, y, raw score, kind, ox, oy    decoders.py:72-75
+ *   part_emb     f32 (B,P,2)                                   decoders.py:66
+ *   anchor_smask f32 (B,K)    score, or -1 where score <= conf  decoders.py:84
+ *   part_smask   f32 (B,P)                                     decoders.py:79
+ *   anchor_ind   i32 (B,K)    flat y*w+x                        decoders.py:46
+ *   part_ind     i32 (B,P)
+ *   assign       i32 (B,P)    anchor rank, or -1 when min dist >= dist_px  decoders.py:98-100
+ * conf and dist_px are the fp32-rounded thresholds. */
+size_t sd_decode_workspace_bytes(int B, int M, int N, int h, int w, int K, int P);
+size_t sd_decode_packed_words(int B, int K, int P);
+int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
+              const float* part_hm, int64_t p_sb, int64_t p_sc,
+              const float* offsets, int64_t o_sb, int64_t o_sc,
+              const float* embeddings, int64_t e_sb, int64_t e_sc,
+              int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px,
+              void* packed, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* D4-D5 alone (decoders.py:49-100) from already selected peaks (outputs of sd_decode_peaks):
+ * same `packed` layout as sd_decode. */
+int sd_decode_group(const float* a_score, const int64_t* a_ind, const float* a_cls,
+                    const float* p_score, const int64_t* p_ind, const float* p_cls,
+                    const float* offsets, int64_t o_sb, int64_t o_sc,
+                    const float* embeddings, int64_t e_sb, int64_t e_sc,
+                    int B, int h, int w, int K, int P, float conf, float dist_px,
+                    void* packed, sd_stream_t stream);
+
+/* ---- target rendering: src/sdnet/data/transforms.py:130-205 (Encode) ---------------------- */
+
+/* Heatmaps of a batch (transforms.py:143,160-161,173-174; utils.py:418-419): for every pixel of
+ * channel c of image b, exp(fp32(-min d^2) / two_sigma2) over that channel's keypoint centres,
+ * 0 when the channel has none.  Centres are the truncated output-pixel coordinates
+ * (cx[i], cy[i]) sorted by (image, channel); chan_ptr (B*C+1) is the CSR row pointer.
+ * out: (B,C,h,w) contiguous fp32. */
+int sd_render_targets(const int32_t* cx, const int32_t* cy, const int32_t* chan_ptr,
+                      int B, int C, int h, int w, float two_sigma2, float* out, sd_stream_t stream);
+
+/* ---- loss: src/sdnet/model/loss.py:17-64,91-117 ------------------------------------------- */
+
+#define SD_HM_MSE   0
+#define SD_HM_FOCAL 1
+
+typedef struct sd_loss_desc {
+    /* head output, network.py:77-84 (strided channel-slice views allowed) */
+    const float* anchor_hm;  int64_t a_sb, a_sc;      /* (B,M,h,w) logits */
+    const float* part_hm;    int64_t p_sb, p_sc;      /* (B,N,h,w) logits */
+    const float* offsets;    int64_t o_sb, o_sc;      /* (B,2,h,w) */
+    const float* embeddings; int64_t e_sb, e_sc;      /* (B,2,h,w) */
+    /* collated Encode output, dataset.py:58-87 */
+    const float* t_anchor_hm; int64_t ta_sb, ta_sc;   /* (B,M,h,w) */
+    const float* t_part_hm;   int64_t tp_sb, tp_sc;   /* (B,N,h,w) */
+    const int64_t* anchor_inds;   /* (B,K) */
+    const int64_t* part_inds;     /* (B,P) */
+    const float* anchor_offsets;  /* (B,K,2) */
+    const float* part_offsets;    /* (B,P,2) */
+    const float* t_embeddings;    /* (B,P,2) */
+    const uint8_t* anchor_mask;   /* (B,K) bool */
+    const uint8_t* part_mask;     /* (B,P) bool */
+    int B, M, N, h, w, K, P;
+    int hm_loss_fn;               /* SD_HM_MSE | SD_HM_FOCAL (args.py:96-102) */
+    float hm_weight, offset_weight, embedding_weight;   /* args.py:118-132 */
+} sd_loss_desc;
+
+/* Loss.forward (loss.py:17-50).  out[0..3] = total, hm, offset, embedding (weighted, as
+ * LossStats loss.py:120-165); out[4..7] = num_pos(anchor), num_pos(part), #valid anchors,
+ * #valid parts (kept on device for the backward; no host branch, cf. loss.py:59-61,110). */
+size_t sd_loss_workspace_bytes(int B, int M, int N, int h, int w);
+int sd_loss_fwd(const sd_loss_desc* d, float* out8, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* d total / d head for all M+N+4 channels.  grad_out: device scalar (upstream gradient).
+ * dhead: (B,M+N+4,h,w) contiguous, fully overwritten. */
+int sd_loss_bwd(const sd_loss_desc* d, const float* out8, const float* grad_out, float* dhead, sd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDNET_HIP_H */

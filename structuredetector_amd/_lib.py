@@ -1,0 +1,130 @@
+"""ctypes binding of libsdnet_hip.so (C ABI declared in include/sdnet_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SDNET_HIP_LIB", _HERE / "csrc" / "libsdnet_hip.so"))
+
+_lib = None
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i64 = C.c_int64
+c_int = C.c_int
+c_float = C.c_float
+c_size = C.c_size_t
+c_vp = C.c_void_p
+
+
+class SdError(RuntimeError):
+    pass
+
+
+class LossDesc(C.Structure):
+    _fields_ = [
+        ("anchor_hm", c_vp), ("a_sb", c_i64), ("a_sc", c_i64),
+        ("part_hm", c_vp), ("p_sb", c_i64), ("p_sc", c_i64),
+        ("offsets", c_vp), ("o_sb", c_i64), ("o_sc", c_i64),
+        ("embeddings", c_vp), ("e_sb", c_i64), ("e_sc", c_i64),
+        ("t_anchor_hm", c_vp), ("ta_sb", c_i64), ("ta_sc", c_i64),
+        ("t_part_hm", c_vp), ("tp_sb", c_i64), ("tp_sc", c_i64),
+        ("anchor_inds", c_vp), ("part_inds", c_vp),
+        ("anchor_offsets", c_vp), ("part_offsets", c_vp), ("t_embeddings", c_vp),
+        ("anchor_mask", c_vp), ("part_mask", c_vp),
+        ("B", c_int), ("M", c_int), ("N", c_int), ("h", c_int), ("w", c_int), ("K", c_int), ("P", c_int),
+        ("hm_loss_fn", c_int),
+        ("hm_weight", c_float), ("offset_weight", c_float), ("embedding_weight", c_float),
+    ]
+
+
+_MAP = [c_vp, c_i64, c_i64]          # pointer, batch stride, channel stride
+_PEAK_OUT = [c_vp, c_vp, c_vp, c_vp, c_vp]
+
+_SIGNATURES = {
+    "sd_version": (c_int, []),
+    "sd_last_error": (C.c_char_p, []),
+    "sd_clamped_sigmoid": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "sd_nms5": (c_int, _MAP + [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_topk_workspace_bytes": (c_size, [c_int] * 5),
+    "sd_topk": (c_int, _MAP + [c_int] * 5 + _PEAK_OUT + [c_vp, c_size, c_vp]),
+    "sd_transpose_and_gather": (c_int, _MAP + [c_int, c_int, c_i64, c_vp, c_int, c_vp, c_vp]),
+    "sd_hypot": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "sd_decode_peaks_workspace_bytes": (c_size, [c_int] * 5),
+    "sd_decode_peaks": (c_int, _MAP + [c_int] * 5 + _PEAK_OUT + [c_vp, c_size, c_vp]),
+    "sd_decode_workspace_bytes": (c_size, [c_int] * 7),
+    "sd_decode_packed_words": (c_size, [c_int] * 3),
+    "sd_decode": (c_int, _MAP * 4 + [c_int] * 7 + [c_float, c_float, c_vp, c_vp, c_size, c_vp]),
+    "sd_decode_group": (c_int, [c_vp] * 6 + _MAP * 2 + [c_int] * 5 + [c_float, c_float, c_vp, c_vp]),
+    "sd_render_targets": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp]),
+    "sd_loss_workspace_bytes": (c_size, [c_int] * 5),
+    "sd_loss_fwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_size, c_vp]),
+    "sd_loss_bwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_vp, c_vp]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load the shared library once.  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise SdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C {LIB_PATH.parent}`); structuredetector_amd has no CPU / eager fallback.")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().sd_last_error().decode(errors="replace")
+        raise SdError(f"{what or 'libsdnet_hip'} failed (code {rc}): {msg}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise SdError("structuredetector_amd ops need tensors on the GPU (device 'cuda'); got a "
+                          f"{t.device} tensor and there is no CPU fallback")
+
+
+def map_view(t: torch.Tensor):
+    """(B,C,h,w) fp32 tensor -> (tensor kept alive, ptr, batch stride, channel stride) with contiguous rows.
+    Channel-slice views of the head output (network.py:77-84) pass through without a copy."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    B, Cc, h, w = t.shape
+    ok = t.stride(3) == 1 and t.stride(2) == w and t.stride(1) >= h * w and (B == 1 or t.stride(0) >= h * w) \
+        and t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    if not ok:
+        t = t.contiguous()
+    return t, t.data_ptr(), t.stride(0), t.stride(1)
+
+
+_ws_cache: dict = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-(device, stream) grow-only scratch buffer (torch-allocated; the C ABI never allocates)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

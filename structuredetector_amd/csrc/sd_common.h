@@ -1,0 +1,62 @@
+// Shared host/device helpers for libsdnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sdnet_hip.h"
+
+namespace sd {
+
+void set_error(const char* fmt, ...);
+
+#define SD_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            sd::set_error(__VA_ARGS__);        \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define SD_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            sd::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define SD_LAUNCH_CHECK()                                                               \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            sd::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                             \
+        }                                                                               \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr float kClampLo = 1e-6f;                    // fp32(1e-6)
+constexpr float kClampHi = (float)(1.0 - 1e-6);      // fp32(1-1e-6) = 0.99999898672
+
+// clamp(sigmoid(x), 1e-6, 1-1e-6): src/sdnet/utils/utils.py:355-361
+__device__ __forceinline__ float sigmoid_raw(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float clamped_sigmoid(float x) {
+    return fminf(fmaxf(sigmoid_raw(x), kClampLo), kClampHi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+}  // namespace sd

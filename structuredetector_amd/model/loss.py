@@ -1,0 +1,150 @@
+"""`Loss`: heatmap (MSE or CornerNet focal) + masked-L1 offset / embedding loss.
+
+Mirrors src/sdnet/model/loss.py:8-64,91-165 (`Loss`, `LossStats`; `FocalLoss` / `L1Loss` exist
+as the fused HIP kernels `sd_loss_fwd` / `sd_loss_bwd`).  Differences in mechanism, not in
+result: one fused forward pass + one finalize block instead of ~40 launches, and the
+reference's host branches (`numel == 0`, `num_pos == 0`) run on the device, so a training step
+never synchronises with the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+
+_HM_FN = {"mse": 0, "focal": 1}
+
+
+def _common_base(views):
+    """If the four head views are channel slices of one contiguous (B, C, h, w) tensor
+    (network.py:77-84), return that tensor so the backward writes its gradient in one piece."""
+    a = views[0]
+    base = a._base
+    if base is None or base.dim() != 4 or not base.is_contiguous() or base.dtype != torch.float32:
+        return None
+    B, Cb, h, w = base.shape
+    c0 = 0
+    for v in views:
+        if v._base is not base or v.shape[0] != B or tuple(v.shape[2:]) != (h, w) or v.stride() != base.stride():
+            return None
+        if v.storage_offset() != base.storage_offset() + c0 * h * w:
+            return None
+        c0 += v.shape[1]
+    return base if c0 == Cb else None
+
+
+class _SdLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, head, tgt, cfg):
+        (M, N, K, P, fn, hm_w, off_w, emb_w) = cfg
+        B, Cc, h, w = head.shape
+        keep = []
+
+        def mp(t):
+            t, p, sb, sc = L.map_view(t)
+            keep.append(t)
+            return p, sb, sc
+
+        def flat(t, dtype):
+            t = t.to(dtype).contiguous() if t.dtype != dtype or not t.is_contiguous() else t
+            keep.append(t)
+            return t.data_ptr()
+
+        d = L.LossDesc()
+        d.anchor_hm, d.a_sb, d.a_sc = mp(head[:, :M])
+        d.part_hm, d.p_sb, d.p_sc = mp(head[:, M:M + N])
+        d.offsets, d.o_sb, d.o_sc = mp(head[:, M + N:M + N + 2])
+        d.embeddings, d.e_sb, d.e_sc = mp(head[:, M + N + 2:M + N + 4])
+        d.t_anchor_hm, d.ta_sb, d.ta_sc = mp(tgt["anchor_hm"])
+        d.t_part_hm, d.tp_sb, d.tp_sc = mp(tgt["part_hm"])
+        d.anchor_inds = flat(tgt["anchor_inds"], torch.int64)
+        d.part_inds = flat(tgt["part_inds"], torch.int64)
+        d.anchor_offsets = flat(tgt["anchor_offsets"], torch.float32)
+        d.part_offsets = flat(tgt["part_offsets"], torch.float32)
+        d.t_embeddings = flat(tgt["embeddings"], torch.float32)
+        d.anchor_mask = flat(tgt["anchor_mask"].view(torch.uint8) if tgt["anchor_mask"].dtype == torch.bool
+                             else tgt["anchor_mask"], torch.uint8)
+        d.part_mask = flat(tgt["part_mask"].view(torch.uint8) if tgt["part_mask"].dtype == torch.bool
+                           else tgt["part_mask"], torch.uint8)
+        d.B, d.M, d.N, d.h, d.w, d.K, d.P = B, M, N, h, w, K, P
+        d.hm_loss_fn = fn
+        d.hm_weight, d.offset_weight, d.embedding_weight = hm_w, off_w, emb_w
+        out8 = torch.empty(8, dtype=torch.float32, device=head.device)
+        lib = L.lib()
+        ws = L.workspace(lib.sd_loss_workspace_bytes(B, M, N, h, w), head.device)
+        L.check(lib.sd_loss_fwd(C.byref(d), out8.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_loss_fwd")
+        ctx.desc, ctx.keep, ctx.out8, ctx.shape = d, keep + [head], out8, (B, Cc, h, w)
+        ctx.mark_non_differentiable(out8)
+        return out8[0].clone(), out8
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out8):
+        dhead = torch.empty(ctx.shape, dtype=torch.float32, device=ctx.out8.device)
+        g = g_total.to(torch.float32).contiguous()
+        L.check(L.lib().sd_loss_bwd(C.byref(ctx.desc), ctx.out8.data_ptr(), g.data_ptr(), dhead.data_ptr(), L.stream()),
+                "sd_loss_bwd")
+        return dhead, None, None
+
+
+class Loss(torch.nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if args.hm_loss_fn.lower() not in _HM_FN:
+            raise IOError(f"'hm_loss_fn' should either be 'focal' or 'mse', not {args.hm_loss_fn}.")
+        self.stats = LossStats()
+
+    def forward(self, input, target):
+        views = [input["anchor_hm"], input["part_hm"], input["offsets"], input["embeddings"]]
+        L.require_cuda(*views)
+        M, N = views[0].shape[1], views[1].shape[1]
+        head = _common_base(views)
+        if head is None:                      # separate tensors: one concat, autograd splits the gradient back
+            head = torch.cat([v.float() for v in views], dim=1)
+        a = self.args
+        cfg = (M, N, target["anchor_inds"].shape[1], target["part_inds"].shape[1], _HM_FN[a.hm_loss_fn.lower()],
+               float(a.hm_weight), float(a.offset_weight), float(a.embedding_weight))
+        total, out8 = _SdLoss.apply(head, target, cfg)
+        self.stats.update(out8[1], out8[2], out8[3])
+        return total
+
+
+class LossStats:
+    """Three-field accumulator, src/sdnet/model/loss.py:120-165."""
+
+    def __init__(self, hm_loss=0.0, offset_loss=0.0, embedding_loss=0.0):
+        self.hm_loss, self.offset_loss, self.embedding_loss = hm_loss, offset_loss, embedding_loss
+
+    def reset(self):
+        self.hm_loss = self.offset_loss = self.embedding_loss = 0.0
+
+    def update(self, hm_loss, offset_loss, embedding_loss):
+        self.hm_loss, self.offset_loss, self.embedding_loss = hm_loss, offset_loss, embedding_loss
+
+    @property
+    def total_loss(self):
+        return self.hm_loss + self.offset_loss + self.embedding_loss
+
+    def _zip(self, other, op):
+        return [op(getattr(self, k), getattr(other, k) if isinstance(other, LossStats) else other)
+                for k in ("hm_loss", "offset_loss", "embedding_loss")]
+
+    def __add__(self, other):
+        return LossStats(*self._zip(other, lambda a, b: a + b))
+
+    def __iadd__(self, other):
+        self.update(*self._zip(other, lambda a, b: a + b))
+        return self
+
+    def __truediv__(self, value):
+        return LossStats(*self._zip(value, lambda a, b: a / b))
+
+    def __itruediv__(self, value):
+        self.update(*self._zip(value, lambda a, b: a / b))
+        return self
+
+    def __repr__(self):
+        return (f"total_loss: {self.total_loss}, hm_loss: {self.hm_loss}, offset_loss: {self.offset_loss}, "
+                f"embedding_loss: {self.embedding_loss}")

@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors and
+against the CPU oracle on seeded inputs.  Integer / index results are compared bit-exact;
+floating-point maps to the tolerance stated at each assert (north_star: 1e-4 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdnet_oracle as O
+from tests.helpers import ENC_KEYS, objects_to_arrays, scene_from_flat
+from tests.test_host_cpu import make_args, to_annotation
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SIG_TOL = dict(rtol=4e-7, atol=0)      # clamped sigmoid: <= ~3 ulp between GPU expf/div and the CPU's
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def head_views(head, M, N):
+    return {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2],
+            "embeddings": head[:, M + N + 2:M + N + 4]}
+
+
+def annotation_arrays(args, ann):
+    objs = [(args.labels[o.name], (o.anchor.x, o.anchor.y, o.anchor.score),
+             [(args.parts[k.kind], k.x, k.y, k.score) for k in o.parts]) for o in ann.objects]
+    return objects_to_arrays(objs)
+
+
+# ------------------------------------------------------------------------------------------ prims
+def test_prims_vs_golden(golden_dir):
+    from structuredetector_amd.utils import clamped_sigmoid, hypot, nms, topk, transpose_and_gather
+    g = np.load(golden_dir / "prims.npz")
+    np.testing.assert_allclose(clamped_sigmoid(dev(g["logits"])).cpu().numpy(), g["sig"], **SIG_TOL)
+    np.testing.assert_array_equal(nms(dev(g["sig"])).cpu().numpy(), g["nms"])            # compare/select only: exact
+    for k in (2, 7, 40):
+        s, i, c, y, x = (t.cpu().numpy() for t in topk(dev(g["dense"]), k))
+        np.testing.assert_array_equal(s, g[f"topk{k}_score"]); np.testing.assert_array_equal(i, g[f"topk{k}_ind"])
+        np.testing.assert_array_equal(c, g[f"topk{k}_cls"]); np.testing.assert_array_equal(y, g[f"topk{k}_y"])
+        np.testing.assert_array_equal(x, g[f"topk{k}_x"])
+        assert i.dtype == np.int64
+    np.testing.assert_array_equal(transpose_and_gather(dev(g["feat"]), dev(g["gind"])).cpu().numpy(), g["gathered"])
+    np.testing.assert_array_equal(hypot(dev(g["hyp_in"])).cpu().numpy(), g["hyp_out"])   # mul, add, sqrt: exact, no FMA
+
+
+def test_topk_ties_and_zero_fill():
+    """Order contract: score desc, class asc, flat index asc; zero slots = lowest non-peak indices."""
+    from structuredetector_amd.utils import decode_peaks, topk
+    x = np.zeros((1, 2, 8, 8), np.float32)
+    x[0, 1, 3, 3] = 2.0; x[0, 0, 5, 5] = 2.0; x[0, 0, 1, 1] = 2.0; x[0, 1, 0, 0] = 3.0
+    s, i, c, _, _ = (t.cpu().numpy() for t in topk(dev(x), 6))
+    es, ei, ec, _, _ = O.topk(x, 6)
+    np.testing.assert_array_equal(s, es); np.testing.assert_array_equal(i, ei); np.testing.assert_array_equal(c, ec)
+    # fused path on logits with only three peaks: remaining slots are zeros at flat 0,1,2,... skipping peaks
+    lg = np.full((2, 2, 16, 24), -20.0, np.float32)           # sigmoid clamps to 1e-6 everywhere: one big plateau
+    s, i, c, y, xx = (t.cpu().numpy() for t in decode_peaks(dev(lg), 5))
+    es, ei, ec, ey, ex = O.topk(O.nms(O.clamped_sigmoid(lg)), 5)
+    np.testing.assert_array_equal(i, ei); np.testing.assert_array_equal(c, ec); np.testing.assert_allclose(s, es, **SIG_TOL)
+    lg[:, :, :, :] = np.random.default_rng(0).standard_normal(lg.shape).astype(np.float32) * 0.01 - 30.0   # all clamp to 1e-6
+    lg[0, 1, 4, 4] = 3.0; lg[0, 0, 0, 0] = 2.0; lg[1, 0, 15, 23] = 1.0
+    s, i, c, y, xx = (t.cpu().numpy() for t in decode_peaks(dev(lg), 7))
+    es, ei, ec, ey, ex = O.topk(O.nms(O.clamped_sigmoid(lg)), 7)
+    np.testing.assert_array_equal(i, ei); np.testing.assert_array_equal(c, ec)
+    np.testing.assert_array_equal(y, ey); np.testing.assert_array_equal(xx, ex)
+
+
+@pytest.mark.parametrize("shape,k", [((3, 2, 40, 56), 17), ((2, 3, 128, 128), 40), ((1, 8, 256, 256), 512), ((2, 1, 33 * 4, 20), 1)])
+def test_decode_peaks_vs_oracle_noise(shape, k):
+    """White-noise logits: ~4% of the pixels survive the NMS, exercising the radix-select path."""
+    from structuredetector_amd.utils import decode_peaks
+    rng = np.random.default_rng(shape[2] * 7 + k)
+    lg = (2.0 * rng.standard_normal(shape)).astype(np.float32)
+    s, i, c, y, x = (t.cpu().numpy() for t in decode_peaks(dev(lg), k))
+    es, ei, ec, ey, ex = O.topk(O.nms(O.clamped_sigmoid(lg)), k)
+    # GPU and CPU sigmoids may differ by a few ulp: indices must agree wherever the oracle's ranking has margin
+    gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / es[:, 1:]
+    safe = np.ones_like(es, bool)
+    safe[:, 1:] &= gap > 2e-6; safe[:, :-1] &= gap > 2e-6
+    assert safe.mean() > 0.9
+    np.testing.assert_array_equal(i[safe], ei[safe]); np.testing.assert_array_equal(c[safe], ec[safe])
+    np.testing.assert_array_equal(y[safe], ey[safe]); np.testing.assert_array_equal(x[safe], ex[safe])
+    np.testing.assert_allclose(s, es, **SIG_TOL)
+    assert (np.diff(s, axis=1) <= 0).all()
+
+
+# ------------------------------------------------------------------------------------------ decoder
+@pytest.mark.parametrize("tag", ["scene_cfg512", "scene_small256"])
+def test_decoder_vs_golden(golden_dir, tag):
+    from structuredetector_amd.data import Decoder
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    args = make_args(M, N, K, P)
+    head = dev(g["head"])
+    md = Decoder(args)(head_views(head, M, N), return_metadata=True)
+    for grp, key in (("anchor", "topk_anchor"), ("part", "topk_kp")):
+        s, i, c, y, x = (t.cpu().numpy() for t in md[key])
+        ref_s = g[f"dec_{grp}_score"]
+        pos = ref_s > 0                       # above-threshold peaks (masked ones are -1 in the reference too)
+        assert i.dtype == np.int64
+        np.testing.assert_array_equal(s > 0, pos)
+        np.testing.assert_array_equal(i[pos], g[f"dec_{grp}_ind"][pos])          # bit-exact indices
+        np.testing.assert_array_equal(c[pos], g[f"dec_{grp}_cls"][pos])
+        np.testing.assert_array_equal(x[pos], g[f"dec_{grp}_x"][pos])            # refined coords: same fp32 add
+        np.testing.assert_array_equal(y[pos], g[f"dec_{grp}_y"][pos])
+        np.testing.assert_allclose(s[pos], ref_s[pos], **SIG_TOL)
+    pos = g["dec_part_score"] > 0
+    np.testing.assert_array_equal(md["embeddings"].cpu().numpy()[pos], g["dec_embeddings"][pos])
+    for b in range(head.shape[0]):
+        o, p = annotation_arrays(args, md["annotation"][b])
+        ro, rp = g[f"ann{b}_objs"], g[f"ann{b}_parts"]
+        assert o.shape == ro.shape and p.shape == rp.shape
+        np.testing.assert_array_equal(o[:, :3], ro[:, :3]); np.testing.assert_allclose(o[:, 3], ro[:, 3], **SIG_TOL)
+        np.testing.assert_array_equal(p[:, :4], rp[:, :4]); np.testing.assert_allclose(p[:, 4], rp[:, 4], **SIG_TOL)   # grouping: exact
+        r = np.array([[args.parts[k.kind], k.x, k.y, k.score] for k in md["raw_parts"][b]], np.float64).reshape(-1, 4)
+        rr = g[f"raw{b}"]
+        assert r.shape == rr.shape
+        np.testing.assert_array_equal(r[:, :3], rr[:, :3])
+    assert md["annotation"][0].objects and md["annotation"][0].image_name == "batch_0"
+    # plain call returns just the list
+    anns = Decoder(args)(head_views(head, M, N))
+    assert [len(a) for a in anns] == [len(a) for a in md["annotation"]]
+
+
+@pytest.mark.parametrize("B,img,M,N,K,P", [(5, 256, 2, 1, 20, 40), (2, 512, 8, 8, 128, 512), (3, 128, 1, 1, 3, 2)])
+def test_decoder_vs_oracle_random_scenes(B, img, M, N, K, P):
+    from structuredetector_amd.data import Decoder
+    rng = np.random.default_rng(B * 1000 + img)
+    heads = []
+    for _ in range(B):
+        objs = O.synthetic_scene(rng, img, img, M, N, 4, 30 if K > 20 else 10)
+        e = O.encode(img, img, objs, M, N, K, P, 4.0, 0.1)
+        heads.append(O.head_from_targets(rng, e, M, N, noise=0.3))
+    head = np.stack(heads)
+    args = make_args(M, N, K, P)
+    dec = Decoder(args)
+    packed, (b_, k_, p_, h, w) = dec.decode_packed(head_views(dev(head), M, N), 0.5, 0.1)
+    got = dec.split_packed(packed.cpu().numpy(), B, K, P)
+    t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+    for grp, n in (("anchor", K), ("part", P)):
+        es = t[f"{grp}_out"][..., 2]
+        gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / np.maximum(es[:, 1:], 1e-30)
+        safe = np.ones_like(es, bool)
+        safe[:, 1:] &= gap > 2e-6; safe[:, :-1] &= gap > 2e-6
+        np.testing.assert_array_equal(got[f"{grp}_ind"][safe], t[f"{grp}_inds"][safe])
+        np.testing.assert_array_equal(got[f"{grp}_out"][..., 3][safe], t[f"{grp}_out"][..., 3][safe])
+        np.testing.assert_array_equal(got[f"{grp}_out"][..., 0][safe], t[f"{grp}_out"][..., 0][safe])
+        np.testing.assert_array_equal(got[f"{grp}_out"][..., 1][safe], t[f"{grp}_out"][..., 1][safe])
+        np.testing.assert_allclose(got[f"{grp}_out"][..., 2], es, **SIG_TOL)
+        if safe.all():
+            assign = np.where(t["valid"], t["min_inds"], -1)
+            np.testing.assert_array_equal(got["assign"], assign)
+            np.testing.assert_array_equal(got["part_emb"], t["part_embeddings"])
+
+
+def test_decode_group_matches_fused():
+    """sd_decode_group fed with sd_decode_peaks outputs == the fused sd_decode."""
+    import ctypes
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.data import Decoder
+    from structuredetector_amd.utils import decode_peaks
+    rng = np.random.default_rng(5)
+    B, M, N, K, P, h, w = 3, 2, 2, 9, 14, 48, 64
+    head = dev((2 * rng.standard_normal((B, M + N + 4, h, w))).astype(np.float32))
+    v = head_views(head, M, N)
+    dec = Decoder(make_args(M, N, K, P))
+    packed, _ = dec.decode_packed(v, 0.5, 0.1)
+    a = decode_peaks(v["anchor_hm"], K); p = decode_peaks(v["part_hm"], P)
+    packed2 = torch.empty_like(packed)
+    o, o_p, o_sb, o_sc = L.map_view(v["offsets"]); e, e_p, e_sb, e_sc = L.map_view(v["embeddings"])
+    L.check(L.lib().sd_decode_group(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), p[0].data_ptr(), p[1].data_ptr(),
+                                    p[2].data_ptr(), o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, h, w, K, P,
+                                    float(np.float32(0.5)), float(np.float32(0.1 * min(h, w))), packed2.data_ptr(), L.stream()))
+    assert torch.equal(packed, packed2)
+
+
+# ------------------------------------------------------------------------------------------ encode
+@pytest.mark.parametrize("tag", ["scene_cfg512", "scene_small256"])
+def test_encode_vs_golden(golden_dir, tag):
+    from structuredetector_amd.data import Encode
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    args = make_args(M, N, K, P, device=torch.device(DEV))
+    n_img = g["head"].shape[0]
+    anns = [to_annotation(args, scene_from_flat(g[f"scene{n}_objs"], g[f"scene{n}_parts"])) for n in range(n_img)]
+    out = Encode(args).batch((W, H), anns)
+    for k in ENC_KEYS:
+        ref = np.stack([g[f"enc{n}_{k}"] for n in range(n_img)])
+        got = out[k].cpu().numpy()
+        assert got.dtype == ref.dtype and got.shape == ref.shape, k
+        if k.endswith("_hm"):
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7, err_msg=k)     # expf: few ulp (budget 1e-4)
+            np.testing.assert_array_equal(got == 1.0, ref == 1.0)                    # peaks are exactly 1.0 (focal loss needs it)
+        else:
+            np.testing.assert_array_equal(got, ref, err_msg=k)
+    # single-sample form: same keys / shapes as the reference's Encode.__call__
+    one = Encode(args)(torch.zeros(3, H, W), anns[0])
+    assert set(one) == set(ENC_KEYS) | {"image", "annotation"}
+    assert one["anchor_hm"].shape == (M, H // 4, W // 4) and one["part_inds"].shape == (P,)
+    assert one["anchor_mask"].dtype == torch.bool and one["anchor_inds"].dtype == torch.int64
+
+
+def test_encode_truncation_vs_golden(golden_dir):
+    from structuredetector_amd.data import Encode
+    g = np.load(golden_dir / "encode_trunc.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    args = make_args(M, N, K, P, device=torch.device(DEV))
+    for name in g["cases"]:
+        ann = to_annotation(args, scene_from_flat(g[f"{name}_objs"], g[f"{name}_parts"]))
+        out = Encode(args)(torch.zeros(3, H, W), ann)
+        for k in ENC_KEYS:
+            if k.endswith("_hm"):
+                np.testing.assert_allclose(out[k].cpu().numpy(), g[f"{name}_{k}"], rtol=1e-5, atol=1e-7, err_msg=f"{name} {k}")
+            else:
+                np.testing.assert_array_equal(out[k].cpu().numpy(), g[f"{name}_{k}"], err_msg=f"{name} {k}")
+
+
+# ------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("tag", ["scene_cfg512", "scene_small256"])
+@pytest.mark.parametrize("fn", ["mse", "focal"])
+@pytest.mark.parametrize("as_views", [True, False])
+def test_loss_vs_golden(golden_dir, tag, fn, as_views):
+    from structuredetector_amd.model import Loss
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    n_img = g["head"].shape[0]
+    target = {k: dev(np.stack([g[f"enc{n}_{k}"] for n in range(n_img)])) for k in ENC_KEYS}
+    head = dev(g["head"]).requires_grad_(True)
+    if as_views:
+        inp = head_views(head * 1.0, M, N)                 # non-leaf base -> slices are views of one tensor
+    else:
+        inp = {k: v.clone() for k, v in head_views(head, M, N).items()}
+    crit = Loss(make_args(M, N, K, P, hm_loss_fn=fn))
+    val = crit(inp, target)
+    val.backward()
+    ref = g[f"loss_{fn}"]
+    got = [val.item(), float(crit.stats.hm_loss), float(crit.stats.offset_loss), float(crit.stats.embedding_loss)]
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-7)                        # north_star: 1e-4
+    assert abs(float(crit.stats.total_loss) - ref[0]) <= 1e-4 * abs(ref[0]) + 1e-7
+    gref = g[f"lossgrad_{fn}"]
+    np.testing.assert_allclose(head.grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-4 * np.abs(gref).max())
+
+
+def test_loss_degenerate_batches():
+    """No valid keypoints (L1 terms -> 0, loss.py:59-61) and no positives (focal -> -neg, loss.py:110)."""
+    from structuredetector_amd.model import Loss
+    rng = np.random.default_rng(3)
+    B, M, N, K, P, h, w = 2, 2, 1, 4, 6, 16, 24
+    e = O.collate([O.encode(w * 4, h * 4, [], M, N, K, P, 4.0, 0.1) for _ in range(B)])
+    head = (rng.standard_normal((B, M + N + 4, h, w))).astype(np.float32)
+    for fn in ("mse", "focal"):
+        r = O.loss(head, e, M, N, hm_loss_fn=fn, want_grad=True)
+        x = dev(head).requires_grad_(True)
+        crit = Loss(make_args(M, N, K, P, hm_loss_fn=fn))
+        val = crit(head_views(x * 1.0, M, N), {k: dev(v) for k, v in e.items()})
+        val.backward()
+        np.testing.assert_allclose(val.item(), r["total"], rtol=1e-4)
+        assert float(crit.stats.offset_loss) == 0.0 and float(crit.stats.embedding_loss) == 0.0
+        np.testing.assert_allclose(x.grad.cpu().numpy(), r["grad"], rtol=1e-4, atol=1e-4 * np.abs(r["grad"]).max())
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_roundtrip_full_size_batch():
+    """BASELINE config sizes (bs=64, 512x512, 2 labels / 1 part): Encode -> synthesised head -> Decoder recovers
+    every object and part exactly (the reference's own round-trip identity)."""
+    from structuredetector_amd.data import Decoder, Encode
+    B, img, M, N, K, P = 64, 512, 2, 1, 20, 40
+    args = make_args(M, N, K, P, device=torch.device(DEV))
+    rng = np.random.default_rng(77)
+    scenes = []
+    for _ in range(B):
+        # keep keypoints >= 6 output pixels apart so that every one is its own 5x5 maximum
+        objs, taken = [], []
+        for (l, x, y, ps) in O.synthetic_scene(rng, img, img, M, N, 6, 12, 1, 2):
+            def free(px, py):
+                return all(max(abs(px // 4 - qx), abs(py // 4 - qy)) >= 6 for qx, qy in taken)
+            if not free(x, y):
+                continue
+            taken.append((x // 4, y // 4))
+            kept = []
+            for (k, px, py) in ps:
+                if free(px, py):
+                    taken.append((px // 4, py // 4)); kept.append((k, px, py))
+            objs.append((l, x, y, kept))
+        scenes.append(objs)
+    anns = [to_annotation(args, s) for s in scenes]
+    tgt = Encode(args).batch((img, img), anns)
+    hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 1 - 1e-4)
+    logits = torch.log(hm / (1 - hm))
+    h = w = img // 4
+    reg = torch.zeros(B, 4, h * w, device=DEV)
+    bi = torch.arange(B, device=DEV)[:, None]
+    am, pm = tgt["anchor_mask"], tgt["part_mask"]
+    reg[bi.expand_as(am)[am], 0, tgt["anchor_inds"][am]] = tgt["anchor_offsets"][am][:, 0]
+    reg[bi.expand_as(am)[am], 1, tgt["anchor_inds"][am]] = tgt["anchor_offsets"][am][:, 1]
+    reg[bi.expand_as(pm)[pm], 0, tgt["part_inds"][pm]] = tgt["part_offsets"][pm][:, 0]
+    reg[bi.expand_as(pm)[pm], 1, tgt["part_inds"][pm]] = tgt["part_offsets"][pm][:, 1]
+    reg[bi.expand_as(pm)[pm], 2, tgt["part_inds"][pm]] = tgt["embeddings"][pm][:, 0]
+    reg[bi.expand_as(pm)[pm], 3, tgt["part_inds"][pm]] = tgt["embeddings"][pm][:, 1]
+    head = torch.cat([logits, reg.view(B, 4, h, w)], 1)
+    anns_out = Decoder(args)(head_views(head, M, N))
+    n_obj = n_part = 0
+    for b in range(B):
+        want = sorted((o.name, round(o.x, 2), round(o.y, 2), tuple(sorted((p.kind, round(p.x, 2), round(p.y, 2)) for p in o.parts)))
+                      for o in anns[b].objects)
+        got = sorted((o.name, round(o.x, 2), round(o.y, 2), tuple(sorted((p.kind, round(p.x, 2), round(p.y, 2)) for p in o.parts)))
+                     for o in anns_out[b].objects)
+        assert want == got, f"image {b}"
+        n_obj += len(want); n_part += sum(len(o[3]) for o in want)
+    assert n_obj > 300 and n_part > 300
+
+
+def test_nms_idempotent_and_sorted_full_size():
+    from structuredetector_amd.utils import clamped_sigmoid, decode_peaks, nms
+    x = torch.randn(64, 3, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    s = clamped_sigmoid(x)
+    n1 = nms(s)
+    assert torch.equal(nms(n1), n1)                                  # idempotence
+    frac = (n1 > 0).float().mean().item()
+    assert 0.03 < frac < 0.05                                        # ~4.1 % of white-noise pixels survive
+    sc, ind, cls, ys, xs = decode_peaks(x, 40)
+    assert (sc[:, 1:] <= sc[:, :-1]).all()                           # sortedness
+    flat = n1.view(64, -1)
+    assert torch.equal(sc, flat.topk(40, dim=1).values)              # same score multiset as a dense top-k of the NMS map
+    picked = n1.view(64, 3, -1)[torch.arange(64, device=DEV)[:, None], cls.long(), ind]
+    assert torch.equal(picked, sc)                                   # (cls, ind) really address those scores
+    assert torch.equal(ys * 128 + xs, ind.float())

@@ -1,0 +1,152 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host-side logic
+(value types, Encode's float64 slot planner, LossStats, flag table) behaves like the reference.
+No GPU compute is issued here."""
+import json
+import re
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.helpers import scene_from_flat
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def make_args(M, N, K, P, **kw):
+    labels = {f"label{i}": i for i in range(M)}
+    parts = {f"part{i}": i for i in range(N)}
+    d = dict(labels=labels, parts=parts, _r_labels={v: k for k, v in labels.items()},
+             _r_parts={v: k for k, v in parts.items()}, anchor_name="stem", down_ratio=4.0, max_objects=K, max_parts=P,
+             conf_threshold=0.5, decoder_dist_thresh=0.1, sigma_gauss=0.1, hm_loss_fn="mse", hm_weight=1.0,
+             offset_weight=0.001, embedding_weight=0.001, fpn_depth=128)
+    d.update(kw)
+    return Namespace(**d)
+
+
+def to_annotation(args, objs, name="img.png"):
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object
+    return ImageAnnotation(name, [Object(args._r_labels[l], Keypoint(args.anchor_name, x, y),
+                                         [Keypoint(args._r_parts[k], px, py) for (k, px, py) in ps])
+                                  for (l, x, y, ps) in objs])
+
+
+def test_library_exports_every_declared_symbol():
+    from structuredetector_amd import _lib as L
+    header = (ROOT / "include" / "sdnet_hip.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = L.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/sdnet_hip.h but not exported"
+    assert declared == set(L.declared_symbols()), declared ^ set(L.declared_symbols())
+    assert handle.sd_version() >= 1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.utils import nms
+    with pytest.raises(L.SdError):
+        nms(torch.zeros(1, 1, 8, 8))
+
+
+def test_value_types_roundtrip(tmp_path):
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object, Box
+    ann = ImageAnnotation("a/b.png", [Object("bean", Keypoint("stem", 10.0, 20.0), [Keypoint("leaf", 12.5, 18.0, 0.9)],
+                                             Box(1, 2, 30, 40))], img_size=[100, 200])
+    r = ann.resized((100, 200), (50, 50))
+    assert ann.objects[0].x == 10.0 and r.objects[0].x == 5.0 and r.objects[0].y == 5.0
+    assert r.objects[0].parts[0].x == 6.25 and r.objects[0].box.x_max == 15.0
+    n = ann.normalized()
+    assert n.objects[0].anchor.x == 0.1 and n.objects[0].anchor.y == 0.1
+    p = tmp_path / "x.json"
+    d = ann.json_repr()
+    assert d["objects"][0]["parts"][0]["kind"] == "stem" and d["objects"][0]["parts"][1]["score"] == 0.9
+    p.write_text(json.dumps(d))
+    back = ImageAnnotation.from_json(p, "stem")
+    assert back.objects[0].name == "bean" and back.objects[0].parts[0].kind == "leaf" and back.nb_parts == 1
+    assert len(back) == 1 and not back.is_empty and back.objects[0].box.width == 29
+    with pytest.raises(AssertionError):
+        Object.from_json({"label": "x", "box": None, "parts": []}, "stem")
+    assert abs(Keypoint("a", 0, 0).distance(Keypoint("b", 3, 4)) - 5.0) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["scene_cfg512", "scene_small256"])
+def test_encode_plan_matches_reference(golden_dir, tag):
+    """Host stage of Encode (float64 clip/resize/truncate -> inds, offsets, embeddings, masks): bit-exact."""
+    from structuredetector_amd.data import Encode
+    g = np.load(golden_dir / f"{tag}.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    args = make_args(M, N, K, P)
+    enc = Encode(args)
+    from structuredetector_amd.data.transforms import scenes_to_flat
+    n_img = g["head"].shape[0]
+    anns = [to_annotation(args, scene_from_flat(g[f"scene{n}_objs"], g[f"scene{n}_parts"])) for n in range(n_img)]
+    plan = enc.plan(W, H, *scenes_to_flat(anns, args.labels, args.parts))
+    B = n_img
+    f32, i64, u8 = plan["f32"], plan["i64"], plan["u8"]
+    got = {"anchor_inds": i64[:B * K].reshape(B, K), "part_inds": i64[B * K:].reshape(B, P),
+           "anchor_offsets": f32[:B * K * 2].reshape(B, K, 2), "part_offsets": f32[B * K * 2:B * K * 2 + B * P * 2].reshape(B, P, 2),
+           "embeddings": f32[B * K * 2 + B * P * 2:].reshape(B, P, 2),
+           "anchor_mask": u8[:B * K].reshape(B, K).astype(bool), "part_mask": u8[B * K:].reshape(B, P).astype(bool)}
+    for k, v in got.items():
+        ref = np.stack([g[f"enc{n}_{k}"] for n in range(n_img)])
+        np.testing.assert_array_equal(v, ref, err_msg=k)
+    # renderer inputs: CSR over (image, channel) and the centre pixels equal the flat indices
+    n = plan["n_kp"]
+    cx, cy, ptr = plan["i32"][:n], plan["i32"][n:2 * n], plan["i32"][2 * n:]
+    assert ptr[0] == 0 and ptr[-1] == n and (np.diff(ptr) >= 0).all()
+    assert n == got["anchor_mask"].sum() + got["part_mask"].sum()
+    assert plan["two_sigma2"] == float(np.float32(2 * (0.1 * min(W // 4, H // 4) / 3) ** 2))
+
+
+def test_encode_plan_truncation(golden_dir):
+    from structuredetector_amd.data import Encode
+    from structuredetector_amd.data.transforms import scenes_to_flat
+    g = np.load(golden_dir / "encode_trunc.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    args = make_args(M, N, K, P)
+    for name in g["cases"]:
+        ann = to_annotation(args, scene_from_flat(g[f"{name}_objs"], g[f"{name}_parts"]))
+        from structuredetector_amd.utils import clip_annotation
+        clip_annotation(ann, (W, H))
+        plan = Encode(args).plan(W, H, *scenes_to_flat([ann], args.labels, args.parts))
+        np.testing.assert_array_equal(plan["i64"][:K], g[f"{name}_anchor_inds"], err_msg=name)
+        np.testing.assert_array_equal(plan["i64"][K:], g[f"{name}_part_inds"], err_msg=name)
+        np.testing.assert_array_equal(plan["u8"][:K].astype(bool), g[f"{name}_anchor_mask"], err_msg=name)
+        np.testing.assert_array_equal(plan["u8"][K:].astype(bool), g[f"{name}_part_mask"], err_msg=name)
+        np.testing.assert_array_equal(plan["f32"][:2 * K].reshape(K, 2), g[f"{name}_anchor_offsets"], err_msg=name)
+        np.testing.assert_array_equal(plan["f32"][2 * K + 2 * P:].reshape(P, 2), g[f"{name}_embeddings"], err_msg=name)
+
+
+def test_loss_stats_arithmetic():
+    from structuredetector_amd.model import LossStats
+    s = LossStats(1.0, 2.0, 3.0)
+    assert s.total_loss == 6.0
+    t = s + LossStats(1.0, 1.0, 1.0)
+    assert (t.hm_loss, t.offset_loss, t.embedding_loss) == (2.0, 3.0, 4.0)
+    t /= 2
+    assert t.offset_loss == 1.5
+    s += t
+    assert s.hm_loss == 2.0
+    s.reset()
+    assert s.total_loss == 0.0
+
+
+def test_flag_table_matches_reference_surface():
+    from structuredetector_amd.utils.args import Arguments
+    p = Arguments().parser
+    ns = p.parse_args([])
+    expect = dict(labels="labels.json", anchor_name="anchor", width=512, height=512, in_channels=3, fpn_depth=128,
+                  pretrained_model=None, batch_size=8, epochs=100, no_augmentation=False, learning_rate=1e-3, lr_step=3,
+                  down_ratio=4.0, hm_loss_fn="mse", max_objects=20, max_parts=40, hm_weight=1.0, offset_weight=0.001,
+                  embedding_weight=0.001, sigma_gauss=0.1, conf_threshold=0.5, dist_threshold=0.05,
+                  decoder_dist_thresh=0.1, csi_threshold=0.75, csv_path=None, use_amp=False)
+    for k, v in expect.items():
+        assert getattr(ns, k) == v, k
+    ns = p.parse_args("-W 256 -H 320 -b 4 -n 7 -k 9 -t 0.3 -o m.pth -s stem -f focal".split())
+    assert (ns.width, ns.height, ns.batch_size, ns.max_objects, ns.max_parts) == (256, 320, 4, 7, 9)
+    assert ns.conf_threshold == 0.3 and ns.pretrained_model == "m.pth" and ns.anchor_name == "stem" and ns.hm_loss_fn == "focal"
