@@ -151,6 +151,79 @@ int sd_loss_fwd(const sd_loss_desc* d, float* out8, void* workspace, size_t work
  * dhead: (B,M+N+4,h,w) contiguous, fully overwritten. */
 int sd_loss_bwd(const sd_loss_desc* d, const float* out8, const float* grad_out, float* dhead, sd_stream_t stream);
 
+
+/* ---- network: src/sdnet/model/network.py:6-87 (+ torchvision resnet34 BasicBlocks) --------
+ * Activations are NHWC fp32 (torch channels_last), weights [Cout][R][S][Cin] (torch
+ * channels_last OIHW).  These entry points replace the torch.nn.Conv2d / BatchNorm2d / ReLU /
+ * MaxPool2d / Upsample modules the reference composes, and torch.optim.Adam
+ * (src/sdnet/model/trainer.py:53,124). */
+
+typedef struct sd_conv_desc {
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride, pad;
+} sd_conv_desc;
+
+/* y = [relu]( conv(x, w) * scale[co] + shift[co] [+ residual] ), fp32 MFMA implicit GEMM.
+ * scale/shift/residual nullable.  res_up2: residual is the (Ho/2, Wo/2) map, nearest-upsampled x2
+ * (Fpn.forward, network.py:18-19).  Needs Cin % 32 == 0, Cout % 64 == 0. */
+int sd_conv2d_fwd(const float* x_nhwc, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
+                  const float* scale, const float* shift, const float* residual, int res_up2, int relu,
+                  sd_stream_t stream);
+/* stem: 7x7/2 conv 3 -> 64 reading the NCHW image directly (network.py:43; resnet.conv1). */
+int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
+                       const float* scale, const float* shift, int relu, sd_stream_t stream);
+/* dX = conv_transpose(dY, W): same kernel with the inverted coordinate map; w_t = weights
+ * re-laid as [Cin][R][S][Cout] by sd_conv2d_transpose_weights.  residual (nullable, same layout as
+ * dX) is added (skip-connection gradient). */
+int sd_conv2d_dgrad(const float* dy_nhwc, const float* w_t, float* dx_nhwc, const sd_conv_desc* d,
+                    const float* residual, sd_stream_t stream);
+int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, int Cin, sd_stream_t stream);
+/* dW[co][r][s][ci] (+)= sum_pixels dY * X, split over pixel ranges + deterministic reduce. */
+size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_wgrad(const float* dy_nhwc, const float* x_nhwc, float* dw_krsc, const sd_conv_desc* d,
+                    int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* stem weight gradient from the NCHW image: dW [64][7][7][3]. */
+size_t sd_conv2d_stem_wgrad_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_stem_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw_krsc, const sd_conv_desc* d,
+                         int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* BatchNorm2d over [M][C] (M = B*H*W): training statistics (biased var for normalisation,
+ * running stats with momentum and the unbiased var, torch semantics), apply (+residual, +ReLU),
+ * eval-mode fold into (scale, shift), backward (dy masked by y > 0 when relu; g_out optionally
+ * receives the masked gradient for the skip connection). */
+size_t sd_col_reduce_workspace_bytes(int64_t M, int C);
+int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentum, float* running_mean,
+                      float* running_var, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
+                      sd_stream_t stream);
+int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, const float* invstd,
+                const float* gamma, const float* beta, const float* residual, int relu, sd_stream_t stream);
+int sd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               float eps, int C, float* scale, float* shift, sd_stream_t stream);
+int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean,
+              const float* invstd, const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta,
+              int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* out[c] (+)= sum_m x[m][c]  (bias gradients). */
+int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace,
+               size_t workspace_bytes, sd_stream_t stream);
+
+/* MaxPool2d(3, 2, 1) NHWC; idx (uint8 per element) = winning tap for the backward. */
+int sd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, sd_stream_t stream);
+int sd_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, sd_stream_t stream);
+/* backward of nn.Upsample(scale_factor=2): dx (B,H,W,C) = 2x2 block sums of dy (B,2H,2W,C) [+ add]. */
+int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream);
+
+/* Head (network.py:22-29): 1x1 conv C -> Co with bias; NHWC in, NCHW out (the layout the decoder
+ * and the loss consume).  Co <= 16. */
+int sd_head_fwd(const float* x_nhwc, const float* w, const float* bias, float* y_nchw, int B, int HW, int C, int Co,
+                sd_stream_t stream);
+size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co);
+int sd_head_bwd(const float* dy_nchw, const float* x_nhwc, const float* w, float* dx_nhwc, float* dw, float* dbias,
+                int B, int HW, int C, int Co, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* torch.optim.Adam step (defaults: no weight decay / amsgrad) over a flat fp32 buffer;
+ * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int sd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                 float lr, float beta1, float beta2, float eps, float grad_scale, sd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,10 @@ class LossDesc(C.Structure):
     ]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "R", "S", "stride", "pad")]
+
+
 _MAP = [c_vp, c_i64, c_i64]          # pointer, batch stride, channel stride
 _PEAK_OUT = [c_vp, c_vp, c_vp, c_vp, c_vp]
 
@@ -63,6 +67,27 @@ _SIGNATURES = {
     "sd_loss_workspace_bytes": (c_size, [c_int] * 5),
     "sd_loss_fwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_size, c_vp]),
     "sd_loss_bwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_vp, c_vp]),
+    "sd_conv2d_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "sd_conv2d_stem_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_int, c_vp]),
+    "sd_conv2d_dgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp]),
+    "sd_conv2d_transpose_weights": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "sd_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "sd_conv2d_wgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_stem_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "sd_conv2d_stem_wgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
+    "sd_col_reduce_workspace_bytes": (c_size, [c_i64, c_int]),
+    "sd_bn_train_stats": (c_int, [c_vp, c_i64, c_int, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
+    "sd_bn_apply": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "sd_bn_fold": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp]),
+    "sd_bn_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_size, c_vp]),
+    "sd_col_sum": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_size, c_vp]),
+    "sd_maxpool3x3s2_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_upsample2x_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_head_bwd_workspace_bytes": (c_size, [c_int] * 4),
+    "sd_head_bwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, c_size, c_vp]),
+    "sd_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_float, c_float, c_float, c_float, c_vp]),
 }
 
 

@@ -1,0 +1,610 @@
+// fp32 convolution for the SDNet backbone / FPN on gfx950 as an implicit GEMM on the f32-input
+// MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+// Replaces the ATen/cuDNN convolutions the reference reaches through torch.nn.Conv2d in
+// src/sdnet/model/network.py:6-57 (Fpn, Head, Network) and torchvision's resnet34.
+//
+// Data layout: activations NHWC (torch channels_last), weights [Cout][R][S][Cin] (torch
+// channels_last OIHW), so that every K-chunk of the GEMM (one filter tap x 32 input channels) is
+// 128 contiguous bytes per output pixel (A operand) and per output channel (B operand).
+//
+//   GEMM:  Y[m][n] = sum_k A[m][k] * Wt[n][k],   m = (b, oy, ox), n = cout, k = (r, s, cin)
+//   block tile 128 (m) x BN (n, 128 or 64) x 32 (k); 4 waves, each a 2x2 / 2x1 grid of 32x32 MFMA tiles
+//   LDS: double-buffered A[128][32+4] and W[BN][32+4] (the +4 pad makes the ds_read_b128
+//        fragment reads conflict-free: slot = 9*row mod 16), register-staged prefetch of chunk
+//        k+1 while chunk k is multiplied (one barrier per chunk).
+//
+// The same kernel is the data-gradient: dX = conv(dY, W^T) with the coordinate map inverted
+// (out = (in + pad - r) / stride when divisible), weights pre-transposed to [Cin][R][S][Cout].
+#include "sd_common.h"
+
+namespace sd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BK = 32, LDK = BK + 4;
+
+struct ConvArgs {
+    const float* x;       // A source, NHWC [B][Hi][Wi][Ck]   (STEM: NCHW [B][3][Hi][Wi])
+    const float* w;       // [Nn][R*S][Ck]
+    float* y;             // [M][Nn], M = B*Ho*Wo
+    const float* scale;   // per-n multiplier (nullable)
+    const float* shift;   // per-n addend (nullable): bias or folded BN
+    const float* res;     // residual, [M][Nn] or (res_up2) [B][Ho/2][Wo/2][Nn] (nullable)
+    int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S;
+    int mul, div, off, rsign;   // input coord t = o*mul + off + rsign*r ; valid iff t>=0, t%div==0, t/div < Hi
+    int relu, res_up2;
+    int M, nk, kchunks;   // kchunks = Ck/32 (STEM: unused), nk = number of 32-wide K chunks
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
+    // tiles so that neighbouring tiles (shared input rows / weight panels) hit the same L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BN, bool STEM>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
+    constexpr int NT = BN / 64;            // 32-wide MFMA tiles per wave along n (wave tile = 64 x BN/2)
+    constexpr int BROWS = BN / 32;         // float4 rows of the W tile each thread stages
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                       // [2][BM][LDK]
+    float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = p.Nn / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;   // n fastest: the A tile is reused from L2
+
+    // ---- staging assignment: thread -> (row = tid/8 + 32*i, 4 consecutive k = (tid%8)*4)
+    const int srow = tid >> 3, sk = (tid & 7) * 4;
+    int a_ty[4], a_tx[4];                  // o*mul + off for the 4 staged rows
+    int64_t a_base[4];                     // batch offset into x (elements); -1 => row beyond M
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (m < p.M) {
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            a_ty[i] = oy * p.mul + p.off;
+            a_tx[i] = ox * p.mul + p.off;
+            a_base[i] = (int64_t)b * p.Hi * p.Wi * (STEM ? 3 : p.Ck);
+        } else {
+            a_ty[i] = a_tx[i] = 0;
+            a_base[i] = -1;
+        }
+    }
+    const float* wrow[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (int64_t)(n0 + srow + 32 * i) * p.R * p.S * (STEM ? 3 : p.Ck);
+
+    float4 ra[4], rb[BROWS];
+    auto load_chunk = [&](int kc) {
+        if (!STEM) {
+            const int tap = kc / p.kchunks, c0 = (kc - tap * p.kchunks) * BK;
+            const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ty = a_ty[i] + p.rsign * r, tx = a_tx[i] + p.rsign * s;
+                bool ok = (a_base[i] >= 0) && ty >= 0 && tx >= 0;
+                if (p.div > 1) {
+                    ok = ok && (ty % p.div == 0) && (tx % p.div == 0);
+                    ty /= p.div; tx /= p.div;
+                }
+                ok = ok && ty < p.Hi && tx < p.Wi;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_base[i] + ((int64_t)ty * p.Wi + tx) * p.Ck + c0 + sk)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (int64_t)tap * p.Ck + c0 + sk);
+        } else {
+            // stem: k = (r*S + s)*3 + ci over 147 values padded to 160; x is NCHW
+            const int ktot = p.R * p.S * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kc * BK + sk + j;
+                    const int tap = k / 3, ci = k - tap * 3;
+                    const int r = tap / p.S, s = tap - r * p.S;
+                    const int ty = a_ty[i] + r, tx = a_tx[i] + s;
+                    const bool ok = (a_base[i] >= 0) && k < ktot && ty >= 0 && tx >= 0 && ty < p.Hi && tx < p.Wi;
+                    v[j] = ok ? p.x[a_base[i] + ((int64_t)ci * p.Hi + ty) * p.Wi + tx] : 0.f;
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kc * BK + sk + j;
+                    v[j] = k < ktot ? wrow[i][k] : 0.f;
+                }
+                rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (buf * BM + srow + 32 * i) * LDK + sk) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (buf * BN + srow + 32 * i) * LDK + sk) = rb[i];
+    };
+
+    // ---- wave tile: 64 (m) x BN/2 (n)
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < p.nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < p.nk) load_chunk(kc + 1);
+        const float* Ab = As + (cur * BM + wm0 + fr) * LDK + fh * 4;
+        const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK + fh * 4;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 a[2], b[NT];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float4*>(Ab + mi * 32 * LDK + ks * 8);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const float4*>(Bb + ni * 32 * LDK + ks * 8);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < p.nk) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + fr;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (m >= p.M) continue;
+                float v = acc[mi][ni][e] * sc + sh;
+                if (p.res) {
+                    int64_t rm = m;
+                    if (p.res_up2) {       // nearest-neighbour x2 upsample of the coarser map (network.py:10,19)
+                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                    }
+                    v += p.res[rm * p.Nn + n];
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.y[(int64_t)m * p.Nn + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][tap][c] = sum_m dY[m][n] * X[pix(m, tap)][c]  -- a GEMM whose reduction
+// index is the pixel.  Output tile 128 (n) x 128 (c-chunk, one tap) per block, split over
+// `splits` pixel ranges (grid.y); partial tiles are summed by k_wgrad_reduce (deterministic).
+// Operands are read from LDS "transposed" (k = pixel is the slow LDS index), which for
+// ds_read_b32 with 32 consecutive n / c per half-wave is conflict-free.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dy;   // [M][Nn]
+    const float* x;    // NHWC [B][Hi][Wi][Ck]
+    float* part;       // [splits][Nn][R*S][Ck]
+    int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S, stride, pad;
+    int M, splits, m_per_split;
+};
+
+template <int TN, int TC>   // tile sizes along n (Cout) and c (Cin): 128/64 and 128/64
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
+    constexpr int PK = 32;                        // pixels per chunk
+    constexpr int LDN = TN + 4, LDC = TC + 4;     // row pads keep the ds_write_b128 rows 16-byte aligned
+    constexpr int NT = TN / 64, CT = TC / 64;     // wave tile = TN/2 x TC/2 -> (TN/64) x (TC/64) MFMA tiles
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ds = lds;                              // [2][PK][LDN]   dY chunk  (k = pixel, n)
+    float* Xs = lds + 2 * PK * LDN;               // [2][PK][LDC]   X chunk   (k = pixel, c)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c_tiles = p.Ck / TC, n_tiles = p.Nn / TN;
+    int t = blockIdx.x;
+    const int ct = t % c_tiles; t /= c_tiles;
+    const int nt = t % n_tiles; t /= n_tiles;
+    const int tap = t;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int n0 = nt * TN, c0 = ct * TC;
+    const int split = blockIdx.y;
+    const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
+
+    // staging: dY chunk = PK rows x TN floats; X chunk = PK rows x TC floats; float4 per thread-slot
+    constexpr int DV = PK * TN / 4 / 256, XV = PK * TC / 4 / 256;   // float4 per thread
+    float4 rd[DV], rx[XV];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (TN / 4), col = (idx % (TN / 4)) * 4;
+            const int m = mc + row;
+            rd[i] = (m < m_end) ? *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.Nn + n0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (TC / 4), col = (idx % (TC / 4)) * 4;
+            const int m = mc + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
+                const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;
+                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                    v = *reinterpret_cast<const float4*>(p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + c0 + col);
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (TN / 4), col = (idx % (TN / 4)) * 4;
+            *reinterpret_cast<float4*>(Ds + (buf * PK + row) * LDN + col) = rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = tid + 256 * i, row = idx / (TC / 4), col = (idx % (TC / 4)) * 4;
+            *reinterpret_cast<float4*>(Xs + (buf * PK + row) * LDC + col) = rx[i];
+        }
+    };
+
+    const int wn0 = (wave >> 1) * (TN / 2), wc0 = (wave & 1) * (TC / 2);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[NT][CT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nchunks = (m_end - m_beg + PK - 1) / PK;
+    if (nchunks > 0) {
+        load_chunk(m_beg);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) load_chunk(m_beg + (ch + 1) * PK);
+        const float* Db = Ds + cur * PK * LDN + wn0 + fr;
+        const float* Xb = Xs + cur * PK * LDC + wc0 + fr;
+#pragma unroll
+        for (int kk = 0; kk < PK / 2; ++kk) {
+            float a[NT], b[CT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) a[i] = Db[(2 * kk + fh) * LDN + i * 32];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) b[j] = Xb[(2 * kk + fh) * LDC + j * 32];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+    // D[n][c]: row index (m of the MFMA) = n, column (lane&31) = c  -> contiguous c per half-wave
+    float* out = p.part + (int64_t)split * p.Nn * p.R * p.S * p.Ck;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int c = c0 + wc0 + j * 32 + fr;
+                out[((int64_t)n * p.R * p.S + tap) * p.Ck + c] = acc[i][j][e];
+            }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient: dW[co][k] = sum_m dY[m][co] * patch[m][k], k = (r*7+s)*3 + ci (147 -> 160),
+// patches gathered from the NCHW image.  n = 64 -> 2 MFMA row tiles, k = 160 -> 5 column tiles;
+// wave w owns row tile (w&1) and column tiles (w>>1), (w>>1)+2, (w>>1)+4.
+// ---------------------------------------------------------------------------------------------
+constexpr int STEM_K = 147, STEM_KP = 160;
+
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad(WgradArgs p) {
+    constexpr int PK = 32, LDN = 64 + 4, LDC = STEM_KP + 4;
+    __shared__ __attribute__((aligned(16))) float Ds[2][PK][LDN];
+    __shared__ __attribute__((aligned(16))) float Xs[2][PK][LDC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x;
+    const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
+    constexpr int XE = PK * STEM_KP / 256;   // 20 gathered elements per thread
+    float4 rd[2];
+    float rx[XE];
+    auto load_chunk = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, col = (idx & 15) * 4;
+            const int m = mc + row;
+            rd[i] = (m < m_end) ? *reinterpret_cast<const float4*>(p.dy + (int64_t)m * 64 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < XE; ++i) {
+            const int idx = tid + 256 * i, row = idx / STEM_KP, k = idx - row * STEM_KP;
+            const int m = mc + row;
+            float v = 0.f;
+            if (m < m_end && k < STEM_K) {
+                const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
+                const int tap = k / 3, ci = k - tap * 3, r = tap / p.S, s = tap - r * p.S;
+                const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;
+                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) v = p.x[(((int64_t)b * 3 + ci) * p.Hi + iy) * p.Wi + ix];
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, col = (idx & 15) * 4;
+            *reinterpret_cast<float4*>(&Ds[buf][row][col]) = rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XE; ++i) {
+            const int idx = tid + 256 * i, row = idx / STEM_KP, k = idx - row * STEM_KP;
+            Xs[buf][row][k] = rx[i];
+        }
+    };
+    const int nt = wave & 1, kt0 = wave >> 1;
+    const int nkt = (kt0 == 0) ? 3 : 2;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int nchunks = (m_end - m_beg + PK - 1) / PK;
+    if (nchunks > 0) { load_chunk(m_beg); store_chunk(0); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) load_chunk(m_beg + (ch + 1) * PK);
+#pragma unroll
+        for (int kk = 0; kk < PK / 2; ++kk) {
+            const float a = Ds[cur][2 * kk + fh][nt * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < nkt) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[cur][2 * kk + fh][(kt0 + 2 * j) * 32 + fr], acc[j], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = p.part + (int64_t)split * 64 * STEM_K;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j >= nkt) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            const int k = (kt0 + 2 * j) * 32 + fr;
+            if (k < STEM_K) out[n * STEM_K + k] = acc[j][e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int64_t n4, int splits,
+                                                       int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = accumulate ? reinterpret_cast<const float4*>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+// [N][T][C] -> [C][T][N]  (forward weights -> data-gradient weights, flipping nothing: the
+// dgrad coordinate map already walks the taps with rsign = -1)
+__global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w, float* __restrict__ wt, int N, int T, int C) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j, c = c0 + tx;
+        tile[j][tx] = (n < N && c < C) ? w[((int64_t)n * T + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, n = n0 + tx;
+        if (n < N && c < C) wt[((int64_t)c * T + tap) * N + n] = tile[tx][j];
+    }
+}
+
+static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
+    const int BN = (a.Nn % 128 == 0) ? 128 : 64;
+    const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    if (stem) {
+        hipLaunchKernelGGL((k_conv_igemm<64, true>), dim3(tiles), dim3(256), lds, st, a);
+    } else if (BN == 128) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((k_conv_igemm<128, false>), dim3(tiles), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((k_conv_igemm<64, false>), dim3(tiles), dim3(256), lds, st, a);
+    }
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_conv(const char* what, const sd_conv_desc* d) {
+    SD_REQUIRE(d != nullptr, SD_ERR_INVALID, "%s: null descriptor", what);
+    SD_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0 && d->pad >= 0,
+               SD_ERR_INVALID, "%s: bad sizes", what);
+    SD_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->S) / d->stride + 1,
+               SD_ERR_INVALID, "%s: Ho/Wo do not match the convolution geometry", what);
+    SD_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->B * d->Hi * d->Wi < (1ll << 31), SD_ERR_INVALID,
+               "%s: too many pixels for 32-bit pixel indices", what);
+    return 0;
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" {
+
+int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* d, const float* scale, const float* shift,
+                  const float* residual, int res_up2, int relu, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_fwd", d)) return e;
+    SD_REQUIRE(x && w && y, SD_ERR_INVALID, "sd_conv2d_fwd: null pointer");
+    SD_REQUIRE(d->Cin % 32 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)",
+               d->Cin, d->Cout);
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd: pointers must be 16-byte aligned");
+    SD_REQUIRE(!res_up2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd: res_up2 needs even Ho, Wo");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.relu = relu; a.res_up2 = res_up2;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / BK; a.nk = d->R * d->S * a.kchunks;
+    return launch_igemm(a, false, (hipStream_t)stream);
+}
+
+int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
+                       sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_fwd", d)) return e;
+    SD_REQUIRE(x_nchw && w && y, SD_ERR_INVALID, "sd_conv2d_stem_fwd: null pointer");
+    SD_REQUIRE(d->Cin == 3 && d->Cout == 64, SD_ERR_INVALID, "sd_conv2d_stem_fwd: the stem is 3 -> 64 channels (network.py:43)");
+    ConvArgs a{};
+    a.x = x_nchw; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.relu = relu;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = 3; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = 64; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = 1; a.nk = cdiv(d->R * d->S * 3, BK);
+    return launch_igemm(a, true, (hipStream_t)stream);
+}
+
+int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_dgrad", d)) return e;
+    SD_REQUIRE(dy && w_t && dx, SD_ERR_INVALID, "sd_conv2d_dgrad: null pointer");
+    SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad: needs Cout %% 32 == 0 and Cin %% 64 == 0");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad: pointers must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = dy; a.w = w_t; a.y = dx; a.res = residual;
+    a.B = d->B; a.Hi = d->Ho; a.Wi = d->Wo; a.Ck = d->Cout; a.Ho = d->Hi; a.Wo = d->Wi; a.Nn = d->Cin; a.R = d->R; a.S = d->S;
+    a.mul = 1; a.div = d->stride; a.off = d->pad; a.rsign = -1;
+    a.M = d->B * d->Hi * d->Wi; a.kchunks = d->Cout / BK; a.nk = d->R * d->S * a.kchunks;
+    return launch_igemm(a, false, (hipStream_t)stream);
+}
+
+int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, int Cin, sd_stream_t stream) {
+    SD_REQUIRE(w && w_t && Cout > 0 && taps > 0 && Cin > 0, SD_ERR_INVALID, "sd_conv2d_transpose_weights: bad arguments");
+    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, taps, Cin);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int wgrad_splits(const sd_conv_desc* d, int tiles) {
+    const int M = d->B * d->Ho * d->Wo;
+    int s = (2 * 256 + tiles - 1) / tiles;                 // aim at >= 2 blocks per CU
+    s = std::max(1, std::min(s, cdiv(M, 256)));           // at least 256 pixels per split
+    return s;
+}
+
+size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 64 || d->Cout % 64) return 0;
+    const int TN = d->Cout % 128 == 0 ? 128 : 64, TC = d->Cin % 128 == 0 ? 128 : 64;
+    const int tiles = d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
+    return (size_t)wgrad_splits(d, tiles) * d->Cout * d->R * d->S * d->Cin * sizeof(float);
+}
+
+int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                    size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_wgrad", d)) return e;
+    SD_REQUIRE(dy && x && dw && workspace, SD_ERR_INVALID, "sd_conv2d_wgrad: null pointer");
+    SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_wgrad: needs Cin, Cout %% 64 == 0");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_wgrad: workspace too small");
+    const int TN = d->Cout % 128 == 0 ? 128 : 64, TC = d->Cin % 128 == 0 ? 128 : 64;
+    const int tiles = d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
+    WgradArgs a{};
+    a.dy = dy; a.x = x; a.part = (float*)workspace;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.stride = d->stride; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.splits = wgrad_splits(d, tiles);
+    a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * 32 * (TN + 4 + TC + 4) * sizeof(float);
+    dim3 grid(tiles, a.splits);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (128 + 4 + 128 + 4) * 4);
+        attr = true;
+    }
+    if (TN == 128 && TC == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), lds, st, a);
+    else if (TN == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), lds, st, a);
+    else if (TC == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), lds, st, a);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int stem_splits(const sd_conv_desc* d) {
+    const int M = d->B * d->Ho * d->Wo;
+    return std::max(1, std::min(512, cdiv(M, 1024)));
+}
+
+size_t sd_conv2d_stem_wgrad_workspace_bytes(const sd_conv_desc* d) {
+    if (!d) return 0;
+    return (size_t)stem_splits(d) * 64 * STEM_K * sizeof(float);
+}
+
+int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                         size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_wgrad", d)) return e;
+    SD_REQUIRE(dy && x_nchw && dw && workspace, SD_ERR_INVALID, "sd_conv2d_stem_wgrad: null pointer");
+    SD_REQUIRE(d->Cin == 3 && d->Cout == 64 && d->R * d->S * 3 == STEM_K, SD_ERR_INVALID, "sd_conv2d_stem_wgrad: the stem is 7x7, 3 -> 64");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_wgrad: workspace too small");
+    WgradArgs a{};
+    a.dy = dy; a.x = x_nchw; a.part = (float*)workspace;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = 3; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = 64; a.R = d->R; a.S = d->S;
+    a.stride = d->stride; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.splits = stem_splits(d);
+    a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stem_wgrad, dim3(a.splits), dim3(256), 0, st, a);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = 64 * STEM_K / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,581 @@
+// Non-GEMM layers of the SDNet backbone / FPN on gfx950 (all HBM-bound, NHWC fp32):
+// BatchNorm2d (training statistics, apply + residual + ReLU, backward), MaxPool2d(3,2,1),
+// nearest-x2 upsample backward, the 1x1 head (NHWC -> NCHW) forward/backward, column sums for
+// bias gradients and the fused Adam step.  They replace the torch.nn modules used by
+// src/sdnet/model/network.py:6-57 and torchvision's resnet34 (BasicBlock), and
+// torch.optim.Adam in src/sdnet/model/trainer.py:53,124.
+#include "sd_common.h"
+
+namespace sd {
+
+// ------------------------------------------------------------------------------------------
+// column reductions over a [M][C] matrix (C % 4 == 0, C <= 1024): per-block partial sums of up
+// to two quantities, then a finalize kernel in double.  Thread layout: C/4 float4 columns x
+// (256 / (C/4)) row lanes.
+// ------------------------------------------------------------------------------------------
+constexpr int RED_ROWS_PER_BLOCK = 2048;
+
+// MODE 0: sum x, sum x^2                      (BN statistics)
+// MODE 1: sum g, sum g*xhat  with g = dy * [y > 0 if relu]   (BN backward)
+// MODE 2: sum x                               (bias gradient)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                     int64_t M, int C, float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
+    const int cols = C >> 2;                       // float4 columns
+    const int lanes = 256 / cols;                  // row lanes (cols <= 256)
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK;
+    const int64_t r1 = min(r0 + RED_ROWS_PER_BLOCK, M);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    float4 mu = s0, is = s0;
+    if (MODE == 1 && rl < lanes) {
+        mu = reinterpret_cast<const float4*>(mean)[col];
+        is = reinterpret_cast<const float4*>(invstd)[col];
+    }
+    if (rl < lanes) {
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const float4 v = reinterpret_cast<const float4*>(a + r * C)[col];
+            if (MODE == 0) {
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+                s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
+            } else if (MODE == 2) {
+                s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            } else {
+                float4 g = v;
+                if (relu) {
+                    const float4 yy = reinterpret_cast<const float4*>(y + r * C)[col];
+                    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                }
+                const float4 xv = reinterpret_cast<const float4*>(b + r * C)[col];
+                s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+                s1.x += g.x * ((xv.x - mu.x) * is.x); s1.y += g.y * ((xv.y - mu.y) * is.y);
+                s1.z += g.z * ((xv.z - mu.z) * is.z); s1.w += g.w * ((xv.w - mu.w) * is.w);
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) {
+            const float4 u = red[0][l * cols + col], w = red[1][l * cols + col];
+            s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+        }
+        float* dst = partial + (int64_t)blockIdx.x * 2 * C;
+        reinterpret_cast<float4*>(dst)[col] = s0;
+        reinterpret_cast<float4*>(dst + C)[col] = s1;
+    }
+}
+
+// FIN 0: BN statistics -> mean, invstd, running stats (momentum, unbiased running var)
+// FIN 1: BN backward   -> dgamma (+=), dbeta (+=), and the two means needed by the apply pass
+// FIN 2: bias gradient -> out0 (+=)
+template <int FIN>
+__global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ partial, int nblocks, int C, double M, float eps,
+                                                       float momentum, float* __restrict__ out0, float* __restrict__ out1,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       float* __restrict__ aux0, float* __restrict__ aux1, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s0 += (double)partial[(int64_t)b * 2 * C + c];
+        s1 += (double)partial[(int64_t)b * 2 * C + C + c];
+    }
+    if (FIN == 0) {
+        const double mean = s0 / M;
+        const double var = fmax(s1 / M - mean * mean, 0.0);             // biased variance (normalisation)
+        out0[c] = (float)mean;
+        out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;     // torch: running_var uses the unbiased estimate
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+        }
+    } else if (FIN == 1) {
+        out0[c] = (accumulate ? out0[c] : 0.f) + (float)s1;             // dgamma = sum g * xhat
+        out1[c] = (accumulate ? out1[c] : 0.f) + (float)s0;             // dbeta  = sum g
+        aux0[c] = (float)(s0 / M);
+        aux1[c] = (float)(s1 / M);
+    } else {
+        out0[c] = (accumulate ? out0[c] : 0.f) + (float)s0;
+    }
+}
+
+// y = [relu]( (x - mean) * invstd * gamma + beta [+ res] )
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y, int64_t n4, int C,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ res, int relu) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int cols = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int col = (int)(i % cols);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+        const float4 g = reinterpret_cast<const float4*>(gamma)[col], b = reinterpret_cast<const float4*>(beta)[col];
+        float4 o;
+        o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
+        o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// eval-mode BN folded into a per-channel affine (consumed by the conv epilogue)
+__global__ __launch_bounds__(256) void k_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                                  int C, float* scale, float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * [y > 0];  optionally g_out = g
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                       int relu, int64_t n4, int C, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mg, const float* __restrict__ mgx,
+                                                       float* __restrict__ dx, float* __restrict__ g_out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int cols = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int col = (int)(i % cols);
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
+        const float4 a = reinterpret_cast<const float4*>(mg)[col], b = reinterpret_cast<const float4*>(mgx)[col];
+        float4 o;
+        o.x = ga.x * is.x * (g.x - a.x - (xv.x - mu.x) * is.x * b.x);
+        o.y = ga.y * is.y * (g.y - a.y - (xv.y - mu.y) * is.y * b.y);
+        o.z = ga.z * is.z * (g.z - a.z - (xv.z - mu.z) * is.z * b.z);
+        o.w = ga.w * is.w * (g.w - a.w - (xv.w - mu.w) * is.w * b.w);
+        reinterpret_cast<float4*>(dx)[i] = o;
+        if (g_out) reinterpret_cast<float4*>(g_out)[i] = g;
+    }
+}
+
+// MaxPool2d(3, stride 2, pad 1), NHWC.  idx = winning tap (first maximum in row-major window
+// order, as ATen) for the backward.
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int B,
+                                                      int Hi, int Wi, int Ho, int Wo, int C) {
+    const int cols = C >> 2;
+    const int64_t n4 = (int64_t)B * Ho * Wo * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 w = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int iy = oy * 2 - 1 + r, ix = ox * 2 - 1 + s;
+            if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+            const float4 v = reinterpret_cast<const float4*>(x + (((int64_t)b * Hi + iy) * Wi + ix) * C)[col];
+            const uint8_t tap = (uint8_t)(r * 3 + s);
+            if (v.x > m.x) { m.x = v.x; w.x = tap; }
+            if (v.y > m.y) { m.y = v.y; w.y = tap; }
+            if (v.z > m.z) { m.z = v.z; w.z = tap; }
+            if (v.w > m.w) { m.w = v.w; w.w = tap; }
+        }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+    reinterpret_cast<uchar4*>(idx)[i] = w;
+}
+
+// gather form of the max-pool backward (no atomics): every input pixel looks at the <= 4 windows
+// that contain it.
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                      int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int cols = C >> 2;
+    const int64_t n4 = (int64_t)B * Hi * Wi * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = (iy + 1) / 2 - ((iy + 1) % 2 == 0 ? 1 : 0); oy <= (iy + 1) / 2; ++oy) {
+        if (oy < 0 || oy >= Ho) continue;
+        const int r = iy - (oy * 2 - 1);
+        if (r < 0 || r > 2) continue;
+        for (int ox = (ix + 1) / 2 - ((ix + 1) % 2 == 0 ? 1 : 0); ox <= (ix + 1) / 2; ++ox) {
+            if (ox < 0 || ox >= Wo) continue;
+            const int s = ix - (ox * 2 - 1);
+            if (s < 0 || s > 2) continue;
+            const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * cols + col;
+            const uchar4 w = reinterpret_cast<const uchar4*>(idx)[o];
+            const float4 g = reinterpret_cast<const float4*>(dy)[o];
+            const uint8_t tap = (uint8_t)(r * 3 + s);
+            if (w.x == tap) acc.x += g.x;
+            if (w.y == tap) acc.y += g.y;
+            if (w.z == tap) acc.z += g.z;
+            if (w.w == tap) acc.w += g.w;
+        }
+    }
+    reinterpret_cast<float4*>(dx)[i] = acc;
+}
+
+// backward of nearest x2 upsample: dx[b,y,x,c] = sum of the 2x2 block of dy (+ add, nullable)
+__global__ __launch_bounds__(256) void k_up2_bwd(const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dx, int B,
+                                                  int H, int W, int C) {
+    const int cols = C >> 2;
+    const int64_t n4 = (int64_t)B * H * W * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const float* base = dy + (((int64_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C;
+    const float4 v0 = reinterpret_cast<const float4*>(base)[col], v1 = reinterpret_cast<const float4*>(base + C)[col];
+    const float4 v2 = reinterpret_cast<const float4*>(base + (int64_t)2 * W * C)[col];
+    const float4 v3 = reinterpret_cast<const float4*>(base + (int64_t)2 * W * C + C)[col];
+    float4 o = make_float4(v0.x + v1.x + v2.x + v3.x, v0.y + v1.y + v2.y + v3.y, v0.z + v1.z + v2.z + v3.z, v0.w + v1.w + v2.w + v3.w);
+    if (add) {
+        const float4 a = reinterpret_cast<const float4*>(add)[i];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    reinterpret_cast<float4*>(dx)[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Head: 1x1 conv C -> Co (<= 16) with bias, NHWC in, NCHW out (network.py:22-29,57).
+// 64 pixels per block: the [64][C] tile is one contiguous 64*C*4-byte span, staged in LDS with a
+// 4-float row pad (ds_read_b128 conflict-free), then thread (pixel, group) accumulates its
+// outputs with wave-uniform (broadcast) weight reads.  HBM-bound: AI ~ 3 flop/B.
+// ------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_CO = 16;
+
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ y, int64_t M, int HW, int C, int Co) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int LD = C + 4;
+    float* xs = lds;                 // [64][C+4]
+    float* ws = lds + 64 * LD;       // [Co][C]
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int c4 = C >> 2;
+    for (int i = threadIdx.x; i < 64 * c4; i += 256) {
+        const int row = i / c4, col = i - row * c4;
+        const int64_t m = m0 + row;
+        const float4 v = m < M ? reinterpret_cast<const float4*>(x + m * C)[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + row * LD + col * 4) = v;
+    }
+    for (int i = threadIdx.x; i < Co * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int px = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float acc[HEAD_MAX_CO / 4];
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX_CO / 4; ++j) acc[j] = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xs + px * LD + c);
+#pragma unroll
+        for (int j = 0; j < HEAD_MAX_CO / 4; ++j) {
+            const int co = grp + 4 * j;
+            if (co < Co) {
+                const float4 ww = *reinterpret_cast<const float4*>(ws + co * C + c);
+                acc[j] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+        }
+    }
+    const int64_t m = m0 + px;
+    if (m < M) {
+        const int64_t b = m / HW, pix = m - b * HW;
+#pragma unroll
+        for (int j = 0; j < HEAD_MAX_CO / 4; ++j) {
+            const int co = grp + 4 * j;
+            if (co < Co) y[(b * Co + co) * HW + pix] = acc[j] + bias[co];
+        }
+    }
+}
+
+// head data-gradient: dx[m][c] = sum_co dy[b][co][pix] * w[co][c]   (NCHW grad in, NHWC out)
+__global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                     int64_t M, int HW, int C, int Co) {
+    __shared__ float gs[HEAD_MAX_CO][64];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ws = lds;                 // [Co][C]
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    for (int i = threadIdx.x; i < Co * 64; i += 256) {
+        const int co = i >> 6, px = i & 63;
+        const int64_t m = m0 + px;
+        float v = 0.f;
+        if (m < M) { const int64_t b = m / HW, pix = m - b * HW; v = dy[(b * Co + co) * HW + pix]; }
+        gs[co][px] = v;
+    }
+    for (int i = threadIdx.x; i < Co * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int c4 = C >> 2;
+    for (int i = threadIdx.x; i < 64 * c4; i += 256) {
+        const int row = i / c4, col = i - row * c4;
+        const int64_t m = m0 + row;
+        if (m >= M) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int co = 0; co < Co; ++co) {
+            const float g = gs[co][row];
+            const float4 ww = *reinterpret_cast<const float4*>(ws + co * C + col * 4);
+            o.x += g * ww.x; o.y += g * ww.y; o.z += g * ww.z; o.w += g * ww.w;
+        }
+        reinterpret_cast<float4*>(dx + m * C)[col] = o;
+    }
+}
+
+// head weight/bias gradient partials: block handles 1024 pixels; thread c (< C) keeps Co sums.
+constexpr int HEAD_WG_PIX = 1024;
+__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                     int64_t M, int HW, int C, int Co) {
+    __shared__ float gs[HEAD_MAX_CO][64];
+    const int64_t mb = (int64_t)blockIdx.x * HEAD_WG_PIX;
+    float acc[HEAD_MAX_CO];
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX_CO; ++j) acc[j] = 0.f;
+    float bsum = 0.f;                // thread co < Co also accumulates the bias gradient
+    for (int64_t m0 = mb; m0 < min(mb + HEAD_WG_PIX, M); m0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Co * 64; i += 256) {
+            const int co = i >> 6, px = i & 63;
+            const int64_t m = m0 + px;
+            float v = 0.f;
+            if (m < M) { const int64_t b = m / HW, pix = m - b * HW; v = dy[(b * Co + co) * HW + pix]; }
+            gs[co][px] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            for (int px = 0; px < 64; ++px) {
+                const int64_t m = m0 + px;
+                if (m >= M) break;
+                const float xv = x[m * C + threadIdx.x];
+#pragma unroll
+                for (int j = 0; j < HEAD_MAX_CO; ++j)
+                    if (j < Co) acc[j] += gs[j][px] * xv;
+            }
+        }
+        if (threadIdx.x < Co) {
+            for (int px = 0; px < 64; ++px) bsum += gs[threadIdx.x][px];
+        }
+    }
+    float* dst = partial + (int64_t)blockIdx.x * (Co * C + Co);
+    if (threadIdx.x < C)
+        for (int j = 0; j < Co; ++j) dst[j * C + threadIdx.x] = acc[j];
+    if (threadIdx.x < Co) dst[Co * C + threadIdx.x] = bsum;
+}
+
+__global__ __launch_bounds__(256) void k_head_wgrad_fin(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ dw,
+                                                         float* __restrict__ db, int nw, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * n + i];
+    float* dst = i < nw ? dw + i : db + (i - nw);
+    *dst = (accumulate ? *dst : 0.f) + (float)s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults: no weight decay, no amsgrad), one launch over the flat
+// parameter buffer.  612 MB of traffic per step for 21.85 M parameters: HBM-bound.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float bc1,
+                                               float bc2_sqrt, float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* Mo = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = G[j] * gscale;
+            Mo[j] = b1 * Mo[j] + (1.f - b1) * gr;                     // exp_avg.lerp_(grad, 1 - beta1)
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            const float denom = sqrtf(V[j]) / bc2_sqrt + eps;
+            P[j] -= (lr / bc1) * (Mo[j] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+static inline int ew_grid(int64_t n4) { return (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16); }
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" {
+
+size_t sd_col_reduce_workspace_bytes(int64_t M, int C) {
+    return align_up((size_t)cdiv(M, RED_ROWS_PER_BLOCK) * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float), 256);
+}
+
+static int check_mc(const char* what, int64_t M, int C) {
+    SD_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (C / 4) <= 256 && 256 % (C / 4) == 0, SD_ERR_INVALID,
+               "%s: needs M > 0 and C in {4..1024} with C/4 dividing 256 (got M=%lld C=%d)", what, (long long)M, C);
+    return 0;
+}
+
+int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* invstd, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_train_stats", M, C)) return e;
+    SD_REQUIRE(x && mean && invstd && workspace, SD_ERR_INVALID, "sd_bn_train_stats: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_train_stats: workspace too small");
+    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, M, C, (float*)workspace);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+                       mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                const float* residual, int relu, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_apply", M, C)) return e;
+    SD_REQUIRE(x && y && mean && invstd && gamma && beta, SD_ERR_INVALID, "sd_bn_apply: null pointer");
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, mean, invstd, gamma, beta, residual, relu);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C, float* scale,
+               float* shift, sd_stream_t stream) {
+    SD_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, SD_ERR_INVALID, "sd_bn_fold: bad arguments");
+    hipLaunchKernelGGL(k_bn_fold, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
+              const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta, int accumulate, void* workspace,
+              size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_bwd", M, C)) return e;
+    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && (!relu || y), SD_ERR_INVALID, "sd_bn_bwd: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_bwd: workspace too small");
+    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* mg = partial + (size_t)nb * 2 * C;
+    float* mgx = mg + C;
+    hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, relu, M, C, partial);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+                       (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, y, relu, n4, C, mean, invstd, gamma, (const float*)mg,
+                       (const float*)mgx, dx, g_out);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_col_sum", M, C)) return e;
+    SD_REQUIRE(x && out && workspace, SD_ERR_INVALID, "sd_col_sum: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_col_sum: workspace too small");
+    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, M, C, (float*)workspace);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, sd_stream_t stream) {
+    SD_REQUIRE(x && y && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_maxpool3x3s2_fwd: bad arguments");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, idx, B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, sd_stream_t stream) {
+    SD_REQUIRE(dy && dx && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_maxpool3x3s2_bwd: bad arguments");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int64_t n4 = (int64_t)B * Hi * Wi * C / 4;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream) {
+    SD_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_upsample2x_bwd: bad arguments");
+    const int64_t n4 = (int64_t)B * H * W * C / 4;
+    hipLaunchKernelGGL(k_up2_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, add, dx, B, H, W, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_head_fwd(const float* x, const float* w, const float* bias, float* y, int B, int HW, int C, int Co, sd_stream_t stream) {
+    SD_REQUIRE(x && w && bias && y && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_fwd: bad arguments");
+    SD_REQUIRE(C % 4 == 0 && C <= 512 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_fwd: needs C %% 4 == 0, C <= 512, Co <= %d", HEAD_MAX_CO);
+    const int64_t M = (int64_t)B * HW;
+    const size_t lds = ((size_t)64 * (C + 4) + (size_t)Co * C) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fwd, dim3(cdiv(M, 64)), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, M, HW, C, Co);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co) {
+    return align_up((size_t)cdiv((int64_t)B * HW, HEAD_WG_PIX) * (Co * C + Co) * sizeof(float), 256);
+}
+
+int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, int B, int HW, int C, int Co,
+                int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    SD_REQUIRE(dy && x && w && dx && dw && dbias && workspace && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_bwd: bad arguments");
+    SD_REQUIRE(C % 4 == 0 && C <= 256 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_bwd: needs C %% 4 == 0, C <= 256, Co <= %d", HEAD_MAX_CO);
+    SD_REQUIRE(workspace_bytes >= sd_head_bwd_workspace_bytes(B, HW, C, Co), SD_ERR_WORKSPACE, "sd_head_bwd: workspace too small");
+    const int64_t M = (int64_t)B * HW;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_head_dgrad, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, dx, M, HW, C, Co);
+    SD_LAUNCH_CHECK();
+    const int nb = cdiv(M, HEAD_WG_PIX);
+    hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dy, x, (float*)workspace, M, HW, C, Co);
+    SD_LAUNCH_CHECK();
+    const int n = Co * C + Co;
+    hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1, float beta2,
+                 float eps, float grad_scale, sd_stream_t stream) {
+    SD_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0 && step >= 1, SD_ERR_INVALID, "sd_adam_step: bad arguments (n %% 4 == 0, step >= 1)");
+    SD_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), SD_ERR_ALIGN, "sd_adam_step: pointers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(k_adam, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n / 4, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

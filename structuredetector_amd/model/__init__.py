@@ -1,1 +1,2 @@
 from .loss import Loss, LossStats
+from .network import Network

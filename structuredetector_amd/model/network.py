@@ -1,0 +1,467 @@
+"""`Network`: ResNet-34 trunk + 3-level FPN + 1x1 head on hand-written HIP kernels.
+
+Mirrors `Network` / `Fpn` / `Head` of src/sdnet/model/network.py:6-87 and the torchvision
+resnet34 pieces it borrows (conv1/bn1/relu/maxpool/layer1-4; BasicBlock [3,4,6,3]):
+same constructor signature, same `forward(x) -> dict` of four channel-slice views (or the raw
+tensor with `raw_output=True`), same `save()`, and the same state_dict key schema (including the
+`adpater` spelling) so reference `.pth` checkpoints load unchanged.
+
+Mechanism (MI355X-first, not a module-by-module translation):
+  * every learnable tensor lives in ONE flat fp32 device buffer (`flat_params`), gradients in a
+    second one (`flat_grads`): the optimizer is a single fused Adam launch and the data-parallel
+    exchange is a single RCCL all-reduce over the flat gradient buffer;
+  * activations are NHWC, conv weights [Cout][R][S][Cin] (the parameters are exposed with OIHW
+    *logical* shape and channels_last strides, so state_dicts stay interchangeable);
+  * forward and backward are explicit kernel schedules (`_Engine`) behind one autograd node;
+    no torch.nn.functional / MIOpen call is made anywhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers (no compute): they only give the state_dict its reference key names
+# ------------------------------------------------------------------------------------------
+class ConvParams(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+
+class BNParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Slot(nn.Module):
+    """Parameter-less position (ReLU / MaxPool / Upsample) kept so Sequential indices match the reference."""
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = ConvParams(cin, cout, 3, stride, 1)
+        self.bn1 = BNParams(cout)
+        self.relu = Slot()
+        self.conv2 = ConvParams(cout, cout, 3, 1, 1)
+        self.bn2 = BNParams(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(ConvParams(cin, cout, 1, stride, 0), BNParams(cout))
+
+
+class Fpn(nn.Module):
+    """network.py:6-19: conv3x3+BN+ReLU( upsample2x(input) + lateral1x1(shortcut) )."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.up = Slot()
+        self.lateral = ConvParams(in_channels, out_channels, 1, bias=True)
+        self.conv = nn.Sequential(ConvParams(out_channels, out_channels, 3, 1, 1), BNParams(out_channels), Slot())
+
+
+class Head(nn.Module):
+    """network.py:22-29."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = ConvParams(in_channels, out_channels, 1, bias=True)
+
+
+def _layer(cin, cout, n, stride):
+    return nn.Sequential(*[BasicBlock(cin if i == 0 else cout, cout, stride if i == 0 else 1) for i in range(n)])
+
+
+# ------------------------------------------------------------------------------------------
+# kernel schedule
+# ------------------------------------------------------------------------------------------
+def _desc(B, Hi, Wi, conv: ConvParams):
+    d = L.ConvDesc()
+    d.B, d.Hi, d.Wi, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad = B, Hi, Wi, conv.cin, conv.cout, conv.k, conv.k, conv.stride, conv.pad
+    d.Ho = (Hi + 2 * conv.pad - conv.k) // conv.stride + 1
+    d.Wo = (Wi + 2 * conv.pad - conv.k) // conv.stride + 1
+    return d
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class _Engine:
+    """Explicit forward / backward schedules over the C ABI.  Tensors named *_nhwc are
+    (B, H, W, C) contiguous; `tape` keeps what the backward needs."""
+
+    def __init__(self, net: "Network"):
+        self.net = net
+        self.lib = L.lib()
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _ws(self, nbytes, dev):
+        return L.workspace(max(int(nbytes), 256), dev)
+
+    def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
+        d = _desc(B, Hi, Wi, conv)
+        y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
+        L.check(self.lib.sd_conv2d_fwd(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
+                                       _ptr(res), int(res_up2), int(relu), L.stream()), "sd_conv2d_fwd")
+        return y, d
+
+    def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True):
+        Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
+        L.check(self.lib.sd_bn_train_stats(x.data_ptr(), Mrows, Cc, BN_EPS, BN_MOMENTUM,
+                                           bn.running_mean.data_ptr() if update_running else 0,
+                                           bn.running_var.data_ptr() if update_running else 0,
+                                           mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
+        y = torch.empty_like(x)
+        L.check(self.lib.sd_bn_apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
+                                     bn.bias.data_ptr(), _ptr(res), int(relu), L.stream()), "sd_bn_apply")
+        if update_running:
+            bn.num_batches_tracked += 1
+        return y, mean, invstd
+
+    def bn_fold(self, bn: BNParams):
+        scale = torch.empty(bn.c, dtype=torch.float32, device=bn.weight.device)
+        shift = torch.empty_like(scale)
+        L.check(self.lib.sd_bn_fold(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                    BN_EPS, bn.c, scale.data_ptr(), shift.data_ptr(), L.stream()), "sd_bn_fold")
+        return scale, shift
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward(self, x, training, tape=None):
+        net, lib = self.net, self.lib
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise L.SdError(f"Network expects (B, 3, H, W) input, got {tuple(x.shape)}")
+        L.require_cuda(x)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise L.SdError("input height/width must be multiples of 32 (args.py:181-186)")
+        rec = tape is not None
+
+        # stem: conv7x7/2 + BN + ReLU + maxpool3x3/2 (network.py:43-45)
+        stem, bn0 = net.adpater[0], net.adpater[1]
+        d0 = _desc(B, H, W, stem)
+        s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.float32, device=x.device)
+        if training:
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, L.stream()), "stem")
+            a0, m0, i0 = self.bn_train(s0, bn0)
+        else:
+            sc, sh = self.bn_fold(bn0)
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1,
+                                           L.stream()), "stem")
+            a0, m0, i0 = s0, None, None
+        Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
+        p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x.device)
+        pidx = torch.empty((B, Hp, Wp, 64), dtype=torch.uint8, device=x.device)
+        L.check(lib.sd_maxpool3x3s2_fwd(a0.data_ptr(), p1.data_ptr(), pidx.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
+        if rec:
+            tape["x"], tape["stem"] = x, (d0, s0, a0, m0, i0, pidx)
+
+        # trunk (network.py:47-50)
+        feats, cur, Hc, Wc = [], p1, Hp, Wp
+        blocks_tape = []
+        for layer in (net.down1, net.down2, net.down3, net.down4):
+            for blk in layer:
+                if training:
+                    c1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc)
+                    a1, m1, i1 = self.bn_train(c1, blk.bn1)
+                    c2, d2 = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo)
+                    if blk.downsample is not None:
+                        cd, dd = self.conv(cur, blk.downsample[0], B, Hc, Wc)
+                        idt, md, idd = self.bn_train(cd, blk.downsample[1], relu=False)
+                    else:
+                        cd = dd = md = idd = None
+                        idt = cur
+                    out, m2, i2 = self.bn_train(c2, blk.bn2, res=idt, relu=True)
+                    if rec:
+                        blocks_tape.append((blk, cur, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd))
+                else:
+                    s1, h1 = self.bn_fold(blk.bn1)
+                    a1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc, scale=s1, shift=h1, relu=True)
+                    if blk.downsample is not None:
+                        sd_, hd = self.bn_fold(blk.downsample[1])
+                        idt, _ = self.conv(cur, blk.downsample[0], B, Hc, Wc, scale=sd_, shift=hd)
+                    else:
+                        idt = cur
+                    s2, h2 = self.bn_fold(blk.bn2)
+                    out, _ = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo, scale=s2, shift=h2, res=idt, relu=True)
+                cur, Hc, Wc = out, d1.Ho, d1.Wo
+            feats.append((cur, Hc, Wc))
+        (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
+
+        # FPN (network.py:52-55,6-19): lateral 1x1 (+bias) with the x2-upsampled coarser map added in the epilogue
+        f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias)
+        fpn_tape = []
+        for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
+            t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
+            if training:
+                c, dc = self.conv(t, fpn.conv[0], B, Hs, Ws)
+                fn, mf, if_ = self.bn_train(c, fpn.conv[1])
+                if rec:
+                    fpn_tape.append((fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn))
+            else:
+                sf, hf = self.bn_fold(fpn.conv[1])
+                fn, _ = self.conv(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True)
+            f = fn
+
+        # head (network.py:57): NHWC -> NCHW
+        hc = net.head.conv
+        out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
+        L.check(lib.sd_head_fwd(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
+                                L.stream()), "sd_head_fwd")
+        if rec:
+            tape.update(blocks=blocks_tape, fpn=fpn_tape, p5=(p5, H5, W5), f1=f, B=B, hw=(H2, W2))
+        return out
+
+    # ---- backward ------------------------------------------------------------------------
+    def _wt(self, conv):
+        """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient."""
+        wt = torch.empty(conv.cin * conv.k * conv.k * conv.cout, dtype=torch.float32, device=conv.weight.device)
+        L.check(self.lib.sd_conv2d_transpose_weights(conv.weight.data_ptr(), wt.data_ptr(), conv.cout, conv.k * conv.k, conv.cin, L.stream()),
+                "transpose_weights")
+        return wt
+
+    def _dgrad(self, dy, conv, d, res=None):
+        dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=torch.float32, device=dy.device)
+        wt = self._wt(conv)
+        L.check(self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad")
+        return dx
+
+    def _wgrad(self, dy, x, conv, d):
+        g = self.net.grad_of(conv.weight)
+        nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = self._ws(nbytes, dy.device)
+        L.check(self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
+                "sd_conv2d_wgrad")
+
+    def _bias_grad(self, dy, conv):
+        Mrows, Cc = dy.numel() // dy.shape[-1], dy.shape[-1]
+        ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), dy.device)
+        L.check(self.lib.sd_col_sum(dy.data_ptr(), Mrows, Cc, self.net.grad_of(conv.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()),
+                "sd_col_sum")
+
+    def _bn_bwd(self, dy, x, y, relu, bn, mean, invstd, want_g=False):
+        Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        dx = torch.empty_like(x)
+        g = torch.empty_like(x) if want_g else None
+        ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
+        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), int(relu), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(),
+                                   bn.weight.data_ptr(), dx.data_ptr(), _ptr(g), self.net.grad_of(bn.weight).data_ptr(),
+                                   self.net.grad_of(bn.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_bwd")
+        return dx, g
+
+    def backward(self, tape, dhead):
+        """Writes every parameter gradient into `net.flat_grads` (overwriting, not accumulating)."""
+        net, lib = self.net, self.lib
+        B = tape["B"]
+        H2, W2 = tape["hw"]
+        dhead = dhead.contiguous().float()
+        hc = net.head.conv
+        f1 = tape["f1"]
+        df = torch.empty_like(f1)
+        ws = self._ws(lib.sd_head_bwd_workspace_bytes(B, H2 * W2, hc.cin, hc.cout), dhead.device)
+        L.check(lib.sd_head_bwd(dhead.data_ptr(), f1.data_ptr(), hc.weight.data_ptr(), df.data_ptr(), net.grad_of(hc.weight).data_ptr(),
+                                net.grad_of(hc.bias).data_ptr(), B, H2 * W2, hc.cin, hc.cout, 0, ws.data_ptr(), ws.numel(), L.stream()),
+                "sd_head_bwd")
+
+        # FPN, finest level first.  The lateral 1x1 data-gradients are deferred until the trunk's own
+        # gradient for that tensor exists, so the sum of the two is the dgrad kernel's residual epilogue.
+        lateral_grad = {}
+        for (fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn) in reversed(tape["fpn"]):
+            dcv, _ = self._bn_bwd(df, c, fn, True, fpn.conv[1], mf, if_)
+            self._wgrad(dcv, t, fpn.conv[0], dc)
+            dt = self._dgrad(dcv, fpn.conv[0], dc)
+            self._wgrad(dt, sc_t, fpn.lateral, dl)
+            self._bias_grad(dt, fpn.lateral)
+            lateral_grad[sc_t.data_ptr()] = (dt, fpn.lateral, dl)
+            dfp = torch.empty((B, Hs // 2, Ws // 2, fpn.lateral.cout), dtype=torch.float32, device=dt.device)
+            L.check(lib.sd_upsample2x_bwd(dt.data_ptr(), 0, dfp.data_ptr(), B, Hs // 2, Ws // 2, fpn.lateral.cout, L.stream()), "up2_bwd")
+            df = dfp
+        p5, H5, W5 = tape["p5"]
+        d5 = _desc(B, H5, W5, net.up1)
+        self._wgrad(df, p5, net.up1, d5)
+        self._bias_grad(df, net.up1)
+        dcur = self._dgrad(df, net.up1, d5)
+
+        # trunk, last block first
+        for (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd) in reversed(tape["blocks"]):
+            extra = lateral_grad.pop(out.data_ptr(), None)
+            if extra is not None:                       # `out` also feeds an FPN lateral conv
+                dcur = self._dgrad(extra[0], extra[1], extra[2], res=dcur)
+            dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True)
+            self._wgrad(dc2, a1, blk.conv2, d2)
+            da1 = self._dgrad(dc2, blk.conv2, d2)
+            dc1, _ = self._bn_bwd(da1, c1, a1, True, blk.bn1, m1, i1)
+            self._wgrad(dc1, xin, blk.conv1, d1)
+            if blk.downsample is not None:
+                dcd, _ = self._bn_bwd(g, cd, None, False, blk.downsample[1], md, idd)
+                self._wgrad(dcd, xin, blk.downsample[0], dd)
+                skip = self._dgrad(dcd, blk.downsample[0], dd)
+            else:
+                skip = g
+            dcur = self._dgrad(dc1, blk.conv1, d1, res=skip)
+
+        # stem
+        d0, s0, a0, m0, i0, pidx = tape["stem"]
+        da0 = torch.empty_like(a0)
+        L.check(lib.sd_maxpool3x3s2_bwd(dcur.data_ptr(), pidx.data_ptr(), da0.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool_bwd")
+        ds0, _ = self._bn_bwd(da0, s0, a0, True, net.adpater[1], m0, i0)
+        stem = net.adpater[0]
+        ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
+        L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
+                                         ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
+
+
+class _NetFn(torch.autograd.Function):
+    """One autograd node for the whole network: inputs = image + every parameter."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        tape = {}
+        out = net._engine.forward(x, True, tape)
+        ctx.net, ctx.tape = net, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, dhead):
+        net = ctx.net
+        net._engine.backward(ctx.tape, dhead)
+        ctx.tape = None
+        return (None, None) + tuple(net.grad_of(p) for p in net._flat_order)
+
+
+class Network(nn.Module):
+    def __init__(self, args, pretrained=True, raw_output: bool = False):
+        super().__init__()
+        self.raw_output = raw_output
+        self.label_count = len(args.labels)  # M
+        self.part_count = len(args.parts)  # N
+        self.out_channels = self.label_count + self.part_count + 4
+        self.fpn_depth = args.fpn_depth
+        if self.fpn_depth % 64:
+            raise L.SdError("fpn_depth must be a multiple of 64 for the MFMA tiles")
+        if self.out_channels > 16:
+            raise L.SdError("labels + parts + 4 must be <= 16 (head kernel limit)")
+
+        self.adpater = nn.Sequential(ConvParams(3, 64, 7, 2, 3), BNParams(64), Slot(), Slot())   # sic (network.py:43)
+        self.down1 = _layer(64, 64, 3, 1)
+        self.down2 = _layer(64, 128, 4, 2)
+        self.down3 = _layer(128, 256, 6, 2)
+        self.down4 = _layer(256, 512, 3, 2)
+        self.up1 = ConvParams(512, self.fpn_depth, 1, bias=True)
+        self.up2 = Fpn(256, self.fpn_depth)
+        self.up3 = Fpn(128, self.fpn_depth)
+        self.up4 = Fpn(64, self.fpn_depth)
+        self.head = Head(self.fpn_depth, self.out_channels)
+        # The reference downloads ImageNet weights here (network.py:41); there is no network access and no
+        # torchvision in this environment, so `pretrained` selects nothing: load a checkpoint with --load_model.
+        self.reset_parameters(seed=0)
+        self.flat_params = self.flat_grads = None
+        self._flat_order, self._flat_off = [], {}
+        self._engine = None
+
+    # ---- init / flat storage -------------------------------------------------------------
+    def reset_parameters(self, seed=0):
+        """torchvision's scheme: kaiming_normal_(fan_out, relu) for convs, BN weight 1 / bias 0;
+        torch default (kaiming_uniform a=sqrt(5)) for the biased FPN / head convs."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, ConvParams):
+                    fan_out = m.cout * m.k * m.k
+                    fan_in = m.cin * m.k * m.k
+                    if m.bias is None:
+                        m.weight.copy_(torch.randn(m.weight.shape, generator=g) * math.sqrt(2.0 / fan_out))
+                    else:
+                        bound = 1.0 / math.sqrt(fan_in)
+                        m.weight.copy_((torch.rand(m.weight.shape, generator=g) * 2 - 1) * bound)
+                        m.bias.copy_((torch.rand(m.bias.shape, generator=g) * 2 - 1) * bound)
+
+    def _apply(self, fn, *a, **kw):
+        super()._apply(fn, *a, **kw)
+        self._build_flat()
+        return self
+
+    def _build_flat(self):
+        """Move every parameter into one flat buffer (16-byte aligned slots) and alias it."""
+        params = [p for p in self.parameters()]
+        if not params or not params[0].is_cuda:
+            self.flat_params = self.flat_grads = None
+            return
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._flat_order, self._flat_off = params, {}
+        with torch.no_grad():
+            for p, off in zip(params, offs):
+                n = p.numel()
+                if p.dim() == 4:                      # physical [Cout][R][S][Cin], logical OIHW
+                    co, ci, r, s = p.shape
+                    view = flat[off:off + n].view(co, r, s, ci).permute(0, 3, 1, 2)
+                else:
+                    view = flat[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self._flat_off[id(p)] = (off, n)
+        self.flat_params, self.flat_grads = flat, grads
+        self._engine = _Engine(self)
+
+    def grad_of(self, p):
+        off, n = self._flat_off[id(p)]
+        g = self.flat_grads[off:off + n]
+        if p.dim() == 4:
+            co, ci, r, s = p.shape
+            return g.view(co, r, s, ci).permute(0, 3, 1, 2)
+        return g.view(p.shape)
+
+    # ---- reference API -------------------------------------------------------------------
+    def forward(self, x):  # (B, 3, H, W)
+        if self._engine is None:
+            raise L.SdError("Network must be moved to the GPU first (`net.to('cuda')`): there is no CPU path")
+        if self.training and torch.is_grad_enabled():
+            out = _NetFn.apply(self, x, *self._flat_order)
+        else:
+            out = self._engine.forward(x, self.training)
+        if self.raw_output:
+            return out
+        M, nb = self.label_count, self.label_count + self.part_count
+        return {"anchor_hm": out[:, :M], "part_hm": out[:, M:nb], "offsets": out[:, nb:nb + 2], "embeddings": out[:, nb + 2:nb + 4]}
+
+    def save(self, path="last_model.pth"):
+        torch.save({k: v.clone() for k, v in self.state_dict().items()}, path)
+
+    # ---- explicit (autograd-free) training path used by the trainer / bench ----------------
+    def forward_train(self, x):
+        """Forward in training mode recording the tape; returns (head tensor, tape)."""
+        tape = {}
+        return self._engine.forward(x, True, tape), tape
+
+    def backward_from(self, tape, dhead):
+        """Backward of `forward_train`: fills `flat_grads` in place."""
+        self._engine.backward(tape, dhead)

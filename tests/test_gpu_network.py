@@ -1,0 +1,262 @@
+"""GPU parity of the MFMA conv stack and the whole Network against a plain PyTorch fp32 CPU
+reference of the same op (floating-point kernels: torch reference, tolerance stated per test)."""
+import ctypes as C
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sdnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc(t):   # (B,C,H,W) cpu -> (B,H,W,C) device contiguous
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def krsc(w):   # OIHW cpu -> [O][R][S][I] device
+    return w.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def make_desc(L, B, Hi, Wi, cin, cout, k, stride, pad):
+    d = L.ConvDesc()
+    d.B, d.Hi, d.Wi, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad = B, Hi, Wi, cin, cout, k, k, stride, pad
+    d.Ho = (Hi + 2 * pad - k) // stride + 1
+    d.Wo = (Wi + 2 * pad - k) // stride + 1
+    return d
+
+
+def close(got, ref, tol):
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+CONV_CASES = [  # B, H, W, cin, cout, k, stride, pad
+    (2, 16, 24, 64, 64, 3, 1, 1),
+    (1, 20, 12, 64, 128, 3, 2, 1),
+    (3, 8, 8, 128, 128, 3, 1, 1),
+    (2, 12, 12, 64, 128, 1, 2, 0),
+    (1, 6, 10, 512, 128, 1, 1, 0),
+    (2, 9, 7, 256, 256, 3, 1, 1),      # odd sizes: ragged last tile (M = 126)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    xd, wd = nhwc(x), krsc(w)
+    y = torch.empty(B, d.Ho, d.Wo, cout, device=DEV)
+    # plain conv
+    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, L.stream()))
+    ref = F.conv2d(x, w, None, stride, pad)
+    close(from_nhwc(y), ref, 2e-6 * (cin * k * k) ** 0.5)            # fp32 fma chain, k-ordered
+    # fused epilogue: affine + residual + relu
+    res = torch.randn(B, cout, d.Ho, d.Wo, generator=g)
+    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale.to(DEV).data_ptr(), shift.to(DEV).data_ptr(),
+                              nhwc(res).data_ptr(), 0, 1, L.stream()))
+    ref2 = F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res)
+    close(from_nhwc(y), ref2, 1e-5)
+    # data gradient (+ skip residual)
+    dy = torch.randn(B, cout, d.Ho, d.Wo, generator=g)
+    wt = torch.empty(cin * k * k * cout, device=DEV)
+    L.check(lib.sd_conv2d_transpose_weights(wd.data_ptr(), wt.data_ptr(), cout, k * k, cin, L.stream()))
+    dx = torch.empty(B, H, W, cin, device=DEV)
+    skip = torch.randn(B, cin, H, W, generator=g)
+    L.check(lib.sd_conv2d_dgrad(nhwc(dy).data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc(skip).data_ptr(), L.stream()))
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, pad).backward(dy)
+    close(from_nhwc(dx), xr.grad + skip, 1e-5)
+    # weight gradient
+    ws = torch.empty(max(lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+    dw = torch.empty(cout, k, k, cin, device=DEV)
+    L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
+
+
+def test_conv_up2_residual_and_stem():
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 8, 12
+    x = torch.randn(B, 64, H, W, generator=g); w = torch.randn(128, 64, 1, 1, generator=g) / 8; b = torch.randn(128, generator=g)
+    coarse = torch.randn(B, 128, H // 2, W // 2, generator=g)
+    d = make_desc(L, B, H, W, 64, 128, 1, 1, 0)
+    y = torch.empty(B, H, W, 128, device=DEV)
+    L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 0, b.to(DEV).data_ptr(),
+                              nhwc(coarse).data_ptr(), 1, 0, L.stream()))
+    ref = F.conv2d(x, w, b) + F.interpolate(coarse, scale_factor=2)          # Fpn.forward, network.py:18-19
+    close(from_nhwc(y), ref, 1e-5)
+    # stem 7x7/2 on the NCHW image + its weight gradient
+    img = torch.randn(2, 3, 64, 96, generator=g); ws_ = torch.randn(64, 3, 7, 7, generator=g) / 12
+    d0 = make_desc(L, 2, 64, 96, 3, 64, 7, 2, 3)
+    y0 = torch.empty(2, d0.Ho, d0.Wo, 64, device=DEV)
+    L.check(lib.sd_conv2d_stem_fwd(img.to(DEV).data_ptr(), krsc(ws_).data_ptr(), y0.data_ptr(), C.byref(d0), 0, 0, 0, L.stream()))
+    close(from_nhwc(y0), F.conv2d(img, ws_, None, 2, 3), 1e-5)
+    dy = torch.randn(2, 64, d0.Ho, d0.Wo, generator=g)
+    wr = ws_.clone().requires_grad_(True)
+    F.conv2d(img, wr, None, 2, 3).backward(dy)
+    wsb = torch.empty(max(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), 256), dtype=torch.uint8, device=DEV)
+    dw = torch.empty(64, 7, 7, 3, device=DEV)
+    L.check(lib.sd_conv2d_stem_wgrad(nhwc(dy).data_ptr(), img.to(DEV).data_ptr(), dw.data_ptr(), C.byref(d0), 0, wsb.data_ptr(), wsb.numel(), L.stream()))
+    close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
+
+
+def test_bn_pool_head_adam():
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    B, Cc, H, W = 3, 64, 10, 14
+    x = torch.randn(B, Cc, H, W, generator=g) * 2 + 0.5
+    res = torch.randn(B, Cc, H, W, generator=g)
+    bn = torch.nn.BatchNorm2d(Cc).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5); bn.bias.copy_(torch.randn(Cc, generator=g))
+    xr = x.clone().requires_grad_(True); rr = res.clone().requires_grad_(True)
+    yr = F.relu(bn(xr) + rr)
+    dy = torch.randn(B, Cc, H, W, generator=g)
+    yr.backward(dy)
+    M = B * H * W
+    xd = nhwc(x); mean = torch.empty(Cc, device=DEV); invstd = torch.empty(Cc, device=DEV)
+    rm = torch.zeros(Cc, device=DEV); rv = torch.ones(Cc, device=DEV)
+    ws = torch.empty(lib.sd_col_reduce_workspace_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_bn_train_stats(xd.data_ptr(), M, Cc, 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), L.stream()))
+    gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    y = torch.empty_like(xd)
+    L.check(lib.sd_bn_apply(xd.data_ptr(), y.data_ptr(), M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                            nhwc(res).data_ptr(), 1, L.stream()))
+    close(from_nhwc(y), yr.detach(), 1e-5)
+    close(rm.cpu(), bn.running_mean, 1e-5); close(rv.cpu(), bn.running_var, 1e-5)
+    dx = torch.empty_like(xd); gout = torch.empty_like(xd); dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+    L.check(lib.sd_bn_bwd(nhwc(dy).data_ptr(), xd.data_ptr(), y.data_ptr(), 1, M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(),
+                          dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(from_nhwc(dx), xr.grad, 2e-5); close(from_nhwc(gout), rr.grad, 1e-6)
+    close(dg.cpu(), bn.weight.grad, 2e-5); close(db.cpu(), bn.bias.grad, 2e-5)
+    # maxpool 3x3/2 fwd + bwd (odd and even sizes)
+    for (h, w_) in ((10, 14), (9, 7)):
+        xp = torch.randn(2, 64, h, w_, generator=g).requires_grad_(True)
+        yp = F.max_pool2d(xp, 3, 2, 1)
+        dyp = torch.randn(yp.shape, generator=g)
+        yp.backward(dyp)
+        yo = torch.empty(2, yp.shape[2], yp.shape[3], 64, device=DEV); idx = torch.empty(yo.shape, dtype=torch.uint8, device=DEV)
+        L.check(lib.sd_maxpool3x3s2_fwd(nhwc(xp.detach()).data_ptr(), yo.data_ptr(), idx.data_ptr(), 2, h, w_, 64, L.stream()))
+        assert torch.equal(from_nhwc(yo), yp.detach())
+        dxp = torch.empty(2, h, w_, 64, device=DEV)
+        L.check(lib.sd_maxpool3x3s2_bwd(nhwc(dyp).data_ptr(), idx.data_ptr(), dxp.data_ptr(), 2, h, w_, 64, L.stream()))
+        close(from_nhwc(dxp), xp.grad, 1e-6)
+    # upsample backward
+    dyu = torch.randn(2, 128, 8, 12, generator=g)
+    dxu = torch.empty(2, 4, 6, 128, device=DEV)
+    L.check(lib.sd_upsample2x_bwd(nhwc(dyu).data_ptr(), 0, dxu.data_ptr(), 2, 4, 6, 128, L.stream()))
+    close(from_nhwc(dxu), F.avg_pool2d(dyu, 2) * 4, 1e-6)
+    # head fwd / bwd
+    xh = torch.randn(2, 128, 6, 10, generator=g).requires_grad_(True)
+    wh = (torch.randn(7, 128, 1, 1, generator=g) / 11).requires_grad_(True); bh = torch.randn(7, generator=g).requires_grad_(True)
+    yh = F.conv2d(xh, wh, bh)
+    dyh = torch.randn(yh.shape, generator=g)
+    yh.backward(dyh)
+    out = torch.empty(2, 7, 6, 10, device=DEV)
+    whd = wh.detach().reshape(7, 128).to(DEV)
+    L.check(lib.sd_head_fwd(nhwc(xh.detach()).data_ptr(), whd.data_ptr(), bh.detach().to(DEV).data_ptr(), out.data_ptr(), 2, 60, 128, 7, L.stream()))
+    close(out.cpu(), yh.detach(), 1e-5)
+    dxh = torch.empty(2, 6, 10, 128, device=DEV); dwh = torch.empty(7, 128, device=DEV); dbh = torch.empty(7, device=DEV)
+    wsh = torch.empty(lib.sd_head_bwd_workspace_bytes(2, 60, 128, 7), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_head_bwd(dyh.to(DEV).data_ptr(), nhwc(xh.detach()).data_ptr(), whd.data_ptr(), dxh.data_ptr(), dwh.data_ptr(), dbh.data_ptr(),
+                            2, 60, 128, 7, 0, wsh.data_ptr(), wsh.numel(), L.stream()))
+    close(from_nhwc(dxh), xh.grad, 1e-5); close(dwh.cpu(), wh.grad.reshape(7, 128), 1e-5); close(dbh.cpu(), bh.grad, 1e-5)
+    # Adam: three steps vs torch.optim.Adam
+    p = torch.randn(1000, generator=g); pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], 1e-3)
+    pd, m, v = p.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone(); opt.step()
+        L.check(lib.sd_adam_step(pd.data_ptr(), gr.to(DEV).data_ptr(), m.data_ptr(), v.data_ptr(), 1000, step, 1e-3, 0.9, 0.999, 1e-8, 1.0, L.stream()))
+    close(pd.cpu(), pr.detach(), 1e-6)
+
+
+def _pair(M=2, N=1, seed=0):
+    from structuredetector_amd.model import Network
+    ref = O.build_reference_network(M, N, seed=seed)
+    args = Namespace(labels={f"l{i}": i for i in range(M)}, parts={f"p{i}": i for i in range(N)}, fpn_depth=128)
+    net = Network(args, pretrained=False, raw_output=True)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.to(DEV)
+
+
+def test_network_eval_forward():
+    ref, net = _pair()
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = ref.eval()(x)
+        got = net.eval()(x.to(DEV))
+    assert got.shape == want.shape == (2, 7, 16, 24)
+    close(got.cpu(), want, 1e-4)                 # north_star: heatmap values within 1e-4 fp32
+    # dict form = channel-slice views of one tensor (network.py:77-84)
+    net.raw_output = False
+    out = net(x.to(DEV))
+    assert set(out) == {"anchor_hm", "part_hm", "offsets", "embeddings"}
+    assert out["anchor_hm"].shape == (2, 2, 16, 24) and out["embeddings"].shape == (2, 2, 16, 24)
+    assert out["part_hm"]._base is out["anchor_hm"]._base
+
+
+def test_network_train_forward_backward():
+    ref, net = _pair(seed=3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    dy = torch.randn(4, 7, 16, 16, generator=g)
+    ref.train(); net.train()
+    want = ref(x)
+    want.backward(dy)
+    got = net(x.to(DEV))
+    got.backward(dy.to(DEV))
+    close(got.detach().cpu(), want.detach(), 1e-4)
+    sd_ref = dict(ref.named_parameters())
+    worst = 0.0
+    for name, p in net.named_parameters():
+        gr, gg = sd_ref[name].grad, p.grad.cpu()
+        assert gg.shape == gr.shape, name
+        err = (gg - gr).abs().max().item() / (gr.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-3, f"{name}: rel err {err:.2e}"       # 44 fp32 layers deep, BN-coupled batch of 4
+    # running statistics follow torch's momentum / unbiased-variance rule
+    for name, b in net.named_buffers():
+        rb = dict(ref.named_buffers())[name]
+        if b.dtype == torch.long:
+            assert int(b) == int(rb), name
+        else:
+            close(b.cpu(), rb, 1e-4)
+    # explicit (autograd-free) path writes the same gradients into the flat buffer
+    flat_before = net.flat_grads.clone()
+    ref2, net2 = _pair(seed=3)
+    net2.train()
+    out2, tape = net2.forward_train(x.to(DEV))
+    net2.backward_from(tape, dy.to(DEV))
+    assert torch.equal(net2.flat_grads, flat_before)
+
+
+def test_state_dict_roundtrip(tmp_path):
+    ref, net = _pair(seed=5)
+    net.save(tmp_path / "m.pth")
+    sd = torch.load(tmp_path / "m.pth", map_location="cpu")
+    ref2 = O.ReferenceNetwork(2, 1)
+    ref2.load_state_dict(sd)                                    # a reference-schema model loads our checkpoint
+    for k, v in ref.state_dict().items():
+        assert torch.equal(ref2.state_dict()[k], v), k
