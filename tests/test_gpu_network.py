@@ -14,8 +14,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+_KEEP = []   # device temporaries whose raw pointers are handed to the C ABI must outlive the launch
+
+
+def keep(t):
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
+
+
 def nhwc(t):   # (B,C,H,W) cpu -> (B,H,W,C) device contiguous
-    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    return keep(t.permute(0, 2, 3, 1).contiguous().to(DEV))
 
 
 def from_nhwc(t):
@@ -23,7 +34,7 @@ def from_nhwc(t):
 
 
 def krsc(w):   # OIHW cpu -> [O][R][S][I] device
-    return w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    return keep(w.permute(0, 2, 3, 1).contiguous().to(DEV))
 
 
 def make_desc(L, B, Hi, Wi, cin, cout, k, stride, pad):
@@ -69,7 +80,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     close(from_nhwc(y), ref, 2e-6 * (cin * k * k) ** 0.5)            # fp32 fma chain, k-ordered
     # fused epilogue: affine + residual + relu
     res = torch.randn(B, cout, d.Ho, d.Wo, generator=g)
-    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale.to(DEV).data_ptr(), shift.to(DEV).data_ptr(),
+    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), keep(scale.to(DEV)).data_ptr(), keep(shift.to(DEV)).data_ptr(),
                               nhwc(res).data_ptr(), 0, 1, L.stream()))
     ref2 = F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res)
     close(from_nhwc(y), ref2, 1e-5)
@@ -99,7 +110,7 @@ def test_conv_up2_residual_and_stem():
     coarse = torch.randn(B, 128, H // 2, W // 2, generator=g)
     d = make_desc(L, B, H, W, 64, 128, 1, 1, 0)
     y = torch.empty(B, H, W, 128, device=DEV)
-    L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 0, b.to(DEV).data_ptr(),
+    L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 0, keep(b.to(DEV)).data_ptr(),
                               nhwc(coarse).data_ptr(), 1, 0, L.stream()))
     ref = F.conv2d(x, w, b) + F.interpolate(coarse, scale_factor=2)          # Fpn.forward, network.py:18-19
     close(from_nhwc(y), ref, 1e-5)
@@ -107,14 +118,14 @@ def test_conv_up2_residual_and_stem():
     img = torch.randn(2, 3, 64, 96, generator=g); ws_ = torch.randn(64, 3, 7, 7, generator=g) / 12
     d0 = make_desc(L, 2, 64, 96, 3, 64, 7, 2, 3)
     y0 = torch.empty(2, d0.Ho, d0.Wo, 64, device=DEV)
-    L.check(lib.sd_conv2d_stem_fwd(img.to(DEV).data_ptr(), krsc(ws_).data_ptr(), y0.data_ptr(), C.byref(d0), 0, 0, 0, L.stream()))
+    L.check(lib.sd_conv2d_stem_fwd(keep(img.to(DEV)).data_ptr(), krsc(ws_).data_ptr(), y0.data_ptr(), C.byref(d0), 0, 0, 0, L.stream()))
     close(from_nhwc(y0), F.conv2d(img, ws_, None, 2, 3), 1e-5)
     dy = torch.randn(2, 64, d0.Ho, d0.Wo, generator=g)
     wr = ws_.clone().requires_grad_(True)
     F.conv2d(img, wr, None, 2, 3).backward(dy)
     wsb = torch.empty(max(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), 256), dtype=torch.uint8, device=DEV)
     dw = torch.empty(64, 7, 7, 3, device=DEV)
-    L.check(lib.sd_conv2d_stem_wgrad(nhwc(dy).data_ptr(), img.to(DEV).data_ptr(), dw.data_ptr(), C.byref(d0), 0, wsb.data_ptr(), wsb.numel(), L.stream()))
+    L.check(lib.sd_conv2d_stem_wgrad(nhwc(dy).data_ptr(), keep(img.to(DEV)).data_ptr(), dw.data_ptr(), C.byref(d0), 0, wsb.data_ptr(), wsb.numel(), L.stream()))
     close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
 
 
@@ -174,11 +185,11 @@ def test_bn_pool_head_adam():
     yh.backward(dyh)
     out = torch.empty(2, 7, 6, 10, device=DEV)
     whd = wh.detach().reshape(7, 128).to(DEV)
-    L.check(lib.sd_head_fwd(nhwc(xh.detach()).data_ptr(), whd.data_ptr(), bh.detach().to(DEV).data_ptr(), out.data_ptr(), 2, 60, 128, 7, L.stream()))
+    L.check(lib.sd_head_fwd(nhwc(xh.detach()).data_ptr(), whd.data_ptr(), keep(bh.detach().to(DEV)).data_ptr(), out.data_ptr(), 2, 60, 128, 7, L.stream()))
     close(out.cpu(), yh.detach(), 1e-5)
     dxh = torch.empty(2, 6, 10, 128, device=DEV); dwh = torch.empty(7, 128, device=DEV); dbh = torch.empty(7, device=DEV)
     wsh = torch.empty(lib.sd_head_bwd_workspace_bytes(2, 60, 128, 7), dtype=torch.uint8, device=DEV)
-    L.check(lib.sd_head_bwd(dyh.to(DEV).data_ptr(), nhwc(xh.detach()).data_ptr(), whd.data_ptr(), dxh.data_ptr(), dwh.data_ptr(), dbh.data_ptr(),
+    L.check(lib.sd_head_bwd(keep(dyh.to(DEV)).data_ptr(), nhwc(xh.detach()).data_ptr(), whd.data_ptr(), dxh.data_ptr(), dwh.data_ptr(), dbh.data_ptr(),
                             2, 60, 128, 7, 0, wsh.data_ptr(), wsh.numel(), L.stream()))
     close(from_nhwc(dxh), xh.grad, 1e-5); close(dwh.cpu(), wh.grad.reshape(7, 128), 1e-5); close(dbh.cpu(), bh.grad, 1e-5)
     # Adam: three steps vs torch.optim.Adam
@@ -188,7 +199,7 @@ def test_bn_pool_head_adam():
     for step in range(1, 4):
         gr = torch.randn(1000, generator=g)
         pr.grad = gr.clone(); opt.step()
-        L.check(lib.sd_adam_step(pd.data_ptr(), gr.to(DEV).data_ptr(), m.data_ptr(), v.data_ptr(), 1000, step, 1e-3, 0.9, 0.999, 1e-8, 1.0, L.stream()))
+        L.check(lib.sd_adam_step(pd.data_ptr(), keep(gr.to(DEV)).data_ptr(), m.data_ptr(), v.data_ptr(), 1000, step, 1e-3, 0.9, 0.999, 1e-8, 1.0, L.stream()))
     close(pd.cpu(), pr.detach(), 1e-6)
 
 
