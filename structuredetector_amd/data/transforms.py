@@ -102,18 +102,23 @@ class Encode:
                     two_sigma2=float(np.float32(2 * sigma ** 2)))
 
     # ------------------------------------------------------------------ device stage
-    def render(self, plan, device=None):
+    def upload(self, plan, device=None):
+        """Host -> device copy of a plan's small arrays (4 transfers per batch)."""
         device = torch.device(device or self.device or "cuda")
         if device.type != "cuda":
             raise L.SdError("Encode renders on the GPU; there is no CPU path")
-        B, C, M, K, P, h, w, n = (plan[k] for k in ("B", "C", "M", "K", "P", "out_h", "out_w", "n_kp"))
-        f32 = torch.from_numpy(plan["f32"]).to(device, non_blocking=True)
-        i64 = torch.from_numpy(plan["i64"]).to(device, non_blocking=True)
-        u8 = torch.from_numpy(plan["u8"]).to(device, non_blocking=True)
-        i32 = torch.from_numpy(plan["i32"]).to(device, non_blocking=True)
-        hm = torch.empty((B, C, h, w), dtype=torch.float32, device=device)
+        dev = {k: plan[k] for k in ("B", "C", "M", "K", "P", "out_h", "out_w", "n_kp", "two_sigma2")}
+        for k in ("f32", "i64", "u8", "i32"):
+            dev[k] = torch.from_numpy(plan[k]).to(device, non_blocking=True)
+        return dev
+
+    def render_device(self, dev):
+        """One `sd_render_targets` launch; everything else is views of the uploaded arrays."""
+        B, C, M, K, P, h, w, n = (dev[k] for k in ("B", "C", "M", "K", "P", "out_h", "out_w", "n_kp"))
+        f32, i64, u8, i32 = dev["f32"], dev["i64"], dev["u8"], dev["i32"]
+        hm = torch.empty((B, C, h, w), dtype=torch.float32, device=f32.device)
         base = i32.data_ptr()
-        L.check(L.lib().sd_render_targets(base, base + 4 * n, base + 8 * n, B, C, h, w, plan["two_sigma2"], hm.data_ptr(),
+        L.check(L.lib().sd_render_targets(base, base + 4 * n, base + 8 * n, B, C, h, w, dev["two_sigma2"], hm.data_ptr(),
                                           L.stream()), "sd_render_targets")
         return {
             "anchor_hm": hm[:, :M], "part_hm": hm[:, M:],
@@ -123,6 +128,9 @@ class Encode:
             "embeddings": f32[B * K * 2 + B * P * 2:].view(B, P, 2),
             "anchor_mask": u8[:B * K].view(B, K).view(torch.bool), "part_mask": u8[B * K:].view(B, P).view(torch.bool),
         }
+
+    def render(self, plan, device=None):
+        return self.render_device(self.upload(plan, device))
 
     def batch(self, img_size, annotations, device=None):
         """Collated targets (the dict CropDataset.collate_fn would build, dataset.py:58-87) for a list of

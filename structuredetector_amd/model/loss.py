@@ -35,57 +35,73 @@ def _common_base(views):
     return base if c0 == Cb else None
 
 
+def loss_forward(head, tgt, cfg):
+    """sd_loss_fwd on the raw head tensor (B, M+N+4, h, w).  Returns (desc, keep-alive list, out8) where
+    out8 = [total, hm, offset, embedding, num_pos_a, num_pos_p, n_valid_a, n_valid_p] on the device."""
+    (M, N, K, P, fn, hm_w, off_w, emb_w) = cfg
+    B, Cc, h, w = head.shape
+    keep = [head]
+
+    def mp(t):
+        t, p, sb, sc = L.map_view(t)
+        keep.append(t)
+        return p, sb, sc
+
+    def flat(t, dtype):
+        if t.dtype == torch.bool and dtype == torch.uint8:
+            t = t.view(torch.uint8)
+        t = t.to(dtype).contiguous() if t.dtype != dtype or not t.is_contiguous() else t
+        keep.append(t)
+        return t.data_ptr()
+
+    d = L.LossDesc()
+    d.anchor_hm, d.a_sb, d.a_sc = mp(head[:, :M])
+    d.part_hm, d.p_sb, d.p_sc = mp(head[:, M:M + N])
+    d.offsets, d.o_sb, d.o_sc = mp(head[:, M + N:M + N + 2])
+    d.embeddings, d.e_sb, d.e_sc = mp(head[:, M + N + 2:M + N + 4])
+    d.t_anchor_hm, d.ta_sb, d.ta_sc = mp(tgt["anchor_hm"])
+    d.t_part_hm, d.tp_sb, d.tp_sc = mp(tgt["part_hm"])
+    d.anchor_inds = flat(tgt["anchor_inds"], torch.int64)
+    d.part_inds = flat(tgt["part_inds"], torch.int64)
+    d.anchor_offsets = flat(tgt["anchor_offsets"], torch.float32)
+    d.part_offsets = flat(tgt["part_offsets"], torch.float32)
+    d.t_embeddings = flat(tgt["embeddings"], torch.float32)
+    d.anchor_mask = flat(tgt["anchor_mask"], torch.uint8)
+    d.part_mask = flat(tgt["part_mask"], torch.uint8)
+    d.B, d.M, d.N, d.h, d.w, d.K, d.P = B, M, N, h, w, K, P
+    d.hm_loss_fn = fn
+    d.hm_weight, d.offset_weight, d.embedding_weight = hm_w, off_w, emb_w
+    out8 = torch.empty(8, dtype=torch.float32, device=head.device)
+    lib = L.lib()
+    ws = L.workspace(lib.sd_loss_workspace_bytes(B, M, N, h, w), head.device)
+    L.check(lib.sd_loss_fwd(C.byref(d), out8.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_loss_fwd")
+    return d, keep, out8
+
+
+def loss_backward(desc, out8, grad_out, shape):
+    """sd_loss_bwd: d total / d head, (B, M+N+4, h, w) contiguous.  grad_out: 0-dim device tensor."""
+    dhead = torch.empty(shape, dtype=torch.float32, device=out8.device)
+    g = grad_out.to(torch.float32).contiguous()
+    L.check(L.lib().sd_loss_bwd(C.byref(desc), out8.data_ptr(), g.data_ptr(), dhead.data_ptr(), L.stream()), "sd_loss_bwd")
+    return dhead
+
+
+def loss_config(args, M, N, K, P):
+    return (M, N, K, P, _HM_FN[args.hm_loss_fn.lower()], float(args.hm_weight), float(args.offset_weight),
+            float(args.embedding_weight))
+
+
 class _SdLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, tgt, cfg):
-        (M, N, K, P, fn, hm_w, off_w, emb_w) = cfg
-        B, Cc, h, w = head.shape
-        keep = []
-
-        def mp(t):
-            t, p, sb, sc = L.map_view(t)
-            keep.append(t)
-            return p, sb, sc
-
-        def flat(t, dtype):
-            t = t.to(dtype).contiguous() if t.dtype != dtype or not t.is_contiguous() else t
-            keep.append(t)
-            return t.data_ptr()
-
-        d = L.LossDesc()
-        d.anchor_hm, d.a_sb, d.a_sc = mp(head[:, :M])
-        d.part_hm, d.p_sb, d.p_sc = mp(head[:, M:M + N])
-        d.offsets, d.o_sb, d.o_sc = mp(head[:, M + N:M + N + 2])
-        d.embeddings, d.e_sb, d.e_sc = mp(head[:, M + N + 2:M + N + 4])
-        d.t_anchor_hm, d.ta_sb, d.ta_sc = mp(tgt["anchor_hm"])
-        d.t_part_hm, d.tp_sb, d.tp_sc = mp(tgt["part_hm"])
-        d.anchor_inds = flat(tgt["anchor_inds"], torch.int64)
-        d.part_inds = flat(tgt["part_inds"], torch.int64)
-        d.anchor_offsets = flat(tgt["anchor_offsets"], torch.float32)
-        d.part_offsets = flat(tgt["part_offsets"], torch.float32)
-        d.t_embeddings = flat(tgt["embeddings"], torch.float32)
-        d.anchor_mask = flat(tgt["anchor_mask"].view(torch.uint8) if tgt["anchor_mask"].dtype == torch.bool
-                             else tgt["anchor_mask"], torch.uint8)
-        d.part_mask = flat(tgt["part_mask"].view(torch.uint8) if tgt["part_mask"].dtype == torch.bool
-                           else tgt["part_mask"], torch.uint8)
-        d.B, d.M, d.N, d.h, d.w, d.K, d.P = B, M, N, h, w, K, P
-        d.hm_loss_fn = fn
-        d.hm_weight, d.offset_weight, d.embedding_weight = hm_w, off_w, emb_w
-        out8 = torch.empty(8, dtype=torch.float32, device=head.device)
-        lib = L.lib()
-        ws = L.workspace(lib.sd_loss_workspace_bytes(B, M, N, h, w), head.device)
-        L.check(lib.sd_loss_fwd(C.byref(d), out8.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_loss_fwd")
-        ctx.desc, ctx.keep, ctx.out8, ctx.shape = d, keep + [head], out8, (B, Cc, h, w)
+        d, keep, out8 = loss_forward(head, tgt, cfg)
+        ctx.desc, ctx.keep, ctx.out8, ctx.shape = d, keep, out8, tuple(head.shape)
         ctx.mark_non_differentiable(out8)
         return out8[0].clone(), out8
 
     @staticmethod
     def backward(ctx, g_total, _g_out8):
-        dhead = torch.empty(ctx.shape, dtype=torch.float32, device=ctx.out8.device)
-        g = g_total.to(torch.float32).contiguous()
-        L.check(L.lib().sd_loss_bwd(C.byref(ctx.desc), ctx.out8.data_ptr(), g.data_ptr(), dhead.data_ptr(), L.stream()),
-                "sd_loss_bwd")
-        return dhead, None, None
+        return loss_backward(ctx.desc, ctx.out8, g_total, ctx.shape), None, None
 
 
 class Loss(torch.nn.Module):
@@ -103,9 +119,7 @@ class Loss(torch.nn.Module):
         head = _common_base(views)
         if head is None:                      # separate tensors: one concat, autograd splits the gradient back
             head = torch.cat([v.float() for v in views], dim=1)
-        a = self.args
-        cfg = (M, N, target["anchor_inds"].shape[1], target["part_inds"].shape[1], _HM_FN[a.hm_loss_fn.lower()],
-               float(a.hm_weight), float(a.offset_weight), float(a.embedding_weight))
+        cfg = loss_config(self.args, M, N, target["anchor_inds"].shape[1], target["part_inds"].shape[1])
         total, out8 = _SdLoss.apply(head, target, cfg)
         self.stats.update(out8[1], out8[2], out8[3])
         return total

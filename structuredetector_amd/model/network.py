@@ -113,6 +113,16 @@ class _Engine:
     def __init__(self, net: "Network"):
         self.net = net
         self.lib = L.lib()
+        self.prof = None      # list -> every conv launch appends (kernel, algorithmic flops, start event, end event)
+
+    def _timed(self, kind, flops, fn):
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()           # torch's current stream == the stream handed to the C ABI (L.stream())
+        fn()
+        e1.record()
+        self.prof.append((kind, flops, e0, e1))
 
     # ---- helpers -------------------------------------------------------------------------
     def _ws(self, nbytes, dev):
@@ -121,8 +131,10 @@ class _Engine:
     def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
         d = _desc(B, Hi, Wi, conv)
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
-        L.check(self.lib.sd_conv2d_fwd(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
-                                       _ptr(res), int(res_up2), int(relu), L.stream()), "sd_conv2d_fwd")
+        flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        self._timed("k_conv_igemm<%d>" % (128 if conv.cout % 128 == 0 else 64), flops, lambda: L.check(
+            self.lib.sd_conv2d_fwd(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
+                                   _ptr(res), int(res_up2), int(relu), L.stream()), "sd_conv2d_fwd"))
         return y, d
 
     def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True):
@@ -246,15 +258,19 @@ class _Engine:
     def _dgrad(self, dy, conv, d, res=None):
         dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=torch.float32, device=dy.device)
         wt = self._wt(conv)
-        L.check(self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad")
+        flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        self._timed("k_conv_igemm<%d>" % (128 if conv.cin % 128 == 0 else 64), flops, lambda: L.check(
+            self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"))
         return dx
 
     def _wgrad(self, dy, x, conv, d):
         g = self.net.grad_of(conv.weight)
         nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = self._ws(nbytes, dy.device)
-        L.check(self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
-                "sd_conv2d_wgrad")
+        flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        self._timed("k_conv_wgrad", flops, lambda: L.check(
+            self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
+            "sd_conv2d_wgrad"))
 
     def _bias_grad(self, dy, conv):
         Mrows, Cc = dy.numel() // dy.shape[-1], dy.shape[-1]
@@ -272,8 +288,10 @@ class _Engine:
                                    self.net.grad_of(bn.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_bwd")
         return dx, g
 
-    def backward(self, tape, dhead):
-        """Writes every parameter gradient into `net.flat_grads` (overwriting, not accumulating)."""
+    def backward(self, tape, dhead, on_stage=None):
+        """Writes every parameter gradient into `net.flat_grads` (overwriting, not accumulating).
+        on_stage(name) is called after the gradients of a parameter group are complete, in the order
+        'fpn_head', 'down4', 'down3', 'down2', 'down1_stem' (bucketed all-reduce hook)."""
         net, lib = self.net, self.lib
         B = tape["B"]
         H2, W2 = tape["hw"]
@@ -304,8 +322,11 @@ class _Engine:
         self._wgrad(df, p5, net.up1, d5)
         self._bias_grad(df, net.up1)
         dcur = self._dgrad(df, net.up1, d5)
+        if on_stage:
+            on_stage("fpn_head")
 
         # trunk, last block first
+        first_of = {id(net.down4[0]): "down4", id(net.down3[0]): "down3", id(net.down2[0]): "down2"}
         for (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd) in reversed(tape["blocks"]):
             extra = lateral_grad.pop(out.data_ptr(), None)
             if extra is not None:                       # `out` also feeds an FPN lateral conv
@@ -322,6 +343,8 @@ class _Engine:
             else:
                 skip = g
             dcur = self._dgrad(dc1, blk.conv1, d1, res=skip)
+            if on_stage and id(blk) in first_of:
+                on_stage(first_of[id(blk)])
 
         # stem
         d0, s0, a0, m0, i0, pidx = tape["stem"]
@@ -332,6 +355,8 @@ class _Engine:
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
                                          ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
+        if on_stage:
+            on_stage("down1_stem")
 
 
 class _NetFn(torch.autograd.Function):
@@ -462,6 +487,14 @@ class Network(nn.Module):
         tape = {}
         return self._engine.forward(x, True, tape), tape
 
-    def backward_from(self, tape, dhead):
+    def backward_from(self, tape, dhead, on_stage=None):
         """Backward of `forward_train`: fills `flat_grads` in place."""
-        self._engine.backward(tape, dhead)
+        self._engine.backward(tape, dhead, on_stage)
+
+    def stage_ranges(self):
+        """Flat-buffer [lo, hi) element ranges of the gradient groups reported by `backward_from(on_stage=...)`."""
+        def span(mods):
+            offs = [self._flat_off[id(p)] for m in mods for p in m.parameters()]
+            return (min(o for o, _ in offs), max((o + n + 3) // 4 * 4 for o, n in offs))
+        return {"fpn_head": span([self.up1, self.up2, self.up3, self.up4, self.head]), "down4": span([self.down4]),
+                "down3": span([self.down3]), "down2": span([self.down2]), "down1_stem": span([self.adpater, self.down1])}

@@ -1,0 +1,78 @@
+"""Training step and loop for the SDNet hot path.
+
+`TrainStep` is the inner step of the reference's `Trainer.train_epoch`
+(src/sdnet/model/trainer.py:113-124: zero_grad, forward, loss, backward, Adam.step with lr 1e-3 and
+default betas/eps, :53) as an explicit kernel schedule with no host synchronisation, extended with
+what the reference lacks: pure data-parallel training, one process per GPU, gradients summed with
+RCCL (`torch.distributed` backend "nccl") in five buckets that follow the backward pass
+(FPN+head, down4, down3, down2, down1+stem), so the 87 MB exchange hides behind the remaining
+backward kernels; the mean is applied inside the fused Adam launch (grad_scale = 1/world).
+BatchNorm statistics stay rank-local (the reference has no SyncBN to match).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib as L
+from .loss import LossStats, loss_backward, loss_config, loss_forward
+
+
+class TrainStep:
+    def __init__(self, net, args, lr=None, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        if net.flat_params is None:
+            raise L.SdError("move the Network to the GPU before building TrainStep")
+        self.net, self.args = net, args
+        self.lr = float(lr if lr is not None else getattr(args, "learning_rate", 1e-3))
+        self.betas, self.eps = betas, eps
+        self.exp_avg = torch.zeros_like(net.flat_params)
+        self.exp_avg_sq = torch.zeros_like(net.flat_params)
+        self.step_count = 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.ranges = net.stage_ranges()
+        self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
+        self.stats = LossStats()
+
+    def sync_parameters(self):
+        """Identical initial weights on every rank (rank 0's)."""
+        if self.world > 1:
+            dist.broadcast(self.net.flat_params, 0, group=self.pg)
+            for b in self.net.buffers():
+                dist.broadcast(b, 0, group=self.pg)
+
+    def __call__(self, images, targets):
+        """One optimizer step; returns the loss vector [total, hm, offset, embedding] as a device tensor."""
+        net = self.net
+        head, tape = net.forward_train(images)
+        M, N = net.label_count, net.part_count
+        cfg = loss_config(self.args, M, N, targets["anchor_inds"].shape[1], targets["part_inds"].shape[1])
+        desc, keep, out8 = loss_forward(head, targets, cfg)
+        dhead = loss_backward(desc, out8, self.one, tuple(head.shape))
+        works = []
+        if self.world > 1:
+            def on_stage(name):
+                lo, hi = self.ranges[name]
+                works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
+        else:
+            on_stage = None
+        net.backward_from(tape, dhead, on_stage)
+        for w in works:
+            w.wait()
+        self.step_count += 1
+        L.check(L.lib().sd_adam_step(net.flat_params.data_ptr(), net.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), net.flat_params.numel(), self.step_count, self.lr, self.betas[0],
+                                     self.betas[1], self.eps, 1.0 / self.world, L.stream()), "sd_adam_step")
+        self.stats.update(out8[1], out8[2], out8[3])
+        return out8[:4]
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma=0.1) over TrainStep.lr (trainer.py:54-56)."""
+
+    def __init__(self, step: TrainStep, step_size: int, gamma: float = 0.1):
+        self.step_obj, self.step_size, self.gamma, self.epoch, self.base = step, max(int(step_size), 1), gamma, 0, step.lr
+
+    def step(self):
+        self.epoch += 1
+        self.step_obj.lr = self.base * self.gamma ** (self.epoch // self.step_size)
