@@ -41,10 +41,11 @@ def make_args(dev, M=2, N=1, K=20, P=40):
                      learning_rate=1e-3, device=dev)
 
 
-def cpu_baseline(M, N, K, P, img, budget_s=25.0):
+def cpu_baseline(M, N, K, P, img, budget_s=20.0):
     """Oracle (torch-CPU restatement of the reference path) timed on the host cores: train fwd+bwd on a bounded sample."""
     from oracle import sdnet_oracle as O
-    cores = os.cpu_count() or 1
+    # threads = the CPU share this process really has (a 1-GPU box grants 16 host cores, not the 256 it reports)
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("SDNET_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     bs = 4
     rng = np.random.default_rng(1)
