@@ -13,7 +13,7 @@ namespace sd {
 // to two quantities, then a finalize kernel in double.  Thread layout: C/4 float4 columns x
 // (256 / (C/4)) row lanes.
 // ------------------------------------------------------------------------------------------
-constexpr int RED_ROWS_PER_BLOCK = 2048;
+constexpr int RED_ROWS_PER_BLOCK = 512;
 
 // MODE 0: sum x, sum x^2                      (BN statistics)
 // MODE 1: sum g, sum g*xhat  with g = dy * [y > 0 if relu]   (BN backward)
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
         is = reinterpret_cast<const float4*>(invstd)[col];
     }
     if (rl < lanes) {
+#pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += lanes) {
             const float4 v = reinterpret_cast<const float4*>(a + r * C)[col];
             if (MODE == 0) {
@@ -79,13 +80,21 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
                                                        float momentum, float* __restrict__ out0, float* __restrict__ out1,
                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
                                                        float* __restrict__ aux0, float* __restrict__ aux1, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // 32 channels x 8 lanes over the partial blocks per workgroup; fixed order -> deterministic
+    __shared__ double r0[8][32], r1[8][32];
+    const int lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lc;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s0 += (double)partial[(int64_t)b * 2 * C + c];
-        s1 += (double)partial[(int64_t)b * 2 * C + C + c];
+    if (c < C) {
+        for (int b = lr; b < nblocks; b += 8) {
+            s0 += (double)partial[(int64_t)b * 2 * C + c];
+            s1 += (double)partial[(int64_t)b * 2 * C + C + c];
+        }
     }
+    r0[lr][lc] = s0; r1[lr][lc] = s1;
+    __syncthreads();
+    if (lr != 0 || c >= C) return;
+    for (int k = 1; k < 8; ++k) { s0 += r0[k][lc]; s1 += r1[k][lc]; }
     if (FIN == 0) {
         const double mean = s0 / M;
         const double var = fmax(s1 / M - mean * mean, 0.0);             // biased variance (normalisation)
@@ -447,7 +456,7 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
                        mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
     SD_LAUNCH_CHECK();
     return 0;
@@ -484,7 +493,7 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
     float* mgx = mg + C;
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, relu, M, C, partial);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
@@ -503,7 +512,7 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
     hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
