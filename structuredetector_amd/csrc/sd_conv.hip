@@ -34,7 +34,11 @@ struct ConvArgs {
     int mul, div, off, rsign;   // input coord t = o*mul + off + rsign*r ; valid iff t>=0, t%div==0, t/div < Hi
     int relu, res_up2;
     int M, nk, kchunks;   // kchunks = Ck/32 (STEM: unused), nk = number of 32-wide K chunks
+    int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
+                          // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
 };
+
+__device__ __attribute__((aligned(128))) float g_zero_line[64];   // zero-initialised: source of padded (out-of-image) rows
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -43,94 +47,151 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int BN, bool STEM>
+__device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
+
+// MODE 0: unit "div" (forward conv of any stride, stride-1 data-gradient)   1: stem (NCHW image, K = 147 -> 160)
+// MODE 2: stride-2 data-gradient, parity classes                             3: generic strided data-gradient
+//
+// NOTE on style: the staging registers are individual named variables filled by macros, not arrays written
+// inside lambdas -- hipcc left such arrays in scratch memory (scratch_store after every global_load and a
+// vmcnt(0) wait per load), which serialised the prefetch.
+template <int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
+    constexpr bool STEM = (MODE == 1);
     constexpr int NT = BN / 64;            // 32-wide MFMA tiles per wave along n (wave tile = 64 x BN/2)
-    constexpr int BROWS = BN / 32;         // float4 rows of the W tile each thread stages
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][BM][LDK]
     float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
+    int* orow = reinterpret_cast<int*>(lds + 2 * (BM + BN) * LDK);   // [BM] output pixel of each tile row, -1 = none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Nn / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;   // n fastest: the A tile is reused from L2
+    const int tile_m = tile / n_tiles;
+    const int n0 = (tile % n_tiles) * BN;                // n fastest: the A tile is reused from L2
+    int m0 = tile_m * BM;
+
+    int r0 = 0, s0 = 0, tstep = 1, nk = p.nk;
+    int cls_base = 0, py = 0, px = 0;
+    if (MODE == 2) {
+        // classes interleaved over the tile index so that every XCD gets the same mix of 1/2/2/4-tap tiles
+        const int Mq = p.M >> 2, cls = tile_m & 3;
+        cls_base = cls * Mq; m0 = cls_base + (tile_m >> 2) * BM;
+        py = cls >> 1; px = cls & 1;
+        r0 = (py + p.off) & 1; s0 = (px + p.off) & 1; tstep = 2;         // r = oy + pad (mod 2), likewise s
+        nk = ((p.R - r0 + 1) >> 1) * ((p.S - s0 + 1) >> 1) * p.kchunks;
+    }
 
     // ---- staging assignment: thread -> (row = tid/8 + 32*i, 4 consecutive k = (tid%8)*4)
     const int srow = tid >> 3, sk = (tid & 7) * 4;
-    int a_ty[4], a_tx[4];                  // o*mul + off for the 4 staged rows
-    int64_t a_base[4];                     // batch offset into x (elements); -1 => row beyond M
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + srow + 32 * i;
-        if (m < p.M) {
-            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-            a_ty[i] = oy * p.mul + p.off;
-            a_tx[i] = ox * p.mul + p.off;
-            a_base[i] = (int64_t)b * p.Hi * p.Wi * (STEM ? 3 : p.Ck);
-        } else {
-            a_ty[i] = a_tx[i] = 0;
-            a_base[i] = -1;
-        }
+    const int img_stride = p.Hi * p.Wi * (STEM ? 3 : p.Ck);
+#define SD_ROW_SETUP(i)                                                                           \
+    int aty##i = 0, atx##i = 0;                                                                   \
+    const float* aptr##i = p.x;                                                                   \
+    bool aok##i;                                                                                  \
+    {                                                                                             \
+        const int m = m0 + srow + 32 * i;                                                         \
+        int pix = -1;                                                                             \
+        aok##i = m < p.M;                                                                         \
+        if (aok##i) {                                                                             \
+            int ox, oy, b;                                                                        \
+            if (MODE == 2) {                                                                      \
+                const int ml = m - cls_base, hw = p.Wo >> 1, hh = p.Ho >> 1;                      \
+                const int qx = ml % hw, t = ml / hw, qy = t % hh;                                 \
+                b = t / hh; oy = 2 * qy + py; ox = 2 * qx + px;                                   \
+            } else {                                                                              \
+                ox = m % p.Wo; const int t = m / p.Wo; oy = t % p.Ho; b = t / p.Ho;               \
+            }                                                                                     \
+            aty##i = oy * p.mul + p.off;                                                          \
+            atx##i = ox * p.mul + p.off;                                                          \
+            aptr##i = p.x + (int64_t)b * img_stride;                                              \
+            pix = (b * p.Ho + oy) * p.Wo + ox;                                                    \
+        }                                                                                         \
+        if ((tid & 7) == 0) orow[srow + 32 * i] = pix;                                            \
     }
-    const float* wrow[BROWS];
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i) wrow[i] = p.w + (int64_t)(n0 + srow + 32 * i) * p.R * p.S * (STEM ? 3 : p.Ck);
+    SD_ROW_SETUP(0) SD_ROW_SETUP(1) SD_ROW_SETUP(2) SD_ROW_SETUP(3)
+#undef SD_ROW_SETUP
+    const int wk = p.R * p.S * (STEM ? 3 : p.Ck);
+    const float* wrow0 = p.w + (int64_t)(n0 + srow) * wk;
+    const float* wrow1 = wrow0 + (int64_t)32 * wk;
+    const float* wrow2 = wrow0 + (int64_t)64 * wk;      // used when BN == 128
+    const float* wrow3 = wrow0 + (int64_t)96 * wk;
 
-    float4 ra[4], rb[BROWS];
-    auto load_chunk = [&](int kc) {
-        if (!STEM) {
-            const int tap = kc / p.kchunks, c0 = (kc - tap * p.kchunks) * BK;
-            const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int ty = a_ty[i] + p.rsign * r, tx = a_tx[i] + p.rsign * s;
-                bool ok = (a_base[i] >= 0) && ty >= 0 && tx >= 0;
-                if (p.div > 1) {
-                    ok = ok && (ty % p.div == 0) && (tx % p.div == 0);
-                    ty /= p.div; tx /= p.div;
-                }
-                ok = ok && ty < p.Hi && tx < p.Wi;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_base[i] + ((int64_t)ty * p.Wi + tx) * p.Ck + c0 + sk)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (int64_t)tap * p.Ck + c0 + sk);
-        } else {
-            // stem: k = (r*S + s)*3 + ci over 147 values padded to 160; x is NCHW
-            const int ktot = p.R * p.S * 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = kc * BK + sk + j;
-                    const int tap = k / 3, ci = k - tap * 3;
-                    const int r = tap / p.S, s = tap - r * p.S;
-                    const int ty = a_ty[i] + r, tx = a_tx[i] + s;
-                    const bool ok = (a_base[i] >= 0) && k < ktot && ty >= 0 && tx >= 0 && ty < p.Hi && tx < p.Wi;
-                    v[j] = ok ? p.x[a_base[i] + ((int64_t)ci * p.Hi + ty) * p.Wi + tx] : 0.f;
-                }
-                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = kc * BK + sk + j;
-                    v[j] = k < ktot ? wrow[i][k] : 0.f;
-                }
-                rb[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(As + (buf * BM + srow + 32 * i) * LDK + sk) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(Bs + (buf * BN + srow + 32 * i) * LDK + sk) = rb[i];
-    };
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ld_c0 = 0, ld_r = r0, ld_s = s0, ld_kc = 0;    // chunk cursor of the loader (chunks are loaded strictly in order)
+
+    // Padding rows read a zero line instead of being predicated: there is no select after the load, so the compiler
+    // cannot turn the load back into a branch with a wait per load.
+#define SD_LOAD_A(i)                                                                              \
+    {                                                                                             \
+        int ty = aty##i + p.rsign * ld_r, tx = atx##i + p.rsign * ld_s;                           \
+        bool ok = aok##i;                                                                         \
+        if (MODE == 2) { ty >>= 1; tx >>= 1; }                                                    \
+        if (MODE == 3) {                                                                          \
+            ok = ok && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);              \
+            ty /= p.div; tx /= p.div;                                                             \
+        }                                                                                         \
+        ok = ok && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;                \
+        const float* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + sk) : g_zero_line + sk; \
+        ra##i = *reinterpret_cast<const float4*>(src);                                            \
+    }
+#define SD_LOAD_A_STEM(i)                                                                         \
+    {                                                                                             \
+        float v[4];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const int k = ld_kc * BK + sk + j;                                                    \
+            const int tap = k / 3, ci = k - tap * 3;                                              \
+            const int r = tap / p.S, s = tap - r * p.S;                                           \
+            const int ty = aty##i + r, tx = atx##i + s;                                           \
+            const bool ok = aok##i && k < wk && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi; \
+            const float* src = ok ? aptr##i + ((ci * p.Hi + ty) * p.Wi + tx) : g_zero_line;      \
+            v[j] = *src;                                                                          \
+        }                                                                                         \
+        ra##i = make_float4(v[0], v[1], v[2], v[3]);                                              \
+    }
+#define SD_LOAD_B_STEM(i)                                                                         \
+    {                                                                                             \
+        float v[4];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const int k = ld_kc * BK + sk + j;                                                    \
+            const float* src = k < wk ? wrow##i + k : g_zero_line;                                \
+            v[j] = *src;                                                                          \
+        }                                                                                         \
+        rb##i = make_float4(v[0], v[1], v[2], v[3]);                                              \
+    }
+#define SD_LOAD_CHUNK()                                                                           \
+    if (!STEM) {                                                                                  \
+        SD_LOAD_A(0) SD_LOAD_A(1) SD_LOAD_A(2) SD_LOAD_A(3)                                       \
+        const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0 + sk;                                 \
+        rb0 = *reinterpret_cast<const float4*>(wrow0 + woff);                                     \
+        rb1 = *reinterpret_cast<const float4*>(wrow1 + woff);                                     \
+        if (BN == 128) {                                                                          \
+            rb2 = *reinterpret_cast<const float4*>(wrow2 + woff);                                 \
+            rb3 = *reinterpret_cast<const float4*>(wrow3 + woff);                                 \
+        }                                                                                         \
+        ld_c0 += BK;                                                                              \
+        if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+    } else {                                                                                      \
+        SD_LOAD_A_STEM(0) SD_LOAD_A_STEM(1) SD_LOAD_A_STEM(2) SD_LOAD_A_STEM(3)                   \
+        SD_LOAD_B_STEM(0) SD_LOAD_B_STEM(1)                                                       \
+        ++ld_kc;                                                                                  \
+    }
+#define SD_STORE_CHUNK(buf)                                                                       \
+    {                                                                                             \
+        float* ad = As + ((buf) * BM + srow) * LDK + sk;                                          \
+        *reinterpret_cast<float4*>(ad) = ra0;                                                     \
+        *reinterpret_cast<float4*>(ad + 32 * LDK) = ra1;                                          \
+        *reinterpret_cast<float4*>(ad + 64 * LDK) = ra2;                                          \
+        *reinterpret_cast<float4*>(ad + 96 * LDK) = ra3;                                          \
+        float* bd = Bs + ((buf) * BN + srow) * LDK + sk;                                          \
+        *reinterpret_cast<float4*>(bd) = rb0;                                                     \
+        *reinterpret_cast<float4*>(bd + 32 * LDK) = rb1;                                          \
+        if (BN == 128) {                                                                          \
+            *reinterpret_cast<float4*>(bd + 64 * LDK) = rb2;                                      \
+            *reinterpret_cast<float4*>(bd + 96 * LDK) = rb3;                                      \
+        }                                                                                         \
+    }
 
     // ---- wave tile: 64 (m) x BN/2 (n)
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
@@ -143,34 +204,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    if (nk > 0) {
+        SD_LOAD_CHUNK()
+        SD_STORE_CHUNK(0)
+    }
     __syncthreads();
-    for (int kc = 0; kc < p.nk; ++kc) {
+    for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < p.nk) load_chunk(kc + 1);
+        if (kc + 1 < nk) { SD_LOAD_CHUNK() }
         const float* Ab = As + (cur * BM + wm0 + fr) * LDK + fh * 4;
         const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK + fh * 4;
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
-            float4 a[2], b[NT];
+            const float4 a0 = *reinterpret_cast<const float4*>(Ab + ks * 8);
+            const float4 a1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + ks * 8);
+            const float4 b0 = *reinterpret_cast<const float4*>(Bb + ks * 8);
+            const float4 b1 = (NT == 2) ? *reinterpret_cast<const float4*>(Bb + 32 * LDK + ks * 8) : b0;
+            // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const float4*>(Ab + mi * 32 * LDK + ks * 8);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b[ni] = *reinterpret_cast<const float4*>(Bb + ni * 32 * LDK + ks * 8);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b0, t), acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b0, t), acc[1][0], 0, 0, 0);
+                if (NT == 2) {
+                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b1, t), acc[0][NT - 1], 0, 0, 0);
+                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b1, t), acc[1][NT - 1], 0, 0, 0);
                 }
+            }
         }
-        if (kc + 1 < p.nk) store_chunk(cur ^ 1);
+        if (kc + 1 < nk) { SD_STORE_CHUNK(cur ^ 1) }
         __syncthreads();
     }
+#undef SD_LOAD_A
+#undef SD_LOAD_A_STEM
+#undef SD_LOAD_B_STEM
+#undef SD_LOAD_CHUNK
+#undef SD_STORE_CHUNK
 
     // ---- epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
@@ -182,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (m >= p.M) continue;
+                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];   // output pixel index
+                if (m < 0) continue;
                 float v = acc[mi][ni][e] * sc + sh;
                 if (p.res) {
                     int64_t rm = m;
@@ -220,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
     constexpr int PK = 32;                        // pixels per chunk
     constexpr int LDN = TN + 4, LDC = TC + 4;     // row pads keep the ds_write_b128 rows 16-byte aligned
     constexpr int NT = TN / 64, CT = TC / 64;     // wave tile = TN/2 x TC/2 -> (TN/64) x (TC/64) MFMA tiles
+    constexpr int DV = PK * TN / 4 / 256, XV = PK * TC / 4 / 256;   // float4 slots per thread: 4 or 2
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ds = lds;                              // [2][PK][LDN]   dY chunk  (k = pixel, n)
     float* Xs = lds + 2 * PK * LDN;               // [2][PK][LDC]   X chunk   (k = pixel, c)
@@ -235,42 +304,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
     const int split = blockIdx.y;
     const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
 
-    // staging: dY chunk = PK rows x TN floats; X chunk = PK rows x TC floats; float4 per thread-slot
-    constexpr int DV = PK * TN / 4 / 256, XV = PK * TC / 4 / 256;   // float4 per thread
-    float4 rd[DV], rx[XV];
-    auto load_chunk = [&](int mc) {
-#pragma unroll
-        for (int i = 0; i < DV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (TN / 4), col = (idx % (TN / 4)) * 4;
-            const int m = mc + row;
-            rd[i] = (m < m_end) ? *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.Nn + n0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (TC / 4), col = (idx % (TC / 4)) * 4;
-            const int m = mc + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
-                const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;
-                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                    v = *reinterpret_cast<const float4*>(p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + c0 + col);
-            }
-            rx[i] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < DV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (TN / 4), col = (idx % (TN / 4)) * 4;
-            *reinterpret_cast<float4*>(Ds + (buf * PK + row) * LDN + col) = rd[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = tid + 256 * i, row = idx / (TC / 4), col = (idx % (TC / 4)) * 4;
-            *reinterpret_cast<float4*>(Xs + (buf * PK + row) * LDC + col) = rx[i];
-        }
-    };
+    // staging slots (named variables, see the note on k_conv_igemm): slot i -> flat float4 index tid + 256*i
+    float4 rd0, rd1, rd2, rd3, rx0, rx1, rx2, rx3;
+    rd2 = rd3 = rx2 = rx3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SD_DSLOT(i) const int drow##i = (tid + 256 * i) / (TN / 4), dcol##i = ((tid + 256 * i) % (TN / 4)) * 4;
+#define SD_XSLOT(i)                                                                                   \
+    const int xrow##i = (tid + 256 * i) / (TC / 4), xcol##i = ((tid + 256 * i) % (TC / 4)) * 4;      \
+    int pxx##i, pxy##i, pxb##i;                                                                       \
+    { const int m = m_beg + xrow##i; pxx##i = m % p.Wo; pxy##i = (m / p.Wo) % p.Ho; pxb##i = m / (p.Wo * p.Ho); }
+    SD_DSLOT(0) SD_DSLOT(1) SD_DSLOT(2) SD_DSLOT(3)
+    SD_XSLOT(0) SD_XSLOT(1) SD_XSLOT(2) SD_XSLOT(3)
+#undef SD_DSLOT
+#undef SD_XSLOT
+    int ld_m = m_beg;                               // chunks are visited strictly in order
+#define SD_LOAD_D(i)                                                                                  \
+    {                                                                                                 \
+        const int m = ld_m + drow##i;                                                                 \
+        const float* src = m < m_end ? p.dy + (int64_t)m * p.Nn + n0 + dcol##i : g_zero_line;        \
+        rd##i = *reinterpret_cast<const float4*>(src);                                                \
+    }
+#define SD_LOAD_X(i)                                                                                  \
+    {                                                                                                 \
+        const int m = ld_m + xrow##i;                                                                 \
+        const int iy = pxy##i * p.stride - p.pad + r, ix = pxx##i * p.stride - p.pad + s;             \
+        const bool ok = m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;  \
+        const float* src = ok ? p.x + ((((int64_t)pxb##i * p.Hi + iy) * p.Wi + ix) * p.Ck + c0 + xcol##i) : g_zero_line; \
+        rx##i = *reinterpret_cast<const float4*>(src);                                                \
+        pxx##i += PK;                                                                                 \
+        while (pxx##i >= p.Wo) { pxx##i -= p.Wo; if (++pxy##i >= p.Ho) { pxy##i = 0; ++pxb##i; } }    \
+    }
+#define SD_LOAD_CHUNK()                                                                               \
+    SD_LOAD_D(0) SD_LOAD_D(1) if (DV == 4) { SD_LOAD_D(2) SD_LOAD_D(3) }                              \
+    SD_LOAD_X(0) SD_LOAD_X(1) if (XV == 4) { SD_LOAD_X(2) SD_LOAD_X(3) }                              \
+    ld_m += PK;
+#define SD_STORE_CHUNK(buf)                                                                           \
+    {                                                                                                 \
+        float* dd = Ds + (buf) * PK * LDN;                                                            \
+        *reinterpret_cast<float4*>(dd + drow0 * LDN + dcol0) = rd0;                                   \
+        *reinterpret_cast<float4*>(dd + drow1 * LDN + dcol1) = rd1;                                   \
+        if (DV == 4) {                                                                                \
+            *reinterpret_cast<float4*>(dd + drow2 * LDN + dcol2) = rd2;                               \
+            *reinterpret_cast<float4*>(dd + drow3 * LDN + dcol3) = rd3;                               \
+        }                                                                                             \
+        float* xd = Xs + (buf) * PK * LDC;                                                            \
+        *reinterpret_cast<float4*>(xd + xrow0 * LDC + xcol0) = rx0;                                   \
+        *reinterpret_cast<float4*>(xd + xrow1 * LDC + xcol1) = rx1;                                   \
+        if (XV == 4) {                                                                                \
+            *reinterpret_cast<float4*>(xd + xrow2 * LDC + xcol2) = rx2;                               \
+            *reinterpret_cast<float4*>(xd + xrow3 * LDC + xcol3) = rx3;                               \
+        }                                                                                             \
+    }
 
     const int wn0 = (wave >> 1) * (TN / 2), wc0 = (wave & 1) * (TC / 2);
     const int fr = lane & 31, fh = lane >> 5;
@@ -284,30 +367,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
 
     const int nchunks = (m_end - m_beg + PK - 1) / PK;
     if (nchunks > 0) {
-        load_chunk(m_beg);
-        store_chunk(0);
+        SD_LOAD_CHUNK()
+        SD_STORE_CHUNK(0)
     }
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunks) load_chunk(m_beg + (ch + 1) * PK);
+        if (ch + 1 < nchunks) { SD_LOAD_CHUNK() }
         const float* Db = Ds + cur * PK * LDN + wn0 + fr;
         const float* Xb = Xs + cur * PK * LDC + wc0 + fr;
 #pragma unroll
         for (int kk = 0; kk < PK / 2; ++kk) {
-            float a[NT], b[CT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) a[i] = Db[(2 * kk + fh) * LDN + i * 32];
-#pragma unroll
-            for (int j = 0; j < CT; ++j) b[j] = Xb[(2 * kk + fh) * LDC + j * 32];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            const float a0 = Db[(2 * kk + fh) * LDN];
+            const float a1 = (NT == 2) ? Db[(2 * kk + fh) * LDN + 32] : a0;
+            const float b0 = Xb[(2 * kk + fh) * LDC];
+            const float b1 = (CT == 2) ? Xb[(2 * kk + fh) * LDC + 32] : b0;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            if (CT == 2) acc[0][CT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][CT - 1], 0, 0, 0);
+            if (NT == 2) acc[NT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[NT - 1][0], 0, 0, 0);
+            if (NT == 2 && CT == 2) acc[NT - 1][CT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[NT - 1][CT - 1], 0, 0, 0);
         }
-        if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+        if (ch + 1 < nchunks) { SD_STORE_CHUNK(cur ^ 1) }
         __syncthreads();
     }
+#undef SD_LOAD_D
+#undef SD_LOAD_X
+#undef SD_LOAD_CHUNK
+#undef SD_STORE_CHUNK
     // D[n][c]: row index (m of the MFMA) = n, column (lane&31) = c  -> contiguous c per half-wave
     float* out = p.part + (int64_t)split * p.Nn * p.R * p.S * p.Ck;
 #pragma unroll
@@ -321,7 +407,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
                 out[((int64_t)n * p.R * p.S + tap) * p.Ck + c] = acc[i][j][e];
             }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Stem weight gradient: dW[co][k] = sum_m dY[m][co] * patch[m][k], k = (r*7+s)*3 + ci (147 -> 160),
@@ -440,21 +525,30 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w
     }
 }
 
+template <int BN, int MODE>
+static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
+    static bool attr = false;              // one flag per instantiation
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv_igemm<BN, MODE>), dim3(tiles), dim3(256), lds, st, a);
+}
+
 static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-    if (stem) {
-        hipLaunchKernelGGL((k_conv_igemm<64, true>), dim3(tiles), dim3(256), lds, st, a);
-    } else if (BN == 128) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        hipLaunchKernelGGL((k_conv_igemm<128, false>), dim3(tiles), dim3(256), lds, st, a);
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
+    const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
+    if (mode == 1) launch_one<64, 1>(a, tiles, lds, st);
+    else if (BN == 128) {
+        if (mode == 0) launch_one<128, 0>(a, tiles, lds, st);
+        else if (mode == 2) launch_one<128, 2>(a, tiles, lds, st);
+        else launch_one<128, 3>(a, tiles, lds, st);
     } else {
-        hipLaunchKernelGGL((k_conv_igemm<64, false>), dim3(tiles), dim3(256), lds, st, a);
+        if (mode == 0) launch_one<64, 0>(a, tiles, lds, st);
+        else if (mode == 2) launch_one<64, 2>(a, tiles, lds, st);
+        else launch_one<64, 3>(a, tiles, lds, st);
     }
     SD_LAUNCH_CHECK();
     return 0;
@@ -517,6 +611,7 @@ int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_
     a.B = d->B; a.Hi = d->Ho; a.Wi = d->Wo; a.Ck = d->Cout; a.Ho = d->Hi; a.Wo = d->Wi; a.Nn = d->Cin; a.R = d->R; a.S = d->S;
     a.mul = 1; a.div = d->stride; a.off = d->pad; a.rsign = -1;
     a.M = d->B * d->Hi * d->Wi; a.kchunks = d->Cout / BK; a.nk = d->R * d->S * a.kchunks;
+    a.par = (d->stride == 2 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && (a.M / 4) % BM == 0) ? 1 : 0;
     return launch_igemm(a, false, (hipStream_t)stream);
 }
 

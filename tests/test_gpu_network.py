@@ -58,6 +58,8 @@ CONV_CASES = [  # B, H, W, cin, cout, k, stride, pad
     (2, 12, 12, 64, 128, 1, 2, 0),
     (1, 6, 10, 512, 128, 1, 1, 0),
     (2, 9, 7, 256, 256, 3, 1, 1),      # odd sizes: ragged last tile (M = 126)
+    (2, 32, 32, 64, 128, 3, 2, 1),     # stride-2 dgrad through the parity-class path (M/4 % 128 == 0)
+    (2, 32, 32, 64, 128, 1, 2, 0),     # 1x1/2 downsample: three of the four parity classes have no tap at all
 ]
 
 
