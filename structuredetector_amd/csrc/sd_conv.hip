@@ -214,12 +214,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         if (kc + 1 < nk) { SD_LOAD_CHUNK() }
         const float* Ab = As + (cur * BM + wm0 + fr) * LDK + fh * 4;
         const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK + fh * 4;
+        float4 na0 = *reinterpret_cast<const float4*>(Ab), na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK);
+        float4 nb0 = *reinterpret_cast<const float4*>(Bb), nb1 = nb0;
+        if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK);
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
-            const float4 a0 = *reinterpret_cast<const float4*>(Ab + ks * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + ks * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(Bb + ks * 8);
-            const float4 b1 = (NT == 2) ? *reinterpret_cast<const float4*>(Bb + 32 * LDK + ks * 8) : b0;
+            const float4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+            if (ks + 1 < BK / 8) {             // fragments of the next k-group are read while this group's MFMAs run
+                na0 = *reinterpret_cast<const float4*>(Ab + (ks + 1) * 8);
+                na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + (ks + 1) * 8);
+                nb0 = *reinterpret_cast<const float4*>(Bb + (ks + 1) * 8);
+                if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + (ks + 1) * 8);
+            }
             // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -317,6 +323,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
 #undef SD_DSLOT
 #undef SD_XSLOT
     int ld_m = m_beg;                               // chunks are visited strictly in order
+    // one chunk = PK pixels further, decomposed once into (images, rows, columns): branch-free stepping
+    const int adv_b = PK / (p.Wo * p.Ho), adv_r = PK - adv_b * p.Wo * p.Ho;
+    const int adv_y = adv_r / p.Wo, adv_x = adv_r - adv_y * p.Wo;
 #define SD_LOAD_D(i)                                                                                  \
     {                                                                                                 \
         const int m = ld_m + drow##i;                                                                 \
@@ -330,8 +339,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
         const bool ok = m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;  \
         const float* src = ok ? p.x + ((((int64_t)pxb##i * p.Hi + iy) * p.Wi + ix) * p.Ck + c0 + xcol##i) : g_zero_line; \
         rx##i = *reinterpret_cast<const float4*>(src);                                                \
-        pxx##i += PK;                                                                                 \
-        while (pxx##i >= p.Wo) { pxx##i -= p.Wo; if (++pxy##i >= p.Ho) { pxy##i = 0; ++pxb##i; } }    \
+        pxx##i += adv_x; pxy##i += adv_y; pxb##i += adv_b;                                            \
+        { const bool wx = pxx##i >= p.Wo; pxx##i -= wx ? p.Wo : 0; pxy##i += wx ? 1 : 0; }            \
+        { const bool wy = pxy##i >= p.Ho; pxy##i -= wy ? p.Ho : 0; pxb##i += wy ? 1 : 0; }            \
     }
 #define SD_LOAD_CHUNK()                                                                               \
     SD_LOAD_D(0) SD_LOAD_D(1) if (DV == 4) { SD_LOAD_D(2) SD_LOAD_D(3) }                              \
@@ -376,16 +386,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
         if (ch + 1 < nchunks) { SD_LOAD_CHUNK() }
         const float* Db = Ds + cur * PK * LDN + wn0 + fr;
         const float* Xb = Xs + cur * PK * LDC + wc0 + fr;
+        // fragments of step kk+1 are read while the MFMAs of step kk run
+        float na0 = Db[fh * LDN], na1 = (NT == 2) ? Db[fh * LDN + 32] : 0.f;
+        float nb0 = Xb[fh * LDC], nb1 = (CT == 2) ? Xb[fh * LDC + 32] : 0.f;
 #pragma unroll
         for (int kk = 0; kk < PK / 2; ++kk) {
-            const float a0 = Db[(2 * kk + fh) * LDN];
-            const float a1 = (NT == 2) ? Db[(2 * kk + fh) * LDN + 32] : a0;
-            const float b0 = Xb[(2 * kk + fh) * LDC];
-            const float b1 = (CT == 2) ? Xb[(2 * kk + fh) * LDC + 32] : b0;
+            const float a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+            if (kk + 1 < PK / 2) {
+                na0 = Db[(2 * kk + 2 + fh) * LDN];
+                if (NT == 2) na1 = Db[(2 * kk + 2 + fh) * LDN + 32];
+                nb0 = Xb[(2 * kk + 2 + fh) * LDC];
+                if (CT == 2) nb1 = Xb[(2 * kk + 2 + fh) * LDC + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this step's MFMAs (hipcc sinks them otherwise)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             if (CT == 2) acc[0][CT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][CT - 1], 0, 0, 0);
             if (NT == 2) acc[NT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[NT - 1][0], 0, 0, 0);
             if (NT == 2 && CT == 2) acc[NT - 1][CT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[NT - 1][CT - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ch + 1 < nchunks) { SD_STORE_CHUNK(cur ^ 1) }
         __syncthreads();
@@ -623,10 +641,21 @@ int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, 
 }
 
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
+    // Pick the split count so that tiles*splits fills whole "rounds" of the chip (256 CUs x 2 resident 128x128
+    // blocks, x4 for the 64x64 tile): a last round that is mostly empty costs as much as a full one.
     const int M = d->B * d->Ho * d->Wo;
-    int s = (2 * 256 + tiles - 1) / tiles;                 // aim at >= 2 blocks per CU
-    s = std::max(1, std::min(s, cdiv(M, 256)));           // at least 256 pixels per split
-    return s;
+    const bool small = (d->Cout % 128 != 0) && (d->Cin % 128 != 0);
+    const int slots = 256 * (small ? 4 : 2);
+    const int max_s = std::max(1, cdiv(M, 512));           // at least 512 pixels (16 chunks) per split
+    int best_s = 1;
+    double best_fill = 0.0;
+    for (int k = 1; k <= 4; ++k) {
+        int s = std::min(std::max(1, k * slots / tiles), max_s);
+        const int rounds = cdiv(tiles * s, slots);
+        const double fill = (double)tiles * s / ((double)rounds * slots);
+        if (fill > best_fill + 0.03) { best_fill = fill; best_s = s; }
+    }
+    return best_s;
 }
 
 size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d) {
