@@ -212,7 +212,7 @@ int sd_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, i
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream);
 
 /* Head (network.py:22-29): 1x1 conv C -> Co with bias; NHWC in, NCHW out (the layout the decoder
- * and the loss consume).  Co <= 16. */
+ * and the loss consume).  Co <= 32. */
 int sd_head_fwd(const float* x_nhwc, const float* w, const float* bias, float* y_nchw, int B, int HW, int C, int Co,
                 sd_stream_t stream);
 size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co);

@@ -80,21 +80,32 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
                                                        float momentum, float* __restrict__ out0, float* __restrict__ out1,
                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
                                                        float* __restrict__ aux0, float* __restrict__ aux1, int accumulate) {
-    // 32 channels x 8 lanes over the partial blocks per workgroup; fixed order -> deterministic
-    __shared__ double r0[8][32], r1[8][32];
-    const int lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + lc;
+    // 8 channels x 32 lanes over the partial blocks per workgroup, 4 loads in flight per lane; fixed order -> deterministic
+    __shared__ double r0[32][8], r1[32][8];
+    const int lc = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + lc;
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-        for (int b = lr; b < nblocks; b += 8) {
-            s0 += (double)partial[(int64_t)b * 2 * C + c];
-            s1 += (double)partial[(int64_t)b * 2 * C + C + c];
+        double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+        int b = lr;
+        for (; b + 96 < nblocks; b += 128) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t0[u] += (double)partial[(int64_t)(b + 32 * u) * 2 * C + c];
+                t1[u] += (double)partial[(int64_t)(b + 32 * u) * 2 * C + C + c];
+            }
         }
+        for (; b < nblocks; b += 32) {
+            t0[0] += (double)partial[(int64_t)b * 2 * C + c];
+            t1[0] += (double)partial[(int64_t)b * 2 * C + C + c];
+        }
+        s0 = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+        s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
     }
     r0[lr][lc] = s0; r1[lr][lc] = s1;
     __syncthreads();
     if (lr != 0 || c >= C) return;
-    for (int k = 1; k < 8; ++k) { s0 += r0[k][lc]; s1 += r1[k][lc]; }
+    for (int k = 1; k < 32; ++k) { s0 += r0[k][lc]; s1 += r1[k][lc]; }
     if (FIN == 0) {
         const double mean = s0 / M;
         const double var = fmax(s1 / M - mean * mean, 0.0);             // biased variance (normalisation)
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256) void k_up2_bwd(const float* __restrict__ dy, c
 // 4-float row pad (ds_read_b128 conflict-free), then thread (pixel, group) accumulates its
 // outputs with wave-uniform (broadcast) weight reads.  HBM-bound: AI ~ 3 flop/B.
 // ------------------------------------------------------------------------------------------
-constexpr int HEAD_MAX_CO = 16;
+constexpr int HEAD_MAX_CO = 32;
 
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                    float* __restrict__ y, int64_t M, int HW, int C, int Co) {
@@ -456,7 +467,7 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
                        mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
     SD_LAUNCH_CHECK();
     return 0;
@@ -493,7 +504,7 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
     float* mgx = mg + C;
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, relu, M, C, partial);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
@@ -512,7 +523,7 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
     hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     SD_LAUNCH_CHECK();
     return 0;

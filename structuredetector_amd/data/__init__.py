@@ -1,3 +1,3 @@
-from .dataset import collate_fn
+from .dataset import CropDataset, collate_fn
 from .decoders import Decoder
 from .transforms import Encode

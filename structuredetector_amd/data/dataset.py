@@ -11,3 +11,39 @@ def collate_fn(elements):
     batch = {k: torch.stack([e[k] for e in elements], dim=0) for k in _TENSOR_KEYS}
     batch["annotation"] = [e["annotation"] for e in elements]
     return batch
+
+
+# ---------------------------------------------------------------------------------------------
+# Minimal directory reader (callers of the hot path; SURVEY.md 8f-2 marks the full augmentation pipeline "next").
+# Same on-disk format as the reference's CropDataset (src/sdnet/data/dataset.py:13-49): one JSON per image
+# with {"image_path", "img_size", "objects": [...]}; images are resized to (width, height) and normalised with
+# the ImageNet statistics (ValidationAugmentation, src/sdnet/data/transforms.py:255-261).  No flips / jitter.
+# ---------------------------------------------------------------------------------------------
+_MEAN = (0.485, 0.456, 0.406)
+_STD = (0.229, 0.224, 0.225)
+
+
+class CropDataset:
+    def __init__(self, args, directories):
+        from pathlib import Path
+        dirs = [directories] if isinstance(directories, (str, Path)) else list(directories)
+        self.args = args
+        self.files = sorted(f for d in dirs for f in Path(d).iterdir() if f.suffix == ".json")
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, index):
+        import numpy as np
+        from PIL import Image
+
+        from ..utils.types import ImageAnnotation
+        ann = ImageAnnotation.from_json(self.files[index], self.args.anchor_name)
+        path = ann.image_path if ann.image_path.is_absolute() else self.files[index].parent / ann.image_path.name
+        img = Image.open(path).convert("RGB")
+        ann.img_size = img.size
+        W, H = self.args.width, self.args.height
+        ann.resize(img.size, (W, H))                                   # Resize transform, transforms.py:47-60
+        arr = np.asarray(img.resize((W, H), Image.BILINEAR), np.float32) / 255.0
+        arr = (arr - np.asarray(_MEAN, np.float32)) / np.asarray(_STD, np.float32)
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous(), ann

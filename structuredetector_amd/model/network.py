@@ -387,8 +387,8 @@ class Network(nn.Module):
         self.fpn_depth = args.fpn_depth
         if self.fpn_depth % 64:
             raise L.SdError("fpn_depth must be a multiple of 64 for the MFMA tiles")
-        if self.out_channels > 16:
-            raise L.SdError("labels + parts + 4 must be <= 16 (head kernel limit)")
+        if self.out_channels > 32:
+            raise L.SdError("labels + parts + 4 must be <= 32 (head kernel limit)")
 
         self.adpater = nn.Sequential(ConvParams(3, 64, 7, 2, 3), BNParams(64), Slot(), Slot())   # sic (network.py:43)
         self.down1 = _layer(64, 64, 3, 1)

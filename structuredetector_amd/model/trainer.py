@@ -76,3 +76,71 @@ class StepLR:
     def step(self):
         self.epoch += 1
         self.step_obj.lr = self.base * self.gamma ** (self.epoch // self.step_size)
+
+
+class Trainer:
+    """Epoch loop around TrainStep with the reference's knobs (src/sdnet/model/trainer.py:23-135): Adam(lr),
+    StepLR(step_size=args.lr_step), `model_best_loss.pth` checkpoints in trainings/<timestamp>/.  Data: a
+    directory of JSON+image samples (no augmentation) or `--synthetic N` seeded scenes rendered on the GPU.
+    TensorBoard logging, the Evaluator-based checkpoints and the PIL augmentations are outside the hot path."""
+
+    def __init__(self, args):
+        from datetime import datetime
+        from pathlib import Path
+
+        import numpy as np
+
+        from ..data import CropDataset, Encode
+        from .network import Network
+        self.args = args
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.net = Network(args, pretrained=True)
+        if args.pretrained_model:
+            self.net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu"))
+        self.net.to(args.device).train()
+        self.step = TrainStep(self.net, args, lr=args.learning_rate)
+        self.step.sync_parameters()
+        self.scheduler = StepLR(self.step, args.lr_step)
+        self.encode = Encode(args)
+        self.rng = np.random.default_rng(926354916 + self.rank)
+        self.dataset = None if args.synthetic else CropDataset(args, args.train_dir)
+        self.save_dir = Path("trainings") / f"{datetime.now():%Y-%m-%d_%H-%M-%S}"
+        self.best_loss = float("inf")
+
+    def batches(self):
+        a, B = self.args, self.args.batch_size
+        world = self.step.world
+        if a.synthetic:
+            from ..data.synthetic import synthetic_batch
+            gen = torch.Generator(device=a.device).manual_seed(926354916 + self.rank)
+            for _ in range(max(a.synthetic // (B * world), 1)):
+                flat = synthetic_batch(self.rng, B, a.width, a.height, len(a.labels), len(a.parts))
+                images = torch.randn(B, 3, a.height, a.width, device=a.device, generator=gen)
+                yield images, self.encode.render(self.encode.plan(a.width, a.height, *flat), a.device)
+        else:
+            order = self.rng.permutation(len(self.dataset))[self.rank::world]
+            for i in range(0, len(order) - B + 1, B):                  # drop_last=True, trainer.py:69
+                items = [self.dataset[int(j)] for j in order[i:i + B]]
+                images = torch.stack([im for im, _ in items]).to(a.device, non_blocking=True)
+                yield images, self.encode.batch((a.width, a.height), [an for _, an in items], a.device)
+
+    def train(self):
+        steps = 0
+        for epoch in range(self.args.epochs):
+            running, n = torch.zeros(4, device=self.args.device), 0
+            for images, targets in self.batches():
+                running += self.step(images, targets)
+                n += 1; steps += 1
+                if self.args.steps and steps >= self.args.steps:
+                    break
+            mean = (running / max(n, 1)).tolist()                      # one host sync per epoch
+            if self.rank == 0:
+                print(f"epoch {epoch}: total {mean[0]:.5f} hm {mean[1]:.5f} offset {mean[2]:.5f} embedding {mean[3]:.5f} "
+                      f"lr {self.step.lr:g} ({n} steps)", flush=True)
+                if mean[0] < self.best_loss:
+                    self.best_loss = mean[0]
+                    self.save_dir.mkdir(parents=True, exist_ok=True)
+                    self.net.save(self.save_dir / "model_best_loss.pth")
+            self.scheduler.step()
+            if self.args.steps and steps >= self.args.steps:
+                break
