@@ -126,23 +126,54 @@ __global__ __launch_bounds__(256) void k_dense_keys(const float* __restrict__ sc
 //                   key, collect the k keys >= it, bitonic sort those.
 // Slots beyond min(n,k) are left as key 0 (filled by the caller).
 // ---------------------------------------------------------------------------------------------
-constexpr int SEL_THREADS = 512;
+constexpr int SEL_THREADS = 512;      // threads of one selection "team" (8 waves)
 constexpr int SORT_CAP = 4096;
 
-__device__ __forceinline__ void bitonic_desc(uint64_t* buf, int npow2) {
-    const int tid = threadIdx.x;
-    for (int k = 2; k <= npow2; k <<= 1) {
+// One team = SEL_THREADS threads working on one candidate list.  k_select_group runs two teams in one
+// 1024-thread block (anchors and parts side by side): every team executes the SAME sequence of block barriers
+// (the sequence depends only on `np2` / `use_radix`, which the caller makes identical for both teams).
+struct Team {
+    int tid;            // 0 .. SEL_THREADS-1 inside the team
+    uint64_t* buf;      // [SORT_CAP]
+    int* hist;          // [256]
+    int* misc;          // [4]
+    int* flags;         // [SD_MAX_TOPK]
+};
+
+// In-place descending bitonic sort of buf[0..np2).  Each wave owns a contiguous range of R elements; stages
+// whose compare distance stays inside a range need no block barrier (LDS operations of one wave execute in
+// order), only the few long-distance stages synchronise the whole block: 6 instead of 66 barriers for 2048 keys.
+__device__ void bitonic_desc(const Team& T, int np2) {
+    const int lane = T.tid & 63, wave = T.tid >> 6;
+    const int R = max(np2 >> 3, 128);                 // elements per wave range
+    const int half_pairs = min(R, np2) >> 1;          // compare-exchange pairs per range and stage
+    const bool active = wave * R < np2;
+    bool local_dirty = false;                         // wave-local stages since the last block barrier
+    for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (npow2 >> 1); t += SEL_THREADS) {
-                const int i = 2 * t - (t & (j - 1));
-                const int l = i + j;
-                const uint64_t a = buf[i], bb = buf[l];
-                const bool desc = ((i & k) == 0);
-                if ((a < bb) == desc) { buf[i] = bb; buf[l] = a; }
+            if (2 * j <= R) {                         // partner inside the wave's own range
+                if (active) {
+                    const int base = wave * R;
+                    for (int t = lane; t < half_pairs; t += 64) {
+                        const int i = base + 2 * t - (t & (j - 1)), l = i + j;
+                        const uint64_t a = T.buf[i], bb = T.buf[l];
+                        if ((a < bb) == ((i & k) == 0)) { T.buf[i] = bb; T.buf[l] = a; }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-level ordering of the LDS traffic
+                local_dirty = true;
+            } else {
+                if (local_dirty) { __syncthreads(); local_dirty = false; }
+                for (int t = T.tid; t < (np2 >> 1); t += SEL_THREADS) {
+                    const int i = 2 * t - (t & (j - 1)), l = i + j;
+                    const uint64_t a = T.buf[i], bb = T.buf[l];
+                    if ((a < bb) == ((i & k) == 0)) { T.buf[i] = bb; T.buf[l] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ int next_pow2(int v) {
@@ -151,75 +182,79 @@ __device__ __forceinline__ int next_pow2(int v) {
     return p;
 }
 
-__device__ void block_select_topk(const uint64_t* __restrict__ cand, int n, int k, uint64_t* buf, int* hist, int* misc) {
-    const int tid = threadIdx.x;
-    if (n <= SORT_CAP) {
-        const int np2 = max(next_pow2(max(n, k)), 2);
-        for (int i = tid; i < np2; i += SEL_THREADS) buf[i] = (i < n) ? cand[i] : 0ull;
+// Exact top-k of n unique keys (descending) into T.buf[0..k).  use_radix / np2 are team-uniform AND identical for
+// all teams of the block.  !use_radix: n <= SORT_CAP, everything is sorted in LDS (np2 >= max(n, k)).
+// use_radix: MSB-first 8-bit radix select over the global list finds the k-th largest key, the k keys >= it are
+// collected and sorted (np2 >= k).  Slots beyond min(n, k) are left as key 0 (filled by the caller).
+__device__ void team_select_topk(const Team& T, const uint64_t* __restrict__ cand, int n, int k, bool use_radix, int np2) {
+    const int tid = T.tid;
+    if (!use_radix) {
+        for (int i = tid; i < np2; i += SEL_THREADS) T.buf[i] = (i < n) ? cand[i] : 0ull;
         __syncthreads();
-        bitonic_desc(buf, np2);
+        bitonic_desc(T, np2);
         return;
     }
-    // radix select: after the loop `prefix` (under `mask`) identifies the k-th largest key.
     uint64_t prefix = 0, mask = 0;
-    int remaining = k;
+    int remaining = min(k, n);
     for (int pass = 7; pass >= 0; --pass) {
-        for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+        for (int i = tid; i < 256; i += SEL_THREADS) T.hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
         for (int i = tid; i < n; i += SEL_THREADS) {
             const uint64_t key = cand[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+            if ((key & mask) == prefix) atomicAdd(&T.hist[(int)((key >> shift) & 255ull)], 1);
         }
         __syncthreads();
         if (tid == 0) {
             int acc = 0, d = 255;
             for (; d > 0; --d) {
-                if (acc + hist[d] >= remaining) break;
-                acc += hist[d];
+                if (acc + T.hist[d] >= remaining) break;
+                acc += T.hist[d];
             }
-            misc[0] = d;
-            misc[1] = remaining - acc;   // how many keys to take inside digit d
+            T.misc[0] = d;
+            T.misc[1] = remaining - acc;   // how many keys to take inside digit d
         }
         __syncthreads();
-        prefix |= (uint64_t)misc[0] << shift;
+        prefix |= (uint64_t)T.misc[0] << shift;
         mask |= 255ull << shift;
-        remaining = misc[1];
+        remaining = T.misc[1];
         __syncthreads();
     }
-    // keys are unique, so exactly k keys are >= prefix
-    const int np2 = max(next_pow2(k), 2);
-    for (int i = tid; i < np2; i += SEL_THREADS) buf[i] = 0ull;
-    if (tid == 0) misc[2] = 0;
+    // keys are unique, so exactly min(k, n) keys are >= prefix
+    for (int i = tid; i < np2; i += SEL_THREADS) T.buf[i] = 0ull;
+    if (tid == 0) T.misc[2] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += SEL_THREADS) {
         const uint64_t key = cand[i];
         if (key >= prefix) {
-            const int slot = atomicAdd(&misc[2], 1);
-            if (slot < np2) buf[slot] = key;
+            const int slot = atomicAdd(&T.misc[2], 1);
+            if (slot < np2) T.buf[slot] = key;
         }
     }
     __syncthreads();
-    bitonic_desc(buf, np2);
+    bitonic_desc(T, np2);
 }
 
-// Suppressed pixels have score exactly 0; when fewer than k peaks exist the reference's
-// remaining top-k slots are zeros (utils.py:451 on the NMS'ed map).  Fill them with the lowest
-// class-major flat indices that are not peaks (stable order).
-__device__ void fill_zero_slots(uint64_t* buf, int npos, int k, int* flags) {
-    const int tid = threadIdx.x;
-    if (npos >= k) return;
-    for (int f = tid; f < k; f += SEL_THREADS) {
-        int used = 0;
-        for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~buf[j]) == (uint32_t)f);
-        flags[f] = used ? 0 : 1;
+// Suppressed pixels have score exactly 0; when fewer than k peaks exist the reference's remaining top-k slots
+// are zeros (utils.py:451 on the NMS'ed map).  Fill them with the lowest class-major flat indices that are not
+// peaks (stable order).  Always executes two block barriers (team-uniform control flow).
+__device__ void fill_zero_slots(const Team& T, int npos, int k) {
+    const int tid = T.tid;
+    if (npos < k) {
+        for (int f = tid; f < k; f += SEL_THREADS) {
+            int used = 0;
+            for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~T.buf[j]) == (uint32_t)f);
+            T.flags[f] = used ? 0 : 1;
+        }
     }
     __syncthreads();
-    for (int f = tid; f < k; f += SEL_THREADS) {
-        if (!flags[f]) continue;
-        int rank = 0;
-        for (int j = 0; j < f; ++j) rank += flags[j];
-        if (npos + rank < k) buf[npos + rank] = make_key(0.0f, (uint32_t)f);
+    if (npos < k) {
+        for (int f = tid; f < k; f += SEL_THREADS) {
+            if (!T.flags[f]) continue;
+            int rank = 0;
+            for (int j = 0; j < f; ++j) rank += T.flags[j];
+            if (npos + rank < k) T.buf[npos + rank] = make_key(0.0f, (uint32_t)f);
+        }
     }
     __syncthreads();
 }
@@ -242,8 +277,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_peaks(const uint64_t* __
     __shared__ int flags[SD_MAX_TOPK];
     const int b = blockIdx.x;
     const int n = counters ? counters[b * counter_stride] : fixed_n;
-    block_select_topk(cand + (int64_t)b * cap, n, k, buf, hist, misc);
-    if (do_fill) fill_zero_slots(buf, min(n, k), k, flags);
+    const Team T{(int)threadIdx.x, buf, hist, misc, flags};
+    const bool use_radix = n > SORT_CAP;
+    const int np2 = max(next_pow2(use_radix ? k : max(n, k)), 2);
+    team_select_topk(T, cand + (int64_t)b * cap, n, k, use_radix, np2);
+    if (do_fill) fill_zero_slots(T, min(n, k), k);
     for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
         const uint64_t key = buf[i];
         const uint32_t flat = ~(uint32_t)key;
@@ -301,7 +339,7 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
     const int tid = threadIdx.x;
     const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
     const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
-    for (int a = tid; a < K; a += SEL_THREADS) {
+    for (int a = tid; a < K; a += (int)blockDim.x) {
         const int ind = ai_[a];
         const int y = ind / w, x = ind - y * w;
         const float score = as_[a];
@@ -316,7 +354,7 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         L.anchor_ind[(int64_t)b * K + a] = ind;
     }
     __syncthreads();
-    for (int p = tid; p < P; p += SEL_THREADS) {
+    for (int p = tid; p < P; p += (int)blockDim.x) {
         const int ind = pi_[p];
         const int y = ind / w, x = ind - y * w;
         const float score = ps_[p];
@@ -344,37 +382,37 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
     }
 }
 
-// fused: select anchors, select parts, associate (2nd and last launch of sd_decode)
-__global__ __launch_bounds__(SEL_THREADS) void k_select_group(const uint64_t* __restrict__ cand0, const uint64_t* __restrict__ cand1,
-                                                               const int* __restrict__ counters, int M, int N, int h, int w,
-                                                               int K, int P, float conf, float dist_px, RegMaps rm,
-                                                               void* packed, int B) {
-    __shared__ uint64_t buf[SORT_CAP];
-    __shared__ int hist[256];
-    __shared__ int misc[4];
-    __shared__ int flags[SD_MAX_TOPK];
+// fused: select anchors and parts side by side (two teams), then associate (2nd and last launch of sd_decode)
+__global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t* __restrict__ cand0, const uint64_t* __restrict__ cand1,
+                                                                   const int* __restrict__ counters, int M, int N, int h, int w,
+                                                                   int K, int P, float conf, float dist_px, RegMaps rm,
+                                                                   void* packed, int B) {
+    __shared__ uint64_t buf[2][SORT_CAP];
+    __shared__ int hist[2][256];
+    __shared__ int misc[2][4];
+    __shared__ int flags[2][SD_MAX_TOPK];
     __shared__ float as_[SD_MAX_TOPK], ps_[SD_MAX_TOPK], posx[SD_MAX_TOPK], posy[SD_MAX_TOPK];
     __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
-    const int b = blockIdx.x, tid = threadIdx.x, hw = h * w;
+    const int b = blockIdx.x, hw = h * w;
+    const int team = threadIdx.x >> 9, tid = threadIdx.x & (SEL_THREADS - 1);
+    const Team T{tid, buf[team], hist[team], misc[team], flags[team]};
 
-    int n = counters[b * 2 + 0];
-    block_select_topk(cand0 + (int64_t)b * M * hw, n, K, buf, hist, misc);
-    fill_zero_slots(buf, min(n, K), K, flags);
-    for (int i = tid; i < K; i += SEL_THREADS) {
-        const uint64_t key = buf[i];
+    const int n0 = counters[b * 2 + 0], n1 = counters[b * 2 + 1];
+    // identical barrier sequence for both teams: the path and the sort size come from the larger list
+    const bool use_radix = max(n0, n1) > SORT_CAP;
+    const int np2 = max(next_pow2(use_radix ? max(K, P) : max(max(n0, n1), max(K, P))), 2);
+    const int n = team ? n1 : n0, k = team ? P : K;
+    const uint64_t* cand = team ? cand1 + (int64_t)b * N * hw : cand0 + (int64_t)b * M * hw;
+    team_select_topk(T, cand, n, k, use_radix, np2);
+    fill_zero_slots(T, min(n, k), k);
+    float* os = team ? ps_ : as_;
+    int* oi = team ? pi_ : ai_;
+    int* oc = team ? pc_ : ac_;
+    for (int i = tid; i < k; i += SEL_THREADS) {
+        const uint64_t key = T.buf[i];
         const uint32_t flat = ~(uint32_t)key;
         const int cls = flat / hw;
-        as_[i] = ord2f((uint32_t)(key >> 32)); ai_[i] = flat - cls * hw; ac_[i] = cls;
-    }
-    __syncthreads();
-    n = counters[b * 2 + 1];
-    block_select_topk(cand1 + (int64_t)b * N * hw, n, P, buf, hist, misc);
-    fill_zero_slots(buf, min(n, P), P, flags);
-    for (int i = tid; i < P; i += SEL_THREADS) {
-        const uint64_t key = buf[i];
-        const uint32_t flat = ~(uint32_t)key;
-        const int cls = flat / hw;
-        ps_[i] = ord2f((uint32_t)(key >> 32)); pi_[i] = flat - cls * hw; pc_[i] = cls;
+        os[i] = ord2f((uint32_t)(key >> 32)); oi[i] = flat - cls * hw; oc[i] = cls;
     }
     __syncthreads();
     const PackedLayout L = packed_layout(packed, B, K, P);
@@ -589,7 +627,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
                        ws.cand0, ws.cand1, ws.counters);
     SD_LAUNCH_CHECK();
     RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
-    hipLaunchKernelGGL(k_select_group, dim3(B), dim3(SEL_THREADS), 0, st, ws.cand0, ws.cand1, ws.counters, M, N, h, w, K, P, conf,
+    hipLaunchKernelGGL(k_select_group, dim3(B), dim3(2 * SEL_THREADS), 0, st, ws.cand0, ws.cand1, ws.counters, M, N, h, w, K, P, conf,
                        dist_px, rm, packed, B);
     SD_LAUNCH_CHECK();
     return 0;
