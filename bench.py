@@ -174,6 +174,16 @@ def main():
         extra["fwd_eval_ms_bs%d" % B] = round(fwd * 1e3, 3)
         extra["fwd_eval_tflops"] = round(B * FWD_GFLOP_PER_IMG / fwd / 1e3, 2)
         extra["fwd_eval_frac_of_mfma_peak"] = round(B * FWD_GFLOP_PER_IMG / fwd / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
+        # BASELINE configs[1]: bs=1 inference latency (split-K convs fill the chip at small M)
+        with torch.no_grad():
+            x1 = images[:1].contiguous()
+            for _ in range(3):
+                net(x1)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(10):
+                o1 = net(x1)
+            torch.cuda.synchronize()
+            extra["fwd_eval_ms_bs1"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
         dec = Decoder(args)
         tgt = enc.render_device(plans[0])
         hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
@@ -196,6 +206,11 @@ def main():
         for _ in range(20):
             dec(one)
         extra["decode_e2e_us_per_img_bs1"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)   # 2 launches + D2H + host assembly
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dec(net(x1))
+            extra["infer_e2e_ms_per_img_bs1"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)     # forward + decode + host objects
         net.train()
 
     if rank == 0:

@@ -164,10 +164,12 @@ typedef struct sd_conv_desc {
 
 /* y = [relu]( conv(x, w) * scale[co] + shift[co] [+ residual] ), fp32 MFMA implicit GEMM.
  * scale/shift/residual nullable.  res_up2: residual is the (Ho/2, Wo/2) map, nearest-upsampled x2
- * (Fpn.forward, network.py:18-19).  Needs Cin % 32 == 0, Cout % 64 == 0. */
+ * (Fpn.forward, network.py:18-19).  Needs Cin % 32 == 0, Cout % 64 == 0.  When the tile grid cannot fill
+ * the chip (small batch) and a workspace is supplied, K is split over blocks and a second pass applies the epilogue. */
+size_t sd_conv2d_fwd_workspace_bytes(const sd_conv_desc* d);   /* > 0 only when split-K pays (small batch) */
 int sd_conv2d_fwd(const float* x_nhwc, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
                   const float* scale, const float* shift, const float* residual, int res_up2, int relu,
-                  sd_stream_t stream);
+                  void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* stem: 7x7/2 conv 3 -> 64 reading the NCHW image directly (network.py:43; resnet.conv1). */
 int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
                        const float* scale, const float* shift, int relu, sd_stream_t stream);

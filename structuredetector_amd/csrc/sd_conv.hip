@@ -34,6 +34,8 @@ struct ConvArgs {
     int mul, div, off, rsign;   // input coord t = o*mul + off + rsign*r ; valid iff t>=0, t%div==0, t/div < Hi
     int relu, res_up2;
     int M, nk, kchunks;   // kchunks = Ck/32 (STEM: unused), nk = number of 32-wide K chunks
+    int splits;           // split-K (small-batch inference): blockIdx.y = K slice, raw partial tiles go to `part`
+    float* part;          // [splits][M][Nn]
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
                           // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
 };
@@ -120,6 +122,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     int ld_c0 = 0, ld_r = r0, ld_s = s0, ld_kc = 0;    // chunk cursor of the loader (chunks are loaded strictly in order)
+    if (MODE == 0 && p.splits > 1) {
+        // split-K: this block multiplies chunks [kbeg, kend) only
+        const int per = (p.nk + p.splits - 1) / p.splits;
+        const int kbeg = min((int)blockIdx.y * per, p.nk), kend = min(kbeg + per, p.nk);
+        nk = kend - kbeg;
+        const int tap = kbeg / p.kchunks;
+        ld_c0 = (kbeg - tap * p.kchunks) * BK; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
+    }
 
     // Padding rows read a zero line instead of being predicated: there is no select after the load, so the compiler
     // cannot turn the load back into a branch with a wait per load.
@@ -247,6 +257,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 #undef SD_STORE_CHUNK
 
     // ---- epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if (MODE == 0 && p.splits > 1) {
+        float* dst = p.part + (int64_t)blockIdx.y * p.M * p.Nn;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                    if (m >= 0) dst[(int64_t)m * p.Nn + n0 + wn0 + ni * 32 + fr] = acc[mi][ni][e];
+                }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -543,6 +566,33 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w
     }
 }
 
+// split-K second pass: y = epilogue( sum over K slices of the partial tiles )
+__global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
+    const int64_t n4 = (int64_t)p.M * p.Nn / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < p.splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(p.part)[(int64_t)k * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const int n = (int)((i * 4) % p.Nn);
+    const int m = (int)((i * 4) / p.Nn);
+    if (p.scale) { const float4 sc = *reinterpret_cast<const float4*>(p.scale + n); a.x *= sc.x; a.y *= sc.y; a.z *= sc.z; a.w *= sc.w; }
+    if (p.shift) { const float4 sh = *reinterpret_cast<const float4*>(p.shift + n); a.x += sh.x; a.y += sh.y; a.z += sh.z; a.w += sh.w; }
+    if (p.res) {
+        int64_t rm = m;
+        if (p.res_up2) {
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+        }
+        const float4 r = *reinterpret_cast<const float4*>(p.res + rm * p.Nn + n);
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    reinterpret_cast<float4*>(p.y)[i] = a;
+}
+
 template <int BN, int MODE>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     static bool attr = false;              // one flag per instantiation
@@ -550,7 +600,7 @@ static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_igemm<BN, MODE>), dim3(tiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_conv_igemm<BN, MODE>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), lds, st, a);
 }
 
 static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
@@ -569,7 +619,22 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
         else launch_one<64, 3>(a, tiles, lds, st);
     }
     SD_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv((int64_t)a.M * a.Nn / 4, 256)), dim3(256), 0, st, a);
+        SD_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+// Split-K factor of the forward conv: only when the tile grid cannot fill the chip (small batch).
+static int fwd_splits(const sd_conv_desc* d) {
+    const int M = d->B * d->Ho * d->Wo;
+    const int BN = (d->Cout % 128 == 0) ? 128 : 64;
+    const int tiles = cdiv(M, BM) * (d->Cout / BN);
+    const int nk = d->R * d->S * (d->Cin / BK);
+    if (tiles >= 256 || nk < 8) return 1;
+    int s = std::min(cdiv(512, tiles), nk / 4);          // fill ~2 blocks per CU, keep >= 4 chunks per slice
+    return std::max(1, std::min(s, 64));
 }
 
 static int check_conv(const char* what, const sd_conv_desc* d) {
@@ -589,8 +654,14 @@ using namespace sd;
 
 extern "C" {
 
+size_t sd_conv2d_fwd_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 32 || d->Cout % 64) return 0;
+    const int s = fwd_splits(d);
+    return s > 1 ? (size_t)s * d->B * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
+}
+
 int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* d, const float* scale, const float* shift,
-                  const float* residual, int res_up2, int relu, sd_stream_t stream) {
+                  const float* residual, int res_up2, int relu, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_conv("sd_conv2d_fwd", d)) return e;
     SD_REQUIRE(x && w && y, SD_ERR_INVALID, "sd_conv2d_fwd: null pointer");
     SD_REQUIRE(d->Cin % 32 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)",
@@ -603,6 +674,12 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
     a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
     a.relu = relu; a.res_up2 = res_up2;
     a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / BK; a.nk = d->R * d->S * a.kchunks;
+    a.splits = fwd_splits(d);
+    if (a.splits > 1) {
+        // split-K needs its partial buffer; without one the single-pass kernel is still correct, just slower
+        if (workspace && workspace_bytes >= sd_conv2d_fwd_workspace_bytes(d)) a.part = (float*)workspace;
+        else a.splits = 1;
+    }
     return launch_igemm(a, false, (hipStream_t)stream);
 }
 

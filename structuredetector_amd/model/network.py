@@ -132,9 +132,12 @@ class _Engine:
         d = _desc(B, Hi, Wi, conv)
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        nws = self.lib.sd_conv2d_fwd_workspace_bytes(C.byref(d))          # > 0 only for small batches (split-K)
+        ws = self._ws(nws, x.device) if nws else None
         self._timed("k_conv_igemm<%d>" % (128 if conv.cout % 128 == 0 else 64), flops, lambda: L.check(
             self.lib.sd_conv2d_fwd(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
-                                   _ptr(res), int(res_up2), int(relu), L.stream()), "sd_conv2d_fwd"))
+                                   _ptr(res), int(res_up2), int(relu), _ptr(ws), ws.numel() if nws else 0, L.stream()),
+            "sd_conv2d_fwd"))
         return y, d
 
     def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True):
@@ -154,10 +157,14 @@ class _Engine:
         return y, mean, invstd
 
     def bn_fold(self, bn: BNParams):
+        cached = self.net._folded.get(id(bn))
+        if cached is not None:
+            return cached
         scale = torch.empty(bn.c, dtype=torch.float32, device=bn.weight.device)
         shift = torch.empty_like(scale)
         L.check(self.lib.sd_bn_fold(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                     BN_EPS, bn.c, scale.data_ptr(), shift.data_ptr(), L.stream()), "sd_bn_fold")
+        self.net._folded[id(bn)] = (scale, shift)
         return scale, shift
 
     # ---- forward -------------------------------------------------------------------------
@@ -405,6 +412,7 @@ class Network(nn.Module):
         self.reset_parameters(seed=0)
         self.flat_params = self.flat_grads = None
         self._flat_order, self._flat_off = [], {}
+        self._folded = {}        # eval-mode (scale, shift) per BN, valid until the parameters can have changed
         self._engine = None
 
     # ---- init / flat storage -------------------------------------------------------------
@@ -455,6 +463,7 @@ class Network(nn.Module):
                 p.data = view
                 self._flat_off[id(p)] = (off, n)
         self.flat_params, self.flat_grads = flat, grads
+        self._folded = {}
         self._engine = _Engine(self)
 
     def grad_of(self, p):
@@ -464,6 +473,18 @@ class Network(nn.Module):
             co, ci, r, s = p.shape
             return g.view(co, r, s, ci).permute(0, 3, 1, 2)
         return g.view(p.shape)
+
+    def invalidate_folded(self):
+        """Drop the cached eval-mode BN affines (call after editing parameters in place while in eval mode)."""
+        self._folded = {}
+
+    def train(self, mode=True):
+        self._folded = {}
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **kw):
+        self._folded = {}
+        return super().load_state_dict(*a, **kw)
 
     # ---- reference API -------------------------------------------------------------------
     def forward(self, x):  # (B, 3, H, W)
@@ -480,6 +501,33 @@ class Network(nn.Module):
 
     def save(self, path="last_model.pth"):
         torch.save({k: v.clone() for k, v in self.state_dict().items()}, path)
+
+    # ---- hipGraph replay of the eval forward (launch-bound small batches) --------------------
+    def graphed(self, example: torch.Tensor):
+        """Capture the eval-mode forward for `example`'s shape into a hipGraph and return `run(x) -> head tensor`.
+        The ~90 launches of a bs=1 forward then cost one graph launch; input and output buffers are static
+        (the returned tensor is overwritten by the next call)."""
+        if self.training:
+            raise L.SdError("graphed() captures the inference forward: call net.eval() first")
+        static_in = example.detach().clone().contiguous().float()
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm-up on the capture stream: allocations, one-time attributes
+                for _ in range(2):
+                    self._engine.forward(static_in, False)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                static_out = self._engine.forward(static_in, False)
+
+        def run(x):
+            static_in.copy_(x, non_blocking=True)
+            graph.replay()
+            return static_out
+
+        run.graph, run.static_in, run.static_out = graph, static_in, static_out
+        return run
 
     # ---- explicit (autograd-free) training path used by the trainer / bench ----------------
     def forward_train(self, x):

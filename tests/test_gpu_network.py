@@ -77,13 +77,13 @@ def test_conv_fwd_dgrad_wgrad(case):
     xd, wd = nhwc(x), krsc(w)
     y = torch.empty(B, d.Ho, d.Wo, cout, device=DEV)
     # plain conv
-    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, L.stream()))
+    L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, 0, 0, L.stream()))
     ref = F.conv2d(x, w, None, stride, pad)
     close(from_nhwc(y), ref, 2e-6 * (cin * k * k) ** 0.5)            # fp32 fma chain, k-ordered
     # fused epilogue: affine + residual + relu
     res = torch.randn(B, cout, d.Ho, d.Wo, generator=g)
     L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), keep(scale.to(DEV)).data_ptr(), keep(shift.to(DEV)).data_ptr(),
-                              nhwc(res).data_ptr(), 0, 1, L.stream()))
+                              nhwc(res).data_ptr(), 0, 1, 0, 0, L.stream()))
     ref2 = F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res)
     close(from_nhwc(y), ref2, 1e-5)
     # data gradient (+ skip residual)
@@ -103,6 +103,30 @@ def test_conv_fwd_dgrad_wgrad(case):
     close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
 
 
+def test_conv_fwd_split_k_small_batch():
+    """Small batch: the tile grid cannot fill the chip, K is split over blocks (+ reduce/epilogue pass)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    for (B, H, cin, cout, k) in ((1, 16, 512, 512, 3), (1, 32, 256, 256, 3), (2, 16, 512, 128, 1), (1, 128, 64, 64, 3)):
+        x = torch.randn(B, cin, H, H, generator=g); w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        scale = torch.rand(cout, generator=g) + 0.5; shift = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, H, generator=g)
+        d = make_desc(L, B, H, H, cin, cout, k, 1, k // 2)
+        nws = lib.sd_conv2d_fwd_workspace_bytes(C.byref(d))
+        assert nws > 0, "these shapes are meant to take the split-K path"
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        y = torch.empty(B, H, H, cout, device=DEV)
+        L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), keep(scale.to(DEV)).data_ptr(),
+                                  keep(shift.to(DEV)).data_ptr(), nhwc(res).data_ptr(), 0, 1, ws.data_ptr(), ws.numel(), L.stream()))
+        ref = F.relu(F.conv2d(x, w, None, 1, k // 2) * scale[None, :, None, None] + shift[None, :, None, None] + res)
+        close(from_nhwc(y), ref, 1e-5)
+        y2 = torch.empty_like(y)                       # no workspace -> single-pass kernel, same result up to summation order
+        L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y2.data_ptr(), C.byref(d), keep(scale.to(DEV)).data_ptr(),
+                                  keep(shift.to(DEV)).data_ptr(), nhwc(res).data_ptr(), 0, 1, 0, 0, L.stream()))
+        close(from_nhwc(y2), ref, 1e-5)
+
+
 def test_conv_up2_residual_and_stem():
     from structuredetector_amd import _lib as L
     lib = L.lib()
@@ -113,7 +137,7 @@ def test_conv_up2_residual_and_stem():
     d = make_desc(L, B, H, W, 64, 128, 1, 1, 0)
     y = torch.empty(B, H, W, 128, device=DEV)
     L.check(lib.sd_conv2d_fwd(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 0, keep(b.to(DEV)).data_ptr(),
-                              nhwc(coarse).data_ptr(), 1, 0, L.stream()))
+                              nhwc(coarse).data_ptr(), 1, 0, 0, 0, L.stream()))
     ref = F.conv2d(x, w, b) + F.interpolate(coarse, scale_factor=2)          # Fpn.forward, network.py:18-19
     close(from_nhwc(y), ref, 1e-5)
     # stem 7x7/2 on the NCHW image + its weight gradient

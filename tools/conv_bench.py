@@ -58,7 +58,7 @@ def main():
         L.check(lib.sd_conv2d_transpose_weights(w.data_ptr(), wt.data_ptr(), cout, k * k, cin, L.stream()))
         gflop = 2.0 * B * d.Ho * d.Wo * cout * cin * k * k / 1e9
         fns = {
-            "fwd": lambda: lib.sd_conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, L.stream()),
+            "fwd": lambda: lib.sd_conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, 0, 0, L.stream()),
             "dgrad": lambda: lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), 0, L.stream()),
             "wgrad": lambda: lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
         }
