@@ -200,9 +200,11 @@ int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, c
                 const float* gamma, const float* beta, const float* residual, int relu, sd_stream_t stream);
 int sd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                float eps, int C, float* scale, float* shift, sd_stream_t stream);
+/* relu: 0 = none, 1 = ReLU mask from the saved output y, 2 = mask recomputed from x (layers without a residual
+ * input: y is not read at all; needs beta). */
 int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean,
-              const float* invstd, const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta,
-              int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+              const float* invstd, const float* gamma, const float* beta, float* dx, float* g_out, float* dgamma,
+              float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* out[c] (+)= sum_m x[m][c]  (bias gradients). */
 int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace,
                size_t workspace_bytes, sd_stream_t stream);

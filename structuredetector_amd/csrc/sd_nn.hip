@@ -20,7 +20,8 @@ constexpr int RED_ROWS_PER_BLOCK = 512;
 // MODE 2: sum x                               (bias gradient)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
-                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      int64_t M, int C, float* __restrict__ partial) {
     __shared__ float4 red[2][256];
     const int cols = C >> 2;                       // float4 columns
@@ -29,10 +30,11 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
     const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK;
     const int64_t r1 = min(r0 + RED_ROWS_PER_BLOCK, M);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    float4 mu = s0, is = s0;
+    float4 mu = s0, is = s0, ga = s0, be = s0;
     if (MODE == 1 && rl < lanes) {
         mu = reinterpret_cast<const float4*>(mean)[col];
         is = reinterpret_cast<const float4*>(invstd)[col];
+        if (relu == 2) { ga = reinterpret_cast<const float4*>(gamma)[col]; be = reinterpret_cast<const float4*>(beta)[col]; }
     }
     if (rl < lanes) {
 #pragma unroll 4
@@ -45,12 +47,15 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                 s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
             } else {
                 float4 g = v;
-                if (relu) {
+                const float4 xv = reinterpret_cast<const float4*>(b + r * C)[col];
+                if (relu == 1) {            // mask from the saved post-activation (layers with a residual input)
                     const float4 yy = reinterpret_cast<const float4*>(y + r * C)[col];
                     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                } else if (relu == 2) {     // mask recomputed from x (same expression as k_bn_apply): one tensor read less
+                    g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+                    g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
                 }
-                const float4 xv = reinterpret_cast<const float4*>(b + r * C)[col];
                 s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
                 s1.x += g.x * ((xv.x - mu.x) * is.x); s1.y += g.y * ((xv.y - mu.y) * is.y);
                 s1.z += g.z * ((xv.z - mu.z) * is.z); s1.w += g.w * ((xv.w - mu.w) * is.w);
@@ -164,20 +169,24 @@ __global__ __launch_bounds__(256) void k_bn_fold(const float* gamma, const float
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                        int relu, int64_t n4, int C, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ mg, const float* __restrict__ mgx,
-                                                       float* __restrict__ dx, float* __restrict__ g_out) {
+                                                       const float* __restrict__ beta, const float* __restrict__ mg,
+                                                       const float* __restrict__ mgx, float* __restrict__ dx, float* __restrict__ g_out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int col = (int)(i % cols);
         float4 g = reinterpret_cast<const float4*>(dy)[i];
-        if (relu) {
-            const float4 yy = reinterpret_cast<const float4*>(y)[i];
-            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-        }
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
         const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
         const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
+        if (relu == 1) {
+            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        } else if (relu == 2) {
+            const float4 be = reinterpret_cast<const float4*>(beta)[col];
+            g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+            g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+        }
         const float4 a = reinterpret_cast<const float4*>(mg)[col], b = reinterpret_cast<const float4*>(mgx)[col];
         float4 o;
         o.x = ga.x * is.x * (g.x - a.x - (xv.x - mu.x) * is.x * b.x);
@@ -362,16 +371,21 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dy
     }
 }
 
-// head weight/bias gradient partials: block handles 1024 pixels; thread c (< C) keeps Co sums.
+// head weight/bias gradient partials: block handles HEAD_WG_PIX pixels in 64-pixel chunks; thread (c, half)
+// accumulates Co sums over its half of every chunk (all 256 threads busy when C == 128), 8 loads in flight.
 constexpr int HEAD_WG_PIX = 1024;
 __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
                                                      int64_t M, int HW, int C, int Co) {
     __shared__ float gs[HEAD_MAX_CO][64];
+    __shared__ float comb[HEAD_MAX_CO][256];
     const int64_t mb = (int64_t)blockIdx.x * HEAD_WG_PIX;
+    const int halves = max(1, 256 / C);                 // pixel sub-ranges handled in parallel
+    const int c = threadIdx.x % C, hf = threadIdx.x / C;
+    const int span = 64 / halves;
     float acc[HEAD_MAX_CO];
 #pragma unroll
     for (int j = 0; j < HEAD_MAX_CO; ++j) acc[j] = 0.f;
-    float bsum = 0.f;                // thread co < Co also accumulates the bias gradient
+    float bsum = 0.f;                                   // thread co < Co also accumulates the bias gradient
     for (int64_t m0 = mb; m0 < min(mb + HEAD_WG_PIX, M); m0 += 64) {
         __syncthreads();
         for (int i = threadIdx.x; i < Co * 64; i += 256) {
@@ -382,32 +396,54 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dy
             gs[co][px] = v;
         }
         __syncthreads();
-        if (threadIdx.x < C) {
-            for (int px = 0; px < 64; ++px) {
-                const int64_t m = m0 + px;
-                if (m >= M) break;
-                const float xv = x[m * C + threadIdx.x];
+        if (hf < halves) {
+            const int p0 = hf * span;
+#pragma unroll 1
+            for (int pb = 0; pb < span; pb += 8) {
+                float xv[8];
 #pragma unroll
-                for (int j = 0; j < HEAD_MAX_CO; ++j)
-                    if (j < Co) acc[j] += gs[j][px] * xv;
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t m = m0 + p0 + pb + u;
+                    xv[u] = x[(m < M ? m : mb) * C + c];          // unconditional load; masked rows have gs == 0
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < HEAD_MAX_CO; ++j)
+                        if (j < Co) acc[j] += gs[j][p0 + pb + u] * xv[u];
             }
         }
         if (threadIdx.x < Co) {
             for (int px = 0; px < 64; ++px) bsum += gs[threadIdx.x][px];
         }
     }
+    // combine the pixel halves
+    for (int j = 0; j < Co; ++j) comb[j][threadIdx.x] = (hf < halves) ? acc[j] : 0.f;
+    __syncthreads();
     float* dst = partial + (int64_t)blockIdx.x * (Co * C + Co);
-    if (threadIdx.x < C)
-        for (int j = 0; j < Co; ++j) dst[j * C + threadIdx.x] = acc[j];
+    if (threadIdx.x < C) {
+        for (int j = 0; j < Co; ++j) {
+            float t = 0.f;
+            for (int h2 = 0; h2 < halves; ++h2) t += comb[j][h2 * C + threadIdx.x];
+            dst[j * C + threadIdx.x] = t;
+        }
+    }
     if (threadIdx.x < Co) dst[Co * C + threadIdx.x] = bsum;
 }
 
+// 8 outputs x 32 lanes over the partial blocks per workgroup (deterministic order)
 __global__ __launch_bounds__(256) void k_head_wgrad_fin(const float* __restrict__ partial, int nblocks, int n, float* __restrict__ dw,
                                                          float* __restrict__ db, int nw, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double red[32][8];
+    const int lo = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + lo;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * n + i];
+    if (i < n)
+        for (int b = lr; b < nblocks; b += 32) s += (double)partial[(int64_t)b * n + i];
+    red[lr][lo] = s;
+    __syncthreads();
+    if (lr != 0 || i >= n) return;
+    for (int k = 1; k < 32; ++k) s += red[k][lo];
     float* dst = i < nw ? dw + i : db + (i - nw);
     *dst = (accumulate ? *dst : 0.f) + (float)s;
 }
@@ -465,7 +501,7 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, 0, M, C, (float*)workspace);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
                        mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
@@ -492,24 +528,26 @@ int sd_bn_fold(const float* gamma, const float* beta, const float* running_mean,
 }
 
 int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
-              const float* gamma, float* dx, float* g_out, float* dgamma, float* dbeta, int accumulate, void* workspace,
+              const float* gamma, const float* beta, float* dx, float* g_out, float* dgamma, float* dbeta, int accumulate, void* workspace,
               size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_mc("sd_bn_bwd", M, C)) return e;
-    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && (!relu || y), SD_ERR_INVALID, "sd_bn_bwd: null pointer");
+    SD_REQUIRE(relu >= 0 && relu <= 2, SD_ERR_INVALID, "sd_bn_bwd: relu must be 0 (none), 1 (mask from y) or 2 (mask recomputed from x)");
+    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && (relu != 1 || y) && (relu != 2 || beta),
+               SD_ERR_INVALID, "sd_bn_bwd: null pointer");
     SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_bwd: workspace too small");
     const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
-    hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, relu, M, C, partial);
+    hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta, relu, M, C, partial);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, y, relu, n4, C, mean, invstd, gamma, (const float*)mg,
-                       (const float*)mgx, dx, g_out);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
+                       (const float*)mg, (const float*)mgx, dx, g_out);
     SD_LAUNCH_CHECK();
     return 0;
 }
@@ -521,7 +559,7 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
     const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, 0, M, C, (float*)workspace);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
@@ -572,7 +610,8 @@ size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co) {
 int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, int B, int HW, int C, int Co,
                 int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     SD_REQUIRE(dy && x && w && dx && dw && dbias && workspace && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_bwd: bad arguments");
-    SD_REQUIRE(C % 4 == 0 && C <= 256 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_bwd: needs C %% 4 == 0, C <= 256, Co <= %d", HEAD_MAX_CO);
+    SD_REQUIRE(C % 4 == 0 && C <= 256 && (256 % C == 0) && (64 % (256 / C) == 0) && ((64 / (256 / C)) % 8 == 0) && Co > 0 && Co <= HEAD_MAX_CO,
+               SD_ERR_INVALID, "sd_head_bwd: needs C in {64, 128, 256} and Co <= %d", HEAD_MAX_CO);
     SD_REQUIRE(workspace_bytes >= sd_head_bwd_workspace_bytes(B, HW, C, Co), SD_ERR_WORKSPACE, "sd_head_bwd: workspace too small");
     const int64_t M = (int64_t)B * HW;
     hipStream_t st = (hipStream_t)stream;
@@ -582,7 +621,7 @@ int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, floa
     hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dy, x, (float*)workspace, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     const int n = Co * C + Co;
-    hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);
+    hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
 }

@@ -290,8 +290,10 @@ class _Engine:
         dx = torch.empty_like(x)
         g = torch.empty_like(x) if want_g else None
         ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
-        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), int(relu), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(),
-                                   bn.weight.data_ptr(), dx.data_ptr(), _ptr(g), self.net.grad_of(bn.weight).data_ptr(),
+        # relu: False/0 = none, True/1 = mask from y (residual layers), 2 = mask recomputed from x (y is not read)
+        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) == 1 else 0, int(relu), Mrows, Cc, mean.data_ptr(),
+                                   invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), dx.data_ptr(), _ptr(g),
+                                   self.net.grad_of(bn.weight).data_ptr(),
                                    self.net.grad_of(bn.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_bwd")
         return dx, g
 
@@ -315,7 +317,7 @@ class _Engine:
         # gradient for that tensor exists, so the sum of the two is the dgrad kernel's residual epilogue.
         lateral_grad = {}
         for (fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn) in reversed(tape["fpn"]):
-            dcv, _ = self._bn_bwd(df, c, fn, True, fpn.conv[1], mf, if_)
+            dcv, _ = self._bn_bwd(df, c, fn, 2, fpn.conv[1], mf, if_)
             self._wgrad(dcv, t, fpn.conv[0], dc)
             dt = self._dgrad(dcv, fpn.conv[0], dc)
             self._wgrad(dt, sc_t, fpn.lateral, dl)
@@ -341,7 +343,7 @@ class _Engine:
             dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True)
             self._wgrad(dc2, a1, blk.conv2, d2)
             da1 = self._dgrad(dc2, blk.conv2, d2)
-            dc1, _ = self._bn_bwd(da1, c1, a1, True, blk.bn1, m1, i1)
+            dc1, _ = self._bn_bwd(da1, c1, a1, 2, blk.bn1, m1, i1)
             self._wgrad(dc1, xin, blk.conv1, d1)
             if blk.downsample is not None:
                 dcd, _ = self._bn_bwd(g, cd, None, False, blk.downsample[1], md, idd)
@@ -357,7 +359,7 @@ class _Engine:
         d0, s0, a0, m0, i0, pidx = tape["stem"]
         da0 = torch.empty_like(a0)
         L.check(lib.sd_maxpool3x3s2_bwd(dcur.data_ptr(), pidx.data_ptr(), da0.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool_bwd")
-        ds0, _ = self._bn_bwd(da0, s0, a0, True, net.adpater[1], m0, i0)
+        ds0, _ = self._bn_bwd(da0, s0, a0, 2, net.adpater[1], m0, i0)
         stem = net.adpater[0]
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,

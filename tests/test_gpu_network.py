@@ -183,9 +183,15 @@ def test_bn_pool_head_adam():
     close(rm.cpu(), bn.running_mean, 1e-5); close(rv.cpu(), bn.running_var, 1e-5)
     dx = torch.empty_like(xd); gout = torch.empty_like(xd); dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
     L.check(lib.sd_bn_bwd(nhwc(dy).data_ptr(), xd.data_ptr(), y.data_ptr(), 1, M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(),
-                          dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
+                          bet.data_ptr(), dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
     close(from_nhwc(dx), xr.grad, 2e-5); close(from_nhwc(gout), rr.grad, 1e-6)
     close(dg.cpu(), bn.weight.grad, 2e-5); close(db.cpu(), bn.bias.grad, 2e-5)
+    # mask recomputed from x (relu mode 2): relu(bn(x)) without residual, y is never read
+    xr2 = x.clone().requires_grad_(True); bn.zero_grad()
+    F.relu(bn(xr2)).backward(dy)
+    L.check(lib.sd_bn_bwd(nhwc(dy).data_ptr(), xd.data_ptr(), 0, 2, M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(),
+                          bet.data_ptr(), dx.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(from_nhwc(dx), xr2.grad, 2e-5); close(dg.cpu(), bn.weight.grad, 2e-5); close(db.cpu(), bn.bias.grad, 2e-5)
     # maxpool 3x3/2 fwd + bwd (odd and even sizes)
     for (h, w_) in ((10, 14), (9, 7)):
         xp = torch.randn(2, 64, h, w_, generator=g).requires_grad_(True)
