@@ -171,8 +171,10 @@ int sd_conv2d_fwd(const float* x_nhwc, const float* w_krsc, float* y_nhwc, const
                   const float* scale, const float* shift, const float* residual, int res_up2, int relu,
                   void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* stem: 7x7/2 conv 3 -> 64 reading the NCHW image directly (network.py:43; resnet.conv1). */
+size_t sd_conv2d_stem_fwd_workspace_bytes(const sd_conv_desc* d);
 int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
-                       const float* scale, const float* shift, int relu, sd_stream_t stream);
+                       const float* scale, const float* shift, int relu, void* workspace, size_t workspace_bytes,
+                       sd_stream_t stream);
 /* dX = conv_transpose(dY, W): same kernel with the inverted coordinate map; w_t = weights
  * re-laid as [Cin][R][S][Cout] by sd_conv2d_transpose_weights.  residual (nullable, same layout as
  * dX) is added (skip-connection gradient). */

@@ -21,7 +21,7 @@ namespace sd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BK = 32, LDK = BK + 4;
+constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
 struct ConvArgs {
     const float* x;       // A source, NHWC [B][Hi][Wi][Ck]   (STEM: NCHW [B][3][Hi][Wi])
@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
 #define SD_STORE_CHUNK(buf)                                                                       \
     {                                                                                             \
-        float* ad = As + ((buf) * BM + srow) * LDK + sk;                                          \
+        float* ad = As + ((buf) * BM + srow) * LDK + st_sk;                                       \
         *reinterpret_cast<float4*>(ad) = ra0;                                                     \
         *reinterpret_cast<float4*>(ad + 32 * LDK) = ra1;                                          \
         *reinterpret_cast<float4*>(ad + 64 * LDK) = ra2;                                          \
         *reinterpret_cast<float4*>(ad + 96 * LDK) = ra3;                                          \
-        float* bd = Bs + ((buf) * BN + srow) * LDK + sk;                                          \
+        float* bd = Bs + ((buf) * BN + srow) * LDK + st_sk;                                       \
         *reinterpret_cast<float4*>(bd) = rb0;                                                     \
         *reinterpret_cast<float4*>(bd + 32 * LDK) = rb1;                                          \
         if (BN == 128) {                                                                          \
@@ -203,9 +203,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         }                                                                                         \
     }
 
+    // LDS image: row r keeps its 16-byte k-slot q at slot q ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 rows
+    // distinct mod 16, same q) then touches 16 different slots of the 256-byte bank row -- conflict-free without
+    // row padding (staged rows srow + 32 i and fragment rows tile + fr all share the swizzle of srow / fr).
+    const int st_sk = (((sk >> 2) ^ ((srow >> 1) & 7)) << 2);
+
     // ---- wave tile: 64 (m) x BN/2 (n)
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (BN / 2);
     const int fr = lane & 31, fh = lane >> 5;
+    const int rd_swz = (fr >> 1) & 7;
     f32x16 acc[2][NT];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -222,19 +228,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nk) { SD_LOAD_CHUNK() }
-        const float* Ab = As + (cur * BM + wm0 + fr) * LDK + fh * 4;
-        const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK + fh * 4;
-        float4 na0 = *reinterpret_cast<const float4*>(Ab), na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK);
-        float4 nb0 = *reinterpret_cast<const float4*>(Bb), nb1 = nb0;
-        if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK);
+        const float* Ab = As + (cur * BM + wm0 + fr) * LDK;
+        const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK;
+#define SD_SLOT(ks) ((((ks) * 2 + fh) ^ rd_swz) << 2)
+        float4 na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(0)), na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(0));
+        float4 nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(0)), nb1 = nb0;
+        if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(0));
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             const float4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
             if (ks + 1 < BK / 8) {             // fragments of the next k-group are read while this group's MFMAs run
-                na0 = *reinterpret_cast<const float4*>(Ab + (ks + 1) * 8);
-                na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + (ks + 1) * 8);
-                nb0 = *reinterpret_cast<const float4*>(Bb + (ks + 1) * 8);
-                if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + (ks + 1) * 8);
+                na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(ks + 1));
+                na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(ks + 1));
+                nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(ks + 1));
+                if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(ks + 1));
             }
             // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         if (kc + 1 < nk) { SD_STORE_CHUNK(cur ^ 1) }
         __syncthreads();
     }
+#undef SD_SLOT
 #undef SD_LOAD_A
 #undef SD_LOAD_A_STEM
 #undef SD_LOAD_B_STEM
@@ -536,6 +544,223 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad(WgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem (7x7 / stride 2 / pad 3, 3 -> 64 channels, NCHW image) with the input patch staged in LDS.
+// One block = 128 consecutive output pixels of one output row: the 7 input rows x 261 columns x 3 channels
+// it touches (22 KB) are loaded ONCE, coalesced, and every MFMA A-operand is read from that patch
+// (address = row(ci, r) * 264 + 2 * px + s) -- no per-element global gathers.  k = (r*7 + s)*3 + ci.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP_PITCH = 264, SP_ROWS = 21, SP_USED = 261;
+constexpr int STEM_KPAD = 148;
+
+struct StemArgs {
+    const float* x;       // NCHW image
+    const float* wt;      // [147][64] transposed weights (forward)
+    const float* dy;      // [M][64] (weight gradient)
+    float* y;             // [M][64] forward output / partial dW [blocks][64][147]
+    const float* scale;
+    const float* shift;
+    int relu;
+    int B, H, W, Ho, Wo, tiles_x, ntiles;
+};
+
+__device__ __forceinline__ int stem_koff(int k) {      // patch offset of reduction index k (without the pixel term)
+    const int ci = k % 3, tap = k / 3, r = tap / 7, s = tap - r * 7;
+    return (ci * 7 + r) * SP_PITCH + s;
+}
+
+// All global loads of a staging pass are issued before the first LDS store (fully unrolled, values in registers):
+// a load-store-load-store loop would expose one global round trip per element.
+__device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* patch, int b, int oy, int ox0) {
+    constexpr int TOTAL = SP_ROWS * SP_PITCH, NLD = (TOTAL + 255) / 256;
+    const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 3;
+    const float* img = p.x + (int64_t)b * 3 * p.H * p.W;
+    float v[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int row = i / SP_PITCH, col = i - row * SP_PITCH;
+        const int ci = row / 7, r = row - ci * 7;
+        const int iy = iy0 + r, ix = ix0 + col;
+        const bool ok = i < TOTAL && col < SP_USED && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = ok ? img + (ci * p.H + iy) * p.W + ix : g_zero_line;
+        v[j] = *src;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < TOTAL) patch[i] = v[j];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;                              // [21][264]
+    float* wl = lds + SP_ROWS * SP_PITCH;            // [148][64], row 147 = 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
+    const int ox0 = tx * 128;
+    stem_load_patch(p, patch, b, oy, ox0);
+    {
+        constexpr int NW = (STEM_KPAD * 64 / 4 + 255) / 256;      // 10 float4 per thread
+        float4 wv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + 256 * j;
+            const float* src = (i * 4 < STEM_K * 64) ? p.wt + i * 4 : g_zero_line;
+            wv[j] = *reinterpret_cast<const float4*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + 256 * j;
+            if (i < STEM_KPAD * 64 / 4) reinterpret_cast<float4*>(wl)[i] = wv[j];
+        }
+    }
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    const int px = wave * 32 + fr;
+    const float* pa = patch + 2 * px;
+    const float* pb = wl + fh * 64 + fr;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // operands of step kk+1 are read while the MFMAs of step kk run
+    float na = pa[fh ? stem_koff(1) : stem_koff(0)], nb0 = pb[0], nb1 = pb[32];
+#pragma unroll
+    for (int kk = 0; kk < STEM_KPAD / 2; ++kk) {
+        const float a = na, b0 = nb0, b1 = nb1;
+        if (kk + 1 < STEM_KPAD / 2) {
+            const int k0 = 2 * kk + 2, k1 = (2 * kk + 3 < STEM_K) ? 2 * kk + 3 : STEM_K - 1;   // k = 147 multiplies a zero weight row
+            na = pa[fh ? stem_koff(k1) : stem_koff(k0)];
+            nb0 = pb[(2 * kk + 2) * 64];
+            nb1 = pb[(2 * kk + 2) * 64 + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = ni * 32 + fr;
+        const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ox = ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (ox >= p.Wo) continue;
+            float v = (ni ? acc1[e] : acc0[e]) * sc + sh;
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.y[(row0 + ox) * 64 + n] = v;
+        }
+    }
+}
+
+// Weight gradient of the stem: persistent blocks walk the 128-pixel tiles, accumulating the whole 64 x 160 dW tile in
+// registers (each wave takes 32 of the 128 pixels: 10 accumulators = 160 VGPRs), then the four waves are summed
+// through LDS and the block writes ONE partial dW.
+__global__ __launch_bounds__(256, 1) void k_stem_wgrad2(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;                              // [21][264]
+    float* dys = lds + SP_ROWS * SP_PITCH;           // [128][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    int koff[5];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+        const int kc = kt * 32 + fr;
+        koff[kt] = stem_koff(kc < STEM_K ? kc : STEM_K - 1);     // columns >= 147 are computed on valid data and dropped
+    }
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
+        const int ox0 = tx * 128;
+        __syncthreads();
+        stem_load_patch(p, patch, b, oy, ox0);
+        const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo + ox0;
+        {
+            float4 dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = tid + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
+                const float* src = (ox0 + px < p.Wo) ? p.dy + (row0 + px) * 64 + c4 : g_zero_line;
+                dv[j] = *reinterpret_cast<const float4*>(src);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = tid + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
+                *reinterpret_cast<float4*>(dys + px * 64 + c4) = dv[j];
+            }
+        }
+        __syncthreads();
+        const float* da = dys + (wave * 32 + fh) * 64 + fr;
+        const float* xb = patch + 2 * (wave * 32 + fh);
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a0 = da[kk * 128], a1 = da[kk * 128 + 32];
+            float bv[5];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) bv[kt] = xb[koff[kt] + 4 * kk];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                acc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[kt], acc[0][kt], 0, 0, 0);
+                acc[1][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[kt], acc[1][kt], 0, 0, 0);
+            }
+        }
+    }
+    // sum the four waves through LDS: R[n][160]
+    __syncthreads();
+    float* R = lds;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, kc = j * 32 + fr;
+                        float* dst = R + n * 160 + kc;
+                        *dst = (w == 0 ? 0.f : *dst) + acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = p.y + (int64_t)blockIdx.x * 64 * STEM_K;
+    for (int i = tid; i < 64 * STEM_K; i += 256) {
+        const int n = i / STEM_K, k = i - n * STEM_K;
+        out[i] = R[n * 160 + k];
+    }
+}
+
+// parallel split reduction: 8 float4 outputs x 32 lanes over the partial copies per block (deterministic order)
+__global__ __launch_bounds__(256) void k_wgrad_reduce_par(const float* __restrict__ part, float* __restrict__ dw, int64_t n4, int splits,
+                                                           int accumulate) {
+    __shared__ float4 red[32][8];
+    const int lo = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 8 + lo;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4)
+        for (int k = lr; k < splits; k += 32) {
+            const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[lr][lo] = s;
+    __syncthreads();
+    if (lr != 0 || i >= n4) return;
+    for (int k = 1; k < 32; ++k) { const float4 v = red[k][lo]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    if (accumulate) { const float4 v = reinterpret_cast<const float4*>(dw)[i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    reinterpret_cast<float4*>(dw)[i] = s;
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int64_t n4, int splits,
                                                        int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -683,17 +908,42 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
     return launch_igemm(a, false, (hipStream_t)stream);
 }
 
+static void stem_args(StemArgs& a, const sd_conv_desc* d) {
+    a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.tiles_x = cdiv(d->Wo, 128);
+    a.ntiles = d->B * d->Ho * a.tiles_x;
+}
+static bool stem_is_7x7s2(const sd_conv_desc* d) { return d->Cin == 3 && d->Cout == 64 && d->R == 7 && d->S == 7 && d->stride == 2 && d->pad == 3; }
+
+size_t sd_conv2d_stem_fwd_workspace_bytes(const sd_conv_desc* d) { (void)d; return (size_t)STEM_K * 64 * sizeof(float); }
+
 int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
-                       sd_stream_t stream) {
+                       void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_conv("sd_conv2d_stem_fwd", d)) return e;
     SD_REQUIRE(x_nchw && w && y, SD_ERR_INVALID, "sd_conv2d_stem_fwd: null pointer");
     SD_REQUIRE(d->Cin == 3 && d->Cout == 64, SD_ERR_INVALID, "sd_conv2d_stem_fwd: the stem is 3 -> 64 channels (network.py:43)");
+    hipStream_t st = (hipStream_t)stream;
+    if (stem_is_7x7s2(d) && workspace && workspace_bytes >= sd_conv2d_stem_fwd_workspace_bytes(d)) {
+        // LDS-patch kernel: weights are re-laid as [k][cout] once per call (37 KB)
+        float* wt = (float*)workspace;
+        hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
+        SD_LAUNCH_CHECK();
+        StemArgs a{};
+        a.x = x_nchw; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift; a.relu = relu;
+        stem_args(a, d);
+        const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(k_stem_fwd, dim3(a.ntiles), dim3(256), lds, st, a);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
     ConvArgs a{};
     a.x = x_nchw; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.relu = relu;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = 3; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = 64; a.R = d->R; a.S = d->S;
     a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
     a.M = d->B * d->Ho * d->Wo; a.kchunks = 1; a.nk = cdiv(d->R * d->S * 3, BK);
-    return launch_igemm(a, true, (hipStream_t)stream);
+    return launch_igemm(a, true, st);
 }
 
 int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual, sd_stream_t stream) {
@@ -771,39 +1021,40 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     else hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), lds, st, a);
     SD_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    if (a.splits >= 16) hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    else hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
 }
 
-static int stem_splits(const sd_conv_desc* d) {
-    const int M = d->B * d->Ho * d->Wo;
-    return std::max(1, std::min(512, cdiv(M, 1024)));
+static int stem_blocks(const sd_conv_desc* d) {
+    const int ntiles = d->B * d->Ho * cdiv(d->Wo, 128);
+    return std::max(1, std::min(512, ntiles));          // two persistent blocks per CU (252 VGPRs, 55 KB LDS each)
 }
 
 size_t sd_conv2d_stem_wgrad_workspace_bytes(const sd_conv_desc* d) {
     if (!d) return 0;
-    return (size_t)stem_splits(d) * 64 * STEM_K * sizeof(float);
+    return (size_t)stem_blocks(d) * 64 * STEM_K * sizeof(float);
 }
 
 int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
                          size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_conv("sd_conv2d_stem_wgrad", d)) return e;
     SD_REQUIRE(dy && x_nchw && dw && workspace, SD_ERR_INVALID, "sd_conv2d_stem_wgrad: null pointer");
-    SD_REQUIRE(d->Cin == 3 && d->Cout == 64 && d->R * d->S * 3 == STEM_K, SD_ERR_INVALID, "sd_conv2d_stem_wgrad: the stem is 7x7, 3 -> 64");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_wgrad: the stem is 7x7 / stride 2 / pad 3, 3 -> 64");
     SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_wgrad: workspace too small");
-    WgradArgs a{};
-    a.dy = dy; a.x = x_nchw; a.part = (float*)workspace;
-    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = 3; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = 64; a.R = d->R; a.S = d->S;
-    a.stride = d->stride; a.pad = d->pad;
-    a.M = d->B * d->Ho * d->Wo;
-    a.splits = stem_splits(d);
-    a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
+    StemArgs a{};
+    a.x = x_nchw; a.dy = dy; a.y = (float*)workspace;
+    stem_args(a, d);
+    const int blocks = stem_blocks(d);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem_wgrad, dim3(a.splits), dim3(256), 0, st, a);
+    const size_t lds = (size_t)(SP_ROWS * SP_PITCH + 128 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(k_stem_wgrad2, dim3(blocks), dim3(256), lds, st, a);
     SD_LAUNCH_CHECK();
     const int64_t n4 = 64 * STEM_K / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
 }

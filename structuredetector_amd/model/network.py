@@ -183,13 +183,15 @@ class _Engine:
         stem, bn0 = net.adpater[0], net.adpater[1]
         d0 = _desc(B, H, W, stem)
         s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.float32, device=x.device)
+        wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
         if training:
-            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, L.stream()), "stem")
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, wss.data_ptr(),
+                                           wss.numel(), L.stream()), "stem")
             a0, m0, i0 = self.bn_train(s0, bn0)
         else:
             sc, sh = self.bn_fold(bn0)
             L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1,
-                                           L.stream()), "stem")
+                                           wss.data_ptr(), wss.numel(), L.stream()), "stem")
             a0, m0, i0 = s0, None, None
         Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
         p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x.device)
