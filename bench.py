@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the eval-mode forward (bs=B and bs=1) after the timed region; off by default so that the "
+                         "rocprofv3 per-kernel averages of the default command describe the timed training steps only")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,10 +147,13 @@ def main():
     assert all(np.isfinite(loss_host)), f"non-finite loss {loss_host}"
 
     # ---- roofline of the dominant kernel (live, from the timed region)
-    per = {}
-    for kind, flops, e0, e1 in prof:
+    per, phases = {}, {}
+    for kind, flops, e0, e1, phase in prof:
+        t = e0.elapsed_time(e1) * 1e-3
         d = per.setdefault(kind, [0, 0.0, 0.0])
-        d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1) * 1e-3
+        d[0] += 1; d[1] += flops; d[2] += t
+        q = phases.setdefault(phase, [0.0, 0.0])
+        q[0] += flops; q[1] += t
     kernels = {k: {"launches_per_step": v[0] // max(a.steps, 1), "avg_launch_us": round(v[2] / v[0] * 1e6, 2),
                    "gflop_per_launch": round(v[1] / v[0] / 1e9, 3), "tflops": round(v[1] / v[2] / 1e12, 2)} for k, v in per.items()}
     dom = max(per, key=lambda k: per[k][2])
@@ -157,11 +163,13 @@ def main():
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                 "flops_per_launch": round(per[dom][1] / per[dom][0], 1), "avg_launch_us": kernels[dom]["avg_launch_us"],
                 "launches_per_step": kernels[dom]["launches_per_step"], "all_conv_kernels": kernels,
+                "conv_phases": {ph: {"ms_per_step": round(v[1] / a.steps * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2),
+                                     "frac_of_peak": round(v[0] / v[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)} for ph, v in phases.items()},
                 "conv_share_of_step_time": round(conv_time_frac, 3)}
 
     # ---- forward-only and decode figures (same process, after the timed region)
     extra = {}
-    if rank == 0:
+    if rank == 0 and a.extras:
         net.eval()
         with torch.no_grad():
             for _ in range(2):
@@ -175,6 +183,7 @@ def main():
         extra["fwd_eval_tflops"] = round(B * FWD_GFLOP_PER_IMG / fwd / 1e3, 2)
         extra["fwd_eval_frac_of_mfma_peak"] = round(B * FWD_GFLOP_PER_IMG / fwd / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)
         # BASELINE configs[1]: bs=1 inference latency (split-K convs fill the chip at small M)
+        dec1 = Decoder(args)
         with torch.no_grad():
             x1 = images[:1].contiguous()
             for _ in range(3):
@@ -184,6 +193,12 @@ def main():
                 o1 = net(x1)
             torch.cuda.synchronize()
             extra["fwd_eval_ms_bs1"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dec1(net(x1))
+            extra["infer_e2e_ms_per_img_bs1"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)     # forward + decode + host objects
+        net.train()
+    if rank == 0:
         dec = Decoder(args)
         tgt = enc.render_device(plans[0])
         hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
@@ -206,12 +221,6 @@ def main():
         for _ in range(20):
             dec(one)
         extra["decode_e2e_us_per_img_bs1"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)   # 2 launches + D2H + host assembly
-        with torch.no_grad():
-            t1 = time.perf_counter()
-            for _ in range(10):
-                dec(net(x1))
-            extra["infer_e2e_ms_per_img_bs1"] = round((time.perf_counter() - t1) / 10 * 1e3, 3)     # forward + decode + host objects
-        net.train()
 
     if rank == 0:
         imgs_per_s = B * world * a.steps / dt

@@ -21,6 +21,10 @@ namespace sd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef SD_IGEMM_NBUF
+#define SD_IGEMM_NBUF 2
+#endif
+constexpr int NBUF = SD_IGEMM_NBUF;   // LDS stages of the igemm tiles: 2 = double buffer (1 barrier / chunk), 1 = single buffer (2 barriers, more blocks per CU)
 constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
 struct ConvArgs {
@@ -63,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     constexpr int NT = BN / 64;            // 32-wide MFMA tiles per wave along n (wave tile = 64 x BN/2)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][BM][LDK]
-    float* Bs = lds + 2 * BM * LDK;        // [2][BN][LDK]
-    int* orow = reinterpret_cast<int*>(lds + 2 * (BM + BN) * LDK);   // [BM] output pixel of each tile row, -1 = none
+    float* Bs = lds + NBUF * BM * LDK;     // [NBUF][BN][LDK]
+    int* orow = reinterpret_cast<int*>(lds + NBUF * (BM + BN) * LDK);   // [BM] output pixel of each tile row, -1 = none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Nn / BN;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1;
+        const int cur = (NBUF == 2) ? (kc & 1) : 0;
         if (kc + 1 < nk) { SD_LOAD_CHUNK() }
         const float* Ab = As + (cur * BM + wm0 + fr) * LDK;
         const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK;
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }
             }
         }
-        if (kc + 1 < nk) { SD_STORE_CHUNK(cur ^ 1) }
+        if (NBUF == 1) __syncthreads();            // every wave is done reading the single buffer
+        if (kc + 1 < nk) { SD_STORE_CHUNK((NBUF == 2) ? (cur ^ 1) : 0) }
         __syncthreads();
     }
 #undef SD_SLOT
@@ -457,92 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
             }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stem weight gradient: dW[co][k] = sum_m dY[m][co] * patch[m][k], k = (r*7+s)*3 + ci (147 -> 160),
-// patches gathered from the NCHW image.  n = 64 -> 2 MFMA row tiles, k = 160 -> 5 column tiles;
-// wave w owns row tile (w&1) and column tiles (w>>1), (w>>1)+2, (w>>1)+4.
-// ---------------------------------------------------------------------------------------------
-constexpr int STEM_K = 147, STEM_KP = 160;
-
-__global__ __launch_bounds__(256, 2) void k_stem_wgrad(WgradArgs p) {
-    constexpr int PK = 32, LDN = 64 + 4, LDC = STEM_KP + 4;
-    __shared__ __attribute__((aligned(16))) float Ds[2][PK][LDN];
-    __shared__ __attribute__((aligned(16))) float Xs[2][PK][LDC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x;
-    const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
-    constexpr int XE = PK * STEM_KP / 256;   // 20 gathered elements per thread
-    float4 rd[2];
-    float rx[XE];
-    auto load_chunk = [&](int mc) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 4, col = (idx & 15) * 4;
-            const int m = mc + row;
-            rd[i] = (m < m_end) ? *reinterpret_cast<const float4*>(p.dy + (int64_t)m * 64 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < XE; ++i) {
-            const int idx = tid + 256 * i, row = idx / STEM_KP, k = idx - row * STEM_KP;
-            const int m = mc + row;
-            float v = 0.f;
-            if (m < m_end && k < STEM_K) {
-                const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
-                const int tap = k / 3, ci = k - tap * 3, r = tap / p.S, s = tap - r * p.S;
-                const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;
-                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) v = p.x[(((int64_t)b * 3 + ci) * p.Hi + iy) * p.Wi + ix];
-            }
-            rx[i] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 4, col = (idx & 15) * 4;
-            *reinterpret_cast<float4*>(&Ds[buf][row][col]) = rd[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XE; ++i) {
-            const int idx = tid + 256 * i, row = idx / STEM_KP, k = idx - row * STEM_KP;
-            Xs[buf][row][k] = rx[i];
-        }
-    };
-    const int nt = wave & 1, kt0 = wave >> 1;
-    const int nkt = (kt0 == 0) ? 3 : 2;
-    const int fr = lane & 31, fh = lane >> 5;
-    f32x16 acc[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const int nchunks = (m_end - m_beg + PK - 1) / PK;
-    if (nchunks > 0) { load_chunk(m_beg); store_chunk(0); }
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nchunks) load_chunk(m_beg + (ch + 1) * PK);
-#pragma unroll
-        for (int kk = 0; kk < PK / 2; ++kk) {
-            const float a = Ds[cur][2 * kk + fh][nt * 32 + fr];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < nkt) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[cur][2 * kk + fh][(kt0 + 2 * j) * 32 + fr], acc[j], 0, 0, 0);
-        }
-        if (ch + 1 < nchunks) store_chunk(cur ^ 1);
-        __syncthreads();
-    }
-    float* out = p.part + (int64_t)split * 64 * STEM_K;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j >= nkt) continue;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-            const int k = (kt0 + 2 * j) * 32 + fr;
-            if (k < STEM_K) out[n * STEM_K + k] = acc[j][e];
-        }
-    }
-}
+constexpr int STEM_K = 147;   // 7 * 7 * 3
 
 // ---------------------------------------------------------------------------------------------
 // Stem (7x7 / stride 2 / pad 3, 3 -> 64 channels, NCHW image) with the input patch staged in LDS.
@@ -831,7 +751,7 @@ static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st)
 static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
+    const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
     if (mode == 1) launch_one<64, 1>(a, tiles, lds, st);
     else if (BN == 128) {

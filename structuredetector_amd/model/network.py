@@ -113,16 +113,17 @@ class _Engine:
     def __init__(self, net: "Network"):
         self.net = net
         self.lib = L.lib()
-        self.prof = None      # list -> every conv launch appends (kernel, algorithmic flops, start event, end event)
+        self.prof = None      # list -> every conv launch appends (kernel, algorithmic flops, start event, end event, phase)
+        self._nbt = []        # num_batches_tracked counters touched by the running forward (bumped with one launch)
 
-    def _timed(self, kind, flops, fn):
+    def _timed(self, kind, flops, fn, phase="fwd"):
         if self.prof is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()           # torch's current stream == the stream handed to the C ABI (L.stream())
         fn()
         e1.record()
-        self.prof.append((kind, flops, e0, e1))
+        self.prof.append((kind, flops, e0, e1, phase))
 
     # ---- helpers -------------------------------------------------------------------------
     def _ws(self, nbytes, dev):
@@ -153,7 +154,7 @@ class _Engine:
         L.check(self.lib.sd_bn_apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
                                      bn.bias.data_ptr(), _ptr(res), int(relu), L.stream()), "sd_bn_apply")
         if update_running:
-            bn.num_batches_tracked += 1
+            self._nbt.append(bn.num_batches_tracked)
         return y, mean, invstd
 
     def bn_fold(self, bn: BNParams):
@@ -254,6 +255,9 @@ class _Engine:
                                 L.stream()), "sd_head_fwd")
         if rec:
             tape.update(blocks=blocks_tape, fpn=fpn_tape, p5=(p5, H5, W5), f1=f, B=B, hw=(H2, W2))
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
         return out
 
     # ---- backward ------------------------------------------------------------------------
@@ -269,7 +273,8 @@ class _Engine:
         wt = self._wt(conv)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         self._timed("k_conv_igemm<%d>" % (128 if conv.cin % 128 == 0 else 64), flops, lambda: L.check(
-            self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"))
+            self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"),
+            phase="dgrad")
         return dx
 
     def _wgrad(self, dy, x, conv, d):
@@ -279,7 +284,7 @@ class _Engine:
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         self._timed("k_conv_wgrad", flops, lambda: L.check(
             self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
-            "sd_conv2d_wgrad"))
+            "sd_conv2d_wgrad"), phase="wgrad")
 
     def _bias_grad(self, dy, conv):
         Mrows, Cc = dy.numel() // dy.shape[-1], dy.shape[-1]
