@@ -172,9 +172,21 @@ int sd_conv2d_fwd(const float* x_nhwc, const float* w_krsc, float* y_nhwc, const
                   void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* stem: 7x7/2 conv 3 -> 64 reading the NCHW image directly (network.py:43; resnet.conv1). */
 size_t sd_conv2d_stem_fwd_workspace_bytes(const sd_conv_desc* d);
-int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, float* y_nhwc, const sd_conv_desc* d,
-                       const float* scale, const float* shift, int relu, void* workspace, size_t workspace_bytes,
-                       sd_stream_t stream);
+int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, const sd_conv_desc* d,
+                       const float* scale, const float* shift, int relu, int out_bf16, void* workspace,
+                       size_t workspace_bytes, sd_stream_t stream);
+
+/* bf16 backbone (inference; BASELINE stress config "bf16 backbone + fp32 decode"): activations and weights bf16
+ * NHWC / [Cout][R][S][Cin], v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 epilogue (folded BN, bias,
+ * residual, ReLU), bf16 stores.  Needs Cin % 64 == 0. */
+int sd_cast_f32_to_bf16(const float* x, void* y_bf16, int64_t n, sd_stream_t stream);
+size_t sd_conv2d_fwd_bf16_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_fwd_bf16(const void* x_nhwc_bf16, const void* w_krsc_bf16, void* y_nhwc_bf16, const sd_conv_desc* d,
+                       const float* scale, const float* shift, const void* residual_bf16, int res_up2, int relu,
+                       void* workspace, size_t workspace_bytes, sd_stream_t stream);
+int sd_maxpool3x3s2_fwd_bf16(const void* x_bf16, void* y_bf16, int B, int Hi, int Wi, int C, sd_stream_t stream);
+int sd_head_fwd_bf16(const void* x_nhwc_bf16, const float* w, const float* bias, float* y_nchw, int B, int HW, int C,
+                     int Co, sd_stream_t stream);
 /* dX = conv_transpose(dY, W): same kernel with the inverted coordinate map; w_t = weights
  * re-laid as [Cin][R][S][Cout] by sd_conv2d_transpose_weights.  residual (nullable, same layout as
  * dX) is added (skip-connection gradient). */

@@ -70,7 +70,12 @@ _SIGNATURES = {
     "sd_conv2d_fwd_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_fwd_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
-    "sd_conv2d_stem_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_stem_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
+    "sd_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "sd_conv2d_fwd_bf16_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "sd_conv2d_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
+    "sd_maxpool3x3s2_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_head_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_dgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp]),
     "sd_conv2d_transpose_weights": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),

@@ -20,6 +20,10 @@
 namespace sd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }   // round-to-nearest-even (v_cvt_pk_bf16_f32)
 
 #ifndef SD_IGEMM_NBUF
 #define SD_IGEMM_NBUF 2
@@ -28,16 +32,18 @@ constexpr int NBUF = SD_IGEMM_NBUF;   // LDS stages of the igemm tiles: 2 = doub
 constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
 struct ConvArgs {
-    const float* x;       // A source, NHWC [B][Hi][Wi][Ck]   (STEM: NCHW [B][3][Hi][Wi])
-    const float* w;       // [Nn][R*S][Ck]
-    float* y;             // [M][Nn], M = B*Ho*Wo
+    // x / w / y / res are fp32, or bf16 in the BF16 instantiation (inference with a bf16 backbone); the accumulator,
+    // scale / shift and the split-K partials are always fp32
+    const void* x;        // A source, NHWC [B][Hi][Wi][Ck]   (STEM: NCHW [B][3][Hi][Wi])
+    const void* w;        // [Nn][R*S][Ck]
+    void* y;              // [M][Nn], M = B*Ho*Wo
     const float* scale;   // per-n multiplier (nullable)
     const float* shift;   // per-n addend (nullable): bias or folded BN
-    const float* res;     // residual, [M][Nn] or (res_up2) [B][Ho/2][Wo/2][Nn] (nullable)
+    const void* res;      // residual, [M][Nn] or (res_up2) [B][Ho/2][Wo/2][Nn] (nullable)
     int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S;
     int mul, div, off, rsign;   // input coord t = o*mul + off + rsign*r ; valid iff t>=0, t%div==0, t/div < Hi
     int relu, res_up2;
-    int M, nk, kchunks;   // kchunks = Ck/32 (STEM: unused), nk = number of 32-wide K chunks
+    int M, nk, kchunks;   // kchunks = Ck / (elements per 128-byte chunk: 32 fp32 or 64 bf16); nk = number of K chunks
     int splits;           // split-K (small-batch inference): blockIdx.y = K slice, raw partial tiles go to `part`
     float* part;          // [splits][M][Nn]
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
@@ -61,9 +67,15 @@ __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v
 // NOTE on style: the staging registers are individual named variables filled by macros, not arrays written
 // inside lambdas -- hipcc left such arrays in scratch memory (scratch_store after every global_load and a
 // vmcnt(0) wait per load), which serialised the prefetch.
-template <int BN, int MODE>
+template <int BN, int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     constexpr bool STEM = (MODE == 1);
+    using T = typename std::conditional<BF16, uint16_t, float>::type;
+    constexpr int KE = BF16 ? 64 : 32;     // K elements per 128-byte chunk row
+    constexpr int VE = BF16 ? 8 : 4;       // elements per 16-byte staging vector
+    const T* const px_ = reinterpret_cast<const T*>(p.x);
+    const T* const pw_ = reinterpret_cast<const T*>(p.w);
+    const T* const zero_ = reinterpret_cast<const T*>(g_zero_line);
     constexpr int NT = BN / 64;            // 32-wide MFMA tiles per wave along n (wave tile = 64 x BN/2)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][BM][LDK]
@@ -89,11 +101,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
 
     // ---- staging assignment: thread -> (row = tid/8 + 32*i, 4 consecutive k = (tid%8)*4)
-    const int srow = tid >> 3, sk = (tid & 7) * 4;
+    const int srow = tid >> 3, sk = (tid & 7) * 4;        // sk: LDS float offset of the staged 16-byte slot
+    const int ske = (tid & 7) * VE;                        // the same slot in elements of the source tensors
     const int img_stride = p.Hi * p.Wi * (STEM ? 3 : p.Ck);
 #define SD_ROW_SETUP(i)                                                                           \
     int aty##i = 0, atx##i = 0;                                                                   \
-    const float* aptr##i = p.x;                                                                   \
+    const T* aptr##i = px_;                                                                       \
     bool aok##i;                                                                                  \
     {                                                                                             \
         const int m = m0 + srow + 32 * i;                                                         \
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             }                                                                                     \
             aty##i = oy * p.mul + p.off;                                                          \
             atx##i = ox * p.mul + p.off;                                                          \
-            aptr##i = p.x + (int64_t)b * img_stride;                                              \
+            aptr##i = px_ + (int64_t)b * img_stride;                                              \
             pix = (b * p.Ho + oy) * p.Wo + ox;                                                    \
         }                                                                                         \
         if ((tid & 7) == 0) orow[srow + 32 * i] = pix;                                            \
@@ -118,10 +131,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     SD_ROW_SETUP(0) SD_ROW_SETUP(1) SD_ROW_SETUP(2) SD_ROW_SETUP(3)
 #undef SD_ROW_SETUP
     const int wk = p.R * p.S * (STEM ? 3 : p.Ck);
-    const float* wrow0 = p.w + (int64_t)(n0 + srow) * wk;
-    const float* wrow1 = wrow0 + (int64_t)32 * wk;
-    const float* wrow2 = wrow0 + (int64_t)64 * wk;      // used when BN == 128
-    const float* wrow3 = wrow0 + (int64_t)96 * wk;
+    const T* wrow0 = pw_ + (int64_t)(n0 + srow) * wk;
+    const T* wrow1 = wrow0 + (int64_t)32 * wk;
+    const T* wrow2 = wrow0 + (int64_t)64 * wk;          // used when BN == 128
+    const T* wrow3 = wrow0 + (int64_t)96 * wk;
 
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         const int kbeg = min((int)blockIdx.y * per, p.nk), kend = min(kbeg + per, p.nk);
         nk = kend - kbeg;
         const int tap = kbeg / p.kchunks;
-        ld_c0 = (kbeg - tap * p.kchunks) * BK; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
+        ld_c0 = (kbeg - tap * p.kchunks) * KE; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
     }
 
     // Padding rows read a zero line instead of being predicated: there is no select after the load, so the compiler
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             ty /= p.div; tx /= p.div;                                                             \
         }                                                                                         \
         ok = ok && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;                \
-        const float* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + sk) : g_zero_line + sk; \
+        const T* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + ske) : zero_ + ske;     \
         ra##i = *reinterpret_cast<const float4*>(src);                                            \
     }
 #define SD_LOAD_A_STEM(i)                                                                         \
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             const int r = tap / p.S, s = tap - r * p.S;                                           \
             const int ty = aty##i + r, tx = atx##i + s;                                           \
             const bool ok = aok##i && k < wk && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi; \
-            const float* src = ok ? aptr##i + ((ci * p.Hi + ty) * p.Wi + tx) : g_zero_line;      \
+            const float* src = ok ? reinterpret_cast<const float*>(aptr##i) + ((ci * p.Hi + ty) * p.Wi + tx) : g_zero_line; \
             v[j] = *src;                                                                          \
         }                                                                                         \
         ra##i = make_float4(v[0], v[1], v[2], v[3]);                                              \
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         float v[4];                                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
             const int k = ld_kc * BK + sk + j;                                                    \
-            const float* src = k < wk ? wrow##i + k : g_zero_line;                                \
+            const float* src = k < wk ? reinterpret_cast<const float*>(wrow##i) + k : g_zero_line; \
             v[j] = *src;                                                                          \
         }                                                                                         \
         rb##i = make_float4(v[0], v[1], v[2], v[3]);                                              \
@@ -177,14 +190,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 #define SD_LOAD_CHUNK()                                                                           \
     if (!STEM) {                                                                                  \
         SD_LOAD_A(0) SD_LOAD_A(1) SD_LOAD_A(2) SD_LOAD_A(3)                                       \
-        const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0 + sk;                                 \
+        const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0 + ske;                                \
         rb0 = *reinterpret_cast<const float4*>(wrow0 + woff);                                     \
         rb1 = *reinterpret_cast<const float4*>(wrow1 + woff);                                     \
         if (BN == 128) {                                                                          \
             rb2 = *reinterpret_cast<const float4*>(wrow2 + woff);                                 \
             rb3 = *reinterpret_cast<const float4*>(wrow3 + woff);                                 \
         }                                                                                         \
-        ld_c0 += BK;                                                                              \
+        ld_c0 += KE;                                                                              \
         if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
     } else {                                                                                      \
         SD_LOAD_A_STEM(0) SD_LOAD_A_STEM(1) SD_LOAD_A_STEM(2) SD_LOAD_A_STEM(3)                   \
@@ -247,6 +260,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(ks + 1));
                 if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(ks + 1));
             }
+            if (BF16) {
+                // one 16-byte slot = 8 bf16 = this lane's k-half of a 32x32x16 MFMA step
+                const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);
+                const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);
+                if (NT == 2) {
+                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][NT - 1], 0, 0, 0);
+                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][NT - 1], 0, 0, 0);
+                }
+            } else {
             // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                     acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b1, t), acc[0][NT - 1], 0, 0, 0);
                     acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b1, t), acc[1][NT - 1], 0, 0, 0);
                 }
+            }
             }
         }
         if (NBUF == 1) __syncthreads();            // every wave is done reading the single buffer
@@ -301,10 +326,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                         const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
                         rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
                     }
-                    v += p.res[rm * p.Nn + n];
+                    v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
-                p.y[(int64_t)m * p.Nn + n] = v;
+                if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
+                else reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
             }
         }
     }
@@ -481,6 +507,7 @@ struct StemArgs {
     const float* scale;
     const float* shift;
     int relu;
+    int out_bf16;         // forward: store the NHWC output as bf16 (bf16 backbone)
     int B, H, W, Ho, Wo, tiles_x, ntiles;
 };
 
@@ -572,7 +599,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             if (ox >= p.Wo) continue;
             float v = (ni ? acc1[e] : acc0[e]) * sc + sh;
             if (p.relu) v = fmaxf(v, 0.f);
-            p.y[(row0 + ox) * 64 + n] = v;
+            if (p.out_bf16) reinterpret_cast<uint16_t*>(p.y)[(row0 + ox) * 64 + n] = f2bf(v);
+            else p.y[(row0 + ox) * 64 + n] = v;
         }
     }
 }
@@ -712,6 +740,7 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w
 }
 
 // split-K second pass: y = epilogue( sum over K slices of the partial tiles )
+template <bool BF16>
 __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
     const int64_t n4 = (int64_t)p.M * p.Nn / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -731,28 +760,38 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
         }
-        const float4 r = *reinterpret_cast<const float4*>(p.res + rm * p.Nn + n);
-        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        if (BF16) {
+            const ushort4 r = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(p.res) + rm * p.Nn + n);
+            a.x += bf2f(r.x); a.y += bf2f(r.y); a.z += bf2f(r.z); a.w += bf2f(r.w);
+        } else {
+            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
     }
     if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    reinterpret_cast<float4*>(p.y)[i] = a;
+    if (BF16) reinterpret_cast<ushort4*>(p.y)[i] = make_ushort4(f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w));
+    else reinterpret_cast<float4*>(p.y)[i] = a;
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     static bool attr = false;              // one flag per instantiation
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BN, MODE, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_igemm<BN, MODE>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_conv_igemm<BN, MODE, BF16>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), lds, st, a);
 }
 
-static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
+static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 = false) {
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
+    if (bf16) {                            // inference forward only (MODE 0)
+        if (BN == 128) launch_one<128, 0, true>(a, tiles, lds, st);
+        else launch_one<64, 0, true>(a, tiles, lds, st);
+    } else
     if (mode == 1) launch_one<64, 1>(a, tiles, lds, st);
     else if (BN == 128) {
         if (mode == 0) launch_one<128, 0>(a, tiles, lds, st);
@@ -765,18 +804,19 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st) {
     }
     SD_LAUNCH_CHECK();
     if (a.splits > 1) {
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv((int64_t)a.M * a.Nn / 4, 256)), dim3(256), 0, st, a);
+        if (bf16) hipLaunchKernelGGL(k_splitk_reduce<true>, dim3(cdiv((int64_t)a.M * a.Nn / 4, 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_splitk_reduce<false>, dim3(cdiv((int64_t)a.M * a.Nn / 4, 256)), dim3(256), 0, st, a);
         SD_LAUNCH_CHECK();
     }
     return 0;
 }
 
 // Split-K factor of the forward conv: only when the tile grid cannot fill the chip (small batch).
-static int fwd_splits(const sd_conv_desc* d) {
+static int fwd_splits(const sd_conv_desc* d, int ke = BK) {
     const int M = d->B * d->Ho * d->Wo;
     const int BN = (d->Cout % 128 == 0) ? 128 : 64;
     const int tiles = cdiv(M, BM) * (d->Cout / BN);
-    const int nk = d->R * d->S * (d->Cin / BK);
+    const int nk = d->R * d->S * (d->Cin / ke);
     if (tiles >= 256 || nk < 8) return 1;
     int s = std::min(cdiv(512, tiles), nk / 4);          // fill ~2 blocks per CU, keep >= 4 chunks per slice
     return std::max(1, std::min(s, 64));
@@ -837,8 +877,36 @@ static bool stem_is_7x7s2(const sd_conv_desc* d) { return d->Cin == 3 && d->Cout
 
 size_t sd_conv2d_stem_fwd_workspace_bytes(const sd_conv_desc* d) { (void)d; return (size_t)STEM_K * 64 * sizeof(float); }
 
-int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
-                       void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+size_t sd_conv2d_fwd_bf16_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 64 || d->Cout % 64) return 0;
+    const int s = fwd_splits(d, 64);
+    return s > 1 ? (size_t)s * d->B * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
+}
+
+int sd_conv2d_fwd_bf16(const void* x, const void* w, void* y, const sd_conv_desc* d, const float* scale, const float* shift,
+                       const void* residual, int res_up2, int relu, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_fwd_bf16", d)) return e;
+    SD_REQUIRE(x && w && y, SD_ERR_INVALID, "sd_conv2d_fwd_bf16: null pointer");
+    SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd_bf16: needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)",
+               d->Cin, d->Cout);
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd_bf16: pointers must be 16-byte aligned");
+    SD_REQUIRE(!res_up2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd_bf16: res_up2 needs even Ho, Wo");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.relu = relu; a.res_up2 = res_up2;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / 64; a.nk = d->R * d->S * a.kchunks;
+    a.splits = fwd_splits(d, 64);
+    if (a.splits > 1) {
+        if (workspace && workspace_bytes >= sd_conv2d_fwd_bf16_workspace_bytes(d)) a.part = (float*)workspace;
+        else a.splits = 1;
+    }
+    return launch_igemm(a, false, (hipStream_t)stream, true);
+}
+
+int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
+                       int out_bf16, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_conv("sd_conv2d_stem_fwd", d)) return e;
     SD_REQUIRE(x_nchw && w && y, SD_ERR_INVALID, "sd_conv2d_stem_fwd: null pointer");
     SD_REQUIRE(d->Cin == 3 && d->Cout == 64, SD_ERR_INVALID, "sd_conv2d_stem_fwd: the stem is 3 -> 64 channels (network.py:43)");
@@ -849,7 +917,7 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, float* y, const sd_c
         hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
         SD_LAUNCH_CHECK();
         StemArgs a{};
-        a.x = x_nchw; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift; a.relu = relu;
+        a.x = x_nchw; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift; a.relu = relu; a.out_bf16 = out_bf16;
         stem_args(a, d);
         const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
         static bool attr = false;
@@ -858,6 +926,7 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, float* y, const sd_c
         SD_LAUNCH_CHECK();
         return 0;
     }
+    SD_REQUIRE(!out_bf16, SD_ERR_INVALID, "sd_conv2d_stem_fwd: bf16 output needs the 7x7/2 geometry and a workspace");
     ConvArgs a{};
     a.x = x_nchw; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.relu = relu;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = 3; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = 64; a.R = d->R; a.S = d->S;

@@ -475,6 +475,102 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 backbone (inference): weight cast, max-pool and head reading bf16 NHWC activations
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f_(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf_(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<ushort4*>(y)[i] = make_ushort4(f2bf_(v.x), f2bf_(v.y), f2bf_(v.z), f2bf_(v.w));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_fwd_bf16(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int B, int Hi, int Wi,
+                                                           int Ho, int Wo, int C) {
+    const int cols = C >> 3;                       // 8 bf16 = 16 bytes per thread
+    const int64_t n8 = (int64_t)B * Ho * Wo * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int iy = oy * 2 - 1 + r, ix = ox * 2 - 1 + s;
+            if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+            const uint4 v = reinterpret_cast<const uint4*>(x + (((int64_t)b * Hi + iy) * Wi + ix) * C)[col];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m[2 * j] = fmaxf(m[2 * j], __uint_as_float(w[j] << 16));
+                m[2 * j + 1] = fmaxf(m[2 * j + 1], __uint_as_float(w[j] & 0xffff0000u));
+            }
+        }
+    uint4 o;
+    o.x = (uint32_t)f2bf_(m[0]) | ((uint32_t)f2bf_(m[1]) << 16); o.y = (uint32_t)f2bf_(m[2]) | ((uint32_t)f2bf_(m[3]) << 16);
+    o.z = (uint32_t)f2bf_(m[4]) | ((uint32_t)f2bf_(m[5]) << 16); o.w = (uint32_t)f2bf_(m[6]) | ((uint32_t)f2bf_(m[7]) << 16);
+    reinterpret_cast<uint4*>(y)[i] = o;
+}
+
+// head on a bf16 NHWC input: fp32 weights / accumulation / NCHW output (the decoder always runs in fp32)
+__global__ __launch_bounds__(256) void k_head_fwd_bf16(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int64_t M, int HW, int C, int Co) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int LD = C + 4;
+    float* xs = lds;                 // [64][C+4] fp32
+    float* ws = lds + 64 * LD;       // [Co][C]
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int c8 = C >> 3;
+    for (int i = threadIdx.x; i < 64 * c8; i += 256) {
+        const int row = i / c8, col = i - row * c8;
+        const int64_t m = m0 + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) v = reinterpret_cast<const uint4*>(x + m * C)[col];
+        float* d = xs + row * LD + col * 8;
+        d[0] = __uint_as_float(v.x << 16); d[1] = __uint_as_float(v.x & 0xffff0000u);
+        d[2] = __uint_as_float(v.y << 16); d[3] = __uint_as_float(v.y & 0xffff0000u);
+        d[4] = __uint_as_float(v.z << 16); d[5] = __uint_as_float(v.z & 0xffff0000u);
+        d[6] = __uint_as_float(v.w << 16); d[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    for (int i = threadIdx.x; i < Co * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int px = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float acc[HEAD_MAX_CO / 4];
+#pragma unroll
+    for (int j = 0; j < HEAD_MAX_CO / 4; ++j) acc[j] = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xs + px * LD + c);
+#pragma unroll
+        for (int j = 0; j < HEAD_MAX_CO / 4; ++j) {
+            const int co = grp + 4 * j;
+            if (co < Co) {
+                const float4 ww = *reinterpret_cast<const float4*>(ws + co * C + c);
+                acc[j] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+        }
+    }
+    const int64_t m = m0 + px;
+    if (m < M) {
+        const int64_t b = m / HW, pix = m - b * HW;
+#pragma unroll
+        for (int j = 0; j < HEAD_MAX_CO / 4; ++j) {
+            const int co = grp + 4 * j;
+            if (co < Co) y[(b * Co + co) * HW + pix] = acc[j] + bias[co];
+        }
+    }
+}
+
 static inline int ew_grid(int64_t n4) { return (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16); }
 
 }  // namespace sd
@@ -589,6 +685,32 @@ int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H
     SD_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_upsample2x_bwd: bad arguments");
     const int64_t n4 = (int64_t)B * H * W * C / 4;
     hipLaunchKernelGGL(k_up2_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, add, dx, B, H, W, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_cast_f32_to_bf16(const float* x, void* y, int64_t n, sd_stream_t stream) {
+    SD_REQUIRE(x && y && n > 0 && n % 4 == 0 && aligned16(x), SD_ERR_INVALID, "sd_cast_f32_to_bf16: bad arguments (n %% 4 == 0, 16-byte aligned source)");
+    hipLaunchKernelGGL(k_cast_bf16, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n / 4);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int Hi, int Wi, int C, sd_stream_t stream) {
+    SD_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 8 == 0, SD_ERR_INVALID, "sd_maxpool3x3s2_fwd_bf16: bad arguments");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int64_t n8 = (int64_t)B * Ho * Wo * C / 8;
+    hipLaunchKernelGGL(k_maxpool_fwd_bf16, dim3(cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_head_fwd_bf16(const void* x, const float* w, const float* bias, float* y, int B, int HW, int C, int Co, sd_stream_t stream) {
+    SD_REQUIRE(x && w && bias && y && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_fwd_bf16: bad arguments");
+    SD_REQUIRE(C % 8 == 0 && C <= 512 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_fwd_bf16: needs C %% 8 == 0, C <= 512, Co <= %d", HEAD_MAX_CO);
+    const int64_t M = (int64_t)B * HW;
+    const size_t lds = ((size_t)64 * (C + 4) + (size_t)Co * C) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fwd_bf16, dim3(cdiv(M, 64)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, w, bias, y, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     return 0;
 }

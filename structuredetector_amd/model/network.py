@@ -186,12 +186,12 @@ class _Engine:
         s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.float32, device=x.device)
         wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
         if training:
-            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, wss.data_ptr(),
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, 0, wss.data_ptr(),
                                            wss.numel(), L.stream()), "stem")
             a0, m0, i0 = self.bn_train(s0, bn0)
         else:
             sc, sh = self.bn_fold(bn0)
-            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1,
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 0,
                                            wss.data_ptr(), wss.numel(), L.stream()), "stem")
             a0, m0, i0 = s0, None, None
         Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
@@ -258,6 +258,73 @@ class _Engine:
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)
             self._nbt = []
+        return out
+
+    # ---- bf16 backbone, inference only (BASELINE stress config: "bf16 backbone + fp32 decode") -------------
+    def _w_bf16(self, conv):
+        """bf16 copy of a conv weight in its physical [Cout][R][S][Cin] order (cached with the folded BN affines)."""
+        key = ("w", id(conv))
+        w = self.net._folded.get(key)
+        if w is None:
+            n = conv.weight.numel()
+            w = torch.empty(n, dtype=torch.bfloat16, device=conv.weight.device)
+            L.check(self.lib.sd_cast_f32_to_bf16(conv.weight.data_ptr(), w.data_ptr(), n, L.stream()), "sd_cast_f32_to_bf16")
+            self.net._folded[key] = w
+        return w
+
+    def conv_bf16(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
+        d = _desc(B, Hi, Wi, conv)
+        y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
+        nws = self.lib.sd_conv2d_fwd_bf16_workspace_bytes(C.byref(d))
+        ws = self._ws(nws, x.device) if nws else None
+        L.check(self.lib.sd_conv2d_fwd_bf16(x.data_ptr(), self._w_bf16(conv).data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
+                                            _ptr(res), int(res_up2), int(relu), _ptr(ws), ws.numel() if nws else 0, L.stream()),
+                "sd_conv2d_fwd_bf16")
+        return y, d
+
+    def forward_bf16(self, x):
+        """Eval-mode forward with bf16 activations / weights and fp32 accumulation; BN folded into fp32 epilogues.
+        The stem reads the fp32 image with fp32 weights and stores bf16; the head returns fp32 NCHW."""
+        net, lib = self.net, self.lib
+        L.require_cuda(x)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        if x.dim() != 4 or x.shape[1] != 3 or H % 32 or W % 32:
+            raise L.SdError("Network expects (B, 3, H, W) input with H, W multiples of 32")
+        stem, bn0 = net.adpater[0], net.adpater[1]
+        d0 = _desc(B, H, W, stem)
+        a0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.bfloat16, device=x.device)
+        sc, sh = self.bn_fold(bn0)
+        wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
+        L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), a0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 1,
+                                       wss.data_ptr(), wss.numel(), L.stream()), "stem")
+        Hc, Wc = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
+        cur = torch.empty((B, Hc, Wc, 64), dtype=torch.bfloat16, device=x.device)
+        L.check(lib.sd_maxpool3x3s2_fwd_bf16(a0.data_ptr(), cur.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
+        feats = []
+        for layer in (net.down1, net.down2, net.down3, net.down4):
+            for blk in layer:
+                s1, h1 = self.bn_fold(blk.bn1)
+                a1, d1 = self.conv_bf16(cur, blk.conv1, B, Hc, Wc, scale=s1, shift=h1, relu=True)
+                if blk.downsample is not None:
+                    sd_, hd = self.bn_fold(blk.downsample[1])
+                    idt, _ = self.conv_bf16(cur, blk.downsample[0], B, Hc, Wc, scale=sd_, shift=hd)
+                else:
+                    idt = cur
+                s2, h2 = self.bn_fold(blk.bn2)
+                cur, _ = self.conv_bf16(a1, blk.conv2, B, d1.Ho, d1.Wo, scale=s2, shift=h2, res=idt, relu=True)
+                Hc, Wc = d1.Ho, d1.Wo
+            feats.append((cur, Hc, Wc))
+        (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
+        f, _ = self.conv_bf16(p5, net.up1, B, H5, W5, shift=net.up1.bias)
+        for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
+            t, _ = self.conv_bf16(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
+            sf, hf = self.bn_fold(fpn.conv[1])
+            f, _ = self.conv_bf16(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True)
+        hc = net.head.conv
+        out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
+        L.check(lib.sd_head_fwd_bf16(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
+                                     L.stream()), "sd_head_fwd_bf16")
         return out
 
     # ---- backward ------------------------------------------------------------------------
@@ -397,6 +464,9 @@ class Network(nn.Module):
     def __init__(self, args, pretrained=True, raw_output: bool = False):
         super().__init__()
         self.raw_output = raw_output
+        # `--amp` (args.use_amp): the reference autocasts the TRAINING forward (trainer.py:115-121); here it selects the
+        # bf16 backbone for inference (BASELINE stress config).  Training always runs the fp32 kernels.
+        self.bf16_inference = bool(getattr(args, "use_amp", False))
         self.label_count = len(args.labels)  # M
         self.part_count = len(args.parts)  # N
         self.out_channels = self.label_count + self.part_count + 4
@@ -501,6 +571,8 @@ class Network(nn.Module):
             raise L.SdError("Network must be moved to the GPU first (`net.to('cuda')`): there is no CPU path")
         if self.training and torch.is_grad_enabled():
             out = _NetFn.apply(self, x, *self._flat_order)
+        elif self.bf16_inference and not self.training:
+            out = self._engine.forward_bf16(x)
         else:
             out = self._engine.forward(x, self.training)
         if self.raw_output:

@@ -1,0 +1,101 @@
+"""bf16 backbone (inference): hand-written bf16 MFMA convs against a PyTorch reference of the same op
+(bf16-rounded operands, fp32 accumulation) and the whole network against the CPU oracle under bf16 autocast."""
+import ctypes as C
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sdnet_oracle as O
+from tests.test_gpu_network import close, make_desc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc_bf16(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 3, 1, 1), (1, 20, 12, 64, 128, 3, 2, 1), (2, 12, 12, 128, 128, 1, 1, 0),
+                                  (1, 16, 16, 512, 512, 3, 1, 1), (3, 9, 7, 256, 128, 3, 1, 1)])
+def test_conv_fwd_bf16(case):
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()          # exactly representable operands
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16().float()
+    scale = torch.rand(cout, generator=g) + 0.5; shift = torch.randn(cout, generator=g)
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    res = torch.randn(B, cout, d.Ho, d.Wo, generator=g).bfloat16().float()
+    xd, wd, rd = nhwc_bf16(x), nhwc_bf16(w), nhwc_bf16(res)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    y = torch.empty(B, d.Ho, d.Wo, cout, dtype=torch.bfloat16, device=DEV)
+    nws = lib.sd_conv2d_fwd_bf16_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), sc.data_ptr(), sh.data_ptr(), rd.data_ptr(), 0, 1,
+                                   ws.data_ptr(), ws.numel(), L.stream()))
+    ref = F.relu(F.conv2d(x, w, None, stride, pad) * scale[None, :, None, None] + shift[None, :, None, None] + res)
+    got = y.float().permute(0, 3, 1, 2).cpu()
+    # products of bf16 values are exact in fp32; only the accumulation order and the final bf16 rounding (2^-9) differ
+    close(got, ref, 6e-3)
+
+
+def _pair(M=2, N=1, seed=0):
+    from structuredetector_amd.model import Network
+    ref = O.build_reference_network(M, N, seed=seed)
+    args = Namespace(labels={f"l{i}": i for i in range(M)}, parts={f"p{i}": i for i in range(N)}, fpn_depth=128, use_amp=True)
+    net = Network(args, pretrained=False, raw_output=True)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.to(DEV)
+
+
+def test_network_bf16_inference_vs_oracle():
+    ref, net = _pair(seed=2)
+    x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(1))
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        want32 = ref(x)
+        with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+            want16 = ref(x).float()
+        got = net(x.to(DEV)).cpu()
+    assert got.dtype == torch.float32 and got.shape == want32.shape
+    scale = want32.abs().max().item()
+    err_ours = (got - want32).abs().max().item() / scale
+    err_autocast = (want16 - want32).abs().max().item() / scale
+    # fp32 epilogues make the hand-written path at least as accurate as torch's bf16 autocast of the same network
+    assert err_ours <= max(1.5 * err_autocast, 2e-2), (err_ours, err_autocast)
+    # fp32 path of the same object still available and exact
+    net.bf16_inference = False
+    with torch.no_grad():
+        close(net(x.to(DEV)).cpu(), want32, 1e-4)
+
+
+def test_stress_config_bf16_backbone_fp32_decode():
+    """BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, >= 64 objects per image, bf16 backbone + fp32 decode.
+    Decoder parity at this size is asserted against the oracle on the SAME head tensor (bit-exact indices / grouping)."""
+    from structuredetector_amd.data import Decoder
+    from structuredetector_amd.model import Network
+    from tests.test_host_cpu import make_args
+    M = N = 8; K, P = 128, 512
+    args = make_args(M, N, K, P, device=torch.device(DEV), use_amp=True)
+    net = Network(args, pretrained=False).to(DEV).eval()
+    x = torch.randn(1, 3, 1024, 1024, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    with torch.no_grad():
+        out = net(x)
+    assert out["anchor_hm"].shape == (1, 8, 256, 256) and out["anchor_hm"].dtype == torch.float32
+    head = torch.cat([out["anchor_hm"], out["part_hm"], out["offsets"], out["embeddings"]], 1)
+    assert torch.isfinite(head).all()
+    dec = Decoder(args)
+    packed, _ = dec.decode_packed(out, 0.5, 0.1)
+    got = dec.split_packed(packed.cpu().numpy(), 1, K, P)
+    h = head.cpu().numpy()
+    t = O.decode_tensors(h[:, :M], h[:, M:M + N], h[:, M + N:M + N + 2], h[:, M + N + 2:], K, P, 0.5, 0.1)
+    for grp in ("anchor", "part"):
+        es = t[f"{grp}_out"][..., 2]
+        gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / np.maximum(es[:, 1:], 1e-30)
+        safe = np.ones_like(es, bool); safe[:, 1:] &= gap > 2e-6; safe[:, :-1] &= gap > 2e-6
+        np.testing.assert_array_equal(got[f"{grp}_ind"][safe], t[f"{grp}_inds"][safe])

@@ -145,11 +145,11 @@ def test_conv_up2_residual_and_stem():
     d0 = make_desc(L, 2, 64, 96, 3, 64, 7, 2, 3)
     y0 = torch.empty(2, d0.Ho, d0.Wo, 64, device=DEV)
     wsf = torch.empty(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), dtype=torch.uint8, device=DEV)
-    L.check(lib.sd_conv2d_stem_fwd(keep(img.to(DEV)).data_ptr(), krsc(ws_).data_ptr(), y0.data_ptr(), C.byref(d0), 0, 0, 0, wsf.data_ptr(),
+    L.check(lib.sd_conv2d_stem_fwd(keep(img.to(DEV)).data_ptr(), krsc(ws_).data_ptr(), y0.data_ptr(), C.byref(d0), 0, 0, 0, 0, wsf.data_ptr(),
                                    wsf.numel(), L.stream()))
     close(from_nhwc(y0), F.conv2d(img, ws_, None, 2, 3), 1e-5)
     y0b = torch.empty_like(y0)                           # without a workspace: generic gather kernel, same result
-    L.check(lib.sd_conv2d_stem_fwd(keep(img.to(DEV)).data_ptr(), krsc(ws_).data_ptr(), y0b.data_ptr(), C.byref(d0), 0, 0, 0, 0, 0, L.stream()))
+    L.check(lib.sd_conv2d_stem_fwd(keep(img.to(DEV)).data_ptr(), krsc(ws_).data_ptr(), y0b.data_ptr(), C.byref(d0), 0, 0, 0, 0, 0, 0, L.stream()))
     close(from_nhwc(y0b), F.conv2d(img, ws_, None, 2, 3), 1e-5)
     dy = torch.randn(2, 64, d0.Ho, d0.Wo, generator=g)
     wr = ws_.clone().requires_grad_(True)
