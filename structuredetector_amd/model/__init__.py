@@ -1,2 +1,3 @@
+from .evaluator import Evaluation, Evaluations, Evaluator
 from .loss import Loss, LossStats
 from .network import Network

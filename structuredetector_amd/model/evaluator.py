@@ -1,0 +1,308 @@
+"""`Evaluator`: keypoint / structure metrics of the `evaluate` entry point (the first "next" row).
+
+Same metrics, thresholds and table layout as the reference's `Evaluator` / `Evaluations` / `Evaluation`
+(src/sdnet/model/evaluator.py:13-646): greedy matching of predictions (by descending score) to their NEAREST
+ground truth -- a prediction whose nearest ground truth is already taken is a false positive, there is no
+second choice (:244-286) -- for anchors (:244), raw parts (:288), whole structures by CSI (:380, :538) and the
+count-classification metric (:427).  The O(preds x gts) Python loops of the reference become one distance matrix
+and an argmin per image (numpy, float64 like `np.hypot` in `Keypoint.distance`), which keeps `evaluate` from being
+dominated by host matching once the decoder takes microseconds.  Counters merge associatively (`+=`), so ranks of a
+data-parallel evaluation can be combined by summing (`Evaluator.merge`).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+
+
+def greedy_nearest(pred_xy, pred_score, gt_xy, threshold, inclusive=False):
+    """Match predictions (score-descending, stable) to their nearest ground truth.
+    Returns (number of true positives, distances of the true positives in match order)."""
+    if len(pred_xy) == 0 or len(gt_xy) == 0:
+        return 0, []
+    p = np.asarray(pred_xy, np.float64).reshape(-1, 2)
+    g = np.asarray(gt_xy, np.float64).reshape(-1, 2)
+    order = np.argsort(-np.asarray(pred_score, np.float64), kind="stable")
+    d = np.hypot(p[order, None, 0] - g[None, :, 0], p[order, None, 1] - g[None, :, 1])
+    j = d.argmin(axis=1)                                   # first minimum, like the reference's strict `<` scan
+    dmin = d[np.arange(len(order)), j]
+    ok = (dmin <= threshold) if inclusive else (dmin < threshold)
+    rows = np.nonzero(ok)[0]
+    _, first = np.unique(j[rows], return_index=True)       # the first (best-scored) claimant of each ground truth wins
+    winners = np.sort(rows[first])
+    return len(winners), dmin[winners].tolist()
+
+
+class Evaluation:
+    def __init__(self, tp=0, npos=0, ndet=0, acc=None, counts=None):
+        assert tp >= 0 and ndet >= 0 and npos >= 0, "tp, npos and ndet should be positive"
+        assert tp <= ndet, "tp must be lower than or equal to ndet"
+        assert tp <= npos, "tp must be lower than or equal to npos"
+        self.tp, self.npos, self.ndet = tp, npos, ndet
+        self.acc = acc or []
+        self.count_errors = counts or []
+
+    def reset(self):
+        self.__init__()
+
+    def __iadd__(self, other):
+        self.tp += other.tp; self.npos += other.npos; self.ndet += other.ndet
+        self.acc = self.acc + other.acc
+        self.count_errors = self.count_errors + other.count_errors
+        return self
+
+    def __add__(self, other):
+        out = Evaluation(self.tp, self.npos, self.ndet, list(self.acc), list(self.count_errors))
+        out += other
+        return out
+
+    fp = property(lambda s: s.ndet - s.tp)
+    fn = property(lambda s: s.npos - s.tp)
+
+    @property
+    def csi(self):
+        den = self.npos + self.ndet - self.tp
+        return self.tp / den if den != 0 else 1
+
+    @property
+    def precision(self):
+        return self.tp / self.ndet if self.ndet != 0 else 1 if self.npos == 0 else 0
+
+    @property
+    def recall(self):
+        return self.tp / self.npos if self.npos != 0 else 1 if self.ndet == 0 else 0
+
+    @property
+    def f1_score(self):
+        s = self.npos + self.ndet
+        return 2 * self.tp / s if s != 0 else 1
+
+    @property
+    def avg_acc(self):
+        return np.mean(self.acc) if len(self.acc) != 0 else float("nan")
+
+    @property
+    def acc_err(self):
+        return np.std(self.acc) / np.sqrt(len(self.acc)) if len(self.acc) != 0 else float("nan")
+
+    HEADERS = ("Gts.", "Preds.", "Rec.", "Prec.", "F1 Score", "L. Acc.", "L. Err.")
+
+    def stats(self):
+        return (f"{self.npos}", f"{self.ndet}", f"{self.recall:.2%}", f"{self.precision:.2%}", f"{self.f1_score:.2%}",
+                f"{self.avg_acc:.4%}", f"{self.acc_err:.4%}")
+
+    def __repr__(self):
+        return (f"f1: {self.f1_score:.2%}, rec: {self.recall:.2%}, prec: {self.precision:.2%}, npos: {self.npos}, ndet: {self.ndet}, "
+                f"tp/fp/fn: {self.tp}/{self.fp}/{self.fn}, avg_acc: {self.avg_acc:.2}")
+
+
+class Evaluations:
+    def __init__(self, labels=None):
+        self.evals = {label: Evaluation() for label in labels} if labels else {}
+
+    def reset(self):
+        for e in self.evals.values():
+            e.reset()
+
+    labels = property(lambda s: s.evals.keys())
+
+    def items(self):
+        return self.evals.items()
+
+    def __getitem__(self, label):
+        return self.evals[label]
+
+    def __setitem__(self, label, item):
+        self.evals[label] = item
+
+    def __len__(self):
+        return len(self.evals)
+
+    def __iadd__(self, other):
+        assert self.labels == other.labels, "The Evaluations should have the same labels"
+        for label, e in other.items():
+            self.evals[label] += e
+        return self
+
+    def __add__(self, other):
+        assert self.labels == other.labels, "The Evaluations should have the same labels"
+        out = Evaluations()
+        out.evals = {label: self.evals[label] + e for label, e in other.items()}
+        return out
+
+    def __or__(self, other):
+        out = Evaluations()
+        out.evals = {label: self[label] + other[label] for label in self.labels & other.labels}
+        out.evals.update({label: self[label] for label in self.labels - other.labels})
+        out.evals.update({label: other[label] for label in other.labels - self.labels})
+        return out
+
+    def reduce(self):
+        total = Evaluation()
+        for e in self.evals.values():
+            total += e
+        return total
+
+    def __repr__(self):
+        lines = [f"total: {self.reduce()}"] if len(self) > 1 else []
+        return "\n".join(lines + [f"{label}: {e}" for label, e in self.items()])
+
+
+def _by(items, key):
+    out = defaultdict(list)
+    for it in items:
+        out[key(it)].append(it)
+    return out
+
+
+class Evaluator:
+    def __init__(self, args):
+        self.args = args
+        self.labels = args.labels.keys()
+        self.kp_labels = args.parts.keys()
+        self.reset()
+
+    def reset(self):
+        self.anchor_eval = Evaluations(self.labels)
+        self.part_eval = Evaluations(self.kp_labels)
+        self.csi_eval = Evaluations(self.labels)
+        self.classification_eval = Evaluations(Evaluator.get_classification_labels())
+
+    @property
+    def kps_eval(self):
+        return self.anchor_eval | self.part_eval
+
+    @staticmethod
+    def get_classification_labels():
+        """Hard-coded in the reference too (evaluator.py:421-425)."""
+        return [f"bean_{i}" for i in range(10)] + [f"maize_{i}" for i in range(10)]
+
+    def merge(self, other):
+        """Combine the counters of another rank's Evaluator (data-parallel evaluation)."""
+        self.anchor_eval += other.anchor_eval; self.part_eval += other.part_eval
+        self.csi_eval += other.csi_eval; self.classification_eval += other.classification_eval
+        return self
+
+    # ------------------------------------------------------------------ per-image accumulation (evaluator.py:226-242)
+    def accumulate(self, prediction, annotation, part_heatmap=None, eval_csi=False, eval_classif=False):
+        self.anchor_eval += self.eval_anchor(prediction, annotation)
+        if part_heatmap is not None:
+            self.part_eval += self.eval_part(annotation, part_heatmap)
+        if eval_csi:
+            self.csi_eval += self.eval_csi(prediction, annotation)
+        if eval_classif:
+            self.classification_eval += self.eval_classif(prediction, annotation)
+
+    def _to_image(self, ann, img_size):
+        return ann.resized((self.args.width, self.args.height), img_size)
+
+    def _match_objects(self, prediction, annotation, labels, key, inclusive):
+        img_size = annotation.img_size
+        annotation, prediction = self._to_image(annotation, img_size), self._to_image(prediction, img_size)
+        thr = min(img_size) * self.args.dist_threshold
+        preds, gts = _by(prediction.objects, key), _by(annotation.objects, key)
+        result = Evaluations(labels)
+        for label in labels:
+            pl, gl = preds.get(label, []), gts.get(label, [])
+            tp, dists = greedy_nearest([(o.x, o.y) for o in pl], [o.anchor.score for o in pl], [(o.x, o.y) for o in gl], thr, inclusive)
+            result[label] = Evaluation(tp, len(gl), len(pl), [d / min(img_size) for d in dists])
+        return result
+
+    def eval_anchor(self, prediction, annotation):                                     # evaluator.py:244-286
+        return self._match_objects(prediction, annotation, self.labels, lambda o: o.name, False)
+
+    def eval_classif(self, prediction, annotation):                                    # evaluator.py:427-474 (<= threshold)
+        return self._match_objects(prediction, annotation, Evaluator.get_classification_labels(),
+                                   lambda o: f"{o.name}_{o.nb_parts}", True)
+
+    def eval_part(self, annotation, part_heatmap):                                     # evaluator.py:288-334
+        img_size = annotation.img_size
+        annotation = self._to_image(annotation, img_size)
+        kps = [kp.resized((self.args.width, self.args.height), img_size) for kp in part_heatmap]
+        thr = min(img_size) * self.args.dist_threshold
+        preds = _by(kps, lambda kp: kp.kind)
+        gts = _by((kp for obj in annotation.objects for kp in obj.parts), lambda kp: kp.kind)
+        result = Evaluations(self.kp_labels)
+        for label in self.kp_labels:
+            pl, gl = preds.get(label, []), gts.get(label, [])
+            tp, dists = greedy_nearest([(k.x, k.y) for k in pl], [k.score for k in pl], [(k.x, k.y) for k in gl], thr)
+            result[label] = Evaluation(tp, len(gl), len(pl), [d / min(img_size) for d in dists])
+        return result
+
+    @staticmethod
+    def compute_csi(prediction, target, dist_thresh):                                  # evaluator.py:538-581
+        if prediction.name != target.name:
+            return 0.0
+        e = Evaluation(0, 1, 1)
+        e.tp += int(prediction.distance(target) < dist_thresh)
+        preds_kp, gts_kp = _by(prediction.parts, lambda kp: kp.kind), _by(target.parts, lambda kp: kp.kind)
+        for kind in gts_kp.keys() | preds_kp.keys():
+            pl, gl = preds_kp.get(kind, []), gts_kp.get(kind, [])
+            e.npos += len(gl); e.ndet += len(pl)
+            tp, _ = greedy_nearest([(k.x, k.y) for k in pl], [k.score for k in pl], [(k.x, k.y) for k in gl], dist_thresh)
+            e.tp += tp
+        return e.csi
+
+    def eval_csi(self, prediction, annotation):                                        # evaluator.py:380-419
+        img_size = annotation.img_size
+        annotation, prediction = self._to_image(annotation, img_size), self._to_image(prediction, img_size)
+        thr = min(img_size) * self.args.dist_threshold
+        preds, gts = _by(prediction.objects, lambda o: o.name), _by(annotation.objects, lambda o: o.name)
+        result = Evaluations(self.labels)
+        for label in self.labels:
+            pl, gl = preds.get(label, []), gts.get(label, [])
+            res = result[label]
+            res.ndet, res.npos = len(pl), len(gl)
+            visited = np.zeros(len(gl), bool)
+            for pred in sorted(pl, key=lambda o: o.anchor.score, reverse=True):
+                best, idx = 0.0, None
+                for j, gt in enumerate(gl):
+                    c = Evaluator.compute_csi(pred, gt, thr)
+                    if c > best:
+                        best, idx = c, j
+                if best >= self.args.csi_threshold and not visited[idx]:
+                    visited[idx] = True
+                    res.tp += 1
+                    res.acc.append(best)
+        return result
+
+    # ------------------------------------------------------------------ reporting (evaluator.py:583-646)
+    def _sections(self):
+        return {"Anchor Location": self.anchor_eval, "Part Location": self.part_eval, "All Kps Location": self.kps_eval,
+                "CSI": self.csi_eval, "Classification": self.classification_eval}
+
+    def pretty_print(self):
+        try:
+            from rich import print as rprint
+            from rich.table import Column, Table
+        except ImportError:                                    # plain text when rich is absent
+            print(repr(self))
+            return
+        for title, evals in self._sections().items():
+            cols = [Column(h, justify="right", style="green" if h == "F1 Score" else None) for h in Evaluation.HEADERS]
+            table = Table(Column("Label", style="bold"), *cols, title=title)
+            for label, e in evals.items():
+                table.add_row(label, *e.stats())
+            if len(evals) > 1:
+                table.add_row("Total", *evals.reduce().stats(), style="bold")
+            rprint(table)
+
+    def _csv_kps_str(self) -> str:
+        evals = self.kps_eval
+        return "\n".join(",".join((label, str(evals[label].recall), str(evals[label].precision), str(evals[label].f1_score),
+                                   str(evals[label].avg_acc))) for label in sorted(evals.labels))
+
+    def save_kps_csv(self, path: Path):
+        Path(path).write_text(self._csv_kps_str())
+
+    def __repr__(self):
+        out = ""
+        for name, evals in self._sections().items():
+            out += f"{name}\n"
+            if len(evals) > 1:
+                out += f"  total: {evals.reduce()}\n"
+            for label, e in sorted(evals.items(), key=lambda t: t[0]):
+                out += f"  {label}: {e}\n"
+        return out

@@ -39,6 +39,7 @@ import sdnet.utils as RU  # noqa: E402  (the reference)
 from sdnet.data.dataset import CropDataset  # noqa: E402
 from sdnet.data.decoders import Decoder  # noqa: E402
 from sdnet.data.transforms import Encode  # noqa: E402
+from sdnet.model.evaluator import Evaluator  # noqa: E402
 from sdnet.model.loss import Loss  # noqa: E402
 from sdnet.model.network import Fpn, Head  # noqa: E402
 
@@ -196,6 +197,42 @@ def gen_truncation(rng):
     np.savez_compressed(HERE / "encode_trunc.npz", **out)
 
 
+def gen_evaluator(rng):
+    """Reference Evaluator on decoded scenes (labels bean / maize / leaf so that the hard-coded classification labels apply)."""
+    M, N, K, P, img = 2, 1, 20, 40, 512
+    args = make_args(M, N, K, P)
+    args.labels = {"bean": 0, "maize": 1}; args.parts = {"leaf": 0}
+    args._r_labels = {0: "bean", 1: "maize"}; args._r_parts = {0: "leaf"}
+    args.width = args.height = img; args.dist_threshold = 0.05; args.csi_threshold = 0.75
+    ev = Evaluator(args)
+    dec_ref, enc_ref = Decoder(args), Encode(args)
+    out = {"meta": META, "cfg": np.array([img, img, M, N, K, P], np.int64)}
+    n_img = 6
+    for n in range(n_img):
+        objs = O.synthetic_scene(rng, img, img, M, N, 4, 10, 0, 3)
+        ann = to_annotation(args, objs); ann.img_size = (img + 64 * (n % 2), img)     # also exercises the resize to the image size
+        e = enc_ref(torch.zeros(3, img, img), to_annotation(args, objs))
+        enp = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in e.items()}
+        head = torch.from_numpy(O.head_from_targets(rng, enp, M, N, noise=0.6, reg_noise=0.5))[None]   # noisy: FPs, FNs, bad links
+        md = dec_ref({"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2],
+                      "embeddings": head[:, M + N + 2:]}, return_metadata=True)
+        pred, raw = md["annotation"][0], md["raw_parts"][0]
+        so, sp = flat_scene(objs)
+        out[f"gt{n}_objs"] = so; out[f"gt{n}_parts"] = sp; out[f"gt{n}_size"] = np.array(ann.img_size, np.int64)
+        po, pp = annotation_to_arrays(args, pred)
+        out[f"pred{n}_objs"] = po; out[f"pred{n}_parts"] = pp
+        out[f"raw{n}"] = np.array([[args.parts[k.kind], k.x, k.y, k.score] for k in raw], np.float64).reshape(-1, 4)
+        ev.accumulate(pred, ann, raw, True, True)
+    for sec, evals in (("anchor", ev.anchor_eval), ("part", ev.part_eval), ("csi", ev.csi_eval), ("classif", ev.classification_eval)):
+        out[f"{sec}_labels"] = np.array(list(evals.labels))
+        out[f"{sec}_counts"] = np.array([[e.tp, e.npos, e.ndet] for _, e in evals.items()], np.int64)
+        for label, e in evals.items():
+            out[f"{sec}_acc_{label}"] = np.array(e.acc, np.float64)
+    out["csv"] = np.array(ev._csv_kps_str())
+    np.savez_compressed(HERE / "evaluator.npz", **out)
+    print("evaluator:", ev.anchor_eval.reduce(), "|", ev.csi_eval.reduce())
+
+
 def gen_fpn_head(rng):
     torch.manual_seed(1234)
     fpn = Fpn(16, 8).train(); head = Head(8, 7)
@@ -217,4 +254,5 @@ if __name__ == "__main__":
     gen_encode_decode(rng, "scene_small256", 256, 3, 2, 12, 24, n_img=4, n_min=3, n_max=8, noise=0.2)
     gen_truncation(rng)
     gen_fpn_head(rng)
+    gen_evaluator(np.random.default_rng(77))
     print("goldens written to", HERE)

@@ -1,0 +1,64 @@
+"""Evaluator against the reference's own Evaluator on decoded noisy scenes (tests/golden/evaluator.npz).
+Host-side code: CPU only."""
+from argparse import Namespace
+
+import numpy as np
+
+from tests.helpers import scene_from_flat
+
+
+def build(golden_dir):
+    from structuredetector_amd.model import Evaluator
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object
+    g = np.load(golden_dir / "evaluator.npz")
+    labels, parts = {"bean": 0, "maize": 1}, {"leaf": 0}
+    rl, rp = {0: "bean", 1: "maize"}, {0: "leaf"}
+    args = Namespace(labels=labels, parts=parts, width=512, height=512, dist_threshold=0.05, csi_threshold=0.75)
+    ev = Evaluator(args)
+    n = 0
+    while f"gt{n}_objs" in g:
+        gt = ImageAnnotation(f"g{n}", [Object(rl[l], Keypoint("stem", x, y), [Keypoint(rp[k], px, py) for k, px, py in ps])
+                                       for l, x, y, ps in scene_from_flat(g[f"gt{n}_objs"], g[f"gt{n}_parts"])],
+                             img_size=tuple(int(v) for v in g[f"gt{n}_size"]))
+        po, pp = g[f"pred{n}_objs"], g[f"pred{n}_parts"]
+        objs = []
+        for oi, (l, x, y, s) in enumerate(po):
+            kps = [Keypoint(rp[int(k)], px, py, ps) for (o, k, px, py, ps) in pp if int(o) == oi]
+            objs.append(Object(rl[int(l)], Keypoint("stem", x, y, s), kps))
+        pred = ImageAnnotation(f"p{n}", objs)
+        raw = [Keypoint(rp[int(k)], x, y, s) for (k, x, y, s) in g[f"raw{n}"]]
+        ev.accumulate(pred, gt, raw, True, True)
+        n += 1
+    assert n == 6
+    return g, ev
+
+
+def test_evaluator_matches_reference(golden_dir):
+    g, ev = build(golden_dir)
+    for sec, evals in (("anchor", ev.anchor_eval), ("part", ev.part_eval), ("csi", ev.csi_eval), ("classif", ev.classification_eval)):
+        assert list(evals.labels) == list(g[f"{sec}_labels"])
+        counts = np.array([[e.tp, e.npos, e.ndet] for _, e in evals.items()], np.int64)
+        np.testing.assert_array_equal(counts, g[f"{sec}_counts"], err_msg=sec)
+        for label, e in evals.items():
+            np.testing.assert_array_equal(np.array(e.acc, np.float64), g[f"{sec}_acc_{label}"], err_msg=f"{sec} {label}")
+    assert ev._csv_kps_str() == str(g["csv"])
+    tot = ev.anchor_eval.reduce()
+    assert tot.tp == 38 and tot.ndet == 65 and 0 < ev.csi_eval.reduce().tp < tot.tp      # the golden really has FPs and CSI misses
+    assert "Anchor Location" in repr(ev)
+    ev.pretty_print()
+
+
+def test_evaluator_merge_is_associative(golden_dir):
+    """Data-parallel evaluation: summing per-rank Evaluators equals one Evaluator over all images."""
+    from structuredetector_amd.model import Evaluation, Evaluations
+    g, ev = build(golden_dir)
+    _, ev2 = build(golden_dir)
+    ev2.merge(ev)
+    for a, b in ((ev.anchor_eval, ev2.anchor_eval), (ev.csi_eval, ev2.csi_eval)):
+        for label in a.labels:
+            assert b[label].tp == 2 * a[label].tp and b[label].npos == 2 * a[label].npos and len(b[label].acc) == 2 * len(a[label].acc)
+    e = Evaluation()
+    assert e.precision == 1 and e.recall == 1 and e.f1_score == 1 and e.csi == 1 and np.isnan(e.avg_acc)
+    assert Evaluation(0, 0, 3).precision == 0 and Evaluation(0, 3, 0).recall == 0
+    u = Evaluations(["a"]) | Evaluations(["b"])
+    assert set(u.labels) == {"a", "b"}

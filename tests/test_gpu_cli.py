@@ -21,9 +21,11 @@ def test_train_and_evaluate_cli(tmp_path, monkeypatch, capsys):
     assert len(ckpts) == 1
     sd = torch.load(ckpts[0], map_location="cpu")
     assert "adpater.0.weight" in sd and sd["head.conv.weight"].shape == (7, 128, 1, 1)
-    evaluate.main(common + ["--synthetic", "3", "-o", str(ckpts[0])])
+    ev = evaluate.main(common + ["--synthetic", "3", "-o", str(ckpts[0]), "--save_csv_eval", str(tmp_path / "kps.csv")])
     out = capsys.readouterr().out
-    assert "anchor  precision" in out and "part    precision" in out
+    assert "Anchor Location" in out and "CSI" in out and "Classification" in out
+    assert ev.anchor_eval.reduce().npos > 0
+    assert (tmp_path / "kps.csv").read_text().startswith("bean,")
 
 
 def test_training_reduces_loss():
