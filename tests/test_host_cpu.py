@@ -150,3 +150,30 @@ def test_flag_table_matches_reference_surface():
     ns = p.parse_args("-W 256 -H 320 -b 4 -n 7 -k 9 -t 0.3 -o m.pth -s stem -f focal".split())
     assert (ns.width, ns.height, ns.batch_size, ns.max_objects, ns.max_parts) == (256, 320, 4, 7, 9)
     assert ns.conf_threshold == 0.3 and ns.pretrained_model == "m.pth" and ns.anchor_name == "stem" and ns.hm_loss_fn == "focal"
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Every entry point validates before it launches: invalid calls return a negative SD_ERR_* code and set
+    sd_last_error(); the *_workspace_bytes queries are pure host arithmetic."""
+    import ctypes as C
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    assert lib.sd_clamped_sigmoid(0, 0, 16, 0) == -1 and b"sd_clamped_sigmoid" in lib.sd_last_error()
+    assert lib.sd_clamped_sigmoid(8, 24, 16, 0) == -3                      # misaligned pointers -> SD_ERR_ALIGN
+    assert lib.sd_topk(0, 0, 0, 1, 1, 8, 8, 4, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert lib.sd_decode_peaks(16, 64, 64, 1, 1, 8, 8, 4096, 16, 16, 16, 16, 16, 16, 1 << 20, 0) == -1   # k > SD_MAX_TOPK
+    assert b"out of range" in lib.sd_last_error()
+    assert lib.sd_render_targets(16, 16, 16, 1, 3, 8, 6, C.c_float(1.0), 16, 0) == -1                    # w % 4 != 0
+    assert lib.sd_adam_step(16, 16, 16, 16, 10, 1, C.c_float(1e-3), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), C.c_float(1.0), 0) == -1
+    d = L.ConvDesc()
+    d.B, d.Hi, d.Wi, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 1, 8, 8, 48, 64, 3, 3, 1, 1, 8, 8
+    assert lib.sd_conv2d_fwd(16, 16, 16, C.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1 and b"Cin" in lib.sd_last_error()
+    d.Cin, d.Ho = 64, 7
+    assert lib.sd_conv2d_fwd(16, 16, 16, C.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1 and b"geometry" in lib.sd_last_error()
+    assert lib.sd_bn_apply(16, 16, 100, 6, 16, 16, 16, 16, 0, 1, 0) == -1                                  # C % 4 != 0
+    # workspace queries
+    assert lib.sd_decode_workspace_bytes(64, 2, 1, 128, 128, 20, 40) >= 64 * 3 * 128 * 128 * 8
+    assert lib.sd_decode_packed_words(64, 20, 40) == 64 * (6 * 20 + 11 * 40)
+    d.Ho = 8
+    assert lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d)) >= 64 * 9 * 64 * 4
+    assert lib.sd_loss_workspace_bytes(64, 2, 1, 128, 128) > 0
