@@ -13,7 +13,7 @@ namespace sd {
 // to two quantities, then a finalize kernel in double.  Thread layout: C/4 float4 columns x
 // (256 / (C/4)) row lanes.
 // ------------------------------------------------------------------------------------------
-constexpr int RED_ROWS_PER_BLOCK = 512;
+constexpr int RED_ROWS_PER_BLOCK = 256;
 
 // MODE 0: sum x, sum x^2                      (BN statistics)
 // MODE 1: sum g, sum g*xhat  with g = dy * [y > 0 if relu]   (BN backward)
