@@ -1,0 +1,81 @@
+"""Data-parallel TrainStep end to end on GPU tensors: 2 processes share the one GPU of the test box and exchange
+gradients through gloo (RCCL cannot place two ranks on one device; the bucket / async / Adam-scaling logic is
+backend-independent).  Checks: both ranks end with bit-identical weights, and the update equals Adam applied to the
+MEAN of the two ranks' gradients computed independently."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(rank_seed):
+    from structuredetector_amd.data import Encode
+    from structuredetector_amd.data.synthetic import synthetic_batch
+    from structuredetector_amd.model import Network
+    from tests.test_host_cpu import make_args
+    dev = torch.device("cuda", 0)
+    args = make_args(2, 1, 20, 40, device=dev, learning_rate=1e-3)
+    torch.manual_seed(0)
+    net = Network(args, pretrained=False).to(dev).train()
+    enc = Encode(args)
+    tgt = enc.render(enc.plan(128, 128, *synthetic_batch(np.random.default_rng(100 + rank_seed), 2, 128, 128, 2, 1)), dev)
+    x = torch.randn(2, 3, 128, 128, device=dev, generator=torch.Generator(dev).manual_seed(200 + rank_seed))
+    return args, net, x, tgt
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from structuredetector_amd.model.trainer import TrainStep
+        args, net, x, tgt = _setup(rank)
+        step = TrainStep(net, args)
+        assert step.world == 2
+        step.sync_parameters()
+        step(x, tgt)
+        torch.cuda.synchronize()
+        out[rank] = net.flat_params.cpu()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_mean_gradient_adam():
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.model.loss import loss_backward, loss_config, loss_forward
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    p0, p1 = out[0], out[1]
+    assert torch.equal(p0, p1), "ranks diverged"
+    # reference: gradients of each rank computed alone, averaged, one Adam step on rank 0's initial weights
+    grads = []
+    for r in range(world):
+        args, net, x, tgt = _setup(r)
+        head, tape = net.forward_train(x)
+        cfg = loss_config(args, 2, 1, 20, 40)
+        desc, keep, out8 = loss_forward(head, tgt, cfg)
+        dhead = loss_backward(desc, out8, torch.ones((), device=head.device), tuple(head.shape))
+        net.backward_from(tape, dhead)
+        grads.append(net.flat_grads.clone())
+        if r == 0:
+            init = net.flat_params.clone()
+    mean_g = ((grads[0] + grads[1]) * 0.5).contiguous()
+    m = torch.zeros_like(init); v = torch.zeros_like(init)
+    # grad_scale = 1/world is applied inside the kernel on the SUM, so feed the sum like TrainStep does
+    gsum = (grads[0] + grads[1]).contiguous()
+    L.check(L.lib().sd_adam_step(init.data_ptr(), gsum.data_ptr(), m.data_ptr(), v.data_ptr(), init.numel(), 1, 1e-3, 0.9, 0.999, 1e-8, 0.5, L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(init.cpu(), p0), "DP step != Adam on the mean gradient"
+    assert not torch.equal(mean_g, grads[0])
