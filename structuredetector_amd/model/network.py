@@ -115,6 +115,13 @@ class _Engine:
         self.lib = L.lib()
         self.prof = None      # list -> every conv launch appends (kernel, algorithmic flops, start event, end event, phase)
         self._nbt = []        # num_batches_tracked counters touched by the running forward (bumped with one launch)
+        # Optional: weight-gradient GEMMs on a side stream (they only depend on the layer's output gradient), free-running
+        # beside the data-gradient chain.  Measured +3.5 % images/s at bs=64; OFF by default because concurrent kernels
+        # stretch each other's durations and the per-kernel roofline numbers of bench.py / rocprofv3 stop describing a
+        # kernel running alone.  (Chaining dgrad -> wgrad -> dgrad across the streams so that only the BatchNorm passes
+        # overlap was measured too: slower than no overlap, the HBM-bound passes slow the wgrad they run under.)
+        self.overlap_wgrad = False
+        self._side = None
 
     def _timed(self, kind, flops, fn, phase="fwd"):
         if self.prof is None:
@@ -344,7 +351,27 @@ class _Engine:
             phase="dgrad")
         return dx
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _wgrad(self, dy, x, conv, d):
+        if not self.overlap_wgrad:
+            return self._wgrad_now(dy, x, conv, d)
+        main, side = torch.cuda.current_stream(), self._side_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)                       # dy (and x) are complete at this point of the main stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self._wgrad_now(dy, x, conv, d)      # L.stream() now hands the side stream to the C ABI
+        dy.record_stream(side); x.record_stream(side)
+
+    def _join_side(self):
+        if self.overlap_wgrad and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def _wgrad_now(self, dy, x, conv, d):
         g = self.net.grad_of(conv.weight)
         nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = self._ws(nbytes, dy.device)
@@ -392,8 +419,8 @@ class _Engine:
         lateral_grad = {}
         for (fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn) in reversed(tape["fpn"]):
             dcv, _ = self._bn_bwd(df, c, fn, 2, fpn.conv[1], mf, if_)
-            self._wgrad(dcv, t, fpn.conv[0], dc)
             dt = self._dgrad(dcv, fpn.conv[0], dc)
+            self._wgrad(dcv, t, fpn.conv[0], dc)
             self._wgrad(dt, sc_t, fpn.lateral, dl)
             self._bias_grad(dt, fpn.lateral)
             lateral_grad[sc_t.data_ptr()] = (dt, fpn.lateral, dl)
@@ -406,6 +433,7 @@ class _Engine:
         self._bias_grad(df, net.up1)
         dcur = self._dgrad(df, net.up1, d5)
         if on_stage:
+            self._join_side()
             on_stage("fpn_head")
 
         # trunk, last block first
@@ -415,18 +443,19 @@ class _Engine:
             if extra is not None:                       # `out` also feeds an FPN lateral conv
                 dcur = self._dgrad(extra[0], extra[1], extra[2], res=dcur)
             dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True)
-            self._wgrad(dc2, a1, blk.conv2, d2)
             da1 = self._dgrad(dc2, blk.conv2, d2)
+            self._wgrad(dc2, a1, blk.conv2, d2)
             dc1, _ = self._bn_bwd(da1, c1, a1, 2, blk.bn1, m1, i1)
-            self._wgrad(dc1, xin, blk.conv1, d1)
             if blk.downsample is not None:
                 dcd, _ = self._bn_bwd(g, cd, None, False, blk.downsample[1], md, idd)
-                self._wgrad(dcd, xin, blk.downsample[0], dd)
                 skip = self._dgrad(dcd, blk.downsample[0], dd)
+                self._wgrad(dcd, xin, blk.downsample[0], dd)
             else:
                 skip = g
             dcur = self._dgrad(dc1, blk.conv1, d1, res=skip)
+            self._wgrad(dc1, xin, blk.conv1, d1)
             if on_stage and id(blk) in first_of:
+                self._join_side()
                 on_stage(first_of[id(blk)])
 
         # stem
@@ -438,6 +467,7 @@ class _Engine:
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
                                          ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
+        self._join_side()
         if on_stage:
             on_stage("down1_stem")
 
