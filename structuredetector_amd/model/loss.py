@@ -41,6 +41,16 @@ def loss_forward(head, tgt, cfg):
     (M, N, K, P, fn, hm_w, off_w, emb_w) = cfg
     B, Cc, h, w = head.shape
     keep = [head]
+    used = ("anchor_hm", "part_hm", "anchor_inds", "part_inds", "anchor_offsets", "part_offsets", "embeddings", "anchor_mask", "part_mask")
+    L.require_cuda(head, *[tgt[k] for k in used])      # raw pointers go to the kernels: a host tensor here would fault the GPU
+    for k, n in (("anchor_inds", K), ("part_inds", P), ("anchor_mask", K), ("part_mask", P)):
+        if tuple(tgt[k].shape) != (B, n):
+            raise L.SdError(f"target['{k}'] has shape {tuple(tgt[k].shape)}, expected {(B, n)}")
+    for k, n in (("anchor_offsets", K), ("part_offsets", P), ("embeddings", P)):
+        if tuple(tgt[k].shape) != (B, n, 2):
+            raise L.SdError(f"target['{k}'] has shape {tuple(tgt[k].shape)}, expected {(B, n, 2)}")
+    if tuple(tgt["anchor_hm"].shape) != (B, M, h, w) or tuple(tgt["part_hm"].shape) != (B, N, h, w) or Cc != M + N + 4:
+        raise L.SdError("heatmap targets / head channels do not match the label and part counts")
 
     def mp(t):
         t, p, sb, sc = L.map_view(t)

@@ -242,6 +242,20 @@ def test_loss_vs_golden(golden_dir, tag, fn, as_views):
     np.testing.assert_allclose(head.grad.cpu().numpy(), gref, rtol=1e-4, atol=1e-4 * np.abs(gref).max())
 
 
+def test_loss_rejects_host_targets_and_bad_shapes():
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.model import Loss
+    e = O.collate([O.encode(64, 96, [], 2, 1, 4, 6, 4.0, 0.1)])
+    head = torch.zeros(1, 7, 24, 16, device=DEV)
+    crit = Loss(make_args(2, 1, 4, 6))
+    with pytest.raises(L.SdError):
+        crit(head_views(head, 2, 1), {k: torch.from_numpy(v) for k, v in e.items()})            # targets left on the host
+    bad = {k: dev(v) for k, v in e.items()}
+    bad["part_inds"] = bad["part_inds"][:, :3]
+    with pytest.raises(L.SdError):
+        crit(head_views(head, 2, 1), bad)
+
+
 def test_loss_degenerate_batches():
     """No valid keypoints (L1 terms -> 0, loss.py:59-61) and no positives (focal -> -neg, loss.py:110)."""
     from structuredetector_amd.model import Loss
