@@ -28,6 +28,16 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_IGEMM_NBUF
 #define SD_IGEMM_NBUF 2
 #endif
+#ifndef SD_IGEMM_SPLIT_STORE
+#define SD_IGEMM_SPLIT_STORE 0
+#endif
+#ifndef SD_IGEMM_DMA
+// 1 = stage the igemm tiles with global_load_lds (LDS-DMA): no staging VGPRs, no ds_write pass.  Correct (same tests pass) but
+// measured 2 % SLOWER than register staging with ROCm 7.2: hipcc puts `s_waitcnt vmcnt(0)` in front of the first ds_read of
+// every chunk (the DMA is a pending LDS write that may alias), which serialises the prefetch with the MFMAs.  Timing-only
+// ablation says the ds_write pass costs 9 % of the loop, so this is the lever once the waits are hand-placed (next round).
+#define SD_IGEMM_DMA 0
+#endif
 constexpr int NBUF = SD_IGEMM_NBUF;   // LDS stages of the igemm tiles: 2 = double buffer (1 barrier / chunk), 1 = single buffer (2 barriers, more blocks per CU)
 constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
@@ -57,6 +67,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // tiles so that neighbouring tiles (shared input rows / weight panels) hit the same L2.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// 16-byte LDS-DMA: each lane's global address is its own, the LDS destination is (wave-uniform base + 16 * lane).
+// (The address-space cast only exists in the device pass; the host pass of hipcc just needs a stub body.)
+__device__ __forceinline__ void lds_dma16(const void* gsrc, float* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#else
+    (void)gsrc; (void)lds_wave_base;
+#endif
 }
 
 __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
@@ -150,6 +170,35 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 
     // Padding rows read a zero line instead of being predicated: there is no select after the load, so the compiler
     // cannot turn the load back into a branch with a wait per load.
+    constexpr bool DMA = (SD_IGEMM_DMA != 0) && !STEM && (NBUF == 2);
+    // LDS-DMA: lane l of a wave-instruction writes 16 bytes at (wave-uniform base + 16 l) = row l/8, physical slot l%8 of
+    // an 8-row group; the swizzle therefore goes on the SOURCE: this lane fetches logical k-slot (l%8) ^ swizzle(row).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int qe = (((tid & 7) ^ ((srow >> 1) & 7)) * VE);       // element offset of the logical slot this lane fetches
+#define SD_DMA_A(i, buf)                                                                          \
+    {                                                                                             \
+        int ty = aty##i + p.rsign * ld_r, tx = atx##i + p.rsign * ld_s;                           \
+        bool ok = aok##i;                                                                         \
+        if (MODE == 2) { ty >>= 1; tx >>= 1; }                                                    \
+        if (MODE == 3) {                                                                          \
+            ok = ok && ty >= 0 && tx >= 0 && (ty % p.div == 0) && (tx % p.div == 0);              \
+            ty /= p.div; tx /= p.div;                                                             \
+        }                                                                                         \
+        ok = ok && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;                \
+        const T* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + qe) : zero_ + qe;       \
+        lds_dma16(src, As + ((buf) * BM + 32 * i + 8 * wave_u) * LDK);                            \
+    }
+#define SD_DMA_B(i, buf)                                                                          \
+    lds_dma16(wrow##i + woffd, Bs + ((buf) * BN + 32 * i + 8 * wave_u) * LDK);
+#define SD_DMA_CHUNK(buf)                                                                         \
+    {                                                                                             \
+        SD_DMA_A(0, buf) SD_DMA_A(1, buf) SD_DMA_A(2, buf) SD_DMA_A(3, buf)                       \
+        const int woffd = (ld_r * p.S + ld_s) * p.Ck + ld_c0 + qe;                                \
+        SD_DMA_B(0, buf) SD_DMA_B(1, buf)                                                         \
+        if (BN == 128) { SD_DMA_B(2, buf) SD_DMA_B(3, buf) }                                      \
+        ld_c0 += KE;                                                                              \
+        if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+    }
 #define SD_LOAD_A(i)                                                                              \
     {                                                                                             \
         int ty = aty##i + p.rsign * ld_r, tx = atx##i + p.rsign * ld_s;                           \
@@ -204,13 +253,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         SD_LOAD_B_STEM(0) SD_LOAD_B_STEM(1)                                                       \
         ++ld_kc;                                                                                  \
     }
-#define SD_STORE_CHUNK(buf)                                                                       \
+#define SD_STORE_A(buf)                                                                           \
     {                                                                                             \
         float* ad = As + ((buf) * BM + srow) * LDK + st_sk;                                       \
         *reinterpret_cast<float4*>(ad) = ra0;                                                     \
         *reinterpret_cast<float4*>(ad + 32 * LDK) = ra1;                                          \
         *reinterpret_cast<float4*>(ad + 64 * LDK) = ra2;                                          \
         *reinterpret_cast<float4*>(ad + 96 * LDK) = ra3;                                          \
+    }
+#define SD_STORE_B(buf)                                                                           \
+    {                                                                                             \
         float* bd = Bs + ((buf) * BN + srow) * LDK + st_sk;                                       \
         *reinterpret_cast<float4*>(bd) = rb0;                                                     \
         *reinterpret_cast<float4*>(bd + 32 * LDK) = rb1;                                          \
@@ -219,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             *reinterpret_cast<float4*>(bd + 96 * LDK) = rb3;                                      \
         }                                                                                         \
     }
+#define SD_STORE_CHUNK(buf) { SD_STORE_A(buf) SD_STORE_B(buf) }
 
     // LDS image: row r keeps its 16-byte k-slot q at slot q ^ ((r >> 1) & 7): a ds_read_b128 lane group (16 rows
     // distinct mod 16, same q) then touches 16 different slots of the 256-byte bank row -- conflict-free without
@@ -238,13 +291,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     if (nk > 0) {
-        SD_LOAD_CHUNK()
-        SD_STORE_CHUNK(0)
+        if (DMA) { SD_DMA_CHUNK(0) }
+        else { SD_LOAD_CHUNK() SD_STORE_CHUNK(0) }
     }
-    __syncthreads();
+    __syncthreads();                               // (also waits for the LDS-DMA: vmcnt(0) before the barrier)
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = (NBUF == 2) ? (kc & 1) : 0;
-        if (kc + 1 < nk) { SD_LOAD_CHUNK() }
+#ifndef SD_DBG_NOLOAD
+        if (kc + 1 < nk) {
+            if (DMA) { SD_DMA_CHUNK(cur ^ 1) }     // buffer cur^1 was last read before the previous barrier
+            else { SD_LOAD_CHUNK() }
+        }
+#endif
         const float* Ab = As + (cur * BM + wm0 + fr) * LDK;
         const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK;
 #define SD_SLOT(ks) ((((ks) * 2 + fh) ^ rd_swz) << 2)
@@ -282,10 +340,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }
             }
             }
+            // The next chunk's tile goes to the OTHER LDS buffer, so its stores can be slotted between MFMA groups
+            // (free issue slots) instead of bursting after them, where they delay the co-resident block's fragment reads.
+            if (!DMA && NBUF == 2 && SD_IGEMM_SPLIT_STORE && kc + 1 < nk) {
+                if (ks == 1) { __builtin_amdgcn_sched_barrier(0); SD_STORE_A(cur ^ 1) __builtin_amdgcn_sched_barrier(0); }
+                if (ks == 2) { __builtin_amdgcn_sched_barrier(0); SD_STORE_B(cur ^ 1) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         if (NBUF == 1) __syncthreads();            // every wave is done reading the single buffer
-        if (kc + 1 < nk) { SD_STORE_CHUNK((NBUF == 2) ? (cur ^ 1) : 0) }
+#ifndef SD_DBG_NOSTORE
+        if (!DMA && !(NBUF == 2 && SD_IGEMM_SPLIT_STORE) && kc + 1 < nk) { SD_STORE_CHUNK((NBUF == 2) ? (cur ^ 1) : 0) }
+#endif
+#ifndef SD_DBG_NOBAR
         __syncthreads();
+#endif
     }
 #undef SD_SLOT
 #undef SD_LOAD_A
@@ -293,6 +361,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 #undef SD_LOAD_B_STEM
 #undef SD_LOAD_CHUNK
 #undef SD_STORE_CHUNK
+#undef SD_STORE_A
+#undef SD_STORE_B
+#undef SD_DMA_A
+#undef SD_DMA_B
+#undef SD_DMA_CHUNK
 
     // ---- epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (e&3) + 8*(e>>2) + 4*(lane>>5)
     if (MODE == 0 && p.splits > 1) {
@@ -474,6 +547,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
 #undef SD_LOAD_X
 #undef SD_LOAD_CHUNK
 #undef SD_STORE_CHUNK
+#undef SD_STORE_A
+#undef SD_STORE_B
+#undef SD_DMA_A
+#undef SD_DMA_B
+#undef SD_DMA_CHUNK
     // D[n][c]: row index (m of the MFMA) = n, column (lane&31) = c  -> contiguous c per half-wave
     float* out = p.part + (int64_t)split * p.Nn * p.R * p.S * p.Ck;
 #pragma unroll
