@@ -25,20 +25,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }   // round-to-nearest-even (v_cvt_pk_bf16_f32)
 
-#ifndef SD_IGEMM_NBUF
-#define SD_IGEMM_NBUF 2
-#endif
-#ifndef SD_IGEMM_SPLIT_STORE
-#define SD_IGEMM_SPLIT_STORE 0
-#endif
 #ifndef SD_IGEMM_DMA
-// 1 = stage the igemm tiles with global_load_lds (LDS-DMA): no staging VGPRs, no ds_write pass.  Correct (same tests pass) but
-// measured 2 % SLOWER than register staging with ROCm 7.2: hipcc puts `s_waitcnt vmcnt(0)` in front of the first ds_read of
-// every chunk (the DMA is a pending LDS write that may alias), which serialises the prefetch with the MFMAs.  Timing-only
-// ablation says the ds_write pass costs 9 % of the loop, so this is the lever once the waits are hand-placed (next round).
-#define SD_IGEMM_DMA 0
+// 1 = stage the igemm tiles with global_load_lds (LDS-DMA): no staging VGPRs (167 -> 146), no ds_write pass.  For the prefetch
+// to overlap the MFMAs each pipeline stage must be its OWN __shared__ object and the loop must name the stage statically
+// (SD_ITER(0) / SD_ITER(1)): with one LDS array hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first ds_read of
+// every chunk, because an in-flight LDS-DMA is a pending write that may alias any read of the same object (measured: 2 %
+// slower than register staging in that form, 1.5 % faster in this one).  0 = register staging + ds_write_b128.
+#define SD_IGEMM_DMA 1
 #endif
-constexpr int NBUF = SD_IGEMM_NBUF;   // LDS stages of the igemm tiles: 2 = double buffer (1 barrier / chunk), 1 = single buffer (2 barriers, more blocks per CU)
+constexpr int NBUF = 2;   // LDS stages of the igemm tiles (a single-buffer / 2-barrier variant was measured: no gain)
 constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
 struct ConvArgs {
@@ -97,10 +92,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     const T* const pw_ = reinterpret_cast<const T*>(p.w);
     const T* const zero_ = reinterpret_cast<const T*>(g_zero_line);
     constexpr int NT = BN / 64;            // 32-wide MFMA tiles per wave along n (wave tile = 64 x BN/2)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* As = lds;                       // [2][BM][LDK]
-    float* Bs = lds + NBUF * BM * LDK;     // [NBUF][BN][LDK]
-    int* orow = reinterpret_cast<int*>(lds + NBUF * (BM + BN) * LDK);   // [BM] output pixel of each tile row, -1 = none
+    // One __shared__ object per pipeline stage: hipcc's wait insertion treats an in-flight LDS-DMA as a pending write that
+    // may alias any later ds_read OF THE SAME OBJECT; with separate objects the prefetch of stage k+1 is not waited for
+    // before the fragment reads of stage k.
+    __shared__ __attribute__((aligned(16))) float As0[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float As1[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs0[BN * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs1[BN * LDK];
+    __shared__ int orow[BM];               // output pixel of each tile row, -1 = none
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Nn / BN;
@@ -186,10 +185,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         }                                                                                         \
         ok = ok && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;                \
         const T* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + qe) : zero_ + qe;       \
-        lds_dma16(src, As + ((buf) * BM + 32 * i + 8 * wave_u) * LDK);                            \
+        lds_dma16(src, ((buf) ? As1 : As0) + (32 * i + 8 * wave_u) * LDK);                        \
     }
 #define SD_DMA_B(i, buf)                                                                          \
-    lds_dma16(wrow##i + woffd, Bs + ((buf) * BN + 32 * i + 8 * wave_u) * LDK);
+    lds_dma16(wrow##i + woffd, ((buf) ? Bs1 : Bs0) + (32 * i + 8 * wave_u) * LDK);
 #define SD_DMA_CHUNK(buf)                                                                         \
     {                                                                                             \
         SD_DMA_A(0, buf) SD_DMA_A(1, buf) SD_DMA_A(2, buf) SD_DMA_A(3, buf)                       \
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
 #define SD_STORE_A(buf)                                                                           \
     {                                                                                             \
-        float* ad = As + ((buf) * BM + srow) * LDK + st_sk;                                       \
+        float* ad = ((buf) ? As1 : As0) + srow * LDK + st_sk;                                     \
         *reinterpret_cast<float4*>(ad) = ra0;                                                     \
         *reinterpret_cast<float4*>(ad + 32 * LDK) = ra1;                                          \
         *reinterpret_cast<float4*>(ad + 64 * LDK) = ra2;                                          \
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
 #define SD_STORE_B(buf)                                                                           \
     {                                                                                             \
-        float* bd = Bs + ((buf) * BN + srow) * LDK + st_sk;                                       \
+        float* bd = ((buf) ? Bs1 : Bs0) + srow * LDK + st_sk;                                     \
         *reinterpret_cast<float4*>(bd) = rb0;                                                     \
         *reinterpret_cast<float4*>(bd + 32 * LDK) = rb1;                                          \
         if (BN == 128) {                                                                          \
@@ -295,66 +294,66 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         else { SD_LOAD_CHUNK() SD_STORE_CHUNK(0) }
     }
     __syncthreads();                               // (also waits for the LDS-DMA: vmcnt(0) before the barrier)
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = (NBUF == 2) ? (kc & 1) : 0;
-#ifndef SD_DBG_NOLOAD
-        if (kc + 1 < nk) {
-            if (DMA) { SD_DMA_CHUNK(cur ^ 1) }     // buffer cur^1 was last read before the previous barrier
-            else { SD_LOAD_CHUNK() }
-        }
-#endif
-        const float* Ab = As + (cur * BM + wm0 + fr) * LDK;
-        const float* Bb = Bs + (cur * BN + wn0 + fr) * LDK;
+
 #define SD_SLOT(ks) ((((ks) * 2 + fh) ^ rd_swz) << 2)
-        float4 na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(0)), na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(0));
-        float4 nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(0)), nb1 = nb0;
-        if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(0));
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            const float4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
-            if (ks + 1 < BK / 8) {             // fragments of the next k-group are read while this group's MFMAs run
-                na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(ks + 1));
-                na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(ks + 1));
-                nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(ks + 1));
-                if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(ks + 1));
-            }
-            if (BF16) {
-                // one 16-byte slot = 8 bf16 = this lane's k-half of a 32x32x16 MFMA step
-                const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);
-                const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);
-                if (NT == 2) {
-                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][NT - 1], 0, 0, 0);
-                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][NT - 1], 0, 0, 0);
-                }
-            } else {
-            // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b0, t), acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b0, t), acc[1][0], 0, 0, 0);
-                if (NT == 2) {
-                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b1, t), acc[0][NT - 1], 0, 0, 0);
-                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b1, t), acc[1][NT - 1], 0, 0, 0);
-                }
-            }
-            }
-            // The next chunk's tile goes to the OTHER LDS buffer, so its stores can be slotted between MFMA groups
-            // (free issue slots) instead of bursting after them, where they delay the co-resident block's fragment reads.
-            if (!DMA && NBUF == 2 && SD_IGEMM_SPLIT_STORE && kc + 1 < nk) {
-                if (ks == 1) { __builtin_amdgcn_sched_barrier(0); SD_STORE_A(cur ^ 1) __builtin_amdgcn_sched_barrier(0); }
-                if (ks == 2) { __builtin_amdgcn_sched_barrier(0); SD_STORE_B(cur ^ 1) __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
-        if (NBUF == 1) __syncthreads();            // every wave is done reading the single buffer
-#ifndef SD_DBG_NOSTORE
-        if (!DMA && !(NBUF == 2 && SD_IGEMM_SPLIT_STORE) && kc + 1 < nk) { SD_STORE_CHUNK((NBUF == 2) ? (cur ^ 1) : 0) }
-#endif
-#ifndef SD_DBG_NOBAR
-        __syncthreads();
-#endif
+    // multiply one staged chunk: fragments of k-group ks+1 are read while the MFMAs of group ks run
+#define SD_COMPUTE(AB, BB)                                                                                        \
+    {                                                                                                             \
+        const float* Ab = (AB) + (wm0 + fr) * LDK;                                                                \
+        const float* Bb = (BB) + (wn0 + fr) * LDK;                                                                \
+        float4 na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(0)), na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(0)); \
+        float4 nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(0)), nb1 = nb0;                               \
+        if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(0));                         \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 8; ++ks) {                                                   \
+            const float4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;                                                  \
+            if (ks + 1 < BK / 8) {                                                                                \
+                na0 = *reinterpret_cast<const float4*>(Ab + SD_SLOT(ks + 1));                                     \
+                na1 = *reinterpret_cast<const float4*>(Ab + 32 * LDK + SD_SLOT(ks + 1));                          \
+                nb0 = *reinterpret_cast<const float4*>(Bb + SD_SLOT(ks + 1));                                     \
+                if (NT == 2) nb1 = *reinterpret_cast<const float4*>(Bb + 32 * LDK + SD_SLOT(ks + 1));             \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);      /* keep the prefetch reads ahead of this group's MFMAs */      \
+            if (BF16) {   /* one 16-byte slot = 8 bf16 = this lane's k-half of a 32x32x16 MFMA step */            \
+                const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);          \
+                const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);          \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);                \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);                \
+                if (NT == 2) {                                                                                    \
+                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][NT - 1], 0, 0, 0);  \
+                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][NT - 1], 0, 0, 0);  \
+                }                                                                                                 \
+            } else {      /* k-step outermost: consecutive MFMAs hit different accumulators */                    \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b0, t), acc[0][0], 0, 0, 0); \
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b0, t), acc[1][0], 0, 0, 0); \
+                    if (NT == 2) {                                                                                \
+                        acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a0, t), f4c(b1, t), acc[0][NT - 1], 0, 0, 0); \
+                        acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a1, t), f4c(b1, t), acc[1][NT - 1], 0, 0, 0); \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
     }
+    // one pipeline step with the stage index as a literal, so that every LDS access names its __shared__ object
+#define SD_ITER(CUR)                                                                                              \
+    {                                                                                                             \
+        if (kc + 1 < nk) {                                                                                        \
+            if (DMA) { SD_DMA_CHUNK(1 - CUR) }      /* stage 1-CUR was last read before the previous barrier */   \
+            else { SD_LOAD_CHUNK() }                                                                              \
+        }                                                                                                         \
+        SD_COMPUTE((CUR) ? As1 : As0, (CUR) ? Bs1 : Bs0)                                                          \
+        if (!DMA && kc + 1 < nk) { SD_STORE_CHUNK(1 - CUR) }                                                      \
+        __syncthreads();                                                                                          \
+        ++kc;                                                                                                     \
+    }
+    int kc = 0;
+    while (kc < nk) {
+        SD_ITER(0)
+        if (kc < nk) SD_ITER(1)
+    }
+#undef SD_ITER
+#undef SD_COMPUTE
 #undef SD_SLOT
 #undef SD_LOAD_A
 #undef SD_LOAD_A_STEM
@@ -853,12 +852,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
 
 template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
-    static bool attr = false;              // one flag per instantiation
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<BN, MODE, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_conv_igemm<BN, MODE, BF16>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), lds, st, a);
+    (void)lds;                             // the tiles are static __shared__ objects (65 KB for BN = 128, 49 KB for BN = 64)
+    hipLaunchKernelGGL((k_conv_igemm<BN, MODE, BF16>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), 0, st, a);
 }
 
 static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 = false) {
