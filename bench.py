@@ -209,10 +209,10 @@ def main():
                           0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
         outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
         for _ in range(3):
-            dec.decode_packed(outs, 0.5, 0.1)
+            dec.decode_packed(outs, 0.5, 0.1, exact_topk=False)      # what Decoder.__call__ runs when no metadata is requested
         torch.cuda.synchronize(); t1 = time.perf_counter()
         for _ in range(20):
-            dec.decode_packed(outs, 0.5, 0.1)
+            dec.decode_packed(outs, 0.5, 0.1, exact_topk=False)
         torch.cuda.synchronize()
         d_dev = (time.perf_counter() - t1) / 20
         extra["decode_device_us_per_img_bs%d" % B] = round(d_dev / B * 1e6, 3)

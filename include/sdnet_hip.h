@@ -86,14 +86,18 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
  *   anchor_ind   i32 (B,K)    flat y*w+x                        decoders.py:46
  *   part_ind     i32 (B,P)
  *   assign       i32 (B,P)    anchor rank, or -1 when min dist >= dist_px  decoders.py:98-100
- * conf and dist_px are the fp32-rounded thresholds. */
+ * conf and dist_px are the fp32-rounded thresholds.
+ * exact_topk = 1: every slot equals the reference's top-k, including peaks below conf (needed by return_metadata=True);
+ * exact_topk = 0: peaks with score <= conf are dropped at compaction -- the assembled annotations are identical (the
+ * reference skips / masks those entries, decoders.py:78-86,115-117) and the selection has far fewer candidates to sort;
+ * slots past the surviving peaks are then zero-score fillers. */
 size_t sd_decode_workspace_bytes(int B, int M, int N, int h, int w, int K, int P);
 size_t sd_decode_packed_words(int B, int K, int P);
 int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
               const float* part_hm, int64_t p_sb, int64_t p_sc,
               const float* offsets, int64_t o_sb, int64_t o_sc,
               const float* embeddings, int64_t e_sb, int64_t e_sc,
-              int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px,
+              int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk,
               void* packed, void* workspace, size_t workspace_bytes, sd_stream_t stream);
 
 /* D4-D5 alone (decoders.py:49-100) from already selected peaks (outputs of sd_decode_peaks):

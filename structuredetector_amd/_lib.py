@@ -61,7 +61,7 @@ _SIGNATURES = {
     "sd_decode_peaks": (c_int, _MAP + [c_int] * 5 + _PEAK_OUT + [c_vp, c_size, c_vp]),
     "sd_decode_workspace_bytes": (c_size, [c_int] * 7),
     "sd_decode_packed_words": (c_size, [c_int] * 3),
-    "sd_decode": (c_int, _MAP * 4 + [c_int] * 7 + [c_float, c_float, c_vp, c_vp, c_size, c_vp]),
+    "sd_decode": (c_int, _MAP * 4 + [c_int] * 7 + [c_float, c_float, c_int, c_vp, c_vp, c_size, c_vp]),
     "sd_decode_group": (c_int, [c_vp] * 6 + _MAP * 2 + [c_int] * 5 + [c_float, c_float, c_vp, c_vp]),
     "sd_render_targets": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp]),
     "sd_loss_workspace_bytes": (c_size, [c_int] * 5),

@@ -993,8 +993,9 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
         a.x = x_nchw; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift; a.relu = relu; a.out_bf16 = out_bf16;
         stem_args(a, d);
         const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        // one-time, thread-safe (C++11 static initialisation): allow > 64 KB of dynamic LDS for this kernel
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr_once;
         hipLaunchKernelGGL(k_stem_fwd, dim3(a.ntiles), dim3(256), lds, st, a);
         SD_LAUNCH_CHECK();
         return 0;
@@ -1072,11 +1073,9 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)2 * 32 * (TN + 4 + TC + 4) * sizeof(float);
     dim3 grid(tiles, a.splits);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (128 + 4 + 128 + 4) * 4);
-        attr = true;
-    }
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<128, 128>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (128 + 4 + 128 + 4) * 4);
+    (void)attr_once;
     if (TN == 128 && TC == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), lds, st, a);
     else if (TN == 128) hipLaunchKernelGGL((k_conv_wgrad<128, 64>), grid, dim3(256), lds, st, a);
     else if (TC == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), lds, st, a);
@@ -1111,8 +1110,8 @@ int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const 
     const int blocks = stem_blocks(d);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)(SP_ROWS * SP_PITCH + 128 * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr_once;
     hipLaunchKernelGGL(k_stem_wgrad2, dim3(blocks), dim3(256), lds, st, a);
     SD_LAUNCH_CHECK();
     const int64_t n4 = 64 * STEM_K / 4;

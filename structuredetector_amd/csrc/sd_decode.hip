@@ -43,7 +43,7 @@ struct Group {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int w, int tiles_x, int apply_sigmoid,
+__global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int w, int tiles_x, int apply_sigmoid, float min_score,
                                                    float* __restrict__ dense_out,    // MODE 0: (B, C0, h, w)
                                                    uint64_t* __restrict__ cand0, uint64_t* __restrict__ cand1,
                                                    int* __restrict__ counters) {     // MODE 1: counters[b*2+g]
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int
         m = fmaxf(m, Hm[r + 4][cc]);
         const float v = S[r + HALO][cc + HALO];
         const bool inside = (y < h) && (x < w);
-        const bool keep = inside && (v == m);
+        const bool keep = inside && (v == m) && (MODE == 0 || v > min_score);
         if (MODE == 0) {
             if (inside) dense_out[(((int64_t)b * g0.C + c) * h + y) * w + x] = keep ? v : 0.0f;
         } else if (keep) {
@@ -527,7 +527,7 @@ int sd_nms5(const float* hm, int64_t sb, int64_t sc, float* out, int B, int C, i
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     Group g0{hm, sb, sc, C}, g1{nullptr, 0, 0, 0};
     hipLaunchKernelGGL(k_nms_tile<0>, dim3(tiles_x * tiles_y, C, B), dim3(256), 0, (hipStream_t)stream, g0, g1, h, w, tiles_x,
-                       apply_sigmoid, out, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr);
+                       apply_sigmoid, 0.f, out, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr);
     SD_LAUNCH_CHECK();
     return 0;
 }
@@ -589,7 +589,7 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
     SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * sizeof(int), st));
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     Group g0{logits, sb, sc, C}, g1{nullptr, 0, 0, 0};
-    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, C, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, (float*)nullptr,
+    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, C, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, 0.f, (float*)nullptr,
                        ws.cand0, ws.cand1, ws.counters);
     SD_LAUNCH_CHECK();
     PeakOut out{out_score, out_ind, out_cls, out_ys, out_xs};
@@ -608,8 +608,8 @@ size_t sd_decode_packed_words(int B, int K, int P) { return (size_t)B * (6 * (si
 
 int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* part_hm, int64_t p_sb, int64_t p_sc,
               const float* offsets, int64_t o_sb, int64_t o_sc, const float* embeddings, int64_t e_sb, int64_t e_sc, int B, int M,
-              int N, int h, int w, int K, int P, float conf, float dist_px, void* packed, void* workspace, size_t workspace_bytes,
-              sd_stream_t stream) {
+              int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk, void* packed, void* workspace,
+              size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_map("sd_decode(anchor_hm)", anchor_hm, a_sb, a_sc, B, M, h, w)) return e;
     if (int e = check_map("sd_decode(part_hm)", part_hm, p_sb, p_sc, B, N, h, w)) return e;
     if (int e = check_map("sd_decode(offsets)", offsets, o_sb, o_sc, B, 2, h, w)) return e;
@@ -623,7 +623,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * sizeof(int), st));
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
-    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, M + N, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, (float*)nullptr,
+    hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, M + N, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, exact_topk ? 0.f : conf, (float*)nullptr,
                        ws.cand0, ws.cand1, ws.counters);
     SD_LAUNCH_CHECK();
     RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};

@@ -26,8 +26,9 @@ class Decoder:
         self.max_parts = args.max_parts  # P
 
     # ------------------------------------------------------------------ device stage
-    def decode_packed(self, outputs, conf_thresh, dist_thresh):
-        """Run sd_decode; returns (packed int32 device buffer, dict of device views)."""
+    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True):
+        """Run sd_decode; returns (packed int32 device buffer, (B, K, P, h, w)).
+        exact_topk=False drops peaks with score <= conf before the selection: same annotations, fewer candidates."""
         a, a_p, a_sb, a_sc = L.map_view(outputs["anchor_hm"])
         p, p_p, p_sb, p_sc = L.map_view(outputs["part_hm"])
         o, o_p, o_sb, o_sc = L.map_view(outputs["offsets"])
@@ -42,7 +43,7 @@ class Decoder:
         conf32 = float(np.float32(conf_thresh))                       # tensor-vs-scalar compares run in fp32
         dist32 = float(np.float32(dist_thresh * min(w, h)))           # decoders.py:100
         L.check(lib.sd_decode(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
-                              conf32, dist32, packed.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_decode")
+                              conf32, dist32, int(bool(exact_topk)), packed.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_decode")
         return packed, (B, K, P, h, w)
 
     @staticmethod
@@ -65,7 +66,8 @@ class Decoder:
         conf_thresh = conf_thresh if conf_thresh is not None else self.args.conf_threshold
         dist_thresh = dist_thresh if dist_thresh is not None else self.args.decoder_dist_thresh
 
-        packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh)
+        # the metadata exposes every top-k slot (also peaks below the threshold): exact selection only when it is asked for
+        packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=return_metadata)
         in_h, in_w = int(self.down_ratio * out_h), int(self.down_ratio * out_w)       # decoders.py:41
         host = self.split_packed(packed.cpu().numpy(), B, K, P)                        # the one D2H (+ sync)
         sx, sy = in_w / out_w, in_h / out_h                                            # utils.py:19-26

@@ -118,9 +118,13 @@ def test_decoder_vs_golden(golden_dir, tag):
         assert r.shape == rr.shape
         np.testing.assert_array_equal(r[:, :3], rr[:, :3])
     assert md["annotation"][0].objects and md["annotation"][0].image_name == "batch_0"
-    # plain call returns just the list
+    # plain call (fast selection: peaks <= conf dropped before the sort) returns exactly the same annotations
     anns = Decoder(args)(head_views(head, M, N))
     assert [len(a) for a in anns] == [len(a) for a in md["annotation"]]
+    for a, bref in zip(anns, md["annotation"]):
+        ao, ap = annotation_arrays(args, a)
+        bo, bp = annotation_arrays(args, bref)
+        np.testing.assert_array_equal(ao, bo); np.testing.assert_array_equal(ap, bp)
 
 
 @pytest.mark.parametrize("B,img,M,N,K,P", [(5, 256, 2, 1, 20, 40), (2, 512, 8, 8, 128, 512), (3, 128, 1, 1, 3, 2)])
