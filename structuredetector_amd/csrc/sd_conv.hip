@@ -33,6 +33,9 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 // slower than register staging in that form, 1.5 % faster in this one).  0 = register staging + ds_write_b128.
 #define SD_IGEMM_DMA 1
 #endif
+#ifndef SD_IGEMM_LATE_DMA
+#define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
+#endif
 constexpr int NBUF = 2;   // LDS stages of the igemm tiles (a single-buffer / 2-barrier variant was measured: no gain)
 constexpr int BM = 128, BK = 32, LDK = BK;   // LDS rows are unpadded; 16-byte slots are XOR-swizzled by ((row >> 1) & 7)
 
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 
 #define SD_SLOT(ks) ((((ks) * 2 + fh) ^ rd_swz) << 2)
     // multiply one staged chunk: fragments of k-group ks+1 are read while the MFMAs of group ks run
-#define SD_COMPUTE(AB, BB)                                                                                        \
+#define SD_COMPUTE(AB, BB, CUR)                                                                                   \
     {                                                                                                             \
         const float* Ab = (AB) + (wm0 + fr) * LDK;                                                                \
         const float* Bb = (BB) + (wn0 + fr) * LDK;                                                                \
@@ -333,16 +336,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }                                                                                                 \
             }                                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (DMA && SD_IGEMM_LATE_DMA && ks == 0 && kc + 1 < nk) { SD_DMA_CHUNK(1 - CUR) }                      \
         }                                                                                                         \
     }
     // one pipeline step with the stage index as a literal, so that every LDS access names its __shared__ object
 #define SD_ITER(CUR)                                                                                              \
     {                                                                                                             \
-        if (kc + 1 < nk) {                                                                                        \
+        if (!(DMA && SD_IGEMM_LATE_DMA) && kc + 1 < nk) {                                                         \
             if (DMA) { SD_DMA_CHUNK(1 - CUR) }      /* stage 1-CUR was last read before the previous barrier */   \
             else { SD_LOAD_CHUNK() }                                                                              \
         }                                                                                                         \
-        SD_COMPUTE((CUR) ? As1 : As0, (CUR) ? Bs1 : Bs0)                                                          \
+        SD_COMPUTE((CUR) ? As1 : As0, (CUR) ? Bs1 : Bs0, CUR)                                                     \
         if (!DMA && kc + 1 < nk) { SD_STORE_CHUNK(1 - CUR) }                                                      \
         __syncthreads();                                                                                          \
         ++kc;                                                                                                     \
