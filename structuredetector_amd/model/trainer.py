@@ -79,10 +79,11 @@ class StepLR:
 
 
 class Trainer:
-    """Epoch loop around TrainStep with the reference's knobs (src/sdnet/model/trainer.py:23-135): Adam(lr),
-    StepLR(step_size=args.lr_step), `model_best_loss.pth` checkpoints in trainings/<timestamp>/.  Data: a
-    directory of JSON+image samples (no augmentation) or `--synthetic N` seeded scenes rendered on the GPU.
-    TensorBoard logging, the Evaluator-based checkpoints and the PIL augmentations are outside the hot path."""
+    """Epoch loop around TrainStep with the reference's knobs (src/sdnet/model/trainer.py:23-237): Adam(lr),
+    StepLR(step_size=args.lr_step), validation every second epoch with the Decoder + Evaluator + Loss and the four
+    `model_best_{loss,csi,classif,kp_reg}.pth` checkpoints in trainings/<timestamp>/.  Data: a directory of JSON+image
+    samples (no augmentation) or `--synthetic N` seeded scenes rendered on the GPU.  TensorBoard logging and the PIL
+    augmentations are outside the hot path."""
 
     def __init__(self, args):
         from datetime import datetime
@@ -106,6 +107,12 @@ class Trainer:
         self.dataset = None if args.synthetic else CropDataset(args, args.train_dir)
         self.save_dir = Path("trainings") / f"{datetime.now():%Y-%m-%d_%H-%M-%S}"
         self.best_loss = float("inf")
+        self.best_csi = self.best_classif = self.best_kp_reg = 0.0
+        from ..data import Decoder
+        from .evaluator import Evaluator
+        from .loss import Loss
+        self.decoder, self.evaluator, self.loss = Decoder(args), Evaluator(args), Loss(args)
+        self.valid_set = None if args.synthetic or not args.valid_dir else CropDataset(args, args.valid_dir)
 
     def batches(self):
         a, B = self.args, self.args.batch_size
@@ -124,6 +131,45 @@ class Trainer:
                 images = torch.stack([im for im, _ in items]).to(a.device, non_blocking=True)
                 yield images, self.encode.batch((a.width, a.height), [an for _, an in items], a.device)
 
+    def valid_samples(self):
+        if self.valid_set is not None:
+            return (self.valid_set[i] for i in range(len(self.valid_set)))
+        from ..data.synthetic import synthetic_samples
+        return synthetic_samples(self.args, min(max(self.args.synthetic, 1), 16), seed=20261003)
+
+    def valid(self):
+        """Validation pass of the reference (src/sdnet/model/trainer.py:137-237): eval-mode forward one image at a time,
+        Decoder + Evaluator + Loss, then the four `model_best_*.pth` checkpoints (rank 0 only)."""
+        a = self.args
+        self.net.eval()
+        self.evaluator.reset()
+        stats, n = LossStats(), 0
+        for image, annotation in self.valid_samples():
+            with torch.no_grad():
+                output = self.net(image[None].to(a.device))
+                data = self.decoder(output, return_metadata=True)
+                self.evaluator.accumulate(data["annotation"][0], annotation, data["raw_parts"][0], eval_csi=True, eval_classif=True)
+                # the annotation is in network-input pixels (CropDataset / the synthetic generator): encode it as the target
+                target = self.encode.batch((a.width, a.height), [annotation], a.device)
+                self.loss(output, target)
+            stats += LossStats(*(float(v) for v in (self.loss.stats.hm_loss, self.loss.stats.offset_loss, self.loss.stats.embedding_loss)))
+            n += 1
+        self.net.train()
+        if n:
+            stats /= n
+        f1_csi = self.evaluator.csi_eval.reduce().f1_score
+        f1_classif = self.evaluator.classification_eval.reduce().f1_score
+        f1_kp = self.evaluator.kps_eval.reduce().f1_score
+        if self.rank == 0:
+            self.save_dir.mkdir(parents=True, exist_ok=True)
+            print(f"validation ({n} images): loss {stats.total_loss:.5f} | kp F1 {f1_kp:.2%} | CSI F1 {f1_csi:.2%} | classification F1 {f1_classif:.2%}", flush=True)
+            for value, attr, name, better in ((stats.total_loss, "best_loss", "loss", lambda v, b: v < b), (f1_csi, "best_csi", "csi", lambda v, b: v > b),
+                                              (f1_classif, "best_classif", "classif", lambda v, b: v > b), (f1_kp, "best_kp_reg", "kp_reg", lambda v, b: v > b)):
+                if better(value, getattr(self, attr)):
+                    setattr(self, attr, value)
+                    self.net.save(self.save_dir / f"model_best_{name}.pth")
+        return stats
+
     def train(self):
         steps = 0
         for epoch in range(self.args.epochs):
@@ -137,10 +183,8 @@ class Trainer:
             if self.rank == 0:
                 print(f"epoch {epoch}: total {mean[0]:.5f} hm {mean[1]:.5f} offset {mean[2]:.5f} embedding {mean[3]:.5f} "
                       f"lr {self.step.lr:g} ({n} steps)", flush=True)
-                if mean[0] < self.best_loss:
-                    self.best_loss = mean[0]
-                    self.save_dir.mkdir(parents=True, exist_ok=True)
-                    self.net.save(self.save_dir / "model_best_loss.pth")
+            if epoch % 2 == 0:                                         # trainer.py:98-99
+                self.valid()
             self.scheduler.step()
             if self.args.steps and steps >= self.args.steps:
                 break

@@ -17,7 +17,7 @@ def clamped_sigmoid(input: torch.Tensor) -> torch.Tensor:
 
 
 def clamp_in_0_1(tensor: torch.Tensor) -> torch.Tensor:
-    """utils.py:360-361 (plain clamp; not on the hot path by itself)."""
+    """utils.py:360-361.  API-parity helper only: nothing on the path calls it (the kernels clamp inline)."""
     return torch.clamp(tensor, min=1e-6, max=1 - 1e-6)
 
 
@@ -64,8 +64,9 @@ def decode_peaks(logits: torch.Tensor, k: int):
 
 
 def gather(feat: torch.Tensor, ind: torch.Tensor) -> torch.Tensor:
-    """utils.py:341-343 on (B, J) / (B, n) operands."""
-    return feat.gather(1, ind)
+    """utils.py:341-343 on (B, J) / (B, n) operands (same HIP gather as transpose_and_gather, with one channel)."""
+    B, J = feat.shape
+    return transpose_and_gather(feat.reshape(B, 1, J, 1), ind)[..., 0]
 
 
 def transpose_and_gather(feat: torch.Tensor, ind: torch.Tensor) -> torch.Tensor:
@@ -92,5 +93,5 @@ def hypot(input: torch.Tensor, dim: int = -1, *, output=None) -> torch.Tensor:
 
 
 def gaussian_2d(X, Y, mu1, mu2, sigma):
-    """utils.py:418-419 (kept for API parity; the batched renderer is data.transforms.Encode)."""
+    """utils.py:418-419.  API-parity helper only (plain tensor expression): targets are rendered by `Encode`'s HIP kernel."""
     return torch.exp((-((X - mu1) ** 2) - (Y - mu2) ** 2) / (2 * sigma**2))

@@ -16,7 +16,7 @@ def test_train_and_evaluate_cli(tmp_path, monkeypatch, capsys):
     common = ["-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json")]
     train.main(common + ["--synthetic", "8", "-b", "4", "-e", "2", "--steps", "3"])
     out = capsys.readouterr().out
-    assert "epoch 0: total" in out
+    assert "epoch 0: total" in out and "validation (" in out
     ckpts = list((tmp_path / "trainings").glob("*/model_best_loss.pth"))
     assert len(ckpts) == 1
     sd = torch.load(ckpts[0], map_location="cpu")

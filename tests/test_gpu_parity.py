@@ -42,6 +42,9 @@ def test_prims_vs_golden(golden_dir):
         np.testing.assert_array_equal(x, g[f"topk{k}_x"])
         assert i.dtype == np.int64
     np.testing.assert_array_equal(transpose_and_gather(dev(g["feat"]), dev(g["gind"])).cpu().numpy(), g["gathered"])
+    from structuredetector_amd.utils import gather
+    flat = dev(g["feat"][:, 0].reshape(2, -1))
+    np.testing.assert_array_equal(gather(flat, dev(g["gind"])).cpu().numpy(), np.take_along_axis(g["feat"][:, 0].reshape(2, -1), g["gind"], 1))
     np.testing.assert_array_equal(hypot(dev(g["hyp_in"])).cpu().numpy(), g["hyp_out"])   # mul, add, sqrt: exact, no FMA
 
 
