@@ -75,6 +75,26 @@ def cpu_baseline(M, N, K, P, img, budget_s=20.0):
             "sample": f"oracle ReferenceNetwork + loss, train fwd+bwd, bs={bs} {img}x{img} fp32, {iters} timed iters after 1 warm-up, torch {torch.__version__} CPU"}
 
 
+PMC_TRAFFIC = Path(__file__).resolve().parent / "profiles" / "r01_pmc_hbm_traffic_conv_kernels.json"
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel kind (e.g. "k_conv_igemm<128>": forward + data-gradient instantiations,
+    launch-weighted) from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.sh: FETCH_SIZE x 2 for
+    gfx950 + WRITE_SIZE, one counter per pass).  PMC counters cannot be read from inside the process, so bench.py reports the
+    profile's figure; None when the profile is absent."""
+    try:
+        prof = json.loads(PMC_TRAFFIC.read_text())
+    except OSError:
+        return None, None
+    stem = "sd::" + kind.rstrip(">")
+    rows = [v for k, v in prof.items() if k.startswith(stem + ",") or k.startswith("sd::" + kind + "<") or k == "sd::" + kind]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return None, None
+    return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n), "profiles/" + PMC_TRAFFIC.name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,8 +182,9 @@ def main():
     dom = max(per, key=lambda k: per[k][2])
     ach = per[dom][1] / per[dom][2] / 1e12
     conv_time_frac = sum(v[2] for v in per.values()) / (dt if world == 1 else max(dt, 1e-9))
+    traffic, traffic_src = pmc_traffic(dom) if (B, img) == (64, 512) else (None, None)
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": round(per[dom][1] / per[dom][0], 1), "avg_launch_us": kernels[dom]["avg_launch_us"],
                 "launches_per_step": kernels[dom]["launches_per_step"], "all_conv_kernels": kernels,
                 "conv_phases": {ph: {"ms_per_step": round(v[1] / a.steps * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2),

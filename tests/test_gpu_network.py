@@ -60,6 +60,9 @@ CONV_CASES = [  # B, H, W, cin, cout, k, stride, pad
     (2, 9, 7, 256, 256, 3, 1, 1),      # odd sizes: ragged last tile (M = 126)
     (2, 32, 32, 64, 128, 3, 2, 1),     # stride-2 dgrad through the parity-class path (M/4 % 128 == 0)
     (2, 32, 32, 64, 128, 1, 2, 0),     # 1x1/2 downsample: three of the four parity classes have no tap at all
+    (2, 16, 32, 64, 64, 3, 1, 1),      # layer1 shape class: all-taps weight-gradient kernel (Wo % 32 == 0), 4 splits
+    (1, 7, 96, 64, 64, 3, 1, 1),       # same, 3 chunks per row, odd row count (ragged last split)
+    (3, 40, 64, 64, 64, 3, 1, 1),      # same, chunks of one split cross image boundaries
 ]
 
 
