@@ -71,8 +71,30 @@ def cpu_baseline(M, N, K, P, img, budget_s=20.0):
     for _ in range(iters):
         one()
     dt = (time.perf_counter() - t0) / iters
+
+    # the other stages of the path: decode incl. host assembly and Encode, per image, median of 10 after 3 warm-ups
+    def median_of(fn, n=10, warm=3):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        return float(np.median(ts))
+
+    scene = O.synthetic_scene(rng, img, img, M, N)
+    one_enc = O.encode(img, img, scene, M, N, K, P, 4.0, 0.1)
+    head = O.head_from_targets(rng, one_enc, M, N)[None]
+    h = img // 4
+
+    def decode_one():
+        t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+        return O.assemble_objects(t, 0, 0.5, 4.0, h, h)
+
+    stages = {"decode_us_per_img": round(median_of(decode_one) * 1e6, 1),
+              "encode_us_per_img": round(median_of(lambda: O.encode(img, img, scene, M, N, K, P, 4.0, 0.1)) * 1e6, 1)}
     return {"value": round(bs / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle ReferenceNetwork + loss, train fwd+bwd, bs={bs} {img}x{img} fp32, {iters} timed iters after 1 warm-up, torch {torch.__version__} CPU"}
+            "sample": f"oracle ReferenceNetwork + loss, train fwd+bwd, bs={bs} {img}x{img} fp32, {iters} timed iters after 1 warm-up, torch {torch.__version__} CPU",
+            "stages": stages}
 
 
 PMC_TRAFFIC = Path(__file__).resolve().parent / "profiles" / "r01_pmc_hbm_traffic_conv_kernels.json"
@@ -105,6 +127,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="run the weight-gradient GEMMs on a side stream (+3.5 %% images/s; per-kernel durations then overlap)")
+    ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
+                    help="gradient all-reduce binding for --gpus > 1: torch.distributed's RCCL (default) or the C-ABI sd_allreduce_*")
     ap.add_argument("--extras", action="store_true",
                     help="also time the eval-mode forward (bs=B and bs=1) after the timed region; off by default so that the "
                          "rocprofv3 per-kernel averages of the default command describe the timed training steps only")
@@ -133,7 +157,7 @@ def main():
     args = make_args(dev, M, N, K, P)
     torch.manual_seed(926354916)                         # args.py:257; identical init on every rank (+ broadcast)
     net = Network(args, pretrained=False).to(dev).train()
-    step = TrainStep(net, args)
+    step = TrainStep(net, args, exchange=a.exchange)
     step.sync_parameters()
     net._engine.overlap_wgrad = bool(a.overlap_wgrad)
     enc = Encode(args)
@@ -254,7 +278,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[2]: train step bs={B}/GPU {img}x{img} fp32, 2 labels / 1 part, K=20 P=40, "
                                    "render targets + fwd + MSE/L1 loss + bwd + Adam; random-init ResNet-34+FPN",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad)},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad),
+                       "exchange": "sd_allreduce (RCCL via C ABI)" if step.rccl is not None else ("torch.distributed nccl" if world > 1 else "none")},
             "train_tflops_per_gpu": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3, 2),
             "train_frac_of_mfma_peak": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "loss": [round(v, 6) for v in loss_host],

@@ -246,6 +246,19 @@ int sd_head_bwd(const float* dy_nchw, const float* x_nhwc, const float* w, float
 int sd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                  float lr, float beta1, float beta2, float eps, float grad_scale, sd_stream_t stream);
 
+/* ---- gradient exchange (the reference's step, trainer.py:113-124, is single-device) -------------------
+ * Thin wrapper over RCCL, one communicator per process (= per GPU).  librccl.so.1 is dlopen()ed on first use (the copy a
+ * PyTorch-ROCm process has already loaded is reused), so libsdnet_hip.so has no link-time dependency on it.
+ * Bootstrap: rank 0 calls sd_allreduce_unique_id and hands the 128 bytes to the other ranks by any host channel
+ * (torch.distributed store, MPI, a file); every rank then calls sd_allreduce_init with the device it computes on current.
+ * sd_allreduce_run: in-place fp32 sum over all ranks of buf[0..count), asynchronous on `stream`.  Positive return values of
+ * these four functions are ncclResult_t codes (text in sd_last_error()). */
+#define SD_COMM_ID_BYTES 128
+int sd_allreduce_unique_id(void* id_out);
+int sd_allreduce_init(const void* id, int rank, int world, void** comm_out);
+int sd_allreduce_run(void* comm, float* buf, int64_t count, sd_stream_t stream);
+int sd_allreduce_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

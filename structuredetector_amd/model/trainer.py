@@ -11,6 +11,8 @@ BatchNorm statistics stay rank-local (the reference has no SyncBN to match).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,8 +20,43 @@ from .. import _lib as L
 from .loss import LossStats, loss_backward, loss_config, loss_forward
 
 
+class RcclExchange:
+    """Gradient sum straight through the C ABI (`sd_allreduce_*`, RCCL): what a host without torch.distributed would
+    call.  The 128-byte RCCL id travels over the already initialised process group's store (any host channel works);
+    each bucket's all-reduce runs on a side stream that first waits for the compute stream (so it is ordered after the
+    weight-gradient kernels issued so far) and `wait()` joins it back before the Adam launch.  Opt-in
+    (`TrainStep(..., exchange="rccl")` or SDNET_EXCHANGE=rccl); the default exchange is torch.distributed's RCCL binding."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes as C
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(L.lib().sd_allreduce_unique_id(ident), "sd_allreduce_unique_id")
+        box = [ident.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=process_group)
+        ident = C.create_string_buffer(box[0], 128)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(L.lib().sd_allreduce_init(ident, rank, world, C.byref(self._comm)), "sd_allreduce_init")
+        self.world = world
+        self.side = torch.cuda.Stream(device)
+
+    def all_reduce(self, flat, lo, hi):
+        self.side.wait_stream(torch.cuda.current_stream())
+        L.check(L.lib().sd_allreduce_run(self._comm, flat.data_ptr() + 4 * lo, hi - lo, self.side.cuda_stream), "sd_allreduce_run")
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+    def close(self):
+        if self._comm:
+            L.check(L.lib().sd_allreduce_destroy(self._comm), "sd_allreduce_destroy")
+            self._comm = None
+
+
 class TrainStep:
-    def __init__(self, net, args, lr=None, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, net, args, lr=None, betas=(0.9, 0.999), eps=1e-8, process_group=None, exchange=None):
         if net.flat_params is None:
             raise L.SdError("move the Network to the GPU before building TrainStep")
         self.net, self.args = net, args
@@ -30,6 +67,10 @@ class TrainStep:
         self.step_count = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        exchange = exchange or os.environ.get("SDNET_EXCHANGE", "torch")
+        if exchange not in ("torch", "rccl"):
+            raise ValueError(f"exchange must be 'torch' or 'rccl', got {exchange!r}")
+        self.rccl = RcclExchange(net.flat_params.device, process_group) if (exchange == "rccl" and self.world > 1) else None
         self.ranges = net.stage_ranges()
         self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
         self.stats = LossStats()
@@ -50,7 +91,10 @@ class TrainStep:
         desc, keep, out8 = loss_forward(head, targets, cfg)
         dhead = loss_backward(desc, out8, self.one, tuple(head.shape))
         works = []
-        if self.world > 1:
+        if self.rccl is not None:
+            def on_stage(name):
+                self.rccl.all_reduce(net.flat_grads, *self.ranges[name])
+        elif self.world > 1:
             def on_stage(name):
                 lo, hi = self.ranges[name]
                 works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
@@ -59,6 +103,8 @@ class TrainStep:
         net.backward_from(tape, dhead, on_stage)
         for w in works:
             w.wait()
+        if self.rccl is not None:
+            self.rccl.wait()
         self.step_count += 1
         L.check(L.lib().sd_adam_step(net.flat_params.data_ptr(), net.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), net.flat_params.numel(), self.step_count, self.lr, self.betas[0],

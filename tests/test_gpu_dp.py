@@ -79,3 +79,31 @@ def test_two_rank_step_matches_mean_gradient_adam():
     torch.cuda.synchronize()
     assert torch.equal(init.cpu(), p0), "DP step != Adam on the mean gradient"
     assert not torch.equal(mean_g, grads[0])
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from structuredetector_amd.model.trainer import RcclExchange
+        dev = torch.device("cuda", 0)
+        ex = RcclExchange(dev)
+        buf = torch.arange(1 << 20, dtype=torch.float32, device=dev) * 0.5
+        ref = buf.clone()
+        for lo, hi in ((0, 1000), (1000, 1 << 20)):
+            ex.all_reduce(buf, lo, hi)
+        ex.wait()
+        torch.cuda.synchronize()
+        out["equal"] = bool(torch.equal(buf, ref))
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_through_c_abi_single_rank():
+    """The C-ABI RCCL wrapper on the one GPU of the test box: id bootstrap, communicator of one rank, bucketed in-place
+    sums on the side stream, destroy.  (Two RCCL ranks need two devices: the driver's multi-GPU bench covers that.)
+    Runs in a child process so that a communicator never lives in the pytest process."""
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out["equal"] is True
