@@ -42,11 +42,15 @@ struct Group {
     int C;
 };
 
+// Candidate counters live one per 128-byte line: every tile block bumps its (image, group) counter once, and at 16384 blocks
+// (stress config) 32 adjacent ints in one line serialised all of them in one L2 channel (measured 151 us for a 67 MB read).
+constexpr int CNT_STRIDE = 32;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int w, int tiles_x, int apply_sigmoid, float min_score,
                                                    float* __restrict__ dense_out,    // MODE 0: (B, C0, h, w)
                                                    uint64_t* __restrict__ cand0, uint64_t* __restrict__ cand1,
-                                                   int* __restrict__ counters) {     // MODE 1: counters[b*2+g]
+                                                   int* __restrict__ counters) {     // MODE 1: counters[(b*2+g) * CNT_STRIDE]
     __shared__ float S[LH][LW];
     __shared__ float Hm[LH][TW];
     __shared__ uint64_t keep_keys[TW * TH];
@@ -63,15 +67,25 @@ __global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int
     const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
 
     if (tid == 0) keep_n = 0;
-    for (int i = tid; i < LH * LW; i += 256) {
+    // all loads of the thread are issued before the first use (a loop with the bounds test around the load is not pipelined
+    // by hipcc: six dependent L2 round trips per block); out-of-image cells read element 0 and are replaced by -inf
+    constexpr int NLD = (LH * LW + 255) / 256;
+    float ld[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + j * 256;
         const int r = i / LW, cc = i - r * LW;
         const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
-        float v = -INFINITY;
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            v = plane[(int64_t)y * w + x];
-            if (apply_sigmoid) v = clamped_sigmoid(v);
-        }
-        S[r][cc] = v;
+        const bool ok = i < LH * LW && y >= 0 && y < h && x >= 0 && x < w;
+        ld[j] = plane[ok ? (int64_t)y * w + x : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / LW, cc = i - r * LW;
+        const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
+        const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+        if (i < LH * LW) S[r][cc] = ok ? (apply_sigmoid ? clamped_sigmoid(ld[j]) : ld[j]) : -INFINITY;
     }
     __syncthreads();
     for (int i = tid; i < LH * TW; i += 256) {
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int
         __syncthreads();
         const int n = keep_n;
         if (n == 0) return;
-        if (tid == 0) keep_base = atomicAdd(&counters[b * 2 + grp], n);
+        if (tid == 0) keep_base = atomicAdd(&counters[(b * 2 + grp) * CNT_STRIDE], n);
         __syncthreads();
         const int64_t cap = (int64_t)g.C * h * w;
         uint64_t* dst = (grp ? cand1 : cand0) + (int64_t)b * cap + keep_base;
@@ -135,9 +149,11 @@ constexpr int SORT_CAP = 4096;
 struct Team {
     int tid;            // 0 .. SEL_THREADS-1 inside the team
     uint64_t* buf;      // [SORT_CAP]
-    int* hist;          // [256]
+    int* hist;          // [2][256]  (double-buffered by radix pass)
     int* misc;          // [4]
     int* flags;         // [SD_MAX_TOPK]
+    int team;           // index of this team inside the block
+    int* alive;         // [2], shared by ALL teams of the block: 1 while a team still needs radix passes
 };
 
 // In-place descending bitonic sort of buf[0..np2).  Each wave owns a contiguous range of R elements; stages
@@ -194,42 +210,76 @@ __device__ void team_select_topk(const Team& T, const uint64_t* __restrict__ can
         bitonic_desc(T, np2);
         return;
     }
+    // MSB-first 8-bit radix select.  Two block barriers per pass (histograms double-buffered by pass parity, bucket scan by
+    // one wave), key loads batched four deep, and the passes stop as soon as the boundary bucket is taken whole in EVERY team
+    // of the block (unique keys: usually after the score bytes) -- `alive` is block-wide so that all teams leave together.
     uint64_t prefix = 0, mask = 0;
     int remaining = min(k, n);
+    bool done = remaining == 0;
+    if (done) prefix = ~0ull;
+    static_assert(SEL_THREADS == 512, "one thread per entry of the double-buffered histogram");
+    T.hist[tid] = 0;
+    if (tid == 0) T.alive[T.team] = done ? 0 : 1;
+    __syncthreads();
     for (int pass = 7; pass >= 0; --pass) {
-        for (int i = tid; i < 256; i += SEL_THREADS) T.hist[i] = 0;
-        __syncthreads();
+        int* hcur = T.hist + (pass & 1) * 256;
+        int* hnext = T.hist + ((pass & 1) ^ 1) * 256;
         const int shift = pass * 8;
-        for (int i = tid; i < n; i += SEL_THREADS) {
-            const uint64_t key = cand[i];
-            if ((key & mask) == prefix) atomicAdd(&T.hist[(int)((key >> shift) & 255ull)], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, d = 255;
-            for (; d > 0; --d) {
-                if (acc + T.hist[d] >= remaining) break;
-                acc += T.hist[d];
+        if (!done) {
+            for (int base = tid; base < n; base += 4 * SEL_THREADS) {
+                uint64_t key[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) key[u] = (base + u * SEL_THREADS < n) ? cand[base + u * SEL_THREADS] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (base + u * SEL_THREADS < n && (key[u] & mask) == prefix) atomicAdd(&hcur[(int)((key[u] >> shift) & 255ull)], 1);
             }
-            T.misc[0] = d;
-            T.misc[1] = remaining - acc;   // how many keys to take inside digit d
+        }
+        if (tid < 256) hnext[tid] = 0;
+        __syncthreads();
+        if (!done && tid < 64) {          // one wave: lane l owns digits 255-4l .. 252-4l (descending)
+            const int c0 = hcur[255 - 4 * tid], c1 = hcur[254 - 4 * tid], c2 = hcur[253 - 4 * tid], c3 = hcur[252 - 4 * tid];
+            const int sum = c0 + c1 + c2 + c3;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (tid >= o) incl += v;
+            }
+            const int excl = incl - sum;
+            if (excl < remaining && remaining <= incl) {      // the lane whose digits hold the k-th key
+                int acc = excl, d = 255 - 4 * tid, cnt = c0;
+                if (acc + c0 < remaining) { acc += c0; --d; cnt = c1;
+                    if (acc + c1 < remaining) { acc += c1; --d; cnt = c2;
+                        if (acc + c2 < remaining) { acc += c2; --d; cnt = c3; } } }
+                T.misc[0] = d;
+                T.misc[1] = remaining - acc;                  // keys to take inside digit d
+                T.alive[T.team] = (cnt == remaining - acc || pass == 0) ? 0 : 1;   // whole bucket taken: threshold known
+            }
         }
         __syncthreads();
-        prefix |= (uint64_t)T.misc[0] << shift;
-        mask |= 255ull << shift;
-        remaining = T.misc[1];
-        __syncthreads();
+        if (!done) {
+            prefix |= (uint64_t)T.misc[0] << shift;
+            mask |= 255ull << shift;
+            remaining = T.misc[1];
+            done = T.alive[T.team] == 0;
+        }
+        if ((T.alive[0] | T.alive[1]) == 0) break;
     }
     // keys are unique, so exactly min(k, n) keys are >= prefix
     for (int i = tid; i < np2; i += SEL_THREADS) T.buf[i] = 0ull;
     if (tid == 0) T.misc[2] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += SEL_THREADS) {
-        const uint64_t key = cand[i];
-        if (key >= prefix) {
-            const int slot = atomicAdd(&T.misc[2], 1);
-            if (slot < np2) T.buf[slot] = key;
-        }
+    for (int base = tid; base < n; base += 4 * SEL_THREADS) {
+        uint64_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = (base + u * SEL_THREADS < n) ? cand[base + u * SEL_THREADS] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * SEL_THREADS < n && key[u] >= prefix) {
+                const int slot = atomicAdd(&T.misc[2], 1);
+                if (slot < np2) T.buf[slot] = key[u];
+            }
     }
     __syncthreads();
     bitonic_desc(T, np2);
@@ -272,12 +322,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_peaks(const uint64_t* __
                                                                int counter_stride, int64_t cap, int fixed_n, int k, int hw, int w,
                                                                int do_fill, PeakOut out) {
     __shared__ uint64_t buf[SORT_CAP];
-    __shared__ int hist[256];
+    __shared__ int hist[2 * 256];
     __shared__ int misc[4];
     __shared__ int flags[SD_MAX_TOPK];
+    __shared__ int alive[2];
     const int b = blockIdx.x;
     const int n = counters ? counters[b * counter_stride] : fixed_n;
-    const Team T{(int)threadIdx.x, buf, hist, misc, flags};
+    if (threadIdx.x < 2) alive[threadIdx.x] = 0;
+    __syncthreads();
+    const Team T{(int)threadIdx.x, buf, hist, misc, flags, 0, alive};
     const bool use_radix = n > SORT_CAP;
     const int np2 = max(next_pow2(use_radix ? k : max(n, k)), 2);
     team_select_topk(T, cand + (int64_t)b * cap, n, k, use_radix, np2);
@@ -388,16 +441,17 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t
                                                                    int K, int P, float conf, float dist_px, RegMaps rm,
                                                                    void* packed, int B) {
     __shared__ uint64_t buf[2][SORT_CAP];
-    __shared__ int hist[2][256];
+    __shared__ int hist[2][2 * 256];
     __shared__ int misc[2][4];
     __shared__ int flags[2][SD_MAX_TOPK];
+    __shared__ int alive[2];
     __shared__ float as_[SD_MAX_TOPK], ps_[SD_MAX_TOPK], posx[SD_MAX_TOPK], posy[SD_MAX_TOPK];
     __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
     const int b = blockIdx.x, hw = h * w;
     const int team = threadIdx.x >> 9, tid = threadIdx.x & (SEL_THREADS - 1);
-    const Team T{tid, buf[team], hist[team], misc[team], flags[team]};
+    const Team T{tid, buf[team], hist[team], misc[team], flags[team], team, alive};
 
-    const int n0 = counters[b * 2 + 0], n1 = counters[b * 2 + 1];
+    const int n0 = counters[(b * 2 + 0) * CNT_STRIDE], n1 = counters[(b * 2 + 1) * CNT_STRIDE];
     // identical barrier sequence for both teams: the path and the sort size come from the larger list
     const bool use_radix = max(n0, n1) > SORT_CAP;
     const int np2 = max(next_pow2(use_radix ? max(K, P) : max(max(n0, n1), max(K, P))), 2);
@@ -488,7 +542,7 @@ static int check_map(const char* what, const void* p, int64_t sb, int64_t sc, in
 }
 
 struct PeaksWs {
-    int* counters;        // B*2
+    int* counters;        // B*2 counters, CNT_STRIDE ints apart
     uint64_t* cand0;      // B*C0*h*w
     uint64_t* cand1;      // B*C1*h*w
     size_t bytes;
@@ -497,7 +551,7 @@ static PeaksWs carve(void* ws, int B, int C0, int C1, int h, int w) {
     PeaksWs r;
     char* p = reinterpret_cast<char*>(ws);
     size_t off = 0;
-    r.counters = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * 2 * sizeof(int), 256);
+    r.counters = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * 2 * CNT_STRIDE * sizeof(int), 256);
     r.cand0 = reinterpret_cast<uint64_t*>(p + off);    off += align_up((size_t)B * C0 * h * w * 8, 256);
     r.cand1 = reinterpret_cast<uint64_t*>(p + off);    off += align_up((size_t)B * C1 * h * w * 8, 256);
     r.bytes = off;
@@ -586,14 +640,14 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
     const PeaksWs ws = carve(workspace, B, C, 0, h, w);
     SD_REQUIRE(workspace_bytes >= ws.bytes, SD_ERR_WORKSPACE, "sd_decode_peaks: workspace %zu < %zu", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
-    SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * sizeof(int), st));
+    SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * CNT_STRIDE * sizeof(int), st));
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     Group g0{logits, sb, sc, C}, g1{nullptr, 0, 0, 0};
     hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, C, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, 0.f, (float*)nullptr,
                        ws.cand0, ws.cand1, ws.counters);
     SD_LAUNCH_CHECK();
     PeakOut out{out_score, out_ind, out_cls, out_ys, out_xs};
-    hipLaunchKernelGGL(k_select_peaks, dim3(B), dim3(SEL_THREADS), 0, st, ws.cand0, ws.counters, 2, (int64_t)C * h * w, 0, k, h * w,
+    hipLaunchKernelGGL(k_select_peaks, dim3(B), dim3(SEL_THREADS), 0, st, ws.cand0, ws.counters, 2 * CNT_STRIDE, (int64_t)C * h * w, 0, k, h * w,
                        w, 1, out);
     SD_LAUNCH_CHECK();
     return 0;
@@ -620,7 +674,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     const PeaksWs ws = carve(workspace, B, M, N, h, w);
     SD_REQUIRE(workspace_bytes >= ws.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
-    SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * sizeof(int), st));
+    SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * CNT_STRIDE * sizeof(int), st));
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
     Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
     hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, M + N, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, exact_topk ? 0.f : conf, (float*)nullptr,

@@ -37,5 +37,5 @@ for B in (64, 1):
     packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=True)
     import ctypes
     from structuredetector_amd import _lib as L
-    cnt = L.workspace(1, dev)[:B * 8].view(torch.int32).cpu().numpy().reshape(B, 2)
+    cnt = L.workspace(1, dev)[:B * 2 * 128].view(torch.int32).cpu().numpy().reshape(B, 2, 32)[:, :, 0]
     print(f"B={B}: device {dt * 1e6:.1f} us/batch = {dt / B * 1e6:.2f} us/img; candidates per image (anchor, part): mean {cnt.mean(0)}, max {cnt.max(0)}")
