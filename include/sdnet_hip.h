@@ -180,6 +180,11 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, c
                        const float* scale, const float* shift, int relu, int out_bf16, void* workspace,
                        size_t workspace_bytes, sd_stream_t stream);
 
+/* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
+ * 2 = sd_conv2d_wgrad), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
+ * with the same names as the kernel trace.  Thread-local storage, valid until the next call on the thread. */
+const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass);
+
 /* bf16 backbone (inference; BASELINE stress config "bf16 backbone + fp32 decode"): activations and weights bf16
  * NHWC / [Cout][R][S][Cin], v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 epilogue (folded BN, bias,
  * residual, ReLU), bf16 stores.  Needs Cin % 64 == 0. */

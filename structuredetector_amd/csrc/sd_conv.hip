@@ -33,6 +33,9 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 // slower than register staging in that form, 1.5 % faster in this one).  0 = register staging + ds_write_b128.
 #define SD_IGEMM_DMA 1
 #endif
+#ifndef SD_ABLATE_HOT
+#define SD_ABLATE_HOT 0       // timing-only experiment: every staging load reads the (cache-hot) zero line -- WRONG RESULTS
+#endif
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
 #endif
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             ty /= p.div; tx /= p.div;                                                             \
         }                                                                                         \
         ok = ok && (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;                \
-        const T* src = ok ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + qe) : zero_ + qe;       \
+        const T* src = (ok && !SD_ABLATE_HOT) ? aptr##i + ((ty * p.Wi + tx) * p.Ck + ld_c0 + qe) : zero_ + qe; \
         lds_dma16(src, ((buf) ? As1 : As0) + (32 * i + 8 * wave_u) * LDK);                        \
     }
 #define SD_DMA_B(i, buf)                                                                          \
-    lds_dma16(wrow##i + woffd, ((buf) ? Bs1 : Bs0) + (32 * i + 8 * wave_u) * LDK);
+    lds_dma16(SD_ABLATE_HOT ? zero_ + qe : wrow##i + woffd, ((buf) ? Bs1 : Bs0) + (32 * i + 8 * wave_u) * LDK);
 #define SD_DMA_CHUNK(buf)                                                                         \
     {                                                                                             \
         SD_DMA_A(0, buf) SD_DMA_A(1, buf) SD_DMA_A(2, buf) SD_DMA_A(3, buf)                       \
@@ -407,6 +410,274 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
                 else reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile fp32 implicit GEMM (MODE 0 / 2): block tile 256 (m) x BN, BK = 16, three LDS stages, counted vmcnt waits.
+// Why: the staging path, not the MFMA pipe, is the tight resource of k_conv_igemm -- a CU takes LDS-DMA pieces at
+// roughly 12 B/clk (one 1 KB piece per ~85 clk; the same figure bounds register staging), and two resident 128x128x32
+// blocks ask for 8 B/clk at full MFMA rate (128x64: 12 B/clk, which is why the 64-channel layers are the slowest).  Measured:
+// every staging load redirected to one cache-hot line still ran 13 % below the no-load time; a dedicated producer wave
+// (warp specialisation) was SLOWER, because one wave cannot feed more than ~1 piece per 300 clk.  A 256-row tile needs
+// 25 % (BN = 128) / 17 % (BN = 64) fewer staged bytes per MFMA, and a 128x64 wave tile 25 % fewer ds_read_b128 per MFMA.
+//   waves: BN = 128 -> 2 (m) x 2 (n), wave tile 128 x 64 (4 x 2 MFMA tiles, 128 accumulator VGPRs)
+//          BN = 64  -> 4 (m) x 1 (n), wave tile  64 x 64
+//   LDS rows are 16 floats (64 B); 16-byte slot q of row r lives at slot q ^ ((r >> 2) & 3) (conflict-free b128 reads).
+//   Pipeline: chunk kc+2 is issued at the top of iteration kc, `s_waitcnt vmcnt(<pieces of chunk kc+2>)` + a bare s_barrier
+//   end it (a __syncthreads() would carry a workgroup fence = vmcnt(0) and drain the stage in flight).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));     // gfx9 encoding: expcnt / lgkmcnt untouched
+#endif
+}
+// all but the N youngest vector-memory operations done AND every LDS read of this wave returned (before a bare s_barrier:
+// the stage this wave was reading may be overwritten by the other waves' DMA right after it)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_and_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+#endif
+}
+
+constexpr int BMB = 256, BKB = 16;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS byte address of a __shared__ object (device pass only; the host pass needs a body)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+#else
+    (void)p; return 0;
+#endif
+}
+// ds_read_b128 the compiler does not know about: its wait insertion would otherwise put `s_waitcnt vmcnt(0)` in front of
+// the fragment reads at the loop header (in-flight LDS-DMA of OTHER stages counted as possibly aliasing) and drain the
+// prefetch once per trip.  The result is valid only after lds_wait_*() below.
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read128_async(uint32_t addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// s_waitcnt lgkmcnt(N) that the fragments are threaded through, so that no consumer can be scheduled above it
+#define SD_LDS_WAIT6(N, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) :: "memory")
+#define SD_LDS_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
+    constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;       // wave grid
+    constexpr int MT = BMB / WM / 32, NTW = BN / WN / 32;                // 32x32 MFMA tiles per wave
+    constexpr int PAW = BMB / 16 / 4, PBW = BN / 16 / 4;                 // 1 KB pieces (16 rows x 64 B) per wave and chunk
+    constexpr int PW = PAW + PBW;
+    constexpr int A_ST = BMB * BKB, B_ST = BN * BKB;
+    constexpr int KSCALE = BK / BKB;                                     // ConvArgs counts 32-wide chunks
+    static_assert(MODE == 0 || MODE == 2, "unit-div coordinate maps only");
+    static_assert(NTW == 2 && (MT == 4 || MT == 2), "wave tile 128x64 or 64x64");
+    __shared__ __attribute__((aligned(16))) float As0[A_ST];
+    __shared__ __attribute__((aligned(16))) float As1[A_ST];
+    __shared__ __attribute__((aligned(16))) float As2[A_ST];
+    __shared__ __attribute__((aligned(16))) float Bs0[B_ST];
+    __shared__ __attribute__((aligned(16))) float Bs1[B_ST];
+    __shared__ __attribute__((aligned(16))) float Bs2[B_ST];
+    __shared__ int orow[BMB];
+    const float* const px_ = reinterpret_cast<const float*>(p.x);
+    const float* const pw_ = reinterpret_cast<const float*>(p.w);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = p.Nn / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / n_tiles;
+    const int n0 = (tile % n_tiles) * BN;
+    int m0 = tile_m * BMB;
+    int r0 = 0, s0 = 0, tstep = 1, nk = p.nk * KSCALE;
+    int cls_base = 0, py = 0, pxc = 0, m_end = p.M;
+    if (MODE == 2) {
+        const int Mq = p.M >> 2, cls = tile_m & 3;
+        cls_base = cls * Mq; m0 = cls_base + (tile_m >> 2) * BMB; m_end = cls_base + Mq;
+        py = cls >> 1; pxc = cls & 1;
+        r0 = (py + p.off) & 1; s0 = (pxc + p.off) & 1; tstep = 2;
+        nk = ((p.R - r0 + 1) >> 1) * ((p.S - s0 + 1) >> 1) * p.kchunks * KSCALE;
+    }
+    int ld_c0 = 0, ld_r = r0, ld_s = s0;
+    // pixel of tile row `row`: (b, oy, ox); ok_ = the row exists
+#define SD_BIG_PIXEL(row, b_, oy_, ox_, ok_)                                                       \
+    int b_ = 0, oy_ = 0, ox_ = 0;                                                                  \
+    const bool ok_ = m0 + (row) < m_end;                                                           \
+    if (ok_) {                                                                                     \
+        const int m = m0 + (row);                                                                  \
+        if (MODE == 2) {                                                                           \
+            const int ml = m - cls_base, hw = p.Wo >> 1, hh = p.Ho >> 1;                           \
+            const int qx = ml % hw, t = ml / hw, qy = t % hh;                                      \
+            b_ = t / hh; oy_ = 2 * qy + py; ox_ = 2 * qx + pxc;                                    \
+        } else {                                                                                   \
+            ox_ = m % p.Wo; const int t = m / p.Wo; oy_ = t % p.Ho; b_ = t / p.Ho;                 \
+        }                                                                                          \
+    }
+    {
+        SD_BIG_PIXEL(tid, b, oy, ox, ok)
+        orow[tid] = ok ? (b * p.Ho + oy) * p.Wo + ox : -1;
+    }
+
+    // ---- staging: wave w owns A pieces 4w .. 4w+3 and B pieces PBW*w ..; lane -> row (lane / 4) of the piece, slot lane % 4.
+    // Per row: pointer to the pixel of the FIRST tap at channel 0 (+ the lane's swizzled slot); per chunk a wave-uniform
+    // offset (tap step, channel chunk) is added and the coordinates are range-checked; padding reads the zero line.
+    const int prow = lane >> 2, pslot = lane & 3;
+    const int qe = (pslot ^ ((prow >> 2) & 3)) * 4;          // (row >> 2) & 3 == (prow >> 2) & 3: pieces start at multiples of 16
+    const float* const zsrc = g_zero_line + qe;
+    const float* abase[PAW];
+    int aty[PAW], atx[PAW];
+#pragma unroll
+    for (int j = 0; j < PAW; ++j) {
+        const int row = (wave * PAW + j) * 16 + prow;
+        SD_BIG_PIXEL(row, b, oy, ox, ok)
+        int ty = oy * p.mul + p.off + p.rsign * r0, tx = ox * p.mul + p.off + p.rsign * s0;
+        if (MODE == 2) { ty >>= 1; tx >>= 1; }               // (exact: the parity class makes both sums even)
+        aty[j] = ok ? ty : -(1 << 28);                        // rows past the end fail every range check
+        atx[j] = tx;
+        abase[j] = px_ + (int64_t)b * p.Hi * p.Wi * p.Ck + ((int64_t)ty * p.Wi + tx) * p.Ck + qe;
+    }
+#undef SD_BIG_PIXEL
+    const int wk = p.R * p.S * p.Ck;
+    const float* bbase[PBW];
+#pragma unroll
+    for (int j = 0; j < PBW; ++j) bbase[j] = pw_ + (int64_t)(n0 + (wave * PBW + j) * 16 + prow) * wk + qe;
+    const int tdiv = MODE == 2 ? 2 : 1;                       // taps advance by tstep, input coordinates by rsign * tstep / tdiv
+    int issued = 0;                                           // chunks issued so far (past-the-end chunks stage zeros)
+#define SD_BIG_ISSUE(AD, BD)                                                                       \
+    {                                                                                              \
+        if (issued < nk) {                                                                         \
+            const int dy = p.rsign * ((ld_r - r0) / tdiv), dx = p.rsign * ((ld_s - s0) / tdiv);    \
+            const int64_t aoff = ((int64_t)dy * p.Wi + dx) * p.Ck + ld_c0;                         \
+            _Pragma("unroll") for (int j = 0; j < PAW; ++j) {                                      \
+                const bool ok = (unsigned)(aty[j] + dy) < (unsigned)p.Hi && (unsigned)(atx[j] + dx) < (unsigned)p.Wi; \
+                lds_dma16(ok ? abase[j] + aoff : zsrc, (AD) + (wave * PAW + j) * 256);             \
+            }                                                                                      \
+            const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0;                                   \
+            _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(bbase[j] + woff, (BD) + (wave * PBW + j) * 256); \
+            ld_c0 += BKB;                                                                          \
+            if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < PAW; ++j) lds_dma16(zsrc, (AD) + (wave * PAW + j) * 256); \
+            _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(zsrc, (BD) + (wave * PBW + j) * 256); \
+        }                                                                                          \
+        ++issued;                                                                                  \
+    }
+
+    const int wm0 = (wave / WN) * (BMB / WM), wn0 = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int rd_swz = (fr >> 2) & 3;
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    SD_BIG_ISSUE(As0, Bs0)
+    SD_BIG_ISSUE(As1, Bs1)
+    wait_vmcnt<PW>();                                         // chunk 0 has landed (chunk 1 may be in flight)
+    __builtin_amdgcn_s_barrier();
+
+    // per-lane LDS byte offsets of the two k-groups' fragments inside a stage (A: rows wm0+fr+32 mi, B: rows wn0+fr+32 ni)
+    const uint32_t a_k0 = ((wm0 + fr) * BKB + (((0 * 2 + fh) ^ rd_swz) << 2)) * 4, a_k1 = ((wm0 + fr) * BKB + (((1 * 2 + fh) ^ rd_swz) << 2)) * 4;
+    const uint32_t b_k0 = ((wn0 + fr) * BKB + (((0 * 2 + fh) ^ rd_swz) << 2)) * 4, b_k1 = ((wn0 + fr) * BKB + (((1 * 2 + fh) ^ rd_swz) << 2)) * 4;
+    constexpr int TSTR = 32 * BKB * 4;                        // bytes between consecutive 32-row MFMA tiles
+#define SD_BIG_MFMA(FA, FB, mi, ni)                                                                \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[t], FB[t], acc[mi][ni], 0, 0, 0);
+    // one chunk: all fragment reads of both k-groups are issued, then each group's MFMAs wait only for their own reads
+#define SD_BIG_COMPUTE(AB, BB)                                                                     \
+    {                                                                                              \
+        const uint32_t ab = lds_addr(AB), bb = lds_addr(BB);                                       \
+        f32x4 a00 = lds_read128_async<0>(ab + a_k0), a01 = lds_read128_async<TSTR>(ab + a_k0);     \
+        f32x4 a02 = a00, a03 = a00;                                                                \
+        if (MT == 4) { a02 = lds_read128_async<2 * TSTR>(ab + a_k0); a03 = lds_read128_async<3 * TSTR>(ab + a_k0); } \
+        f32x4 b00 = lds_read128_async<0>(bb + b_k0), b01 = lds_read128_async<TSTR>(bb + b_k0);     \
+        f32x4 a10 = lds_read128_async<0>(ab + a_k1), a11 = lds_read128_async<TSTR>(ab + a_k1);     \
+        f32x4 a12 = a10, a13 = a10;                                                                \
+        if (MT == 4) { a12 = lds_read128_async<2 * TSTR>(ab + a_k1); a13 = lds_read128_async<3 * TSTR>(ab + a_k1); } \
+        f32x4 b10 = lds_read128_async<0>(bb + b_k1), b11 = lds_read128_async<TSTR>(bb + b_k1);     \
+        if (MT == 4) { SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01); } else { SD_LDS_WAIT4(4, a00, a01, b00, b01); } \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[t], b00[t], acc[0][0], 0, 0, 0);  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[t], b00[t], acc[1][0], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[t], b00[t], acc[MT - 2][0], 0, 0, 0); \
+                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[t], b00[t], acc[MT - 1][0], 0, 0, 0); \
+            }                                                                                      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[t], b01[t], acc[0][1], 0, 0, 0);  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[t], b01[t], acc[1][1], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[t], b01[t], acc[MT - 2][1], 0, 0, 0); \
+                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[t], b01[t], acc[MT - 1][1], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+        if (MT == 4) { SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11); } else { SD_LDS_WAIT4(0, a10, a11, b10, b11); } \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[t], b10[t], acc[0][0], 0, 0, 0);  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[t], b10[t], acc[1][0], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[t], b10[t], acc[MT - 2][0], 0, 0, 0); \
+                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[t], b10[t], acc[MT - 1][0], 0, 0, 0); \
+            }                                                                                      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[t], b11[t], acc[0][1], 0, 0, 0);  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[t], b11[t], acc[1][1], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[t], b11[t], acc[MT - 2][1], 0, 0, 0); \
+                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[t], b11[t], acc[MT - 1][1], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    // iteration with literal stage names: issue chunk kc+2 into the stage read at iteration kc-1, multiply chunk kc,
+    // then make sure this wave's pieces of chunk kc+1 have landed before the barrier publishes them
+#define SD_BIG_ITER(AC, BC, AN, BN_)                                                               \
+    {                                                                                              \
+        SD_BIG_ISSUE(AN, BN_)                                                                      \
+        SD_BIG_COMPUTE(AC, BC)                                                                     \
+        wait_vmcnt_and_lds<PW>();                                                                  \
+        __builtin_amdgcn_s_barrier();                                                              \
+        ++kc;                                                                                      \
+    }
+    int kc = 0;
+    while (kc < nk) {
+        SD_BIG_ITER(As0, Bs0, As2, Bs2)
+        if (kc < nk) SD_BIG_ITER(As1, Bs1, As0, Bs0)
+        if (kc < nk) SD_BIG_ITER(As2, Bs2, As1, Bs1)
+    }
+    wait_vmcnt<0>();
+#undef SD_BIG_ITER
+#undef SD_BIG_COMPUTE
+#undef SD_BIG_MFMA
+#undef SD_BIG_ISSUE
+
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + fr;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                if (m < 0) continue;
+                float v = acc[mi][ni][e] * sc + sh;
+                if (p.res) {
+                    int64_t rm = m;
+                    if (p.res_up2) {
+                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                    }
+                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
             }
         }
     }
@@ -947,9 +1218,28 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
     else reinterpret_cast<float4*>(p.y)[i] = a;
 }
 
+#ifndef SD_IGEMM_BIG
+#define SD_IGEMM_BIG 1         // 1 = fp32 MODE 0 / 2 layers with enough 256-row tiles run k_conv_igemm_big
+#endif
+
+// two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
+// lose 4 % on the 64-channel layers, so only BN = 128
+static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
+    if (!SD_IGEMM_BIG || BN != 128 || (mode != 0 && mode != 2) || a.splits > 1) return 0;
+    const int m_per = mode == 2 ? a.M / 4 : a.M;
+    const int big_tiles = (mode == 2 ? 4 : 1) * cdiv(m_per, BMB) * (a.Nn / BN);
+    return (big_tiles >= 512 && (mode != 2 || m_per % BMB == 0)) ? big_tiles : 0;
+}
+
 template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     (void)lds;                             // the tiles are static __shared__ objects (65 KB for BN = 128, 49 KB for BN = 64)
+    if constexpr (!BF16 && BN == 128 && (MODE == 0 || MODE == 2)) {
+        if (const int big_tiles = igemm_big_tiles(a, BN, MODE)) {
+            hipLaunchKernelGGL((k_conv_igemm_big<BN, MODE>), dim3(big_tiles), dim3(256), 0, st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_conv_igemm<BN, MODE, BF16>), dim3(tiles, a.splits > 1 ? a.splits : 1), dim3(256), 0, st, a);
 }
 
@@ -992,6 +1282,20 @@ static int fwd_splits(const sd_conv_desc* d, int ke = BK) {
     return std::max(1, std::min(s, 64));
 }
 
+// geometry part of the kernel arguments (shared by the launchers and sd_conv2d_kernel_name)
+static void fill_fwd(ConvArgs& a, const sd_conv_desc* d) {
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / BK; a.nk = d->R * d->S * a.kchunks;
+    a.splits = fwd_splits(d);
+}
+static void fill_dgrad(ConvArgs& a, const sd_conv_desc* d) {
+    a.B = d->B; a.Hi = d->Ho; a.Wi = d->Wo; a.Ck = d->Cout; a.Ho = d->Hi; a.Wo = d->Wi; a.Nn = d->Cin; a.R = d->R; a.S = d->S;
+    a.mul = 1; a.div = d->stride; a.off = d->pad; a.rsign = -1;
+    a.M = d->B * d->Hi * d->Wi; a.kchunks = d->Cout / BK; a.nk = d->R * d->S * a.kchunks;
+    a.par = (d->stride == 2 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && (a.M / 4) % BM == 0) ? 1 : 0;
+}
+
 static int check_conv(const char* what, const sd_conv_desc* d) {
     SD_REQUIRE(d != nullptr, SD_ERR_INVALID, "%s: null descriptor", what);
     SD_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0 && d->pad >= 0,
@@ -1024,12 +1328,9 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
     SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd: pointers must be 16-byte aligned");
     SD_REQUIRE(!res_up2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd: res_up2 needs even Ho, Wo");
     ConvArgs a{};
+    fill_fwd(a, d);
     a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual;
-    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
-    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
     a.relu = relu; a.res_up2 = res_up2;
-    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / BK; a.nk = d->R * d->S * a.kchunks;
-    a.splits = fwd_splits(d);
     if (a.splits > 1) {
         // split-K needs its partial buffer; without one the single-pass kernel is still correct, just slower
         if (workspace && workspace_bytes >= sd_conv2d_fwd_workspace_bytes(d)) a.part = (float*)workspace;
@@ -1112,11 +1413,8 @@ int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_
     SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad: needs Cout %% 32 == 0 and Cin %% 64 == 0");
     SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad: pointers must be 16-byte aligned");
     ConvArgs a{};
+    fill_dgrad(a, d);
     a.x = dy; a.w = w_t; a.y = dx; a.res = residual;
-    a.B = d->B; a.Hi = d->Ho; a.Wi = d->Wo; a.Ck = d->Cout; a.Ho = d->Hi; a.Wo = d->Wi; a.Nn = d->Cin; a.R = d->R; a.S = d->S;
-    a.mul = 1; a.div = d->stride; a.off = d->pad; a.rsign = -1;
-    a.M = d->B * d->Hi * d->Wi; a.kchunks = d->Cout / BK; a.nk = d->R * d->S * a.kchunks;
-    a.par = (d->stride == 2 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && (a.M / 4) % BM == 0) ? 1 : 0;
     return launch_igemm(a, false, (hipStream_t)stream);
 }
 
@@ -1231,6 +1529,23 @@ int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const 
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
+}
+
+const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
+    static thread_local char name[64];
+    if (!d || d->Cin <= 0 || d->Cout <= 0) return "";
+    if (pass == 2) {
+        if (wgrad_all_taps(d)) return "k_wgrad3x3_c64";
+        snprintf(name, sizeof(name), "k_conv_wgrad<%d, %d>", d->Cout % 128 == 0 ? 128 : 64, d->Cin % 128 == 0 ? 128 : 64);
+        return name;
+    }
+    ConvArgs a{};
+    if (pass == 0) fill_fwd(a, d); else fill_dgrad(a, d);
+    const int BN = (a.Nn % 128 == 0) ? 128 : 64;
+    const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
+    if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
+    else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
+    return name;
 }
 
 }  // extern "C"

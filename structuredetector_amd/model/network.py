@@ -123,6 +123,10 @@ class _Engine:
         self.overlap_wgrad = False
         self._side = None
 
+    def _kname(self, d, which):
+        """device kernel the C ABI will launch for this conv (profiling label; same names as the rocprofv3 kernel trace)"""
+        return self.lib.sd_conv2d_kernel_name(C.byref(d), which).decode() if self.prof is not None else ""
+
     def _timed(self, kind, flops, fn, phase="fwd"):
         if self.prof is None:
             return fn()
@@ -142,7 +146,7 @@ class _Engine:
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         nws = self.lib.sd_conv2d_fwd_workspace_bytes(C.byref(d))          # > 0 only for small batches (split-K)
         ws = self._ws(nws, x.device) if nws else None
-        self._timed("k_conv_igemm<%d>" % (128 if conv.cout % 128 == 0 else 64), flops, lambda: L.check(
+        self._timed(self._kname(d, 0), flops, lambda: L.check(
             self.lib.sd_conv2d_fwd(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
                                    _ptr(res), int(res_up2), int(relu), _ptr(ws), ws.numel() if nws else 0, L.stream()),
             "sd_conv2d_fwd"))
@@ -346,7 +350,7 @@ class _Engine:
         dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=torch.float32, device=dy.device)
         wt = self._wt(conv)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
-        self._timed("k_conv_igemm<%d>" % (128 if conv.cin % 128 == 0 else 64), flops, lambda: L.check(
+        self._timed(self._kname(d, 1), flops, lambda: L.check(
             self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"),
             phase="dgrad")
         return dx
@@ -376,7 +380,7 @@ class _Engine:
         nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = self._ws(nbytes, dy.device)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
-        self._timed("k_conv_wgrad", flops, lambda: L.check(
+        self._timed(self._kname(d, 2), flops, lambda: L.check(
             self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
             "sd_conv2d_wgrad"), phase="wgrad")
 

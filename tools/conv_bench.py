@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--only", default="")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: same instruction stream at lower power (DVFS check)")
     a = ap.parse_args()
     lib = L.lib()
     dev = torch.device("cuda")
@@ -49,9 +50,13 @@ def main():
         d.Ho = d.Wo = (H + 2 * pad - k) // s + 1
         x = torch.randn(B, H, H, cin, device=dev)
         w = torch.randn(cout, k, k, cin, device=dev) * 0.05
+        if a.zeros:
+            x.zero_(); w.zero_()
         wt = torch.empty(cin * k * k * cout, device=dev)
         y = torch.empty(B, d.Ho, d.Wo, cout, device=dev)
         dy = torch.randn(B, d.Ho, d.Wo, cout, device=dev)
+        if a.zeros:
+            dy.zero_()
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         ws = torch.empty(max(lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=dev)
