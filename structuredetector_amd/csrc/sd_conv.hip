@@ -841,21 +841,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient of a 3x3 / stride 1 / pad 1 conv with Cin = Cout = 64 (the layer1 blocks): ALL NINE taps in one block.
-// PMC showed the one-tap-per-block kernel fabric-bound on these layers (4.6 GB of L2 fills per launch for 0.54 GB of
-// algorithmic traffic: nine blocks re-read the same dY and X ranges).  Here a block stages one dY chunk (32 pixels of an
-// image row) and the 3 x 34 pixel input patch around it ONCE (LDS-DMA) and runs 9 MFMAs per dY operand.
-// acc[tap] : 32 (n) x 32 (c) per wave -> 144 accumulator VGPRs.
+// Weight gradient of a 3x3 / stride 1 / pad 1 conv (channel counts multiples of 64, rows that are whole 32-pixel chunks):
+// ALL NINE taps of a 64 (n) x 64 (c) tile in one block, grid = (pixel splits, (Cout/64) * (Cin/64) tiles).
+// PMC showed the one-tap-per-block kernel fabric-bound on the 64-channel layers (4.6 GB of L2 fills per launch for 0.54 GB
+// of algorithmic traffic: nine blocks re-read the same dY and X ranges).  Here a block stages one dY chunk (32 pixels of an
+// image row, its 64 n) and the 3 x 34 pixel input patch around it (its 64 c) ONCE (LDS-DMA) and runs 9 MFMAs per dY
+// operand: 60 staged bytes per MFMA instead of 128.  acc[tap] : 32 (n) x 32 (c) per wave -> 144 accumulator VGPRs.
+// Blocks of one pixel split are `splits` apart in the linear block order, a multiple of 8: they share an XCD's L2.
 // ---------------------------------------------------------------------------------------------
-constexpr int W9_PX = 34, W9_XFLOATS = 28 * 256;     // 3 rows x 34 px x 64 c = 6528 floats, padded to 28 DMA pieces of 1 KB (7 per wave)
-
-__global__ __launch_bounds__(256, 2) void k_wgrad3x3_c64(WgradArgs p) {
+// ROWW = 32: a chunk is 32 pixels of one image row (Wo % 32 == 0), patch 3 x 34 pixels.
+// ROWW = 16: a chunk is two whole rows of a 16-wide map (Wo == 16, Ho even), patch 4 x 18 pixels.
+template <int ROWW>
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
+    constexpr int W9_PX = ROWW + 2, W9_ROWS = 32 / ROWW + 2;
+    constexpr int W9_PIECES = (W9_ROWS * W9_PX * 16 + 255) / 256 * 4;      // 1 KB DMA pieces, padded to a multiple of 4 (28 / 20)
+    constexpr int W9_XFLOATS = W9_PIECES * 256;
     __shared__ __attribute__((aligned(16))) float Ds0[32 * 64];
     __shared__ __attribute__((aligned(16))) float Ds1[32 * 64];
     __shared__ __attribute__((aligned(16))) float Xs0[W9_XFLOATS];
     __shared__ __attribute__((aligned(16))) float Xs1[W9_XFLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;   // this block's 64 x 64 (n, c) tile
     const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
     const int nchunks = (m_end - m_beg + 31) / 32;
     const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
@@ -873,16 +881,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_c64(WgradArgs p) {
         const int ox0 = m0 % p.Wo, t_ = m0 / p.Wo, oy = t_ % p.Ho, b = t_ / p.Ho;                                 \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
             const int q = wave + 4 * j;                                                                           \
-            const float* src = (m0 < m_end) ? p.dy + (int64_t)m0 * 64 + q * 256 + lane * 4 : g_zero_line;         \
+            const float* src = (m0 < m_end) ? p.dy + (int64_t)(m0 + q * 4 + (lane >> 4)) * p.Nn + tn0 + (lane & 15) * 4 : g_zero_line; \
             lds_dma16(src, (D) + q * 256);                                                                        \
         }                                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 7; ++j) {                                                           \
+        _Pragma("unroll") for (int j = 0; j < W9_PIECES / 4; ++j) {                                               \
             const int q = wave + 4 * j;                                                                           \
-            const int sl = q * 64 + lane;                       /* 16-byte slot inside the [3][34][16] patch */   \
+            const int sl = q * 64 + lane;                       /* 16-byte slot inside the [rows][px][16] patch */ \
             const int r = sl / (W9_PX * 16), rem = sl - r * (W9_PX * 16), px = rem >> 4, c4 = rem & 15;           \
             const int iy = oy - 1 + r, ix = ox0 - 1 + px;                                                         \
-            const bool ok = m0 < m_end && r < 3 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
-            const float* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * 64 + c4 * 4 : g_zero_line;     \
+            const bool ok = m0 < m_end && r < W9_ROWS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
+            const float* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + tc0 + c4 * 4 : g_zero_line; \
             lds_dma16(src, (X) + q * 256);                                                                        \
         }                                                                                                         \
     }
@@ -899,7 +907,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_c64(WgradArgs p) {
             _Pragma("unroll") for (int t = 0; t < 9; ++t) bv[t] = nb[t];                                          \
             if (kk + 1 < 16) {                                                                                    \
                 na = da[(2 * kk + 2) * 64];                                                                       \
-                _Pragma("unroll") for (int t = 0; t < 9; ++t) nb[t] = xb[((t / 3) * W9_PX + (t % 3) + 2 * kk + 2) * 64]; \
+                _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                     \
+                    nb[t] = xb[((t / 3 + (2 * kk + 2) / ROWW) * W9_PX + (t % 3) + (2 * kk + 2) % ROWW) * 64];     \
             }                                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             _Pragma("unroll") for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0); \
@@ -923,13 +932,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_c64(WgradArgs p) {
 #undef W9_ITER
 #undef W9_COMPUTE
 #undef W9_STAGE
-    float* out = p.part + (int64_t)split * 64 * 9 * 64;
+    float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int n = wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = wc0 + fr;
-            out[((int64_t)n * 9 + t) * 64 + c] = acc[t][e];
+            const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
         }
 }
 
@@ -1427,13 +1436,14 @@ int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, 
 
 // layer1-type weight gradients (3x3 / 1 / 1, 64 -> 64 channels, rows that are whole 32-pixel chunks): all taps in one block
 static bool wgrad_all_taps(const sd_conv_desc* d) {
-    return d->Cin == 64 && d->Cout == 64 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Wo % 32 == 0;
+    return d->Cin % 64 == 0 && d->Cout % 64 == 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
+           (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
         const int chunks = d->B * d->Ho * d->Wo / 32;
-        return std::max(1, std::min(512, chunks / 8));      // two resident blocks per CU, >= 8 chunks each
+        return std::max(1, std::min(cdiv(512, tiles), chunks / 8));      // two resident blocks per CU, >= 8 chunks each
     }
     // Pick the split count so that tiles*splits fills whole "rounds" of the chip (256 CUs x 2 resident 128x128
     // blocks, x4 for the 64x64 tile): a last round that is mostly empty costs as much as a full one.
@@ -1455,7 +1465,7 @@ static int wgrad_splits(const sd_conv_desc* d, int tiles) {
 size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d) {
     if (!d || d->Cin % 64 || d->Cout % 64) return 0;
     const int TN = d->Cout % 128 == 0 ? 128 : 64, TC = d->Cin % 128 == 0 ? 128 : 64;
-    const int tiles = wgrad_all_taps(d) ? 1 : d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
+    const int tiles = wgrad_all_taps(d) ? (d->Cout / 64) * (d->Cin / 64) : d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
     return (size_t)wgrad_splits(d, tiles) * d->Cout * d->R * d->S * d->Cin * sizeof(float);
 }
 
@@ -1466,7 +1476,7 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_wgrad: needs Cin, Cout %% 64 == 0");
     SD_REQUIRE(workspace_bytes >= sd_conv2d_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_wgrad: workspace too small");
     const int TN = d->Cout % 128 == 0 ? 128 : 64, TC = d->Cin % 128 == 0 ? 128 : 64;
-    const int tiles = wgrad_all_taps(d) ? 1 : d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
+    const int tiles = wgrad_all_taps(d) ? (d->Cout / 64) * (d->Cin / 64) : d->R * d->S * (d->Cout / TN) * (d->Cin / TC);
     WgradArgs a{};
     a.dy = dy; a.x = x; a.part = (float*)workspace;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
@@ -1477,7 +1487,8 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
     if (wgrad_all_taps(d)) {
-        hipLaunchKernelGGL(k_wgrad3x3_c64, dim3(a.splits), dim3(256), 0, st, a);
+        if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_wgrad3x3<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
         SD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
         SD_LAUNCH_CHECK();
@@ -1535,7 +1546,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     static thread_local char name[64];
     if (!d || d->Cin <= 0 || d->Cout <= 0) return "";
     if (pass == 2) {
-        if (wgrad_all_taps(d)) return "k_wgrad3x3_c64";
+        if (wgrad_all_taps(d)) return d->Wo % 32 == 0 ? "k_wgrad3x3<32>" : "k_wgrad3x3<16>";
         snprintf(name, sizeof(name), "k_conv_wgrad<%d, %d>", d->Cout % 128 == 0 ? 128 : 64, d->Cin % 128 == 0 ? 128 : 64);
         return name;
     }

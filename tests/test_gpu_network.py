@@ -63,6 +63,10 @@ CONV_CASES = [  # B, H, W, cin, cout, k, stride, pad
     (2, 16, 32, 64, 64, 3, 1, 1),      # layer1 shape class: all-taps weight-gradient kernel (Wo % 32 == 0), 4 splits
     (1, 7, 96, 64, 64, 3, 1, 1),       # same, 3 chunks per row, odd row count (ragged last split)
     (3, 40, 64, 64, 64, 3, 1, 1),      # same, chunks of one split cross image boundaries
+    (2, 8, 32, 128, 128, 3, 1, 1),     # all-taps weight gradient with 2 x 2 (n, c) tiles
+    (1, 5, 64, 192, 64, 3, 1, 1),      # 3 c-tiles x 1 n-tile
+    (3, 16, 16, 128, 64, 3, 1, 1),     # 16-wide maps: a chunk is two whole rows (layer4 shape class)
+    (2, 6, 16, 64, 64, 3, 1, 1),
 ]
 
 
