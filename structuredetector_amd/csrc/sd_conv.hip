@@ -36,6 +36,9 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_ABLATE_HOT
 #define SD_ABLATE_HOT 0       // timing-only experiment: every staging load reads the (cache-hot) zero line -- WRONG RESULTS
 #endif
+#ifndef SD_ABLATE_PATCH
+#define SD_ABLATE_PATCH 0     // timing-only experiment: stage the A tile for ~1.6 of the 9 taps only (what patch staging would need) -- WRONG RESULTS
+#endif
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
 #endif
@@ -82,6 +85,9 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, float* lds_wave_base
 
 __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
 
+// K order: channel chunk outermost, filter taps innermost.  The nine taps of one channel chunk re-read (shifted) the same
+// 128-byte input lines, so they hit the XCD's L2; with the taps outermost every tap walked the tile's whole Cin x pixels
+// footprint (256 KB per block, 64 blocks per 4 MB L2) and the PMC showed 4-9x the input size in L2 fills per launch.
 // MODE 0: unit "div" (forward conv of any stride, stride-1 data-gradient)   1: stem (NCHW image, K = 147 -> 160)
 // MODE 2: stride-2 data-gradient, parity classes                             3: generic strided data-gradient
 //
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         const int per = (p.nk + p.splits - 1) / p.splits;
         const int kbeg = min((int)blockIdx.y * per, p.nk), kend = min(kbeg + per, p.nk);
         nk = kend - kbeg;
-        const int tap = kbeg / p.kchunks;
-        ld_c0 = (kbeg - tap * p.kchunks) * KE; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
+        const int ntap = p.R * p.S, cc = kbeg / ntap, tap = kbeg - cc * ntap;       // chunk index = channel chunk * taps + tap
+        ld_c0 = cc * KE; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
     }
 
     // Padding rows read a zero line instead of being predicated: there is no select after the load, so the compiler
@@ -201,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         const int woffd = (ld_r * p.S + ld_s) * p.Ck + ld_c0 + qe;                                \
         SD_DMA_B(0, buf) SD_DMA_B(1, buf)                                                         \
         if (BN == 128) { SD_DMA_B(2, buf) SD_DMA_B(3, buf) }                                      \
-        ld_c0 += KE;                                                                              \
-        if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+        ld_s += tstep;             /* taps innermost: see the note on the K order above the kernel */ \
+        if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; if (ld_r >= p.R) { ld_r = r0; ld_c0 += KE; } }  \
     }
 #define SD_LOAD_A(i)                                                                              \
     {                                                                                             \
@@ -251,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             rb2 = *reinterpret_cast<const float4*>(wrow2 + woff);                                 \
             rb3 = *reinterpret_cast<const float4*>(wrow3 + woff);                                 \
         }                                                                                         \
-        ld_c0 += KE;                                                                              \
-        if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+        ld_s += tstep;             /* taps innermost: see the note on the K order above the kernel */ \
+        if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; if (ld_r >= p.R) { ld_r = r0; ld_c0 += KE; } }  \
     } else {                                                                                      \
         SD_LOAD_A_STEM(0) SD_LOAD_A_STEM(1) SD_LOAD_A_STEM(2) SD_LOAD_A_STEM(3)                   \
         SD_LOAD_B_STEM(0) SD_LOAD_B_STEM(1)                                                       \
@@ -554,14 +560,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
         if (issued < nk) {                                                                         \
             const int dy = p.rsign * ((ld_r - r0) / tdiv), dx = p.rsign * ((ld_s - s0) / tdiv);    \
             const int64_t aoff = ((int64_t)dy * p.Wi + dx) * p.Ck + ld_c0;                         \
+            if (!SD_ABLATE_PATCH || (ld_r == r0 && ld_s == s0) || (ld_r == r0 + 1 && ld_s == s0 && ld_c0 == 0)) {   \
             _Pragma("unroll") for (int j = 0; j < PAW; ++j) {                                      \
                 const bool ok = (unsigned)(aty[j] + dy) < (unsigned)p.Hi && (unsigned)(atx[j] + dx) < (unsigned)p.Wi; \
                 lds_dma16(ok ? abase[j] + aoff : zsrc, (AD) + (wave * PAW + j) * 256);             \
-            }                                                                                      \
+            } }                                                                                    \
             const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0;                                   \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(bbase[j] + woff, (BD) + (wave * PBW + j) * 256); \
-            ld_c0 += BKB;                                                                          \
-            if (ld_c0 >= p.Ck) { ld_c0 = 0; ld_s += tstep; if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; } } \
+            ld_s += tstep;         /* taps innermost (K order note above k_conv_igemm) */           \
+            if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; if (ld_r >= p.R) { ld_r = r0; ld_c0 += BKB; } } \
         } else {                                                                                   \
             _Pragma("unroll") for (int j = 0; j < PAW; ++j) lds_dma16(zsrc, (AD) + (wave * PAW + j) * 256); \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(zsrc, (BD) + (wave * PBW + j) * 256); \
