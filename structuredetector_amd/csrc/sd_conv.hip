@@ -1234,6 +1234,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
     else reinterpret_cast<float4*>(p.y)[i] = a;
 }
 
+#ifndef SD_IGEMM_BIG64
+#define SD_IGEMM_BIG64 0       // 256x64 tiles for the 64-channel layers (measured slower than 128x64: off)
+#endif
 #ifndef SD_IGEMM_BIG
 #define SD_IGEMM_BIG 1         // 1 = fp32 MODE 0 / 2 layers with enough 256-row tiles run k_conv_igemm_big
 #endif
@@ -1241,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
-    if (!SD_IGEMM_BIG || BN != 128 || (mode != 0 && mode != 2) || a.splits > 1) return 0;
+    if (!SD_IGEMM_BIG || (BN != 128 && !SD_IGEMM_BIG64) || (mode != 0 && mode != 2) || a.splits > 1) return 0;
     const int m_per = mode == 2 ? a.M / 4 : a.M;
     const int big_tiles = (mode == 2 ? 4 : 1) * cdiv(m_per, BMB) * (a.Nn / BN);
     return (big_tiles >= 512 && (mode != 2 || m_per % BMB == 0)) ? big_tiles : 0;
@@ -1250,7 +1253,7 @@ static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
 template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     (void)lds;                             // the tiles are static __shared__ objects (65 KB for BN = 128, 49 KB for BN = 64)
-    if constexpr (!BF16 && BN == 128 && (MODE == 0 || MODE == 2)) {
+    if constexpr (!BF16 && (BN == 128 || SD_IGEMM_BIG64) && (MODE == 0 || MODE == 2)) {
         if (const int big_tiles = igemm_big_tiles(a, BN, MODE)) {
             hipLaunchKernelGGL((k_conv_igemm_big<BN, MODE>), dim3(big_tiles), dim3(256), 0, st, a);
             return;
