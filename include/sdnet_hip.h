@@ -180,6 +180,20 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, c
                        const float* scale, const float* shift, int relu, int out_bf16, void* workspace,
                        size_t workspace_bytes, sd_stream_t stream);
 
+/* Training forward of a conv that feeds a BatchNorm2d: y = conv(x, w) and, from the accumulators of the same launch, the batch
+ * statistics of y (mean, invstd = 1/sqrt(biased var + eps), running-stat update as sd_bn_train_stats) -- one pass over y less
+ * than sd_conv2d_fwd + sd_bn_train_stats.  Partial sums per (tile, wave row) go through `workspace` and are finished in double
+ * precision in a fixed order (deterministic).  Falls back to the two-pass form when the forward splits K (tiny batches). */
+size_t sd_conv2d_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_fwd_bn_stats(const float* x, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* invstd, void* workspace,
+                           size_t workspace_bytes, sd_stream_t stream);
+/* second half of sd_bn_train_stats on caller-provided partial sums [rows][2][C] (sum, sum of squares per channel); `scratch`
+ * (nullable) = sd_bn_finalize_scratch_rows(rows) * 2 * C floats for the coalesced first folding level used with many rows */
+int sd_bn_finalize_scratch_rows(int rows);
+int sd_bn_finalize_stats(const float* partial, int rows, int64_t M, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scratch, sd_stream_t stream);
+
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
  * 2 = sd_conv2d_wgrad), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
  * with the same names as the kernel trace.  Thread-local storage, valid until the next call on the thread. */

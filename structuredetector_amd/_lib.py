@@ -96,6 +96,10 @@ _SIGNATURES = {
     "sd_head_bwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "sd_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_float, c_float, c_float, c_float, c_vp]),
     "sd_conv2d_kernel_name": (C.c_char_p, [c_vp, c_int]),
+    "sd_conv2d_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
+    "sd_conv2d_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
+    "sd_bn_finalize_scratch_rows": (c_int, [c_int]),
+    "sd_bn_finalize_stats": (c_int, [c_vp, c_int, c_i64, c_int, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sd_allreduce_unique_id": (c_int, [c_vp]),
     "sd_allreduce_init": (c_int, [c_vp, c_int, c_int, C.POINTER(c_vp)]),
     "sd_allreduce_run": (c_int, [c_vp, c_vp, c_i64, c_vp]),

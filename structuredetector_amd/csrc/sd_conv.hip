@@ -60,6 +60,8 @@ struct ConvArgs {
     int M, nk, kchunks;   // kchunks = Ck / (elements per 128-byte chunk: 32 fp32 or 64 bf16); nk = number of K chunks
     int splits;           // split-K (small-batch inference): blockIdx.y = K slice, raw partial tiles go to `part`
     float* part;          // [splits][M][Nn]
+    float* stat;          // forward + BatchNorm statistics: per (m-tile, wave row) partial column sums [rows][2][Nn] of the
+                          // raw conv output (sum, sum of squares), finished by sd_bn_finalize / k_col_finalize<0> (nullable)
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
                           // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
 };
@@ -393,6 +395,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }
         return;
     }
+    if (MODE == 0 && !BF16 && p.stat) {
+        // BatchNorm statistics of the raw conv output from the accumulators (rows past M staged zeros: they add nothing):
+        // column sums over the wave's 64 rows, the two wave rows combined through LDS, one partial row per tile
+        __shared__ float statred[2][BN];
+        float sv[NT], qv[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; s += a; q += a * a; }
+            sv[ni] = s + __shfl_xor(s, 32); qv[ni] = q + __shfl_xor(q, 32);
+            if ((wave >> 1) == 1 && fh == 0) { statred[0][wn0 + ni * 32 + fr] = sv[ni]; statred[1][wn0 + ni * 32 + fr] = qv[ni]; }
+        }
+        __syncthreads();
+        if ((wave >> 1) == 0 && fh == 0) {
+            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int c = wn0 + ni * 32 + fr;
+                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
+            }
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -663,6 +690,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_MFMA
 #undef SD_BIG_ISSUE
 
+    if (MODE == 0 && p.stat) {
+        // BatchNorm statistics (see k_conv_igemm): one partial row per 256-row tile
+        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
+        __shared__ float statred[2][BN];
+        float sv[NTW], qv[NTW];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; s += a; q += a * a; }
+            sv[ni] = s + __shfl_xor(s, 32); qv[ni] = q + __shfl_xor(q, 32);
+        }
+        // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes
+        if (tid < 2 * BN) statred[tid / BN][tid % BN] = 0.f;
+        __syncthreads();
+        for (int wr = 1; wr < WM; ++wr) {
+            if (wave / WN == wr && fh == 0) {
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) { statred[0][wn0 + ni * 32 + fr] += sv[ni]; statred[1][wn0 + ni * 32 + fr] += qv[ni]; }
+            }
+            __syncthreads();
+        }
+        if (wave / WN == 0 && fh == 0) {
+            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni) {
+                const int c = wn0 + ni * 32 + fr;
+                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
+            }
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -1356,6 +1416,47 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
         else a.splits = 1;
     }
     return launch_igemm(a, false, (hipStream_t)stream);
+}
+
+// rows of the statistics partial buffer the forward kernel of this geometry writes (0 = the split-K path: no fused statistics)
+static int fwd_stat_rows(const sd_conv_desc* d) {
+    ConvArgs a{};
+    fill_fwd(a, d);
+    if (a.splits > 1) return 0;
+    const int BN = (a.Nn % 128 == 0) ? 128 : 64;
+    return igemm_big_tiles(a, BN, 0) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+}
+
+size_t sd_conv2d_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 32 || d->Cout % 64) return 0;
+    const int rows = fwd_stat_rows(d);
+    const size_t fused = (size_t)(rows + sd_bn_finalize_scratch_rows(rows)) * 2 * d->Cout * sizeof(float);
+    const size_t split = sd_conv2d_fwd_workspace_bytes(d) + sd_col_reduce_workspace_bytes((int64_t)d->B * d->Ho * d->Wo, d->Cout);
+    return std::max(fused, split);
+}
+
+int sd_conv2d_fwd_bn_stats(const float* x, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum, float* running_mean,
+                           float* running_var, float* mean, float* invstd, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_fwd_bn_stats", d)) return e;
+    SD_REQUIRE(x && w && y && mean && invstd && workspace, SD_ERR_INVALID, "sd_conv2d_fwd_bn_stats: null pointer");
+    SD_REQUIRE(d->Cin % 32 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd_bn_stats: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)",
+               d->Cin, d->Cout);
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd_bn_stats: pointers must be 16-byte aligned");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_fwd_bn_stats_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_fwd_bn_stats: workspace too small");
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    const int rows = fwd_stat_rows(d);
+    if (rows == 0) {        // small batch (split-K): plain conv, then the separate statistics pass
+        const size_t cw = sd_conv2d_fwd_workspace_bytes(d);
+        if (int e = sd_conv2d_fwd(x, w, y, d, nullptr, nullptr, nullptr, 0, 0, workspace, cw, stream)) return e;
+        return sd_bn_train_stats(y, M, d->Cout, eps, momentum, running_mean, running_var, mean, invstd, (char*)workspace + cw,
+                                 workspace_bytes - cw, stream);
+    }
+    ConvArgs a{};
+    fill_fwd(a, d);
+    a.x = x; a.w = w; a.y = y; a.stat = (float*)workspace;
+    if (int e = launch_igemm(a, false, (hipStream_t)stream)) return e;
+    return sd_bn_finalize_stats((const float*)workspace, rows, M, d->Cout, eps, momentum, running_mean, running_var, mean, invstd,
+                                (float*)workspace + (size_t)rows * 2 * d->Cout, stream);
 }
 
 static void stem_args(StemArgs& a, const sd_conv_desc* d) {

@@ -77,6 +77,28 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
     }
 }
 
+// out[j][w] = sum over the rows of slab j of in[r][w]  (W <= 1024 floats per row, W % 4 == 0): coalesced row reads
+__global__ __launch_bounds__(256) void k_rows_fold(const float* __restrict__ in, int rows, int W, int slab, float* __restrict__ out) {
+    __shared__ float4 red[256];
+    const int cols = W >> 2, lanes = 256 / cols;
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    const int r0 = blockIdx.x * slab, r1 = min(r0 + slab, rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < lanes) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            const float4 v = reinterpret_cast<const float4*>(in + (int64_t)r * W)[col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) { const float4 u = red[l * cols + col]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+        reinterpret_cast<float4*>(out + (int64_t)blockIdx.x * W)[col] = s;
+    }
+}
+
 // FIN 0: BN statistics -> mean, invstd, running stats (momentum, unbiased running var)
 // FIN 1: BN backward   -> dgamma (+=), dbeta (+=), and the two means needed by the apply pass
 // FIN 2: bias gradient -> out0 (+=)
@@ -85,32 +107,40 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
                                                        float momentum, float* __restrict__ out0, float* __restrict__ out1,
                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
                                                        float* __restrict__ aux0, float* __restrict__ aux1, int accumulate) {
-    // 8 channels x 32 lanes over the partial blocks per workgroup, 4 loads in flight per lane; fixed order -> deterministic
-    __shared__ double r0[32][8], r1[32][8];
-    const int lc = threadIdx.x & 7, lr = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + lc;
+    // 4 channels x 64 lanes over the partial rows per workgroup, 8 loads in flight per lane (the pass is latency-bound: up to
+    // 8192 partial rows of a few KB each); fixed order -> deterministic
+    __shared__ double r0[4][4], r1[4][4];
+    const int lc = threadIdx.x & 3, lr = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + lc;
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-        double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+        double t0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int b = lr;
-        for (; b + 96 < nblocks; b += 128) {
+        for (; b + 64 * 7 < nblocks; b += 64 * 8) {
+            float v0[8], v1[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                t0[u] += (double)partial[(int64_t)(b + 32 * u) * 2 * C + c];
-                t1[u] += (double)partial[(int64_t)(b + 32 * u) * 2 * C + C + c];
+            for (int u = 0; u < 8; ++u) {
+                v0[u] = partial[(int64_t)(b + 64 * u) * 2 * C + c];
+                v1[u] = partial[(int64_t)(b + 64 * u) * 2 * C + C + c];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t0[u] += (double)v0[u]; t1[u] += (double)v1[u]; }
         }
-        for (; b < nblocks; b += 32) {
+        for (; b < nblocks; b += 64) {
             t0[0] += (double)partial[(int64_t)b * 2 * C + c];
             t1[0] += (double)partial[(int64_t)b * 2 * C + C + c];
         }
-        s0 = (t0[0] + t0[1]) + (t0[2] + t0[3]);
-        s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+        s0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + (t0[6] + t0[7]));
+        s1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + (t1[6] + t1[7]));
     }
-    r0[lr][lc] = s0; r1[lr][lc] = s1;
+    // the 16 lanes of a wave that share a channel (thread index stride 4), then the 4 waves through LDS
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if ((threadIdx.x & 63) < 4) { r0[threadIdx.x >> 6][lc] = s0; r1[threadIdx.x >> 6][lc] = s1; }
     __syncthreads();
     if (lr != 0 || c >= C) return;
-    for (int k = 1; k < 32; ++k) { s0 += r0[k][lc]; s1 += r1[k][lc]; }
+    s0 = (r0[0][lc] + r0[1][lc]) + (r0[2][lc] + r0[3][lc]);
+    s1 = (r1[0][lc] + r1[1][lc]) + (r1[2][lc] + r1[3][lc]);
     if (FIN == 0) {
         const double mean = s0 / M;
         const double var = fmax(s1 / M - mean * mean, 0.0);             // biased variance (normalisation)
@@ -579,8 +609,22 @@ using namespace sd;
 
 extern "C" {
 
+static int fold_rows(int rows) { return rows > 512 ? cdiv(rows, std::max(16, rows / 128)) : 0; }
+
+// [nb partial rows][2][C] + the two per-channel means of the backward + the slab sums of the two-level finish
 size_t sd_col_reduce_workspace_bytes(int64_t M, int C) {
-    return align_up((size_t)cdiv(M, RED_ROWS_PER_BLOCK) * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float), 256);
+    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    return align_up(((size_t)nb + fold_rows(nb)) * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float), 256);
+}
+
+// Many partial rows: fold them in coalesced slabs first (a column-slice finalize touches every row from every block); returns
+// the rows the finalize kernel then reads (possibly moved to `scratch`).
+static const float* fold_partials(const float* partial, int& rows, int C, float* scratch, hipStream_t st) {
+    if (!scratch || fold_rows(rows) == 0 || 2 * C > 1024) return partial;
+    const int slab = std::max(16, rows / 128), nb2 = cdiv(rows, slab);
+    hipLaunchKernelGGL(k_rows_fold, dim3(nb2), dim3(256), 0, st, partial, rows, 2 * C, slab, scratch);
+    rows = nb2;
+    return scratch;
 }
 
 static int check_mc(const char* what, int64_t M, int C) {
@@ -599,7 +643,25 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+                       mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// rows of `scratch` the two-level finish of `rows` partial rows needs (0 = single level)
+int sd_bn_finalize_scratch_rows(int rows) { return fold_rows(rows); }
+
+int sd_bn_finalize_stats(const float* partial, int rows, int64_t M, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scratch, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_finalize_stats", M, C)) return e;
+    SD_REQUIRE(partial && mean && invstd && rows > 0, SD_ERR_INVALID, "sd_bn_finalize_stats: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    // Many partial rows (one per conv tile: up to 8192): a column-slice finalize would touch every row from every block, so
+    // the rows are first folded in coalesced slabs (full 2C-float rows per block), then the few slab sums are finished.
+    partial = fold_partials(partial, rows, C, scratch, st);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, rows, C, (double)M, eps, momentum,
                        mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
     SD_LAUNCH_CHECK();
     return 0;
@@ -638,7 +700,9 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
     float* mgx = mg + C;
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta, relu, M, C, partial);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)partial, nb, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+    int rows = nb;
+    const float* fin = fold_partials(partial, rows, C, mgx + C, st);
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, dgamma, dbeta,
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
@@ -657,7 +721,7 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
     hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 8)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     SD_LAUNCH_CHECK();
     return 0;

@@ -152,15 +152,35 @@ class _Engine:
             "sd_conv2d_fwd"))
         return y, d
 
-    def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True):
-        Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
-        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    def conv_stats(self, x, conv, B, Hi, Wi, bn: BNParams, update_running=True):
+        """Training forward of conv -> BatchNorm: the conv launch also produces the batch statistics of its output
+        (sd_conv2d_fwd_bn_stats), so bn_train(..., stats=...) only has the apply pass left."""
+        d = _desc(B, Hi, Wi, conv)
+        y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
+        mean = torch.empty(conv.cout, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
-        ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
-        L.check(self.lib.sd_bn_train_stats(x.data_ptr(), Mrows, Cc, BN_EPS, BN_MOMENTUM,
-                                           bn.running_mean.data_ptr() if update_running else 0,
-                                           bn.running_var.data_ptr() if update_running else 0,
-                                           mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
+        flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        ws = self._ws(self.lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), x.device)
+        self._timed(self._kname(d, 0), flops, lambda: L.check(
+            self.lib.sd_conv2d_fwd_bn_stats(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), BN_EPS, BN_MOMENTUM,
+                                            bn.running_mean.data_ptr() if update_running else 0,
+                                            bn.running_var.data_ptr() if update_running else 0,
+                                            mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()),
+            "sd_conv2d_fwd_bn_stats"))
+        return y, d, (mean, invstd)
+
+    def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True, stats=None):
+        Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        if stats is not None:
+            mean, invstd = stats
+        else:
+            mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
+            L.check(self.lib.sd_bn_train_stats(x.data_ptr(), Mrows, Cc, BN_EPS, BN_MOMENTUM,
+                                               bn.running_mean.data_ptr() if update_running else 0,
+                                               bn.running_var.data_ptr() if update_running else 0,
+                                               mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
         y = torch.empty_like(x)
         L.check(self.lib.sd_bn_apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
                                      bn.bias.data_ptr(), _ptr(res), int(relu), L.stream()), "sd_bn_apply")
@@ -218,16 +238,16 @@ class _Engine:
         for layer in (net.down1, net.down2, net.down3, net.down4):
             for blk in layer:
                 if training:
-                    c1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc)
-                    a1, m1, i1 = self.bn_train(c1, blk.bn1)
-                    c2, d2 = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo)
+                    c1, d1, st1 = self.conv_stats(cur, blk.conv1, B, Hc, Wc, blk.bn1)
+                    a1, m1, i1 = self.bn_train(c1, blk.bn1, stats=st1)
+                    c2, d2, st2 = self.conv_stats(a1, blk.conv2, B, d1.Ho, d1.Wo, blk.bn2)
                     if blk.downsample is not None:
-                        cd, dd = self.conv(cur, blk.downsample[0], B, Hc, Wc)
-                        idt, md, idd = self.bn_train(cd, blk.downsample[1], relu=False)
+                        cd, dd, std_ = self.conv_stats(cur, blk.downsample[0], B, Hc, Wc, blk.downsample[1])
+                        idt, md, idd = self.bn_train(cd, blk.downsample[1], relu=False, stats=std_)
                     else:
                         cd = dd = md = idd = None
                         idt = cur
-                    out, m2, i2 = self.bn_train(c2, blk.bn2, res=idt, relu=True)
+                    out, m2, i2 = self.bn_train(c2, blk.bn2, res=idt, relu=True, stats=st2)
                     if rec:
                         blocks_tape.append((blk, cur, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd))
                 else:
@@ -250,8 +270,8 @@ class _Engine:
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
             t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
             if training:
-                c, dc = self.conv(t, fpn.conv[0], B, Hs, Ws)
-                fn, mf, if_ = self.bn_train(c, fpn.conv[1])
+                c, dc, stf = self.conv_stats(t, fpn.conv[0], B, Hs, Ws, fpn.conv[1])
+                fn, mf, if_ = self.bn_train(c, fpn.conv[1], stats=stf)
                 if rec:
                     fpn_tape.append((fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn))
             else:

@@ -110,6 +110,35 @@ def test_conv_fwd_dgrad_wgrad(case):
     close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 3, 1, 1), (2, 9, 7, 256, 256, 3, 1, 1), (16, 64, 64, 64, 128, 3, 2, 1), (1, 16, 16, 512, 512, 3, 1, 1),
+                                  (8, 128, 128, 128, 128, 3, 1, 1)])
+def test_conv_fwd_with_fused_bn_statistics(case):
+    """sd_conv2d_fwd_bn_stats: same y as sd_conv2d_fwd, batch statistics and running-stat update as nn.BatchNorm2d computes them
+    (ragged last tile, the 128- and 256-row tile kernels, and the split-K fallback of a tiny batch)."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    y = torch.empty(B, d.Ho, d.Wo, cout, device=DEV)
+    mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    ws = torch.empty(max(lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_conv2d_fwd_bn_stats(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                                       mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+    ref = F.conv2d(x, w, None, stride, pad)
+    close(from_nhwc(y), ref, 2e-6 * (cin * k * k) ** 0.5)
+    bn = torch.nn.BatchNorm2d(cout).train()
+    bn(ref)
+    r64 = ref.double()
+    close(mean.cpu(), r64.mean((0, 2, 3)).float(), 1e-5)
+    close(invstd.cpu(), (1.0 / torch.sqrt(r64.var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
+    close(rm.cpu(), bn.running_mean, 1e-5)
+    close(rv.cpu(), bn.running_var, 1e-5)
+
+
 def test_conv_fwd_split_k_small_batch():
     """Small batch: the tile grid cannot fill the chip, K is split over blocks (+ reduce/epilogue pass)."""
     from structuredetector_amd import _lib as L
