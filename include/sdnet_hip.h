@@ -194,6 +194,23 @@ int sd_bn_finalize_scratch_rows(int rows);
 int sd_bn_finalize_stats(const float* partial, int rows, int64_t M, int C, float eps, float momentum, float* running_mean,
                          float* running_var, float* mean, float* invstd, float* scratch, sd_stream_t stream);
 
+/* Data-gradient of a conv whose INPUT was the output of a BatchNorm2d (+ReLU): dx = dgrad(dy) [+ residual] as sd_conv2d_dgrad,
+ * and from the values of the same epilogue the reduction of that BatchNorm's backward (sum g, sum g * xhat per channel with
+ * g = dx * relu mask, xhat = (bn_x - mean) * invstd; relu as in sd_bn_bwd) -- one pass over dx and bn_x less than
+ * sd_conv2d_dgrad + sd_bn_bwd.  Writes dgamma / dbeta (+= when accumulate) and means_out = [mean(g) (C), mean(g xhat) (C)],
+ * C = Cin; finish with sd_bn_bwd_apply(dy = dx, x = bn_x, ...).  Deterministic (partials per tile, fixed-order finish). */
+size_t sd_conv2d_dgrad_bn_reduce_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual,
+                              const float* bn_x, const float* bn_y, int relu, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float* dgamma, float* dbeta, int accumulate,
+                              float* means_out, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* the two halves of sd_bn_bwd after its reduction pass */
+int sd_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, float* dgamma, float* dbeta, int accumulate,
+                       float* means_out, float* scratch, sd_stream_t stream);
+int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean,
+                    const float* invstd, const float* gamma, const float* beta, const float* means, float* dx, float* g_out,
+                    sd_stream_t stream);
+
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
  * 2 = sd_conv2d_wgrad), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
  * with the same names as the kernel trace.  Thread-local storage, valid until the next call on the thread. */

@@ -98,6 +98,10 @@ _SIGNATURES = {
     "sd_conv2d_kernel_name": (C.c_char_p, [c_vp, c_int]),
     "sd_conv2d_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
+    "sd_conv2d_dgrad_bn_reduce_workspace_bytes": (c_size, [c_vp]),
+    "sd_conv2d_dgrad_bn_reduce": (c_int, [c_vp] * 5 + [c_vp, c_vp, c_int] + [c_vp] * 6 + [c_int, c_vp, c_vp, c_size, c_vp]),
+    "sd_bn_bwd_finalize": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "sd_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int] + [c_vp] * 8),
     "sd_bn_finalize_scratch_rows": (c_int, [c_int]),
     "sd_bn_finalize_stats": (c_int, [c_vp, c_int, c_i64, c_int, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sd_allreduce_unique_id": (c_int, [c_vp]),

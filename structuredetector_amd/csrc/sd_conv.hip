@@ -60,6 +60,13 @@ struct ConvArgs {
     int M, nk, kchunks;   // kchunks = Ck / (elements per 128-byte chunk: 32 fp32 or 64 bf16); nk = number of K chunks
     int splits;           // split-K (small-batch inference): blockIdx.y = K slice, raw partial tiles go to `part`
     float* part;          // [splits][M][Nn]
+    // data-gradient + BatchNorm-backward reduction: the tensor this launch writes is the gradient w.r.t. the OUTPUT of a
+    // BatchNorm(+ReLU) whose input was bn_x; the epilogue then also accumulates sum(g) and sum(g * xhat) per channel into
+    // `stat` (g = v * relu mask, xhat = (bn_x - mean) * invstd) -- the reduction pass of sd_bn_bwd without re-reading dy
+    const float* bn_x;    // [M][Nn] input of that BatchNorm (nullable = no fused reduction)
+    const float* bn_y;    // its output, for the ReLU mask of residual layers (bn_relu == 1)
+    const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+    int bn_relu;          // 0 none, 1 mask = bn_y > 0, 2 mask recomputed from bn_x
     float* stat;          // forward + BatchNorm statistics: per (m-tile, wave row) partial column sums [rows][2][Nn] of the
                           // raw conv output (sum, sum of squares), finished by sd_bn_finalize / k_col_finalize<0> (nullable)
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
@@ -96,6 +103,18 @@ __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v
 // NOTE on style: the staging registers are individual named variables filled by macros, not arrays written
 // inside lambdas -- hipcc left such arrays in scratch memory (scratch_store after every global_load and a
 // vmcnt(0) wait per load), which serialised the prefetch.
+// Epilogue helpers shared by k_conv_igemm and k_conv_igemm_big.
+// SD_BNRED_TERM: contribution of one stored value v at (m, n) to the fused BatchNorm-backward reduction.
+#define SD_BNRED_TERM(v, m, n, S, Q)                                                               \
+    {                                                                                              \
+        const float xv_ = p.bn_x[(int64_t)(m) * p.Nn + (n)];                                       \
+        const float xh_ = (xv_ - bmu) * bis;                                                       \
+        float g_ = (v);                                                                            \
+        if (p.bn_relu == 1) g_ = p.bn_y[(int64_t)(m) * p.Nn + (n)] > 0.f ? g_ : 0.f;               \
+        else if (p.bn_relu == 2) g_ = (xh_ * bga + bbe) > 0.f ? g_ : 0.f;                          \
+        S += g_; Q += g_ * xh_;                                                                    \
+    }
+
 template <int BN, int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     constexpr bool STEM = (MODE == 1);
@@ -395,29 +414,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }
         return;
     }
-    if (MODE == 0 && !BF16 && p.stat) {
-        // BatchNorm statistics of the raw conv output from the accumulators (rows past M staged zeros: they add nothing):
-        // column sums over the wave's 64 rows, the two wave rows combined through LDS, one partial row per tile
-        __shared__ float statred[2][BN];
-        float sv[NT], qv[NT];
+    // Column sums for a BatchNorm that is fused with this launch (p.stat): forward = statistics of the raw conv output, from
+    // the accumulators (rows past M staged zeros: they add nothing); data-gradient = the BatchNorm-backward reduction over
+    // the values being stored.  Per wave over its 64 rows, the two wave rows combined through LDS, one partial row per tile.
+    const bool fwd_stat = !BF16 && MODE == 0 && p.stat && !p.bn_x;
+    const bool bwd_red = !BF16 && p.stat && p.bn_x;
+    float sv[NT], qv[NT];
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            float s = 0.f, q = 0.f;
+    for (int ni = 0; ni < NT; ++ni) {
+        sv[ni] = qv[ni] = 0.f;
+        if (fwd_stat) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; s += a; q += a * a; }
-            sv[ni] = s + __shfl_xor(s, 32); qv[ni] = q + __shfl_xor(q, 32);
-            if ((wave >> 1) == 1 && fh == 0) { statred[0][wn0 + ni * 32 + fr] = sv[ni]; statred[1][wn0 + ni * 32 + fr] = qv[ni]; }
-        }
-        __syncthreads();
-        if ((wave >> 1) == 0 && fh == 0) {
-            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int c = wn0 + ni * 32 + fr;
-                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
-            }
+                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
 #pragma unroll
@@ -425,6 +435,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         const int n = n0 + wn0 + ni * 32 + fr;
         const float sc = p.scale ? p.scale[n] : 1.f;
         const float sh = p.shift ? p.shift[n] : 0.f;
+        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
+        if (bwd_red) {
+            bmu = p.bn_mean[n]; bis = p.bn_invstd[n];
+            if (p.bn_relu == 2) { bga = p.bn_gamma[n]; bbe = p.bn_beta[n]; }
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -443,6 +458,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
                 else reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
+            }
+        }
+    }
+    if (fwd_stat || bwd_red) {
+        __shared__ float statred[2][BN];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32);
+            if ((wave >> 1) == 1 && fh == 0) { statred[0][wn0 + ni * 32 + fr] = sv[ni]; statred[1][wn0 + ni * 32 + fr] = qv[ni]; }
+        }
+        __syncthreads();
+        if ((wave >> 1) == 0 && fh == 0) {
+            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int c = wn0 + ni * 32 + fr;
+                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
             }
         }
     }
@@ -690,20 +723,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_MFMA
 #undef SD_BIG_ISSUE
 
-    if (MODE == 0 && p.stat) {
-        // BatchNorm statistics (see k_conv_igemm): one partial row per 256-row tile
-        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
-        __shared__ float statred[2][BN];
-        float sv[NTW], qv[NTW];
+    // fused BatchNorm column sums (see k_conv_igemm): one partial row per 256-row tile
+    const bool fwd_stat = MODE == 0 && p.stat && !p.bn_x;
+    const bool bwd_red = p.stat && p.bn_x;
+    float sv[NTW], qv[NTW];
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) {
-            float s = 0.f, q = 0.f;
+    for (int ni = 0; ni < NTW; ++ni) {
+        sv[ni] = qv[ni] = 0.f;
+        if (fwd_stat) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; s += a; q += a * a; }
-            sv[ni] = s + __shfl_xor(s, 32); qv[ni] = q + __shfl_xor(q, 32);
+                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + fr;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
+        if (bwd_red) {
+            bmu = p.bn_mean[n]; bis = p.bn_invstd[n];
+            if (p.bn_relu == 2) { bga = p.bn_gamma[n]; bbe = p.bn_beta[n]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                if (m < 0) continue;
+                float v = acc[mi][ni][e] * sc + sh;
+                if (p.res) {
+                    int64_t rm = m;
+                    if (p.res_up2) {
+                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                    }
+                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
+            }
+        }
+    }
+    if (fwd_stat || bwd_red) {
+        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
+        __shared__ float statred[2][BN];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
         // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes
         if (tid < 2 * BN) statred[tid / BN][tid % BN] = 0.f;
         __syncthreads();
@@ -723,32 +792,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
             }
         }
     }
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + fr;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                if (m < 0) continue;
-                float v = acc[mi][ni][e] * sc + sh;
-                if (p.res) {
-                    int64_t rm = m;
-                    if (p.res_up2) {
-                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-                    }
-                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
-                }
-                if (p.relu) v = fmaxf(v, 0.f);
-                reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
-            }
-        }
-    }
 }
+#undef SD_BNRED_TERM
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dW[n][tap][c] = sum_m dY[m][n] * X[pix(m, tap)][c]  -- a GEMM whose reduction
@@ -1651,6 +1696,44 @@ int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const 
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
+}
+
+// partial rows the data-gradient kernel of this geometry writes for the fused BatchNorm-backward reduction
+static int dgrad_stat_rows(const sd_conv_desc* d) {
+    ConvArgs a{};
+    fill_dgrad(a, d);
+    const int BN = (a.Nn % 128 == 0) ? 128 : 64;
+    const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
+    return igemm_big_tiles(a, BN, mode) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+}
+
+size_t sd_conv2d_dgrad_bn_reduce_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 64 || d->Cout % 32) return 0;
+    const int rows = dgrad_stat_rows(d);
+    return (size_t)(rows + sd_bn_finalize_scratch_rows(rows)) * 2 * d->Cin * sizeof(float);
+}
+
+int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual, const float* bn_x,
+                              const float* bn_y, int relu, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              float* dgamma, float* dbeta, int accumulate, float* means_out, void* workspace, size_t workspace_bytes,
+                              sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_dgrad_bn_reduce", d)) return e;
+    SD_REQUIRE(dy && w_t && dx && bn_x && mean && invstd && gamma && dgamma && dbeta && means_out && workspace, SD_ERR_INVALID,
+               "sd_conv2d_dgrad_bn_reduce: null pointer");
+    SD_REQUIRE(relu >= 0 && relu <= 2 && (relu != 1 || bn_y) && (relu != 2 || beta), SD_ERR_INVALID,
+               "sd_conv2d_dgrad_bn_reduce: relu must be 0, 1 (needs bn_y) or 2 (needs beta)");
+    SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_bn_reduce: needs Cout %% 32 == 0 and Cin %% 64 == 0");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad_bn_reduce: pointers must be 16-byte aligned");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_dgrad_bn_reduce_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_dgrad_bn_reduce: workspace too small");
+    ConvArgs a{};
+    fill_dgrad(a, d);
+    a.x = dy; a.w = w_t; a.y = dx; a.res = residual;
+    a.bn_x = bn_x; a.bn_y = bn_y; a.bn_relu = relu; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_gamma = gamma; a.bn_beta = beta;
+    a.stat = (float*)workspace;
+    if (int e = launch_igemm(a, false, (hipStream_t)stream)) return e;
+    const int rows = dgrad_stat_rows(d);
+    return sd_bn_bwd_finalize((const float*)workspace, rows, (int64_t)a.M, d->Cin, dgamma, dbeta, accumulate, means_out,
+                              (float*)workspace + (size_t)rows * 2 * d->Cin, stream);
 }
 
 const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {

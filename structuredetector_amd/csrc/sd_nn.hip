@@ -712,6 +712,35 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
     return 0;
 }
 
+// second half of the reduction of sd_bn_bwd on caller-provided partial rows [rows][2][C] (sum g, sum g * xhat):
+// dgamma / dbeta (+=) and means_out = [mean(g) (C), mean(g * xhat) (C)] for sd_bn_bwd_apply
+int sd_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, float* dgamma, float* dbeta, int accumulate, float* means_out,
+                       float* scratch, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_bwd_finalize", M, C)) return e;
+    SD_REQUIRE(partial && dgamma && dbeta && means_out && rows > 0, SD_ERR_INVALID, "sd_bn_bwd_finalize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float* fin = fold_partials(partial, rows, C, scratch, st);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+                       (float*)nullptr, (float*)nullptr, means_out, means_out + C, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// apply pass of sd_bn_bwd with the two per-channel means already known (sd_conv2d_dgrad_bn_reduce / sd_bn_bwd_finalize)
+int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, const float* means, float* dx, float* g_out, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_bwd_apply", M, C)) return e;
+    SD_REQUIRE(relu >= 0 && relu <= 2, SD_ERR_INVALID, "sd_bn_bwd_apply: relu must be 0 (none), 1 (mask from y) or 2 (mask recomputed from x)");
+    SD_REQUIRE(dy && x && mean && invstd && gamma && means && dx && (relu != 1 || y) && (relu != 2 || beta), SD_ERR_INVALID,
+               "sd_bn_bwd_apply: null pointer");
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
+                       means, means + C, dx, g_out);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
 int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_mc("sd_col_sum", M, C)) return e;
     SD_REQUIRE(x && out && workspace, SD_ERR_INVALID, "sd_col_sum: null pointer");

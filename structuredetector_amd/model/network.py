@@ -122,6 +122,11 @@ class _Engine:
         # overlap was measured too: slower than no overlap, the HBM-bound passes slow the wgrad they run under.)
         self.overlap_wgrad = False
         self._side = None
+        # BatchNorm-backward reduction inside the data-gradient epilogue (sd_conv2d_dgrad_bn_reduce).  Measured at bs=64: the
+        # separate reduce passes drop from 3.0 to 0.8 ms per step, but the 4-byte epilogue reads of bn_x / bn_y cost the conv
+        # kernels 4.0 ms (a 32x32 MFMA accumulator holds 16 ROWS of one column per lane: no 16-byte access along channels),
+        # so the step gets 1.7 ms slower.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
+        self.fuse_bn_bwd = False
 
     def _kname(self, d, which):
         """device kernel the C ABI will launch for this conv (profiling label; same names as the rocprofv3 kernel trace)"""
@@ -366,14 +371,28 @@ class _Engine:
                 "transpose_weights")
         return wt
 
-    def _dgrad(self, dy, conv, d, res=None):
+    def _dgrad(self, dy, conv, d, res=None, bn_next=None):
+        """dx = dgrad(dy) [+ res].  bn_next = (x, y, relu, bn, mean, invstd) of the BatchNorm whose output gradient dx is:
+        the launch then also does that BatchNorm's backward reduction (sd_conv2d_dgrad_bn_reduce) and the per-channel means
+        come back for _bn_bwd(..., means=...), which only has the apply pass left."""
         dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=torch.float32, device=dy.device)
         wt = self._wt(conv)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        if bn_next is None:
+            self._timed(self._kname(d, 1), flops, lambda: L.check(
+                self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"),
+                phase="dgrad")
+            return dx
+        x, y, relu, bn, mean, invstd = bn_next
+        means = torch.empty(2 * conv.cin, dtype=torch.float32, device=dy.device)
+        ws = self._ws(self.lib.sd_conv2d_dgrad_bn_reduce_workspace_bytes(C.byref(d)), dy.device)
         self._timed(self._kname(d, 1), flops, lambda: L.check(
-            self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"),
-            phase="dgrad")
-        return dx
+            self.lib.sd_conv2d_dgrad_bn_reduce(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), x.data_ptr(),
+                                               _ptr(y) if int(relu) == 1 else 0, int(relu), mean.data_ptr(), invstd.data_ptr(),
+                                               bn.weight.data_ptr(), bn.bias.data_ptr(), self.net.grad_of(bn.weight).data_ptr(),
+                                               self.net.grad_of(bn.bias).data_ptr(), 0, means.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               L.stream()), "sd_conv2d_dgrad_bn_reduce"), phase="dgrad")
+        return dx, means
 
     def _side_stream(self):
         if self._side is None:
@@ -410,10 +429,15 @@ class _Engine:
         L.check(self.lib.sd_col_sum(dy.data_ptr(), Mrows, Cc, self.net.grad_of(conv.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()),
                 "sd_col_sum")
 
-    def _bn_bwd(self, dy, x, y, relu, bn, mean, invstd, want_g=False):
+    def _bn_bwd(self, dy, x, y, relu, bn, mean, invstd, want_g=False, means=None):
         Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
         dx = torch.empty_like(x)
         g = torch.empty_like(x) if want_g else None
+        if means is not None:       # reduction (and dgamma / dbeta) already done by the data-gradient launch that produced dy
+            L.check(self.lib.sd_bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) == 1 else 0, int(relu), Mrows, Cc,
+                                             mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), means.data_ptr(),
+                                             dx.data_ptr(), _ptr(g), L.stream()), "sd_bn_bwd_apply")
+            return dx, g
         ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
         # relu: False/0 = none, True/1 = mask from y (residual layers), 2 = mask recomputed from x (y is not read)
         L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) == 1 else 0, int(relu), Mrows, Cc, mean.data_ptr(),
@@ -455,28 +479,51 @@ class _Engine:
         d5 = _desc(B, H5, W5, net.up1)
         self._wgrad(df, p5, net.up1, d5)
         self._bias_grad(df, net.up1)
-        dcur = self._dgrad(df, net.up1, d5)
+        # With `fuse_bn_bwd` every data-gradient launch that completes the gradient of a BatchNorm output also runs that
+        # BatchNorm's backward reduction in its epilogue (bn_next); `mcur` / `ma1` carry the per-channel means to the apply pass.
+        blocks = tape["blocks"]
+
+        def bn2_of(i):          # bn_next tuple of block i's second BatchNorm (mask from the saved output: residual layer)
+            if i < 0 or not self.fuse_bn_bwd:
+                return None
+            b = blocks[i]       # (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd)
+            return (b[9], b[12], 1, b[0].bn2, b[10], b[11])
+
+        last = len(blocks) - 1
+        has_lateral = blocks[last][12].data_ptr() in lateral_grad
+        nxt = None if has_lateral else bn2_of(last)
+        r = self._dgrad(df, net.up1, d5, bn_next=nxt)
+        dcur, mcur = r if nxt is not None else (r, None)
         if on_stage:
             self._join_side()
             on_stage("fpn_head")
 
         # trunk, last block first
         first_of = {id(net.down4[0]): "down4", id(net.down3[0]): "down3", id(net.down2[0]): "down2"}
-        for (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd) in reversed(tape["blocks"]):
+        for bi in range(last, -1, -1):
+            (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd) = blocks[bi]
             extra = lateral_grad.pop(out.data_ptr(), None)
-            if extra is not None:                       # `out` also feeds an FPN lateral conv
-                dcur = self._dgrad(extra[0], extra[1], extra[2], res=dcur)
-            dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True)
-            da1 = self._dgrad(dc2, blk.conv2, d2)
+            if extra is not None:                       # `out` also feeds an FPN lateral conv: this launch completes d(out)
+                nxt = bn2_of(bi)
+                r = self._dgrad(extra[0], extra[1], extra[2], res=dcur, bn_next=nxt)
+                dcur, mcur = r if nxt is not None else (r, None)
+            dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True, means=mcur)
+            nxt = (c1, None, 2, blk.bn1, m1, i1) if self.fuse_bn_bwd else None
+            r = self._dgrad(dc2, blk.conv2, d2, bn_next=nxt)
+            da1, ma1 = r if nxt is not None else (r, None)
             self._wgrad(dc2, a1, blk.conv2, d2)
-            dc1, _ = self._bn_bwd(da1, c1, a1, 2, blk.bn1, m1, i1)
+            dc1, _ = self._bn_bwd(da1, c1, a1, 2, blk.bn1, m1, i1, means=ma1)
             if blk.downsample is not None:
                 dcd, _ = self._bn_bwd(g, cd, None, False, blk.downsample[1], md, idd)
                 skip = self._dgrad(dcd, blk.downsample[0], dd)
                 self._wgrad(dcd, xin, blk.downsample[0], dd)
             else:
                 skip = g
-            dcur = self._dgrad(dc1, blk.conv1, d1, res=skip)
+            # d(xin) = d(out of the previous block), complete unless that tensor also feeds an FPN lateral (handled above)
+            prev_lateral = bi > 0 and blocks[bi - 1][12].data_ptr() in lateral_grad
+            nxt = None if (bi == 0 or prev_lateral) else bn2_of(bi - 1)
+            r = self._dgrad(dc1, blk.conv1, d1, res=skip, bn_next=nxt)
+            dcur, mcur = r if nxt is not None else (r, None)
             self._wgrad(dc1, xin, blk.conv1, d1)
             if on_stage and id(blk) in first_of:
                 self._join_side()

@@ -402,3 +402,22 @@ def test_training_step_is_deterministic():
         results.append((net.flat_grads.clone(), net.flat_params.clone(), torch.stack(losses)))
     assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
     assert torch.equal(results[0][2], results[1][2])
+
+
+def test_bn_backward_reduction_fused_into_dgrad_matches_separate_pass():
+    """`fuse_bn_bwd` (sd_conv2d_dgrad_bn_reduce + sd_bn_bwd_apply) against the default schedule (sd_conv2d_dgrad + sd_bn_bwd):
+    same gradients up to the summation order of the per-channel reductions, at a size that exercises the 128- and 256-row
+    tile kernels, the stride-2 parity classes and the FPN lateral joins."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 3, 256, 256, generator=g).to(DEV)
+    dy = (torch.randn(4, 7, 64, 64, generator=g) * 0.1).to(DEV)
+    grads = []
+    for fused in (False, True):
+        _, net = _pair(seed=13)
+        net.train()
+        out, tape = net.forward_train(x)
+        net._engine.fuse_bn_bwd = fused
+        net.backward_from(tape, dy)
+        grads.append(net.flat_grads.clone())
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-4 * scale
