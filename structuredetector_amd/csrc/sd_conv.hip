@@ -36,6 +36,9 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_ABLATE_HOT
 #define SD_ABLATE_HOT 0       // timing-only experiment: every staging load reads the (cache-hot) zero line -- WRONG RESULTS
 #endif
+#ifndef SD_ABLATE_STORE
+#define SD_ABLATE_STORE 0     // timing-only experiment: the epilogue stores (almost) nothing -- WRONG RESULTS
+#endif
 #ifndef SD_ABLATE_PATCH
 #define SD_ABLATE_PATCH 0     // timing-only experiment: stage the A tile for ~1.6 of the 9 taps only (what patch staging would need) -- WRONG RESULTS
 #endif
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
-                else reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                else if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
                 if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
             }
         }
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
                     v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
-                reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
                 if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
             }
         }
@@ -1339,6 +1342,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
     else reinterpret_cast<float4*>(p.y)[i] = a;
 }
 
+#ifndef SD_IGEMM_BIG64_S2
+#define SD_IGEMM_BIG64_S2 0    // 256x64 tiles for the stride-2 data-gradients of 64-channel inputs (experiment)
+#endif
 #ifndef SD_IGEMM_BIG64
 #define SD_IGEMM_BIG64 0       // 256x64 tiles for the 64-channel layers (measured slower than 128x64: off)
 #endif
@@ -1349,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
-    if (!SD_IGEMM_BIG || (BN != 128 && !SD_IGEMM_BIG64) || (mode != 0 && mode != 2) || a.splits > 1) return 0;
+    if (!SD_IGEMM_BIG || (BN != 128 && !SD_IGEMM_BIG64 && !(SD_IGEMM_BIG64_S2 && mode == 2)) || (mode != 0 && mode != 2) || a.splits > 1) return 0;
     const int m_per = mode == 2 ? a.M / 4 : a.M;
     const int big_tiles = (mode == 2 ? 4 : 1) * cdiv(m_per, BMB) * (a.Nn / BN);
     return (big_tiles >= 512 && (mode != 2 || m_per % BMB == 0)) ? big_tiles : 0;
@@ -1358,7 +1364,7 @@ static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
 template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     (void)lds;                             // the tiles are static __shared__ objects (65 KB for BN = 128, 49 KB for BN = 64)
-    if constexpr (!BF16 && (BN == 128 || SD_IGEMM_BIG64) && (MODE == 0 || MODE == 2)) {
+    if constexpr (!BF16 && (BN == 128 || SD_IGEMM_BIG64 || (SD_IGEMM_BIG64_S2 && MODE == 2)) && (MODE == 0 || MODE == 2)) {
         if (const int big_tiles = igemm_big_tiles(a, BN, MODE)) {
             hipLaunchKernelGGL((k_conv_igemm_big<BN, MODE>), dim3(big_tiles), dim3(256), 0, st, a);
             return;
