@@ -142,10 +142,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X visible as torch device 'cuda' (there is no CPU path to measure)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local if local < torch.cuda.device_count() else 0)    # (rehearsal: several ranks on one GPU)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SDNET_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the multi-rank path on one GPU / on CPU hosts
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from structuredetector_amd.data import Decoder, Encode
@@ -279,7 +283,7 @@ def main():
             "config": {"workload": f"configs[2]: train step bs={B}/GPU {img}x{img} fp32, 2 labels / 1 part, K=20 P=40, "
                                    "render targets + fwd + MSE/L1 loss + bwd + Adam; random-init ResNet-34+FPN",
                        "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad),
-                       "exchange": "sd_allreduce (RCCL via C ABI)" if step.rccl is not None else ("torch.distributed nccl" if world > 1 else "none")},
+                       "exchange": "sd_allreduce (RCCL via C ABI)" if step.rccl is not None else (f"torch.distributed {dist.get_backend()}" if world > 1 else "none")},
             "train_tflops_per_gpu": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3, 2),
             "train_frac_of_mfma_peak": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "loss": [round(v, 6) for v in loss_host],

@@ -107,3 +107,24 @@ def test_rccl_exchange_through_c_abi_single_rank():
     out = mp.Manager().dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     assert out["equal"] is True
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """bench.py's multi-rank path as the driver launches it (torch.distributed.run, one process per rank, barrier + max-over-ranks
+    timing, rank 0 prints the one JSON line) with two ranks sharing the test GPU and gloo standing in for RCCL."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, SDNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--size", "128"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["exchange"] == "torch.distributed gloo" and "roofline" in rec
