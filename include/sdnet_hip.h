@@ -211,6 +211,11 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
                     const float* invstd, const float* gamma, const float* beta, const float* means, float* dx, float* g_out,
                     sd_stream_t stream);
 
+/* Process-wide tuning / test switches.  "conv_patch_min_tiles": smallest tile grid for which the 3x3 stride-1 convs take the
+ * patch-staging kernel (default 512 = two resident blocks per CU; 1 = always, for tests; 1 << 30 = never);
+ * "conv_patch_bn64": 1 = also for layers with 64 output channels (default 0: slower inside the training step). */
+int sd_set_option(const char* name, int value);
+
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
  * 2 = sd_conv2d_wgrad), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
  * with the same names as the kernel trace.  Thread-local storage, valid until the next call on the thread. */

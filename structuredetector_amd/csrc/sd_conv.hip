@@ -15,6 +15,7 @@
 //
 // The same kernel is the data-gradient: dX = conv(dY, W^T) with the coordinate map inverted
 // (out = (in + pad - r) / stride when divisible), weights pre-transposed to [Cin][R][S][Cout].
+#include <string.h>
 #include "sd_common.h"
 
 namespace sd {
@@ -72,6 +73,8 @@ struct ConvArgs {
     int bn_relu;          // 0 none, 1 mask = bn_y > 0, 2 mask recomputed from bn_x
     float* stat;          // forward + BatchNorm statistics: per (m-tile, wave row) partial column sums [rows][2][Nn] of the
                           // raw conv output (sum, sum of squares), finished by sd_bn_finalize / k_col_finalize<0> (nullable)
+    // k_conv3x3_patch geometry (host-computed): tile = 256 consecutive output pixels = 256/Wo whole rows of a 2^pt_tw_log2-wide map
+    int pt_tw_log2, pt_pw, pt_pieces, pt_rolling, pt_flip;
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
                           // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
 };
@@ -484,6 +487,81 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     }
 }
 
+// Epilogue of the 256-row tile kernels: y = [relu](acc * scale + shift [+ residual]) and the fused BatchNorm column sums (see
+// k_conv_igemm): one partial row per tile.  row_to_m maps a tile row to its output pixel (-1 = none).
+template <int BN, int WM, int WN, int MT, int NTW, bool FWD, typename RowMap>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, int tid, int wave, int fr,
+                                              int fh, int wm0, int wn0, int n0, int tile_m) {
+    const bool fwd_stat = FWD && p.stat && !p.bn_x;
+    const bool bwd_red = p.stat && p.bn_x;
+    float sv[NTW], qv[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        sv[ni] = qv[ni] = 0.f;
+        if (fwd_stat) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + fr;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
+        if (bwd_red) {
+            bmu = p.bn_mean[n]; bis = p.bn_invstd[n];
+            if (p.bn_relu == 2) { bga = p.bn_gamma[n]; bbe = p.bn_beta[n]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = row_to_m(wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh);
+                if (m < 0) continue;
+                float v = acc[mi][ni][e] * sc + sh;
+                if (p.res) {
+                    int64_t rm = m;
+                    if (p.res_up2) {
+                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                    }
+                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                }
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
+            }
+        }
+    }
+    if (fwd_stat || bwd_red) {
+        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
+        __shared__ float statred[2][BN];
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
+        // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes
+        if (tid < 2 * BN) statred[tid / BN][tid % BN] = 0.f;
+        __syncthreads();
+        for (int wr = 1; wr < WM; ++wr) {
+            if (wave / WN == wr && fh == 0) {
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) { statred[0][wn0 + ni * 32 + fr] += sv[ni]; statred[1][wn0 + ni * 32 + fr] += qv[ni]; }
+            }
+            __syncthreads();
+        }
+        if (wave / WN == 0 && fh == 0) {
+            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni) {
+                const int c = wn0 + ni * 32 + fr;
+                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Large-tile fp32 implicit GEMM (MODE 0 / 2): block tile 256 (m) x BN, BK = 16, three LDS stages, counted vmcnt waits.
 // Why: the staging path, not the MFMA pipe, is the tight resource of k_conv_igemm -- a CU takes LDS-DMA pieces at
@@ -726,76 +804,206 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_MFMA
 #undef SD_BIG_ISSUE
 
-    // fused BatchNorm column sums (see k_conv_igemm): one partial row per 256-row tile
-    const bool fwd_stat = MODE == 0 && p.stat && !p.bn_x;
-    const bool bwd_red = p.stat && p.bn_x;
-    float sv[NTW], qv[NTW];
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) {
-        sv[ni] = qv[ni] = 0.f;
-        if (fwd_stat) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
-        }
-    }
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + fr;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
-        if (bwd_red) {
-            bmu = p.bn_mean[n]; bis = p.bn_invstd[n];
-            if (p.bn_relu == 2) { bga = p.bn_gamma[n]; bbe = p.bn_beta[n]; }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                if (m < 0) continue;
-                float v = acc[mi][ni][e] * sc + sh;
-                if (p.res) {
-                    int64_t rm = m;
-                    if (p.res_up2) {
-                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-                    }
-                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
-                }
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
-                if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
-            }
-        }
-    }
-    if (fwd_stat || bwd_red) {
-        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
-        __shared__ float statred[2][BN];
-#pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
-        // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes
-        if (tid < 2 * BN) statred[tid / BN][tid % BN] = 0.f;
-        __syncthreads();
-        for (int wr = 1; wr < WM; ++wr) {
-            if (wave / WN == wr && fh == 0) {
-#pragma unroll
-                for (int ni = 0; ni < NTW; ++ni) { statred[0][wn0 + ni * 32 + fr] += sv[ni]; statred[1][wn0 + ni * 32 + fr] += qv[ni]; }
-            }
-            __syncthreads();
-        }
-        if (wave / WN == 0 && fh == 0) {
-            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
-#pragma unroll
-            for (int ni = 0; ni < NTW; ++ni) {
-                const int c = wn0 + ni * 32 + fr;
-                dst[c] = sv[ni] + statred[0][c]; dst[p.Nn + c] = qv[ni] + statred[1][c];
-            }
-        }
-    }
+    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0>(p, acc, [&](int row) { return orow[row]; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
 }
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution (forward, and data-gradient with the taps flipped) with PATCH STAGING: the nine taps of
+// a channel chunk read (shifted) the same input pixels, so the (rows + 2) x (cols + 2) input patch of the tile is staged ONCE per
+// channel chunk and every tap's A fragments are read from it; only the weights are staged per tap.  Staged bytes per MFMA
+// drop to 0.47x (BN = 128) / 0.56x (BN = 64) of k_conv_igemm_big's -- see DESIGN.md, staging-throughput model.
+//   tile  : 256 consecutive output pixels = 256/Wo whole rows (Wo in {16, 32, 64, 128}, Ho*Wo % 256 == 0) x BN channels
+//   patch : LDS rows of 16 floats, one per patch pixel pp = py * PW + px, slot swizzle q ^ ((pp >> 2) & 3)
+//           Wo <= 64: double-buffered (next chunk's patch lands while the nine taps of this one run)
+//           Wo = 128: ONE buffer of 4 rows x 144 (padded) pixels, refilled row by row behind the taps that are done with a row
+//                     (tap row r reads patch rows r, r+1): rows 2, 3 of THIS chunk go out at taps 0..3, rows 0, 1 of the NEXT
+//                     chunk at taps 4..7
+//   B     : three stages of BN rows x 16 floats, one per tap, ring position = tap % 3 (9 taps = 3 turns)
+//   sync  : per tap one counted `s_waitcnt vmcnt(n)` (n = what this wave issued during the tap) + bare s_barrier
+// ---------------------------------------------------------------------------------------------
+constexpr int PT_STAGE_FLOATS = 25 * 256;          // one double-buffer stage: 25 pieces of 1 KB (Wo = 64: 6 x 66 = 396 patch rows)
+constexpr int PT_FLOATS = 2 * PT_STAGE_FLOATS;     // 51.2 KB; the rolling mode (36 pieces) uses it as one buffer
+constexpr int PT_MAXP = 12;                        // patch pieces a wave can own (rolling: 4 rows x 3 slots)
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
+    constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;
+    constexpr int MT = BMB / WM / 32, NTW = BN / WN / 32;
+    constexpr int PBW = BN / 16 / 4;                 // weight pieces per wave and tap
+    constexpr int B_ST = BN * BKB;
+    static_assert(NTW == 2 && (MT == 4 || MT == 2), "wave tile 128x64 or 64x64");
+    __shared__ __attribute__((aligned(16))) float Pt[PT_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * B_ST];
+    const float* const px_ = reinterpret_cast<const float*>(p.x);
+    const float* const pw_ = reinterpret_cast<const float*>(p.w);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = p.Nn / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / n_tiles;
+    const int n0 = (tile % n_tiles) * BN;
+    const int m0 = tile_m * BMB;
+    const int TWl = p.pt_tw_log2, TW = 1 << TWl, PW = p.pt_pw, TH = BMB >> TWl;
+    const bool rolling = p.pt_rolling != 0;
+    const int hw = p.Ho * p.Wo;
+    const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> TWl;
+    const int nchunks = p.Ck / BKB;
+
+    // ---- patch pieces of this wave.  double-buffer: piece j = wave + 4 i;  rolling: i = 3 r + u -> j = 9 r + wave + 4 u (u = 2: wave 0)
+    const int prow = lane >> 2, pslot = lane & 3;
+    const float* pbase[PT_MAXP];
+    unsigned okmask = 0, ownmask = 0;                 // okmask: the piece reads the image (else the zero line); ownmask: piece exists
+#pragma unroll
+    for (int i = 0; i < PT_MAXP; ++i) {
+        const int j = rolling ? 9 * (i / 3) + wave + 4 * (i % 3) : wave + 4 * i;
+        const bool own = rolling ? (wave + 4 * (i % 3) < 9) : (j < p.pt_pieces);
+        const int pp = j * 16 + prow;
+        const int py = pp / PW, pxx = pp - py * PW;
+        const int iy = y0 - 1 + py, ix = pxx - 1;
+        const bool ok = own && py < TH + 2 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const int qe = (pslot ^ ((pp >> 2) & 3)) * 4;
+        pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : g_zero_line + qe;
+        // (ok differs per lane: keep it per lane in bit i; own is wave-uniform)
+        okmask |= (ok ? 1u : 0u) << i;
+        ownmask |= (own ? 1u : 0u) << i;
+    }
+    const int wk = 9 * p.Ck;
+    const int qeb = (pslot ^ ((prow >> 2) & 3)) * 4;
+    const float* bbase[PBW];
+#pragma unroll
+    for (int j = 0; j < PBW; ++j) bbase[j] = pw_ + (int64_t)(n0 + (wave * PBW + j) * 16 + prow) * wk + qeb;
+    const float* const zsrc = g_zero_line + qeb;
+
+#define PT_PATCH(i, dst, c0) { lds_dma16(((okmask >> (i)) & 1u) ? pbase[i] + (c0) : pbase[i], (dst) + (rolling ? 9 * ((i) / 3) + wave + 4 * ((i) % 3) : wave + 4 * (i)) * 256); }
+#define PT_OWN(i) ((ownmask >> (i)) & 1u)
+    // weights of (chunk ccn, loop tap t2) -> ring stage st; past the end: the zero line (keeps the per-tap issue count fixed).
+    // The data-gradient walks the patch in the same order (rows 0..2: the rolling refill depends on it) with the weight taps
+    // reversed: input pixel o + (1 - r, 1 - s) pairs with weight tap (r, s).
+#define PT_ISSUE_B(ccn, t2, st)                                                                    \
+    {                                                                                              \
+        float* bd = Bs + (st) * B_ST;                                                              \
+        if ((ccn) < nchunks) {                                                                     \
+            const int woff = (p.pt_flip ? 8 - (t2) : (t2)) * p.Ck + (ccn) * BKB;                   \
+            _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(bbase[j] + woff, bd + (wave * PBW + j) * 256); \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(zsrc, bd + (wave * PBW + j) * 256); \
+        }                                                                                          \
+    }
+
+    // ---- MFMA side
+    const int wm0 = (wave / WN) * (BMB / WM), wn0 = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    int bpp[MT];                                       // patch pixel of this lane's output pixel (tap 0, 0), per m-tile
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int ml = wm0 + mi * 32 + fr;
+        bpp[mi] = (ml >> TWl) * PW + (ml & (TW - 1));
+    }
+    const int rd_swz_b = (fr >> 2) & 3;
+    const uint32_t b_k0 = ((wn0 + fr) * BKB + (((0 * 2 + fh) ^ rd_swz_b) << 2)) * 4;
+    constexpr int TSTR = 32 * BKB * 4;
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // ---- prologue: weights of taps 0, 1 and the patch of chunk 0 (rolling: its rows 0 and 1)
+    PT_ISSUE_B(0, 0, 0)
+    PT_ISSUE_B(0, 1, 1)
+#pragma unroll
+    for (int i = 0; i < PT_MAXP; ++i)
+        if (PT_OWN(i) && (!rolling || i < 6)) PT_PATCH(i, Pt, 0)
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    const uint32_t pt_base = lds_addr(Pt), bs_base = lds_addr(Bs);
+    // one tap: issue (weights of tap t+2, this tap's share of the patch traffic), multiply, publish
+#define PT_TAP(t)                                                                                  \
+    {                                                                                              \
+        int n_iss = PBW;                                                                           \
+        PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
+        if (rolling) {                                                                             \
+            /* taps 0..3: rows 2, 3 of this chunk; taps 4..7: rows 0, 1 of the next one; even tap: slot 0, odd: slots 1 (+2) */ \
+            if ((t) < 8) {                                                                         \
+                const int row = (t) < 4 ? 2 + (t) / 2 : ((t) - 4) / 2;                             \
+                const int cch = (t) < 4 ? cc : cc + 1;                                             \
+                if (cch < nchunks) {                                                               \
+                    if (((t) & 1) == 0) { PT_PATCH(3 * row, Pt, cch * BKB) ++n_iss; }              \
+                    else {                                                                         \
+                        if (PT_OWN(3 * row + 1)) { PT_PATCH(3 * row + 1, Pt, cch * BKB) ++n_iss; } \
+                        if (PT_OWN(3 * row + 2)) { PT_PATCH(3 * row + 2, Pt, cch * BKB) ++n_iss; } \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        } else if ((t) < 7 && cc + 1 < nchunks && PT_OWN(t)) {                                     \
+            PT_PATCH(t, pt_nxt, (cc + 1) * BKB) ++n_iss;                                           \
+        }                                                                                          \
+        const int tapoff = ((t) / 3) * PW + ((t) % 3);      /* data-gradient: same walk, weight taps reversed */ \
+        uint32_t aa[MT];                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                        \
+            const int pp = bpp[mi] + tapoff;                                                       \
+            aa[mi] = pt_cur + (uint32_t)pp * 64u + (uint32_t)((fh ^ ((pp >> 2) & 3)) << 4);        \
+        }                                                                                          \
+        const uint32_t bb = bs_base + ((t) % 3) * (B_ST * 4) + b_k0;                               \
+        f32x4 a00 = lds_read128_async<0>(aa[0]), a01 = lds_read128_async<0>(aa[1]);                \
+        f32x4 a02 = a00, a03 = a00;                                                                \
+        if (MT == 4) { a02 = lds_read128_async<0>(aa[MT - 2]); a03 = lds_read128_async<0>(aa[MT - 1]); } \
+        f32x4 b00 = lds_read128_async<0>(bb), b01 = lds_read128_async<TSTR>(bb);                   \
+        f32x4 a10 = lds_read128_async<0>(aa[0] ^ 32u), a11 = lds_read128_async<0>(aa[1] ^ 32u);    \
+        f32x4 a12 = a10, a13 = a10;                                                                \
+        if (MT == 4) { a12 = lds_read128_async<0>(aa[MT - 2] ^ 32u); a13 = lds_read128_async<0>(aa[MT - 1] ^ 32u); } \
+        f32x4 b10 = lds_read128_async<0>(bb ^ 32u), b11 = lds_read128_async<TSTR>(bb ^ 32u);       \
+        if (MT == 4) { SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01); } else { SD_LDS_WAIT4(4, a00, a01, b00, b01); } \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[k], b00[k], acc[0][0], 0, 0, 0);  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[k], b00[k], acc[1][0], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[k], b00[k], acc[MT - 2][0], 0, 0, 0); \
+                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[k], b00[k], acc[MT - 1][0], 0, 0, 0); \
+            }                                                                                      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[k], b01[k], acc[0][1], 0, 0, 0);  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[k], b01[k], acc[1][1], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[k], b01[k], acc[MT - 2][1], 0, 0, 0); \
+                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[k], b01[k], acc[MT - 1][1], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+        if (MT == 4) { SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11); } else { SD_LDS_WAIT4(0, a10, a11, b10, b11); } \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[k], b10[k], acc[0][0], 0, 0, 0);  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[k], b10[k], acc[1][0], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[k], b10[k], acc[MT - 2][0], 0, 0, 0); \
+                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[k], b10[k], acc[MT - 1][0], 0, 0, 0); \
+            }                                                                                      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[k], b11[k], acc[0][1], 0, 0, 0);  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[k], b11[k], acc[1][1], 0, 0, 0);  \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[k], b11[k], acc[MT - 2][1], 0, 0, 0); \
+                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[k], b11[k], acc[MT - 1][1], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+        /* everything this wave issued BEFORE this tap has landed; its LDS reads are done (see k_conv_igemm_big) */ \
+        if (n_iss == PBW) wait_vmcnt_and_lds<PBW>();                                               \
+        else if (n_iss == PBW + 1) wait_vmcnt_and_lds<PBW + 1>();                                  \
+        else wait_vmcnt_and_lds<PBW + 2>();                                                        \
+        __builtin_amdgcn_s_barrier();                                                              \
+    }
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const uint32_t pt_cur = pt_base + (rolling ? 0u : (uint32_t)(cc & 1) * (PT_STAGE_FLOATS * 4));
+        float* const pt_nxt = Pt + (rolling ? 0 : ((cc + 1) & 1) * PT_STAGE_FLOATS);
+        PT_TAP(0) PT_TAP(1) PT_TAP(2) PT_TAP(3) PT_TAP(4) PT_TAP(5) PT_TAP(6) PT_TAP(7) PT_TAP(8)
+    }
+    wait_vmcnt<0>();
+#undef PT_TAP
+#undef PT_ISSUE_B
+#undef PT_OWN
+#undef PT_PATCH
+    tile_epilogue<BN, WM, WN, MT, NTW, true>(p, acc, [&](int row) { return m0 + row; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
+}
+
 #undef SD_BNRED_TERM
 
 // ---------------------------------------------------------------------------------------------
@@ -1352,6 +1560,33 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
 #define SD_IGEMM_BIG 1         // 1 = fp32 MODE 0 / 2 layers with enough 256-row tiles run k_conv_igemm_big
 #endif
 
+#ifndef SD_CONV_PATCH
+#define SD_CONV_PATCH 1        // 1 = 3x3 / stride 1 / pad 1 convs (forward and data-gradient) run k_conv3x3_patch where its geometry fits
+#endif
+
+static int g_patch_bn64 = 0;            // 64-channel layers: the patch kernel wins the isolated layer benchmark (+4 %) but loses inside the
+                                        // training step (754 vs 720 us per launch), so it is off; sd_set_option("conv_patch_bn64", 1)
+static int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_option("conv_patch_min_tiles", n) (tests: 1; off: 1 << 30)
+
+// k_conv3x3_patch applies: unit-stride 3x3 with pad 1 (fwd: rsign +1, off -1; dgrad: rsign -1, off +1), map width 16..128 (power
+// of two), images that are whole 256-pixel tiles, no split-K, and a grid that fills the chip.  Fills the geometry fields.
+static bool conv_patch_geometry(ConvArgs& a, int BN, int mode) {
+    if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64) || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+    if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
+    if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % BKB) return false;
+    int l2 = 0;
+    while ((1 << l2) < a.Wo) ++l2;
+    if ((1 << l2) != a.Wo || a.Wo < 16 || a.Wo > 128 || (a.Ho * a.Wo) % BMB) return false;
+    if ((a.M / BMB) * (a.Nn / BN) < g_patch_min_tiles) return false;
+    const int th = BMB / a.Wo;
+    a.pt_tw_log2 = l2;
+    a.pt_rolling = a.Wo == 128;
+    a.pt_pw = a.pt_rolling ? 144 : a.Wo + 2;
+    a.pt_pieces = a.pt_rolling ? 36 : cdiv((th + 2) * a.pt_pw, 16);
+    a.pt_flip = a.rsign < 0;
+    return a.pt_pieces * 256 <= (a.pt_rolling ? PT_FLOATS : PT_STAGE_FLOATS);
+}
+
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
@@ -1378,6 +1613,16 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
+    if (!bf16 && !stem) {
+        ConvArgs pa = a;
+        if (conv_patch_geometry(pa, BN, mode)) {
+            const int pt_tiles = (pa.M / BMB) * (pa.Nn / BN);
+            if (BN == 128) hipLaunchKernelGGL(k_conv3x3_patch<128>, dim3(pt_tiles), dim3(256), 0, st, pa);
+            else hipLaunchKernelGGL(k_conv3x3_patch<64>, dim3(pt_tiles), dim3(256), 0, st, pa);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (bf16) {                            // inference forward only (MODE 0)
         if (BN == 128) launch_one<128, 0, true>(a, tiles, lds, st);
         else launch_one<64, 0, true>(a, tiles, lds, st);
@@ -1475,7 +1720,8 @@ static int fwd_stat_rows(const sd_conv_desc* d) {
     fill_fwd(a, d);
     if (a.splits > 1) return 0;
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
-    return igemm_big_tiles(a, BN, 0) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+    ConvArgs t = a;
+    return (conv_patch_geometry(t, BN, 0) || igemm_big_tiles(a, BN, 0)) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
 size_t sd_conv2d_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d) {
@@ -1710,7 +1956,8 @@ static int dgrad_stat_rows(const sd_conv_desc* d) {
     fill_dgrad(a, d);
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
-    return igemm_big_tiles(a, BN, mode) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+    ConvArgs t = a;
+    return (conv_patch_geometry(t, BN, mode) || igemm_big_tiles(a, BN, mode)) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
 size_t sd_conv2d_dgrad_bn_reduce_workspace_bytes(const sd_conv_desc* d) {
@@ -1742,6 +1989,13 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
                               (float*)workspace + (size_t)rows * 2 * d->Cin, stream);
 }
 
+int sd_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "conv_patch_min_tiles")) { g_patch_min_tiles = value; return 0; }
+    if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
+    sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
+    return SD_ERR_INVALID;
+}
+
 const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     static thread_local char name[64];
     if (!d || d->Cin <= 0 || d->Cout <= 0) return "";
@@ -1754,7 +2008,9 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     if (pass == 0) fill_fwd(a, d); else fill_dgrad(a, d);
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
-    if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
+    ConvArgs t = a;
+    if (conv_patch_geometry(t, BN, mode)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d>", BN);
+    else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
     return name;
 }

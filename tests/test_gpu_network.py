@@ -421,3 +421,74 @@ def test_bn_backward_reduction_fused_into_dgrad_matches_separate_pass():
         grads.append(net.flat_grads.clone())
     scale = grads[0].abs().max().item()
     assert (grads[0] - grads[1]).abs().max().item() <= 2e-4 * scale
+
+
+PATCH_CASES = [  # B, H, W, cin, cout: 3x3 / 1 / 1 convs whose geometry fits k_conv3x3_patch (rows of 16..128 pixels, 256-pixel tiles)
+    (3, 16, 16, 64, 64), (2, 32, 32, 128, 128), (1, 64, 64, 64, 128), (1, 8, 128, 64, 64), (1, 4, 128, 128, 256), (5, 16, 16, 256, 128),
+    (2, 6, 128, 128, 128),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv3x3_patch_kernel_fwd_dgrad(case):
+    """k_conv3x3_patch (forced on for small grids through sd_set_option): forward with the fused epilogue and the fused
+    BatchNorm statistics, data-gradient with a residual, against torch; double-buffered patches (16/32/64-wide maps) and
+    the rolling single buffer (128-wide maps), both tile widths (64 / 128 output channels)."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout = case
+    lib = L.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
+    L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
+    L.check(lib.sd_set_option(b"conv_patch_bn64", 1))
+    try:
+        # (the forward of such small problems would split K when handed a workspace; without one it is a single pass)
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 1).decode().startswith("k_conv3x3_patch")
+        xd, wd = nhwc(x), krsc(w)
+        y = torch.empty(B, H, W, cout, device=DEV)
+        L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), keep(scale.to(DEV)).data_ptr(),
+                                  keep(shift.to(DEV)).data_ptr(), nhwc(res).data_ptr(), 0, 1, 0, 0, L.stream()))
+        ref = F.conv2d(x, w, None, 1, 1)
+        close(from_nhwc(y), F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res), 1e-5)
+        dy = torch.randn(B, cout, H, W, generator=g)
+        skip = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.empty(cin * 9 * cout, device=DEV)
+        L.check(lib.sd_conv2d_transpose_weights(wd.data_ptr(), wt.data_ptr(), cout, 9, cin, L.stream()))
+        dx = torch.empty(B, H, W, cin, device=DEV)
+        L.check(lib.sd_conv2d_dgrad(nhwc(dy).data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc(skip).data_ptr(), L.stream()))
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, 1, 1).backward(dy)
+        close(from_nhwc(dx), xr.grad + skip, 1e-5)
+    finally:
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+        L.check(lib.sd_set_option(b"conv_patch_bn64", 0))
+
+
+def test_conv3x3_patch_kernel_with_fused_bn_statistics():
+    """the patch kernel's forward with the BatchNorm statistics from its accumulators, at a size where the forward does not split K"""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout = 8, 64, 64, 64, 128
+    lib = L.lib()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
+    L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_patch<128>"
+        y = torch.empty(B, H, W, cout, device=DEV)
+        mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        ws = torch.empty(max(lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+        L.check(lib.sd_conv2d_fwd_bn_stats(nhwc(x).data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, 0, 0, mean.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+        ref = F.conv2d(x, w, None, 1, 1)
+        close(from_nhwc(y), ref, 2e-6 * (cin * 9) ** 0.5)
+        close(mean.cpu(), ref.double().mean((0, 2, 3)).float(), 1e-5)
+        close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
+    finally:
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
