@@ -271,6 +271,15 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
 /* MaxPool2d(3, 2, 1) NHWC; idx (uint8 per element) = winning tap for the backward. */
 int sd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int Hi, int Wi, int C, sd_stream_t stream);
 int sd_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int Hi, int Wi, int C, sd_stream_t stream);
+/* Stem tail (network.py:43-45) in training mode, fused: BatchNorm2d (batch statistics given) + ReLU + MaxPool2d(3, 2, 1) straight from
+ * the conv output x (B, Hi, Wi, C); the full-resolution activation is never written.  idx as sd_maxpool3x3s2_fwd. */
+int sd_bn_relu_maxpool_fwd(const float* x, int B, int Hi, int Wi, int C, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* y_pool, uint8_t* idx, sd_stream_t stream);
+/* ... and its backward: dpool (B, Ho, Wo, C) -> dx (B, Hi, Wi, C) through max-pool, ReLU and BatchNorm; dgamma / dbeta (+= when
+ * accumulate).  workspace = sd_col_reduce_workspace_bytes(B * Hi * Wi, C). */
+int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* x, int B, int Hi, int Wi, int C, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                           int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* backward of nn.Upsample(scale_factor=2): dx (B,H,W,C) = 2x2 block sums of dy (B,2H,2W,C) [+ add]. */
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream);
 

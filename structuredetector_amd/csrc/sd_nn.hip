@@ -296,6 +296,144 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
     reinterpret_cast<float4*>(dx)[i] = acc;
 }
 
+// ---- stem tail fused: BatchNorm(train) + ReLU + MaxPool2d(3, 2, 1) without materialising the full-resolution activation.
+// forward: the pooled map and the winning taps straight from the conv output x (same affine expression as k_bn_apply, same
+// first-maximum rule as k_maxpool_fwd).
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              uint8_t* __restrict__ idx, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int cols = C >> 2;
+    const int64_t n4 = (int64_t)B * Ho * Wo * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 w = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int iy = oy * 2 - 1 + r, ix = ox * 2 - 1 + s;
+            if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+            const float4 xv = reinterpret_cast<const float4*>(x + (((int64_t)b * Hi + iy) * Wi + ix) * C)[col];
+            float4 v;
+            v.x = fmaxf((xv.x - mu.x) * is.x * ga.x + be.x, 0.f); v.y = fmaxf((xv.y - mu.y) * is.y * ga.y + be.y, 0.f);
+            v.z = fmaxf((xv.z - mu.z) * is.z * ga.z + be.z, 0.f); v.w = fmaxf((xv.w - mu.w) * is.w * ga.w + be.w, 0.f);
+            const uint8_t tap = (uint8_t)(r * 3 + s);
+            if (v.x > m.x) { m.x = v.x; w.x = tap; }
+            if (v.y > m.y) { m.y = v.y; w.y = tap; }
+            if (v.z > m.z) { m.z = v.z; w.z = tap; }
+            if (v.w > m.w) { m.w = v.w; w.w = tap; }
+        }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+    reinterpret_cast<uchar4*>(idx)[i] = w;
+}
+
+// gradient w.r.t. the (never stored) BatchNorm+ReLU output at input pixel (b, iy, ix): gather form of the max-pool backward
+// (k_maxpool_bwd) followed by the ReLU mask recomputed from x
+__device__ __forceinline__ float4 pool_relu_grad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int iy, int ix,
+                                                 int col, int cols, int Ho, int Wo, const float4 xv, const float4 mu, const float4 is,
+                                                 const float4 ga, const float4 be) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = (iy + 1) / 2 - ((iy + 1) % 2 == 0 ? 1 : 0); oy <= (iy + 1) / 2; ++oy) {
+        if (oy < 0 || oy >= Ho) continue;
+        const int r = iy - (oy * 2 - 1);
+        if (r < 0 || r > 2) continue;
+        for (int ox = (ix + 1) / 2 - ((ix + 1) % 2 == 0 ? 1 : 0); ox <= (ix + 1) / 2; ++ox) {
+            if (ox < 0 || ox >= Wo) continue;
+            const int s = ix - (ox * 2 - 1);
+            if (s < 0 || s > 2) continue;
+            const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * cols + col;
+            const uchar4 w = reinterpret_cast<const uchar4*>(idx)[o];
+            const float4 g = reinterpret_cast<const float4*>(dpool)[o];
+            const uint8_t tap = (uint8_t)(r * 3 + s);
+            if (w.x == tap) acc.x += g.x;
+            if (w.y == tap) acc.y += g.y;
+            if (w.z == tap) acc.z += g.z;
+            if (w.w == tap) acc.w += g.w;
+        }
+    }
+    acc.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? acc.x : 0.f; acc.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? acc.y : 0.f;
+    acc.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? acc.z : 0.f; acc.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? acc.w : 0.f;
+    return acc;
+}
+
+// reduction pass of the fused backward: per-channel partial sums of g and g * xhat over RED_ROWS_PER_BLOCK pixels (layout as k_col_reduce)
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                             const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int Hi, int Wi, int Ho, int Wo, int64_t M,
+                                                             int C, float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
+    const int cols = C >> 2, lanes = 256 / cols;
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK, r1 = min(r0 + RED_ROWS_PER_BLOCK, M);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (rl < lanes) {
+        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const int ix = (int)(r % Wi);
+            const int64_t t = r / Wi;
+            const int iy = (int)(t % Hi), b = (int)(t / Hi);
+            const float4 xv = reinterpret_cast<const float4*>(x + r * C)[col];
+            const float4 g = pool_relu_grad(dpool, idx, b, iy, ix, col, cols, Ho, Wo, xv, mu, is, ga, be);
+            s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+            s1.x += g.x * ((xv.x - mu.x) * is.x); s1.y += g.y * ((xv.y - mu.y) * is.y);
+            s1.z += g.z * ((xv.z - mu.z) * is.z); s1.w += g.w * ((xv.w - mu.w) * is.w);
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) {
+            const float4 u = red[0][l * cols + col], w = red[1][l * cols + col];
+            s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+        }
+        float* dst = partial + (int64_t)blockIdx.x * 2 * C;
+        reinterpret_cast<float4*>(dst)[col] = s0;
+        reinterpret_cast<float4*>(dst + C)[col] = s1;
+    }
+}
+
+// apply pass of the fused backward: dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_apply(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mg,
+                                                            const float* __restrict__ mgx, int Hi, int Wi, int Ho, int Wo, int64_t n4, int C,
+                                                            float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int cols = C >> 2;
+    const int col = (int)(i % cols);
+    const int64_t r = i / cols;
+    const int ix = (int)(r % Wi);
+    const int64_t t = r / Wi;
+    const int iy = (int)(t % Hi), b = (int)(t / Hi);
+    const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 g = pool_relu_grad(dpool, idx, b, iy, ix, col, cols, Ho, Wo, xv, mu, is, ga, be);
+    const float4 a = reinterpret_cast<const float4*>(mg)[col], bb = reinterpret_cast<const float4*>(mgx)[col];
+    float4 o;
+    o.x = ga.x * is.x * (g.x - a.x - (xv.x - mu.x) * is.x * bb.x);
+    o.y = ga.y * is.y * (g.y - a.y - (xv.y - mu.y) * is.y * bb.y);
+    o.z = ga.z * is.z * (g.z - a.z - (xv.z - mu.z) * is.z * bb.z);
+    o.w = ga.w * is.w * (g.w - a.w - (xv.w - mu.w) * is.w * bb.w);
+    reinterpret_cast<float4*>(dx)[i] = o;
+}
+
 // backward of nearest x2 upsample: dx[b,y,x,c] = sum of the 2x2 block of dy (+ add, nullable)
 __global__ __launch_bounds__(256) void k_up2_bwd(const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dx, int B,
                                                   int H, int W, int C) {
@@ -770,6 +908,46 @@ int sd_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, i
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const int64_t n4 = (int64_t)B * Hi * Wi * C / 4;
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_bn_relu_maxpool_fwd(const float* x, int B, int Hi, int Wi, int C, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, float* y_pool, uint8_t* idx, sd_stream_t stream) {
+    SD_REQUIRE(x && mean && invstd && gamma && beta && y_pool && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID,
+               "sd_bn_relu_maxpool_fwd: bad arguments");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y_pool, idx,
+                       B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* x, int B, int Hi, int Wi, int C, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                           void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    const int64_t M = (int64_t)B * Hi * Wi;
+    if (int e = check_mc("sd_maxpool_bn_relu_bwd", M, C)) return e;
+    SD_REQUIRE(dpool && idx && x && mean && invstd && gamma && beta && dx && dgamma && dbeta && workspace, SD_ERR_INVALID,
+               "sd_maxpool_bn_relu_bwd: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_maxpool_bn_relu_bwd: workspace too small");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* mg = partial + (size_t)nb * 2 * C;
+    float* mgx = mg + C;
+    hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
+    SD_LAUNCH_CHECK();
+    int rows = nb;
+    const float* fin = fold_partials(partial, rows, C, mgx + C, st);
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+                       (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
+                       (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
     SD_LAUNCH_CHECK();
     return 0;
 }

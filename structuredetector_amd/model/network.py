@@ -221,21 +221,31 @@ class _Engine:
         d0 = _desc(B, H, W, stem)
         s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.float32, device=x.device)
         wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
+        Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
+        p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x.device)
+        pidx = torch.empty((B, Hp, Wp, 64), dtype=torch.uint8, device=x.device)
         if training:
+            # BatchNorm + ReLU + max-pool in one pass over the conv output: the full-resolution activation (1 GB at bs=64,
+            # 512x512) is neither written nor read back; the backward recomputes what it needs from s0 and the pool indices
             L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, 0, wss.data_ptr(),
                                            wss.numel(), L.stream()), "stem")
-            a0, m0, i0 = self.bn_train(s0, bn0)
+            Mrows = B * d0.Ho * d0.Wo
+            m0 = torch.empty(64, dtype=torch.float32, device=x.device)
+            i0 = torch.empty_like(m0)
+            ws = self._ws(lib.sd_col_reduce_workspace_bytes(Mrows, 64), x.device)
+            L.check(lib.sd_bn_train_stats(s0.data_ptr(), Mrows, 64, BN_EPS, BN_MOMENTUM, bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(),
+                                          m0.data_ptr(), i0.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
+            self._nbt.append(bn0.num_batches_tracked)
+            L.check(lib.sd_bn_relu_maxpool_fwd(s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(), bn0.weight.data_ptr(),
+                                               bn0.bias.data_ptr(), p1.data_ptr(), pidx.data_ptr(), L.stream()), "sd_bn_relu_maxpool_fwd")
         else:
             sc, sh = self.bn_fold(bn0)
             L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 0,
                                            wss.data_ptr(), wss.numel(), L.stream()), "stem")
-            a0, m0, i0 = s0, None, None
-        Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
-        p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x.device)
-        pidx = torch.empty((B, Hp, Wp, 64), dtype=torch.uint8, device=x.device)
-        L.check(lib.sd_maxpool3x3s2_fwd(a0.data_ptr(), p1.data_ptr(), pidx.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
+            m0 = i0 = None
+            L.check(lib.sd_maxpool3x3s2_fwd(s0.data_ptr(), p1.data_ptr(), pidx.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
         if rec:
-            tape["x"], tape["stem"] = x, (d0, s0, a0, m0, i0, pidx)
+            tape["x"], tape["stem"] = x, (d0, s0, m0, i0, pidx)
 
         # trunk (network.py:47-50)
         feats, cur, Hc, Wc = [], p1, Hp, Wp
@@ -530,10 +540,13 @@ class _Engine:
                 on_stage(first_of[id(blk)])
 
         # stem
-        d0, s0, a0, m0, i0, pidx = tape["stem"]
-        da0 = torch.empty_like(a0)
-        L.check(lib.sd_maxpool3x3s2_bwd(dcur.data_ptr(), pidx.data_ptr(), da0.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool_bwd")
-        ds0, _ = self._bn_bwd(da0, s0, a0, 2, net.adpater[1], m0, i0)
+        d0, s0, m0, i0, pidx = tape["stem"]
+        bn0 = net.adpater[1]
+        ds0 = torch.empty_like(s0)
+        ws = self._ws(lib.sd_col_reduce_workspace_bytes(B * d0.Ho * d0.Wo, 64), s0.device)
+        L.check(lib.sd_maxpool_bn_relu_bwd(dcur.data_ptr(), pidx.data_ptr(), s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(),
+                                           bn0.weight.data_ptr(), bn0.bias.data_ptr(), ds0.data_ptr(), net.grad_of(bn0.weight).data_ptr(),
+                                           net.grad_of(bn0.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_maxpool_bn_relu_bwd")
         stem = net.adpater[0]
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,

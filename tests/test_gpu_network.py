@@ -492,3 +492,39 @@ def test_conv3x3_patch_kernel_with_fused_bn_statistics():
         close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
     finally:
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+
+
+def test_fused_bn_relu_maxpool_forward_backward():
+    """sd_bn_relu_maxpool_fwd / sd_maxpool_bn_relu_bwd against nn.BatchNorm2d(train) -> ReLU -> MaxPool2d(3, 2, 1) in torch
+    (odd and even sizes: border windows, pixels that belong to one, two and four windows)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    for (B, H, W, Cc) in ((2, 14, 10, 64), (1, 9, 13, 8)):
+        g = torch.Generator().manual_seed(H * 31 + W)
+        x = torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.2
+        gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+        xr = x.clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ref = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+        Ho, Wo = ref.shape[2:]
+        dpool = torch.randn(B, Cc, Ho, Wo, generator=g)
+        ref.backward(dpool)
+        xd = nhwc(x)
+        M = B * H * W
+        mean, invstd = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+        ws = torch.empty(lib.sd_col_reduce_workspace_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+        L.check(lib.sd_bn_train_stats(xd.data_ptr(), M, Cc, 1e-5, 0.1, 0, 0, mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+        gd, bd = keep(gamma.to(DEV)), keep(beta.to(DEV))
+        yp = torch.empty(B, Ho, Wo, Cc, device=DEV)
+        idx = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=DEV)
+        L.check(lib.sd_bn_relu_maxpool_fwd(xd.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                                           yp.data_ptr(), idx.data_ptr(), L.stream()))
+        close(from_nhwc(yp), ref.detach(), 1e-5)
+        dx = torch.empty(B, H, W, Cc, device=DEV)
+        dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+        L.check(lib.sd_maxpool_bn_relu_bwd(nhwc(dpool).data_ptr(), idx.data_ptr(), xd.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(),
+                                           gd.data_ptr(), bd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                                           L.stream()))
+        close(from_nhwc(dx), xr.grad, 2e-5)
+        close(dg.cpu(), gr.grad, 2e-5)
+        close(db.cpu(), br.grad, 2e-5)
