@@ -366,6 +366,129 @@ __device__ __forceinline__ float4 pool_relu_grad(const float* __restrict__ dpool
     return acc;
 }
 
+// The same gradient for the four pixels (2k + dy, 2j + dx) of an even-aligned 2x2 quad at once (Hi, Wi even): they only see the
+// windows (k, j), (k, j+1), (k+1, j), (k+1, j+1), so four window loads serve four pixels (the per-pixel gather needs nine) and
+// the window set is fixed -- no data-dependent loops.  g[2 * dy + dx].
+__device__ __forceinline__ void pool_relu_grad_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int k, int j,
+                                                    int col, int cols, int Ho, int Wo, const float4* xv, const float4 mu, const float4 is,
+                                                    const float4 ga, const float4 be, float4* g) {
+    const bool hy = k + 1 < Ho, hx = j + 1 < Wo;
+    const int64_t o00 = (((int64_t)b * Ho + k) * Wo + j) * cols + col;
+    const int64_t o01 = hx ? o00 + cols : o00, o10 = hy ? o00 + (int64_t)Wo * cols : o00, o11 = (hx && hy) ? o00 + (int64_t)(Wo + 1) * cols : o00;
+    const uchar4 w00 = reinterpret_cast<const uchar4*>(idx)[o00], w01 = reinterpret_cast<const uchar4*>(idx)[o01];
+    const uchar4 w10 = reinterpret_cast<const uchar4*>(idx)[o10], w11 = reinterpret_cast<const uchar4*>(idx)[o11];
+    const float4 d00 = reinterpret_cast<const float4*>(dpool)[o00];
+    float4 d01 = reinterpret_cast<const float4*>(dpool)[o01], d10 = reinterpret_cast<const float4*>(dpool)[o10];
+    float4 d11 = reinterpret_cast<const float4*>(dpool)[o11];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!hx) d01 = z;
+    if (!hy) d10 = z;
+    if (!(hx && hy)) d11 = z;
+#define SD_PICK(W, D, TAP) make_float4((W).x == (TAP) ? (D).x : 0.f, (W).y == (TAP) ? (D).y : 0.f, (W).z == (TAP) ? (D).z : 0.f, (W).w == (TAP) ? (D).w : 0.f)
+#define SD_ADD4(A, B) { (A).x += (B).x; (A).y += (B).y; (A).z += (B).z; (A).w += (B).w; }
+    // pixel (2k, 2j): window (k, j) tap (1, 1)
+    g[0] = SD_PICK(w00, d00, 4);
+    // pixel (2k, 2j+1): (k, j) tap (1, 2); (k, j+1) tap (1, 0)
+    g[1] = SD_PICK(w00, d00, 5); { const float4 t = SD_PICK(w01, d01, 3); SD_ADD4(g[1], t) }
+    // pixel (2k+1, 2j): (k, j) tap (2, 1); (k+1, j) tap (0, 1)
+    g[2] = SD_PICK(w00, d00, 7); { const float4 t = SD_PICK(w10, d10, 1); SD_ADD4(g[2], t) }
+    // pixel (2k+1, 2j+1): (k, j) tap (2, 2); (k, j+1) tap (2, 0); (k+1, j) tap (0, 2); (k+1, j+1) tap (0, 0)
+    g[3] = SD_PICK(w00, d00, 8);
+    { const float4 t = SD_PICK(w01, d01, 6); SD_ADD4(g[3], t) }
+    { const float4 t = SD_PICK(w10, d10, 2); SD_ADD4(g[3], t) }
+    { const float4 t = SD_PICK(w11, d11, 0); SD_ADD4(g[3], t) }
+#undef SD_PICK
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        g[q].x = ((xv[q].x - mu.x) * is.x * ga.x + be.x) > 0.f ? g[q].x : 0.f; g[q].y = ((xv[q].y - mu.y) * is.y * ga.y + be.y) > 0.f ? g[q].y : 0.f;
+        g[q].z = ((xv[q].z - mu.z) * is.z * ga.z + be.z) > 0.f ? g[q].z : 0.f; g[q].w = ((xv[q].w - mu.w) * is.w * ga.w + be.w) > 0.f ? g[q].w : 0.f;
+    }
+}
+
+// quad form of the reduction pass: a block takes RED_ROWS_PER_BLOCK / 4 quads (same partial-row count as the pixel form)
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int Hi, int Wi, int Ho, int Wo, int64_t MQ,
+                                                                  int C, float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
+    const int cols = C >> 2, lanes = 256 / cols;
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    constexpr int QPB = RED_ROWS_PER_BLOCK / 4;
+    const int64_t q0 = (int64_t)blockIdx.x * QPB, q1 = min(q0 + QPB, MQ);
+    const int Hq = Hi >> 1, Wq = Wi >> 1;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (rl < lanes) {
+        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+        for (int64_t q = q0 + rl; q < q1; q += lanes) {
+            const int j = (int)(q % Wq);
+            const int64_t t = q / Wq;
+            const int k = (int)(t % Hq), b = (int)(t / Hq);
+            const int64_t p00 = (((int64_t)b * Hi + 2 * k) * Wi + 2 * j) * cols + col;
+            float4 xv[4], g[4];
+            xv[0] = reinterpret_cast<const float4*>(x)[p00]; xv[1] = reinterpret_cast<const float4*>(x)[p00 + cols];
+            xv[2] = reinterpret_cast<const float4*>(x)[p00 + (int64_t)Wi * cols]; xv[3] = reinterpret_cast<const float4*>(x)[p00 + (int64_t)(Wi + 1) * cols];
+            pool_relu_grad_quad(dpool, idx, b, k, j, col, cols, Ho, Wo, xv, mu, is, ga, be, g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0.x += g[u].x; s0.y += g[u].y; s0.z += g[u].z; s0.w += g[u].w;
+                s1.x += g[u].x * ((xv[u].x - mu.x) * is.x); s1.y += g[u].y * ((xv[u].y - mu.y) * is.y);
+                s1.z += g[u].z * ((xv[u].z - mu.z) * is.z); s1.w += g[u].w * ((xv[u].w - mu.w) * is.w);
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) {
+            const float4 u = red[0][l * cols + col], w = red[1][l * cols + col];
+            s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+        }
+        float* dst = partial + (int64_t)blockIdx.x * 2 * C;
+        reinterpret_cast<float4*>(dst)[col] = s0;
+        reinterpret_cast<float4*>(dst + C)[col] = s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ mg,
+                                                                 const float* __restrict__ mgx, int Hi, int Wi, int Ho, int Wo, int64_t nq4,
+                                                                 int C, float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq4) return;
+    const int cols = C >> 2;
+    const int col = (int)(i % cols);
+    const int64_t q = i / cols;
+    const int Hq = Hi >> 1, Wq = Wi >> 1;
+    const int j = (int)(q % Wq);
+    const int64_t t = q / Wq;
+    const int k = (int)(t % Hq), b = (int)(t / Hq);
+    const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+    const float4 a = reinterpret_cast<const float4*>(mg)[col], bb = reinterpret_cast<const float4*>(mgx)[col];
+    const int64_t p00 = (((int64_t)b * Hi + 2 * k) * Wi + 2 * j) * cols + col;
+    const int64_t off[4] = {p00, p00 + cols, p00 + (int64_t)Wi * cols, p00 + (int64_t)(Wi + 1) * cols};
+    float4 xv[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = reinterpret_cast<const float4*>(x)[off[u]];
+    pool_relu_grad_quad(dpool, idx, b, k, j, col, cols, Ho, Wo, xv, mu, is, ga, be, g);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float4 o;
+        o.x = ga.x * is.x * (g[u].x - a.x - (xv[u].x - mu.x) * is.x * bb.x);
+        o.y = ga.y * is.y * (g[u].y - a.y - (xv[u].y - mu.y) * is.y * bb.y);
+        o.z = ga.z * is.z * (g[u].z - a.z - (xv[u].z - mu.z) * is.z * bb.z);
+        o.w = ga.w * is.w * (g[u].w - a.w - (xv[u].w - mu.w) * is.w * bb.w);
+        reinterpret_cast<float4*>(dx)[off[u]] = o;
+    }
+}
+#undef SD_ADD4
+
 // reduction pass of the fused backward: per-channel partial sums of g and g * xhat over RED_ROWS_PER_BLOCK pixels (layout as k_col_reduce)
 __global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
                                                              const float* __restrict__ x, const float* __restrict__ mean,
@@ -938,7 +1061,9 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
     float* partial = (float*)workspace;
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
-    hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
+    const bool quad = Hi % 2 == 0 && Wi % 2 == 0;        // even maps: 2x2 quads share their four windows
+    if (quad) hipLaunchKernelGGL(k_pool_bn_bwd_reduce_quad, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M / 4, C, partial);
+    else hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
     SD_LAUNCH_CHECK();
     int rows = nb;
     const float* fin = fold_partials(partial, rows, C, mgx + C, st);
@@ -946,8 +1071,10 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
-                       (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
+    if (quad) hipLaunchKernelGGL(k_pool_bn_bwd_apply_quad, dim3(cdiv(n4 / 4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta,
+                                 (const float*)mg, (const float*)mgx, Hi, Wi, Ho, Wo, n4 / 4, C, dx);
+    else hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
+                            (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
     SD_LAUNCH_CHECK();
     return 0;
 }
