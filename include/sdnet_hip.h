@@ -237,6 +237,12 @@ int sd_head_fwd_bf16(const void* x_nhwc_bf16, const float* w, const float* bias,
  * dX) is added (skip-connection gradient). */
 int sd_conv2d_dgrad(const float* dy_nhwc, const float* w_t, float* dx_nhwc, const sd_conv_desc* d,
                     const float* residual, sd_stream_t stream);
+/* The same with a residual that only exists on the even pixels: residual_half is (B, Hi/2, Wi/2, Cin) and is added to
+ * dx[b, 2y, 2x, :] -- the data-gradient of a 1x1 / stride 2 "downsample" branch (network: BasicBlock.downsample) is zero on
+ * three of four pixels, so it is computed as the stride-1 1x1 data-gradient on the small map and joined here instead of being
+ * zero-filled to full size and read back. */
+int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual_half,
+                             sd_stream_t stream);
 int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, int Cin, sd_stream_t stream);
 /* dW[co][r][s][ci] (+)= sum_pixels dY * X, split over pixel ranges + deterministic reduce. */
 size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d);

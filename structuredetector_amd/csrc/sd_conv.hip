@@ -57,7 +57,7 @@ struct ConvArgs {
     void* y;              // [M][Nn], M = B*Ho*Wo
     const float* scale;   // per-n multiplier (nullable)
     const float* shift;   // per-n addend (nullable): bias or folded BN
-    const void* res;      // residual, [M][Nn] or (res_up2) [B][Ho/2][Wo/2][Nn] (nullable)
+    const void* res;      // residual, [M][Nn] or (res_up2 = 1: upsampled x2, 2: added at even (y, x) only) [B][Ho/2][Wo/2][Nn] (nullable)
     int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S;
     int mul, div, off, rsign;   // input coord t = o*mul + off + rsign*r ; valid iff t>=0, t%div==0, t/div < Hi
     int relu, res_up2;
@@ -455,11 +455,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 float v = acc[mi][ni][e] * sc + sh;
                 if (p.res) {
                     int64_t rm = m;
-                    if (p.res_up2) {       // nearest-neighbour x2 upsample of the coarser map (network.py:10,19)
-                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+                    bool has = true;
+                    if (p.res_up2) {       // 1: nearest-neighbour x2 upsample of the coarser map (network.py:10,19)
+                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;      // 2: half-size map added at even (y, x) only
                         rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                        has = p.res_up2 == 1 || !((ox | oy) & 1);
                     }
-                    v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                    if (has) v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
@@ -524,11 +526,13 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                 float v = acc[mi][ni][e] * sc + sh;
                 if (p.res) {
                     int64_t rm = m;
+                    bool has = true;
                     if (p.res_up2) {
                         const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
                         rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+                        has = p.res_up2 == 1 || !((ox | oy) & 1);
                     }
-                    v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                    if (has) v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
@@ -1822,6 +1826,19 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
     a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
     a.M = d->B * d->Ho * d->Wo; a.kchunks = 1; a.nk = cdiv(d->R * d->S * 3, BK);
     return launch_igemm(a, true, st);
+}
+
+int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual_half,
+                             sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_dgrad_half_res", d)) return e;
+    SD_REQUIRE(dy && w_t && dx && residual_half, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: null pointer");
+    SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: needs Cout %% 32 == 0 and Cin %% 64 == 0");
+    SD_REQUIRE(d->Hi % 2 == 0 && d->Wi % 2 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: needs even Hi, Wi");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad_half_res: pointers must be 16-byte aligned");
+    ConvArgs a{};
+    fill_dgrad(a, d);
+    a.x = dy; a.w = w_t; a.y = dx; a.res = residual_half; a.res_up2 = 2;
+    return launch_igemm(a, false, (hipStream_t)stream);
 }
 
 int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual, sd_stream_t stream) {

@@ -381,7 +381,7 @@ class _Engine:
                 "transpose_weights")
         return wt
 
-    def _dgrad(self, dy, conv, d, res=None, bn_next=None):
+    def _dgrad(self, dy, conv, d, res=None, bn_next=None, res_half=False):
         """dx = dgrad(dy) [+ res].  bn_next = (x, y, relu, bn, mean, invstd) of the BatchNorm whose output gradient dx is:
         the launch then also does that BatchNorm's backward reduction (sd_conv2d_dgrad_bn_reduce) and the per-channel means
         come back for _bn_bwd(..., means=...), which only has the apply pass left."""
@@ -389,10 +389,15 @@ class _Engine:
         wt = self._wt(conv)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         if bn_next is None:
-            self._timed(self._kname(d, 1), flops, lambda: L.check(
-                self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()), "sd_conv2d_dgrad"),
-                phase="dgrad")
+            if res_half:
+                fn = lambda: L.check(self.lib.sd_conv2d_dgrad_half_res(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), res.data_ptr(),
+                                                                       L.stream()), "sd_conv2d_dgrad_half_res")
+            else:
+                fn = lambda: L.check(self.lib.sd_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), L.stream()),
+                                     "sd_conv2d_dgrad")
+            self._timed(self._kname(d, 1), flops, fn, phase="dgrad")
             return dx
+        assert not res_half
         x, y, relu, bn, mean, invstd = bn_next
         means = torch.empty(2 * conv.cin, dtype=torch.float32, device=dy.device)
         ws = self._ws(self.lib.sd_conv2d_dgrad_bn_reduce_workspace_bytes(C.byref(d)), dy.device)
@@ -523,16 +528,27 @@ class _Engine:
             da1, ma1 = r if nxt is not None else (r, None)
             self._wgrad(dc2, a1, blk.conv2, d2)
             dc1, _ = self._bn_bwd(da1, c1, a1, 2, blk.bn1, m1, i1, means=ma1)
+            half = False
             if blk.downsample is not None:
                 dcd, _ = self._bn_bwd(g, cd, None, False, blk.downsample[1], md, idd)
-                skip = self._dgrad(dcd, blk.downsample[0], dd)
-                self._wgrad(dcd, xin, blk.downsample[0], dd)
+                ds = blk.downsample[0]
+                half = ds.k == 1 and ds.stride == 2 and ds.pad == 0 and Hc % 2 == 0 and Wc % 2 == 0 and not self.fuse_bn_bwd
+                if half:
+                    # 1x1 / stride 2: the gradient lives on the even pixels only -> stride-1 data-gradient on the small map,
+                    # joined by conv1's data-gradient epilogue (no zero-filled full-size tensor)
+                    dsm = L.ConvDesc()
+                    dsm.B, dsm.Hi, dsm.Wi, dsm.Cin, dsm.Cout, dsm.R, dsm.S, dsm.stride, dsm.pad = B, dd.Ho, dd.Wo, ds.cin, ds.cout, 1, 1, 1, 0
+                    dsm.Ho, dsm.Wo = dd.Ho, dd.Wo
+                    skip = self._dgrad(dcd, ds, dsm)
+                else:
+                    skip = self._dgrad(dcd, ds, dd)
+                self._wgrad(dcd, xin, ds, dd)
             else:
                 skip = g
             # d(xin) = d(out of the previous block), complete unless that tensor also feeds an FPN lateral (handled above)
             prev_lateral = bi > 0 and blocks[bi - 1][12].data_ptr() in lateral_grad
             nxt = None if (bi == 0 or prev_lateral) else bn2_of(bi - 1)
-            r = self._dgrad(dc1, blk.conv1, d1, res=skip, bn_next=nxt)
+            r = self._dgrad(dc1, blk.conv1, d1, res=skip, bn_next=nxt, res_half=half)
             dcur, mcur = r if nxt is not None else (r, None)
             self._wgrad(dc1, xin, blk.conv1, d1)
             if on_stage and id(blk) in first_of:

@@ -528,3 +528,26 @@ def test_fused_bn_relu_maxpool_forward_backward():
         close(from_nhwc(dx), xr.grad, 2e-5)
         close(dg.cpu(), gr.grad, 2e-5)
         close(db.cpu(), br.grad, 2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1), (1, 8, 128, 128, 128, 3, 1, 1)])
+def test_conv_dgrad_with_half_size_residual(case):
+    """sd_conv2d_dgrad_half_res == sd_conv2d_dgrad with the half-size map zero-filled to full size (generic, parity-class and
+    256-row-tile data-gradient kernels)."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    lib = L.lib()
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    dy = torch.randn(B, cout, d.Ho, d.Wo, generator=g)
+    half = torch.randn(B, cin, H // 2, W // 2, generator=g)
+    full = torch.zeros(B, cin, H, W)
+    full[:, :, ::2, ::2] = half
+    wt = torch.empty(cin * k * k * cout, device=DEV)
+    L.check(lib.sd_conv2d_transpose_weights(krsc(w).data_ptr(), wt.data_ptr(), cout, k * k, cin, L.stream()))
+    dx_a, dx_b = torch.empty(B, H, W, cin, device=DEV), torch.empty(B, H, W, cin, device=DEV)
+    dyd = nhwc(dy)
+    L.check(lib.sd_conv2d_dgrad(dyd.data_ptr(), wt.data_ptr(), dx_a.data_ptr(), C.byref(d), nhwc(full).data_ptr(), L.stream()))
+    L.check(lib.sd_conv2d_dgrad_half_res(dyd.data_ptr(), wt.data_ptr(), dx_b.data_ptr(), C.byref(d), nhwc(half).data_ptr(), L.stream()))
+    assert torch.equal(dx_a, dx_b)
