@@ -491,11 +491,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 
 // Epilogue of the 256-row tile kernels: y = [relu](acc * scale + shift [+ residual]) and the fused BatchNorm column sums (see
 // k_conv_igemm): one partial row per tile.  row_to_m maps a tile row to its output pixel (-1 = none).
-template <int BN, int WM, int WN, int MT, int NTW, bool FWD, typename RowMap>
+template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, typename RowMap>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, int tid, int wave, int fr,
                                               int fh, int wm0, int wn0, int n0, int tile_m) {
-    const bool fwd_stat = FWD && p.stat && !p.bn_x;
-    const bool bwd_red = p.stat && p.bn_x;
+    const bool fwd_stat = !BF16 && FWD && p.stat && !p.bn_x;
+    const bool bwd_red = !BF16 && p.stat && p.bn_x;
     float sv[NTW], qv[NTW];
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
@@ -532,10 +532,11 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                         rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
                         has = p.res_up2 == 1 || !((ox | oy) & 1);
                     }
-                    if (has) v += reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
+                    if (has) v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
+                if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
+                else if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
                 if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
             }
         }
@@ -568,9 +569,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 
 // ---------------------------------------------------------------------------------------------
 // Large-tile fp32 implicit GEMM (MODE 0 / 2): block tile 256 (m) x BN, BK = 16, three LDS stages, counted vmcnt waits.
-// Why: the staging path, not the MFMA pipe, is the tight resource of k_conv_igemm -- a CU takes LDS-DMA pieces at
-// roughly 12 B/clk (one 1 KB piece per ~85 clk; the same figure bounds register staging), and two resident 128x128x32
-// blocks ask for 8 B/clk at full MFMA rate (128x64: 12 B/clk, which is why the 64-channel layers are the slowest).  Measured:
+// Why: the staging path is as busy as the MFMA pipe in k_conv_igemm -- two resident 128x128x32 blocks ask a CU for 8 B/clk of
+// staged data at full MFMA rate (128x64 tiles: 12 B/clk, which is why the 64-channel layers are the slowest).  Measured:
 // every staging load redirected to one cache-hot line still ran 13 % below the no-load time; a dedicated producer wave
 // (warp specialisation) was SLOWER, because one wave cannot feed more than ~1 piece per 300 clk.  A 256-row tile needs
 // 25 % (BN = 128) / 17 % (BN = 64) fewer staged bytes per MFMA, and a 128x64 wave tile 25 % fewer ds_read_b128 per MFMA.
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 // 3x3 / stride 1 / pad 1 convolution (forward, and data-gradient with the taps flipped) with PATCH STAGING: the nine taps of
 // a channel chunk read (shifted) the same input pixels, so the (rows + 2) x (cols + 2) input patch of the tile is staged ONCE per
 // channel chunk and every tap's A fragments are read from it; only the weights are staged per tap.  Staged bytes per MFMA
-// drop to 0.47x (BN = 128) / 0.56x (BN = 64) of k_conv_igemm_big's -- see DESIGN.md, staging-throughput model.
+// drop to 0.47x (BN = 128) / 0.56x (BN = 64) of k_conv_igemm_big's (staged bytes per flop).
 //   tile  : 256 consecutive output pixels = 256/Wo whole rows (Wo in {16, 32, 64, 128}, Ho*Wo % 256 == 0) x BN channels
 //   patch : LDS rows of 16 floats, one per patch pixel pp = py * PW + px, slot swizzle q ^ ((pp >> 2) & 3)
 //           Wo <= 64: double-buffered (next chunk's patch lands while the nine taps of this one run)
@@ -828,8 +828,12 @@ constexpr int PT_STAGE_FLOATS = 25 * 256;          // one double-buffer stage: 2
 constexpr int PT_FLOATS = 2 * PT_STAGE_FLOATS;     // 51.2 KB; the rolling mode (36 pieces) uses it as one buffer
 constexpr int PT_MAXP = 12;                        // patch pieces a wave can own (rolling: 4 rows x 3 slots)
 
-template <int BN>
+// BF16: elements are bf16, a chunk is 32 channels (the same 64-byte LDS rows, one 32x32x16 MFMA per tile and k-group), forward only
+template <int BN, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
+    using T = typename std::conditional<BF16, uint16_t, float>::type;
+    constexpr int EPS = BF16 ? 8 : 4;                // elements per 16-byte slot
+    constexpr int KC = BF16 ? 32 : BKB;              // channels per chunk
     constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;
     constexpr int MT = BMB / WM / 32, NTW = BN / WN / 32;
     constexpr int PBW = BN / 16 / 4;                 // weight pieces per wave and tap
@@ -837,8 +841,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     static_assert(NTW == 2 && (MT == 4 || MT == 2), "wave tile 128x64 or 64x64");
     __shared__ __attribute__((aligned(16))) float Pt[PT_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[3 * B_ST];
-    const float* const px_ = reinterpret_cast<const float*>(p.x);
-    const float* const pw_ = reinterpret_cast<const float*>(p.w);
+    const T* const px_ = reinterpret_cast<const T*>(p.x);
+    const T* const pw_ = reinterpret_cast<const T*>(p.w);
+    const T* const zero_ = reinterpret_cast<const T*>(g_zero_line);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = p.Nn / BN;
@@ -850,11 +855,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     const bool rolling = p.pt_rolling != 0;
     const int hw = p.Ho * p.Wo;
     const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> TWl;
-    const int nchunks = p.Ck / BKB;
+    const int nchunks = p.Ck / KC;
 
     // ---- patch pieces of this wave.  double-buffer: piece j = wave + 4 i;  rolling: i = 3 r + u -> j = 9 r + wave + 4 u (u = 2: wave 0)
     const int prow = lane >> 2, pslot = lane & 3;
-    const float* pbase[PT_MAXP];
+    const T* pbase[PT_MAXP];
     unsigned okmask = 0, ownmask = 0;                 // okmask: the piece reads the image (else the zero line); ownmask: piece exists
 #pragma unroll
     for (int i = 0; i < PT_MAXP; ++i) {
@@ -864,18 +869,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         const int py = pp / PW, pxx = pp - py * PW;
         const int iy = y0 - 1 + py, ix = pxx - 1;
         const bool ok = own && py < TH + 2 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const int qe = (pslot ^ ((pp >> 2) & 3)) * 4;
-        pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : g_zero_line + qe;
+        const int qe = (pslot ^ ((pp >> 2) & 3)) * EPS;
+        pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : zero_ + qe;
         // (ok differs per lane: keep it per lane in bit i; own is wave-uniform)
         okmask |= (ok ? 1u : 0u) << i;
         ownmask |= (own ? 1u : 0u) << i;
     }
     const int wk = 9 * p.Ck;
-    const int qeb = (pslot ^ ((prow >> 2) & 3)) * 4;
-    const float* bbase[PBW];
+    const int qeb = (pslot ^ ((prow >> 2) & 3)) * EPS;
+    const T* bbase[PBW];
 #pragma unroll
     for (int j = 0; j < PBW; ++j) bbase[j] = pw_ + (int64_t)(n0 + (wave * PBW + j) * 16 + prow) * wk + qeb;
-    const float* const zsrc = g_zero_line + qeb;
+    const T* const zsrc = zero_ + qeb;
 
 #define PT_PATCH(i, dst, c0) { lds_dma16(((okmask >> (i)) & 1u) ? pbase[i] + (c0) : pbase[i], (dst) + (rolling ? 9 * ((i) / 3) + wave + 4 * ((i) % 3) : wave + 4 * (i)) * 256); }
 #define PT_OWN(i) ((ownmask >> (i)) & 1u)
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     {                                                                                              \
         float* bd = Bs + (st) * B_ST;                                                              \
         if ((ccn) < nchunks) {                                                                     \
-            const int woff = (p.pt_flip ? 8 - (t2) : (t2)) * p.Ck + (ccn) * BKB;                   \
+            const int woff = (p.pt_flip ? 8 - (t2) : (t2)) * p.Ck + (ccn) * KC;                    \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(bbase[j] + woff, bd + (wave * PBW + j) * 256); \
         } else {                                                                                   \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(zsrc, bd + (wave * PBW + j) * 256); \
@@ -923,6 +928,32 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     __builtin_amdgcn_s_barrier();
 
     const uint32_t pt_base = lds_addr(Pt), bs_base = lds_addr(Bs);
+    // the MFMAs of one k-group: fp32 = four 32x32x2 steps over the slot's four k values, bf16 = one 32x32x16 step over its eight
+#define PT_MFMA1(A, B, mi, ni)                                                                     \
+    if (BF16) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni], 0, 0, 0); \
+    else { _Pragma("unroll") for (int k = 0; k < 4; ++k) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k], B[k], acc[mi][ni], 0, 0, 0); }
+#define PT_MFMA_GROUP(A0, A1, A2, A3, B0, B1)                                                      \
+    if (BF16) {                                                                                    \
+        PT_MFMA1(A0, B0, 0, 0) PT_MFMA1(A1, B0, 1, 0)                                              \
+        if (MT == 4) { PT_MFMA1(A2, B0, MT - 2, 0) PT_MFMA1(A3, B0, MT - 1, 0) }                   \
+        PT_MFMA1(A0, B1, 0, 1) PT_MFMA1(A1, B1, 1, 1)                                              \
+        if (MT == 4) { PT_MFMA1(A2, B1, MT - 2, 1) PT_MFMA1(A3, B1, MT - 1, 1) }                   \
+    } else {                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[k], B0[k], acc[0][0], 0, 0, 0);    \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[k], B0[k], acc[1][0], 0, 0, 0);    \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[k], B0[k], acc[MT - 2][0], 0, 0, 0); \
+                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3[k], B0[k], acc[MT - 1][0], 0, 0, 0); \
+            }                                                                                      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[k], B1[k], acc[0][1], 0, 0, 0);    \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[k], B1[k], acc[1][1], 0, 0, 0);    \
+            if (MT == 4) {                                                                         \
+                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[k], B1[k], acc[MT - 2][1], 0, 0, 0); \
+                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A3[k], B1[k], acc[MT - 1][1], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+    }
     // one tap: issue (weights of tap t+2, this tap's share of the patch traffic), multiply, publish
 #define PT_TAP(t)                                                                                  \
     {                                                                                              \
@@ -934,15 +965,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
                 const int row = (t) < 4 ? 2 + (t) / 2 : ((t) - 4) / 2;                             \
                 const int cch = (t) < 4 ? cc : cc + 1;                                             \
                 if (cch < nchunks) {                                                               \
-                    if (((t) & 1) == 0) { PT_PATCH(3 * row, Pt, cch * BKB) ++n_iss; }              \
+                    if (((t) & 1) == 0) { PT_PATCH(3 * row, Pt, cch * KC) ++n_iss; }               \
                     else {                                                                         \
-                        if (PT_OWN(3 * row + 1)) { PT_PATCH(3 * row + 1, Pt, cch * BKB) ++n_iss; } \
-                        if (PT_OWN(3 * row + 2)) { PT_PATCH(3 * row + 2, Pt, cch * BKB) ++n_iss; } \
+                        if (PT_OWN(3 * row + 1)) { PT_PATCH(3 * row + 1, Pt, cch * KC) ++n_iss; }  \
+                        if (PT_OWN(3 * row + 2)) { PT_PATCH(3 * row + 2, Pt, cch * KC) ++n_iss; }  \
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
         } else if ((t) < 7 && cc + 1 < nchunks && PT_OWN(t)) {                                     \
-            PT_PATCH(t, pt_nxt, (cc + 1) * BKB) ++n_iss;                                           \
+            PT_PATCH(t, pt_nxt, (cc + 1) * KC) ++n_iss;                                            \
         }                                                                                          \
         const int tapoff = ((t) / 3) * PW + ((t) % 3);      /* data-gradient: same walk, weight taps reversed */ \
         uint32_t aa[MT];                                                                           \
@@ -960,35 +991,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         if (MT == 4) { a12 = lds_read128_async<0>(aa[MT - 2] ^ 32u); a13 = lds_read128_async<0>(aa[MT - 1] ^ 32u); } \
         f32x4 b10 = lds_read128_async<0>(bb ^ 32u), b11 = lds_read128_async<TSTR>(bb ^ 32u);       \
         if (MT == 4) { SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01); } else { SD_LDS_WAIT4(4, a00, a01, b00, b01); } \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[k], b00[k], acc[0][0], 0, 0, 0);  \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[k], b00[k], acc[1][0], 0, 0, 0);  \
-            if (MT == 4) {                                                                         \
-                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[k], b00[k], acc[MT - 2][0], 0, 0, 0); \
-                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[k], b00[k], acc[MT - 1][0], 0, 0, 0); \
-            }                                                                                      \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[k], b01[k], acc[0][1], 0, 0, 0);  \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[k], b01[k], acc[1][1], 0, 0, 0);  \
-            if (MT == 4) {                                                                         \
-                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a02[k], b01[k], acc[MT - 2][1], 0, 0, 0); \
-                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a03[k], b01[k], acc[MT - 1][1], 0, 0, 0); \
-            }                                                                                      \
-        }                                                                                          \
+        PT_MFMA_GROUP(a00, a01, a02, a03, b00, b01)                                                \
         if (MT == 4) { SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11); } else { SD_LDS_WAIT4(0, a10, a11, b10, b11); } \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[k], b10[k], acc[0][0], 0, 0, 0);  \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[k], b10[k], acc[1][0], 0, 0, 0);  \
-            if (MT == 4) {                                                                         \
-                acc[MT - 2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[k], b10[k], acc[MT - 2][0], 0, 0, 0); \
-                acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[k], b10[k], acc[MT - 1][0], 0, 0, 0); \
-            }                                                                                      \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[k], b11[k], acc[0][1], 0, 0, 0);  \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[k], b11[k], acc[1][1], 0, 0, 0);  \
-            if (MT == 4) {                                                                         \
-                acc[MT - 2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a12[k], b11[k], acc[MT - 2][1], 0, 0, 0); \
-                acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a13[k], b11[k], acc[MT - 1][1], 0, 0, 0); \
-            }                                                                                      \
-        }                                                                                          \
+        PT_MFMA_GROUP(a10, a11, a12, a13, b10, b11)                                                \
         /* everything this wave issued BEFORE this tap has landed; its LDS reads are done (see k_conv_igemm_big) */ \
         if (n_iss == PBW) wait_vmcnt_and_lds<PBW>();                                               \
         else if (n_iss == PBW + 1) wait_vmcnt_and_lds<PBW + 1>();                                  \
@@ -1002,10 +1007,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     }
     wait_vmcnt<0>();
 #undef PT_TAP
+#undef PT_MFMA_GROUP
+#undef PT_MFMA1
 #undef PT_ISSUE_B
 #undef PT_OWN
 #undef PT_PATCH
-    tile_epilogue<BN, WM, WN, MT, NTW, true>(p, acc, [&](int row) { return m0 + row; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
+    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16>(p, acc, [&](int row) { return m0 + row; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
 }
 
 #undef SD_BNRED_TERM
@@ -1574,10 +1581,10 @@ static int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_op
 
 // k_conv3x3_patch applies: unit-stride 3x3 with pad 1 (fwd: rsign +1, off -1; dgrad: rsign -1, off +1), map width 16..128 (power
 // of two), images that are whole 256-pixel tiles, no split-K, and a grid that fills the chip.  Fills the geometry fields.
-static bool conv_patch_geometry(ConvArgs& a, int BN, int mode) {
+static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false) {
     if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64) || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
-    if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % BKB) return false;
+    if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % (bf16 ? 32 : BKB)) return false;
     int l2 = 0;
     while ((1 << l2) < a.Wo) ++l2;
     if ((1 << l2) != a.Wo || a.Wo < 16 || a.Wo > 128 || (a.Ho * a.Wo) % BMB) return false;
@@ -1617,12 +1624,17 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
-    if (!bf16 && !stem) {
+    if (!stem) {
         ConvArgs pa = a;
-        if (conv_patch_geometry(pa, BN, mode)) {
+        if (conv_patch_geometry(pa, BN, mode, bf16)) {
             const int pt_tiles = (pa.M / BMB) * (pa.Nn / BN);
-            if (BN == 128) hipLaunchKernelGGL(k_conv3x3_patch<128>, dim3(pt_tiles), dim3(256), 0, st, pa);
-            else hipLaunchKernelGGL(k_conv3x3_patch<64>, dim3(pt_tiles), dim3(256), 0, st, pa);
+            if (bf16) {
+                if (BN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                else hipLaunchKernelGGL((k_conv3x3_patch<64, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+            } else {
+                if (BN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                else hipLaunchKernelGGL((k_conv3x3_patch<64, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+            }
             SD_LAUNCH_CHECK();
             return 0;
         }

@@ -44,6 +44,35 @@ def test_conv_fwd_bf16(case):
     close(got, ref, 6e-3)
 
 
+@pytest.mark.parametrize("case", [(3, 16, 16, 64, 64), (2, 32, 32, 128, 128), (1, 64, 64, 64, 128), (1, 8, 128, 64, 64), (1, 4, 128, 256, 128)])
+def test_conv3x3_patch_kernel_bf16(case):
+    """bf16 instantiation of k_conv3x3_patch (forced on for small grids): fused affine + residual + ReLU epilogue, double-buffered
+    and rolling patches, 64- and 128-channel tiles."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).bfloat16().float()
+    scale = torch.rand(cout, generator=g) + 0.5; shift = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g).bfloat16().float()
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
+    xd, wd, rd = nhwc_bf16(x), nhwc_bf16(w), nhwc_bf16(res)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    y = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
+    L.check(lib.sd_set_option(b"conv_patch_bn64", 1))
+    try:
+        # no workspace -> no split-K -> the patch kernel takes the launch
+        L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), sc.data_ptr(), sh.data_ptr(), rd.data_ptr(), 0, 1,
+                                       0, 0, L.stream()))
+    finally:
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+        L.check(lib.sd_set_option(b"conv_patch_bn64", 0))
+    ref = F.relu(F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res)
+    close(y.float().permute(0, 3, 1, 2).cpu(), ref, 6e-3)
+
+
 def _pair(M=2, N=1, seed=0):
     from structuredetector_amd.model import Network
     ref = O.build_reference_network(M, N, seed=seed)
