@@ -2038,7 +2038,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
     ConvArgs t = a;
-    if (conv_patch_geometry(t, BN, mode)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d>", BN);
+    if (conv_patch_geometry(t, BN, mode)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", BN);
     else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
     return name;

@@ -480,7 +480,7 @@ def test_conv3x3_patch_kernel_with_fused_bn_statistics():
     d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
     L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
     try:
-        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_patch<128>"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_patch<128, false>"
         y = torch.empty(B, H, W, cout, device=DEV)
         mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
         ws = torch.empty(max(lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
