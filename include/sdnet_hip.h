@@ -180,6 +180,13 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, c
                        const float* scale, const float* shift, int relu, int out_bf16, void* workspace,
                        size_t workspace_bytes, sd_stream_t stream);
 
+/* The stem conv (7x7 / 2 / 3, NCHW image -> NHWC fp32) with the batch statistics of its output from the same launch
+ * (as sd_conv2d_fwd_bn_stats; one pass over the 16.8 MB/img stem output less). */
+size_t sd_conv2d_stem_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* invstd, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream);
+
 /* Training forward of a conv that feeds a BatchNorm2d: y = conv(x, w) and, from the accumulators of the same launch, the batch
  * statistics of y (mean, invstd = 1/sqrt(biased var + eps), running-stat update as sd_bn_train_stats) -- one pass over y less
  * than sd_conv2d_fwd + sd_bn_train_stats.  Partial sums per (tile, wave row) go through `workspace` and are finished in double

@@ -1296,6 +1296,7 @@ struct StemArgs {
     const float* shift;
     int relu;
     int out_bf16;         // forward: store the NHWC output as bf16 (bf16 backbone)
+    float* stat;          // forward: per-tile partial column sums [ntiles][2][64] of the raw output for the BatchNorm statistics (nullable)
     int B, H, W, Ho, Wo, tiles_x, ntiles;
 };
 
@@ -1389,6 +1390,29 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.out_bf16) reinterpret_cast<uint16_t*>(p.y)[(row0 + ox) * 64 + n] = f2bf(v);
             else p.y[(row0 + ox) * 64 + n] = v;
+        }
+    }
+    if (p.stat) {
+        // BatchNorm statistics of the raw conv output (tile pixels past the row end still see real image columns through the
+        // 7-wide window, so they are masked): column sums per wave (32 pixels), the four waves combined through LDS in a fixed
+        // order, one partial row per tile
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+        }
+        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+        __syncthreads();                                 // every wave is done with the patch / weight LDS
+        float* red = lds;                                // [4 waves][2][64]
+        if (fh == 0) {
+            red[(wave * 2 + 0) * 64 + fr] = s0; red[(wave * 2 + 0) * 64 + 32 + fr] = s1;
+            red[(wave * 2 + 1) * 64 + fr] = q0; red[(wave * 2 + 1) * 64 + 32 + fr] = q1;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, n = tid & 63;
+            const float v = (red[(0 * 2 + which) * 64 + n] + red[(1 * 2 + which) * 64 + n]) + (red[(2 * 2 + which) * 64 + n] + red[(3 * 2 + which) * 64 + n]);
+            p.stat[(int64_t)tile * 128 + which * 64 + n] = v;
         }
     }
 }
@@ -1838,6 +1862,38 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
     a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
     a.M = d->B * d->Ho * d->Wo; a.kchunks = 1; a.nk = cdiv(d->R * d->S * 3, BK);
     return launch_igemm(a, true, st);
+}
+
+size_t sd_conv2d_stem_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d) {
+    if (!d) return 0;
+    StemArgs a{};
+    stem_args(a, d);
+    const size_t wt = align_up((size_t)STEM_K * 64 * sizeof(float), 256);
+    return wt + (size_t)(a.ntiles + sd_bn_finalize_scratch_rows(a.ntiles)) * 2 * 64 * sizeof(float);
+}
+
+int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
+                                sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_fwd_bn_stats", d)) return e;
+    SD_REQUIRE(x_nchw && w && y && mean && invstd && workspace, SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats: the stem is a 7x7 / stride 2 / pad 3 conv, 3 -> 64 channels");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_fwd_bn_stats_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_fwd_bn_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* wt = (float*)workspace;
+    float* partial = (float*)((char*)workspace + align_up((size_t)STEM_K * 64 * sizeof(float), 256));
+    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
+    SD_LAUNCH_CHECK();
+    StemArgs a{};
+    a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
+    stem_args(a, d);
+    const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr_once;
+    hipLaunchKernelGGL(k_stem_fwd, dim3(a.ntiles), dim3(256), lds, st, a);
+    SD_LAUNCH_CHECK();
+    return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+                                partial + (size_t)a.ntiles * 128, stream);
 }
 
 int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual_half,

@@ -227,14 +227,12 @@ class _Engine:
         if training:
             # BatchNorm + ReLU + max-pool in one pass over the conv output: the full-resolution activation (1 GB at bs=64,
             # 512x512) is neither written nor read back; the backward recomputes what it needs from s0 and the pool indices
-            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), 0, 0, 0, 0, wss.data_ptr(),
-                                           wss.numel(), L.stream()), "stem")
-            Mrows = B * d0.Ho * d0.Wo
             m0 = torch.empty(64, dtype=torch.float32, device=x.device)
             i0 = torch.empty_like(m0)
-            ws = self._ws(lib.sd_col_reduce_workspace_bytes(Mrows, 64), x.device)
-            L.check(lib.sd_bn_train_stats(s0.data_ptr(), Mrows, 64, BN_EPS, BN_MOMENTUM, bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(),
-                                          m0.data_ptr(), i0.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
+            ws = self._ws(lib.sd_conv2d_stem_fwd_bn_stats_workspace_bytes(C.byref(d0)), x.device)
+            L.check(lib.sd_conv2d_stem_fwd_bn_stats(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), BN_EPS, BN_MOMENTUM,
+                                                    bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(), m0.data_ptr(), i0.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_fwd_bn_stats")
             self._nbt.append(bn0.num_batches_tracked)
             L.check(lib.sd_bn_relu_maxpool_fwd(s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(), bn0.weight.data_ptr(),
                                                bn0.bias.data_ptr(), p1.data_ptr(), pidx.data_ptr(), L.stream()), "sd_bn_relu_maxpool_fwd")

@@ -551,3 +551,30 @@ def test_conv_dgrad_with_half_size_residual(case):
     L.check(lib.sd_conv2d_dgrad(dyd.data_ptr(), wt.data_ptr(), dx_a.data_ptr(), C.byref(d), nhwc(full).data_ptr(), L.stream()))
     L.check(lib.sd_conv2d_dgrad_half_res(dyd.data_ptr(), wt.data_ptr(), dx_b.data_ptr(), C.byref(d), nhwc(half).data_ptr(), L.stream()))
     assert torch.equal(dx_a, dx_b)
+
+
+def test_stem_conv_with_fused_bn_statistics():
+    """sd_conv2d_stem_fwd_bn_stats: the 7x7/2 stem conv from the NCHW image and the batch statistics of its output (row widths that
+    are and are not multiples of the 128-pixel tile)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    for (B, H, W) in ((2, 64, 96), (1, 32, 320)):
+        g = torch.Generator().manual_seed(H + W)
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+        d = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+        y = torch.empty(B, d.Ho, d.Wo, 64, device=DEV)
+        mean, invstd = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        ws = torch.empty(lib.sd_conv2d_stem_fwd_bn_stats_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+        xd = keep(x.to(DEV))
+        L.check(lib.sd_conv2d_stem_fwd_bn_stats(xd.data_ptr(), krsc(w).data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+        ref = F.conv2d(x, w, None, 2, 3)
+        close(from_nhwc(y), ref, 1e-5)
+        bn = torch.nn.BatchNorm2d(64).train()
+        bn(ref)
+        close(mean.cpu(), ref.double().mean((0, 2, 3)).float(), 1e-5)
+        close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
+        close(rm.cpu(), bn.running_mean, 1e-5)
+        close(rv.cpu(), bn.running_var, 1e-5)
