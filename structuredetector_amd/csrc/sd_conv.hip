@@ -1626,6 +1626,8 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
     if (!SD_IGEMM_BIG || (BN != 128 && !SD_IGEMM_BIG64 && !(SD_IGEMM_BIG64_S2 && mode == 2)) || (mode != 0 && mode != 2) || a.splits > 1) return 0;
+    if (a.R * a.S * a.Ck < 512) return 0;     // short reductions (1x1 convs of <= 256 channels): the 3-stage pipeline never fills,
+                                                // the 128-row tiles are 5-12 % faster
     const int m_per = mode == 2 ? a.M / 4 : a.M;
     const int big_tiles = (mode == 2 ? 4 : 1) * cdiv(m_per, BMB) * (a.Nn / BN);
     return (big_tiles >= 512 && (mode != 2 || m_per % BMB == 0)) ? big_tiles : 0;
