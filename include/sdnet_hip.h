@@ -268,11 +268,14 @@ size_t sd_col_reduce_workspace_bytes(int64_t M, int C);
 int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentum, float* running_mean,
                       float* running_var, float* mean, float* invstd, void* workspace, size_t workspace_bytes,
                       sd_stream_t stream);
+/* relu_mask_out (nullable): M*C/4 bytes, bit j of byte i = element 4i+j of the result is positive -- the ReLU mask the backward of a
+ * residual layer needs, at 1/16 of the bytes of y (relu mode 3 of sd_bn_bwd / sd_bn_bwd_apply / sd_conv2d_dgrad_bn_reduce). */
 int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, const float* invstd,
-                const float* gamma, const float* beta, const float* residual, int relu, sd_stream_t stream);
+                const float* gamma, const float* beta, const float* residual, int relu, uint8_t* relu_mask_out,
+                sd_stream_t stream);
 int sd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                float eps, int C, float* scale, float* shift, sd_stream_t stream);
-/* relu: 0 = none, 1 = ReLU mask from the saved output y, 2 = mask recomputed from x (layers without a residual
+/* relu: 0 = none, 1 = ReLU mask from the saved output y, 3 = mask bytes of sd_bn_apply passed as `y`, 2 = mask recomputed from x (layers without a residual
  * input: y is not read at all; needs beta). */
 int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean,
               const float* invstd, const float* gamma, const float* beta, float* dx, float* g_out, float* dgamma,

@@ -117,6 +117,7 @@ __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v
         const float xh_ = (xv_ - bmu) * bis;                                                       \
         float g_ = (v);                                                                            \
         if (p.bn_relu == 1) g_ = p.bn_y[(int64_t)(m) * p.Nn + (n)] > 0.f ? g_ : 0.f;               \
+        else if (p.bn_relu == 3) g_ = ((reinterpret_cast<const uint8_t*>(p.bn_y)[((int64_t)(m) * p.Nn + (n)) >> 2] >> ((n) & 3)) & 1) ? g_ : 0.f; \
         else if (p.bn_relu == 2) g_ = (xh_ * bga + bbe) > 0.f ? g_ : 0.f;                          \
         S += g_; Q += g_ * xh_;                                                                    \
     }
@@ -2060,8 +2061,8 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
     if (int e = check_conv("sd_conv2d_dgrad_bn_reduce", d)) return e;
     SD_REQUIRE(dy && w_t && dx && bn_x && mean && invstd && gamma && dgamma && dbeta && means_out && workspace, SD_ERR_INVALID,
                "sd_conv2d_dgrad_bn_reduce: null pointer");
-    SD_REQUIRE(relu >= 0 && relu <= 2 && (relu != 1 || bn_y) && (relu != 2 || beta), SD_ERR_INVALID,
-               "sd_conv2d_dgrad_bn_reduce: relu must be 0, 1 (needs bn_y) or 2 (needs beta)");
+    SD_REQUIRE(relu >= 0 && relu <= 3 && ((relu != 1 && relu != 3) || bn_y) && (relu != 2 || beta), SD_ERR_INVALID,
+               "sd_conv2d_dgrad_bn_reduce: relu must be 0, 1 / 3 (need bn_y) or 2 (needs beta)");
     SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_bn_reduce: needs Cout %% 32 == 0 and Cin %% 64 == 0");
     SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad_bn_reduce: pointers must be 16-byte aligned");
     SD_REQUIRE(workspace_bytes >= sd_conv2d_dgrad_bn_reduce_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_dgrad_bn_reduce: workspace too small");

@@ -22,13 +22,13 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                     int64_t M, int C, float* __restrict__ partial) {
+                                                     int64_t M, int C, float* __restrict__ partial, int rpb) {
     __shared__ float4 red[2][256];
     const int cols = C >> 2;                       // float4 columns
     const int lanes = 256 / cols;                  // row lanes (cols <= 256)
     const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
-    const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS_PER_BLOCK;
-    const int64_t r1 = min(r0 + RED_ROWS_PER_BLOCK, M);
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;          // rpb rows per block (red_rows(M): >= 1024 blocks where M allows)
+    const int64_t r1 = min(r0 + rpb, M);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     float4 mu = s0, is = s0, ga = s0, be = s0;
     if (MODE == 1 && rl < lanes) {
@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                 } else if (relu == 2) {     // mask recomputed from x (same expression as k_bn_apply): one tensor read less
                     g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
                     g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+                } else if (relu == 3) {     // mask bytes written by k_bn_apply (residual layers): `y` points at them
+                    const uint8_t mb = reinterpret_cast<const uint8_t*>(y)[r * cols + col];
+                    g.x = (mb & 1) ? g.x : 0.f; g.y = (mb & 2) ? g.y : 0.f; g.z = (mb & 4) ? g.z : 0.f; g.w = (mb & 8) ? g.w : 0.f;
                 }
                 s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
                 s1.x += g.x * ((xv.x - mu.x) * is.x); s1.y += g.y * ((xv.y - mu.y) * is.y);
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y, int64_t n4, int C,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ res, int relu) {
+                                                   const float* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -180,6 +183,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
             const float4 r = reinterpret_cast<const float4*>(res)[i];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
+        // one mask byte per float4 (bit j = element j is positive): the backward of a residual layer reads 1/16 of the bytes of y
+        if (mask) mask[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
     }
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         if (relu == 1) {
             const float4 yy = reinterpret_cast<const float4*>(y)[i];
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        } else if (relu == 3) {
+            const uint8_t mb = reinterpret_cast<const uint8_t*>(y)[i];
+            g.x = (mb & 1) ? g.x : 0.f; g.y = (mb & 2) ? g.y : 0.f; g.z = (mb & 4) ? g.z : 0.f; g.w = (mb & 8) ? g.w : 0.f;
         } else if (relu == 2) {
             const float4 be = reinterpret_cast<const float4*>(beta)[col];
             g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
@@ -870,11 +878,19 @@ using namespace sd;
 
 extern "C" {
 
+// rows per reduction block: 256 for the big maps, fewer for the deep layers so that the pass still spreads over >= 1024 blocks
+// (layer4, M = 16384 at bs=64: 64 blocks of 256 rows read at 0.8 TB/s, 1024 blocks of 16 rows at HBM rate)
+static int red_rows(int64_t M) {
+    int r = RED_ROWS_PER_BLOCK;
+    while (r > 16 && M / r < 1024) r >>= 1;
+    return r;
+}
+
 static int fold_rows(int rows) { return rows > 512 ? cdiv(rows, std::max(16, rows / 128)) : 0; }
 
 // [nb partial rows][2][C] + the two per-channel means of the backward + the slab sums of the two-level finish
 size_t sd_col_reduce_workspace_bytes(int64_t M, int C) {
-    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    const int nb = cdiv(M, red_rows(M));
     return align_up(((size_t)nb + fold_rows(nb)) * 2 * C * sizeof(float) + 2 * (size_t)C * sizeof(float), 256);
 }
 
@@ -899,12 +915,14 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     if (int e = check_mc("sd_bn_train_stats", M, C)) return e;
     SD_REQUIRE(x && mean && invstd && workspace, SD_ERR_INVALID, "sd_bn_train_stats: null pointer");
     SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_train_stats: workspace too small");
-    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace, rpb);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, eps, momentum,
+    int rows = nb;
+    const float* fin = fold_partials((const float*)workspace, rows, C, (float*)workspace + ((size_t)nb + 1) * 2 * C, st);
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, eps, momentum,
                        mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
     SD_LAUNCH_CHECK();
     return 0;
@@ -929,11 +947,12 @@ int sd_bn_finalize_stats(const float* partial, int rows, int64_t M, int C, float
 }
 
 int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                const float* residual, int relu, sd_stream_t stream) {
+                const float* residual, int relu, uint8_t* relu_mask_out, sd_stream_t stream) {
     if (int e = check_mc("sd_bn_apply", M, C)) return e;
     SD_REQUIRE(x && y && mean && invstd && gamma && beta, SD_ERR_INVALID, "sd_bn_apply: null pointer");
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, mean, invstd, gamma, beta, residual, relu);
+    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, mean, invstd, gamma, beta, residual, relu,
+                       relu_mask_out);
     SD_LAUNCH_CHECK();
     return 0;
 }
@@ -950,16 +969,16 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
               const float* gamma, const float* beta, float* dx, float* g_out, float* dgamma, float* dbeta, int accumulate, void* workspace,
               size_t workspace_bytes, sd_stream_t stream) {
     if (int e = check_mc("sd_bn_bwd", M, C)) return e;
-    SD_REQUIRE(relu >= 0 && relu <= 2, SD_ERR_INVALID, "sd_bn_bwd: relu must be 0 (none), 1 (mask from y) or 2 (mask recomputed from x)");
-    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && (relu != 1 || y) && (relu != 2 || beta),
+    SD_REQUIRE(relu >= 0 && relu <= 3, SD_ERR_INVALID, "sd_bn_bwd: relu must be 0 (none), 1 (mask from y), 2 (mask recomputed from x) or 3 (mask bytes)");
+    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && ((relu != 1 && relu != 3) || y) && (relu != 2 || beta),
                SD_ERR_INVALID, "sd_bn_bwd: null pointer");
     SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_bwd: workspace too small");
-    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
-    hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta, relu, M, C, partial);
+    hipLaunchKernelGGL(k_col_reduce<1>, dim3(nb), dim3(256), 0, st, dy, x, y, mean, invstd, gamma, beta, relu, M, C, partial, rpb);
     SD_LAUNCH_CHECK();
     int rows = nb;
     const float* fin = fold_partials(partial, rows, C, mgx + C, st);
@@ -992,8 +1011,8 @@ int sd_bn_bwd_finalize(const float* partial, int rows, int64_t M, int C, float* 
 int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, const float* means, float* dx, float* g_out, sd_stream_t stream) {
     if (int e = check_mc("sd_bn_bwd_apply", M, C)) return e;
-    SD_REQUIRE(relu >= 0 && relu <= 2, SD_ERR_INVALID, "sd_bn_bwd_apply: relu must be 0 (none), 1 (mask from y) or 2 (mask recomputed from x)");
-    SD_REQUIRE(dy && x && mean && invstd && gamma && means && dx && (relu != 1 || y) && (relu != 2 || beta), SD_ERR_INVALID,
+    SD_REQUIRE(relu >= 0 && relu <= 3, SD_ERR_INVALID, "sd_bn_bwd_apply: relu must be 0 (none), 1 (mask from y), 2 (mask recomputed from x) or 3 (mask bytes)");
+    SD_REQUIRE(dy && x && mean && invstd && gamma && means && dx && ((relu != 1 && relu != 3) || y) && (relu != 2 || beta), SD_ERR_INVALID,
                "sd_bn_bwd_apply: null pointer");
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
@@ -1006,12 +1025,14 @@ int sd_col_sum(const float* x, int64_t M, int C, float* out, int accumulate, voi
     if (int e = check_mc("sd_col_sum", M, C)) return e;
     SD_REQUIRE(x && out && workspace, SD_ERR_INVALID, "sd_col_sum: null pointer");
     SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_col_sum: workspace too small");
-    const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_col_reduce<2>, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace, rpb);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, nb, C, (double)M, 0.f, 0.f, out,
+    int rows = nb;
+    const float* fin = fold_partials((const float*)workspace, rows, C, (float*)workspace + ((size_t)nb + 1) * 2 * C, st);
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, out,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     SD_LAUNCH_CHECK();
     return 0;

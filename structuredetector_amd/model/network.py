@@ -174,7 +174,7 @@ class _Engine:
             "sd_conv2d_fwd_bn_stats"))
         return y, d, (mean, invstd)
 
-    def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True, stats=None):
+    def bn_train(self, x, bn: BNParams, res=None, relu=True, update_running=True, stats=None, want_mask=False):
         Mrows, Cc = x.numel() // x.shape[-1], x.shape[-1]
         if stats is not None:
             mean, invstd = stats
@@ -187,11 +187,13 @@ class _Engine:
                                                bn.running_var.data_ptr() if update_running else 0,
                                                mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_train_stats")
         y = torch.empty_like(x)
+        # residual layers: the backward needs the ReLU mask of y; one byte per four elements instead of re-reading y twice
+        mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device) if want_mask else None
         L.check(self.lib.sd_bn_apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
-                                     bn.bias.data_ptr(), _ptr(res), int(relu), L.stream()), "sd_bn_apply")
+                                     bn.bias.data_ptr(), _ptr(res), int(relu), _ptr(mask), L.stream()), "sd_bn_apply")
         if update_running:
             self._nbt.append(bn.num_batches_tracked)
-        return y, mean, invstd
+        return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
 
     def bn_fold(self, bn: BNParams):
         cached = self.net._folded.get(id(bn))
@@ -260,9 +262,9 @@ class _Engine:
                     else:
                         cd = dd = md = idd = None
                         idt = cur
-                    out, m2, i2 = self.bn_train(c2, blk.bn2, res=idt, relu=True, stats=st2)
+                    out, m2, i2, msk = self.bn_train(c2, blk.bn2, res=idt, relu=True, stats=st2, want_mask=True)
                     if rec:
-                        blocks_tape.append((blk, cur, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd))
+                        blocks_tape.append((blk, cur, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd, msk))
                 else:
                     s1, h1 = self.bn_fold(blk.bn1)
                     a1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc, scale=s1, shift=h1, relu=True)
@@ -401,7 +403,7 @@ class _Engine:
         ws = self._ws(self.lib.sd_conv2d_dgrad_bn_reduce_workspace_bytes(C.byref(d)), dy.device)
         self._timed(self._kname(d, 1), flops, lambda: L.check(
             self.lib.sd_conv2d_dgrad_bn_reduce(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), x.data_ptr(),
-                                               _ptr(y) if int(relu) == 1 else 0, int(relu), mean.data_ptr(), invstd.data_ptr(),
+                                               _ptr(y) if int(relu) in (1, 3) else 0, int(relu), mean.data_ptr(), invstd.data_ptr(),
                                                bn.weight.data_ptr(), bn.bias.data_ptr(), self.net.grad_of(bn.weight).data_ptr(),
                                                self.net.grad_of(bn.bias).data_ptr(), 0, means.data_ptr(), ws.data_ptr(), ws.numel(),
                                                L.stream()), "sd_conv2d_dgrad_bn_reduce"), phase="dgrad")
@@ -447,13 +449,13 @@ class _Engine:
         dx = torch.empty_like(x)
         g = torch.empty_like(x) if want_g else None
         if means is not None:       # reduction (and dgamma / dbeta) already done by the data-gradient launch that produced dy
-            L.check(self.lib.sd_bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) == 1 else 0, int(relu), Mrows, Cc,
+            L.check(self.lib.sd_bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) in (1, 3) else 0, int(relu), Mrows, Cc,
                                              mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), means.data_ptr(),
                                              dx.data_ptr(), _ptr(g), L.stream()), "sd_bn_bwd_apply")
             return dx, g
         ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
-        # relu: False/0 = none, True/1 = mask from y (residual layers), 2 = mask recomputed from x (y is not read)
-        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) == 1 else 0, int(relu), Mrows, Cc, mean.data_ptr(),
+        # relu: False/0 = none, True/1 = mask from y, 3 = y holds the mask bytes of sd_bn_apply (residual layers), 2 = mask recomputed from x
+        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) in (1, 3) else 0, int(relu), Mrows, Cc, mean.data_ptr(),
                                    invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), dx.data_ptr(), _ptr(g),
                                    self.net.grad_of(bn.weight).data_ptr(),
                                    self.net.grad_of(bn.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_bwd")
@@ -499,8 +501,8 @@ class _Engine:
         def bn2_of(i):          # bn_next tuple of block i's second BatchNorm (mask from the saved output: residual layer)
             if i < 0 or not self.fuse_bn_bwd:
                 return None
-            b = blocks[i]       # (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd)
-            return (b[9], b[12], 1, b[0].bn2, b[10], b[11])
+            b = blocks[i]       # (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd, relu mask bytes)
+            return (b[9], b[17], 3, b[0].bn2, b[10], b[11])
 
         last = len(blocks) - 1
         has_lateral = blocks[last][12].data_ptr() in lateral_grad
@@ -514,13 +516,13 @@ class _Engine:
         # trunk, last block first
         first_of = {id(net.down4[0]): "down4", id(net.down3[0]): "down3", id(net.down2[0]): "down2"}
         for bi in range(last, -1, -1):
-            (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd) = blocks[bi]
+            (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd, msk) = blocks[bi]
             extra = lateral_grad.pop(out.data_ptr(), None)
             if extra is not None:                       # `out` also feeds an FPN lateral conv: this launch completes d(out)
                 nxt = bn2_of(bi)
                 r = self._dgrad(extra[0], extra[1], extra[2], res=dcur, bn_next=nxt)
                 dcur, mcur = r if nxt is not None else (r, None)
-            dc2, g = self._bn_bwd(dcur, c2, out, True, blk.bn2, m2, i2, want_g=True, means=mcur)
+            dc2, g = self._bn_bwd(dcur, c2, msk, 3, blk.bn2, m2, i2, want_g=True, means=mcur)
             nxt = (c1, None, 2, blk.bn1, m1, i1) if self.fuse_bn_bwd else None
             r = self._dgrad(dc2, blk.conv2, d2, bn_next=nxt)
             da1, ma1 = r if nxt is not None else (r, None)

@@ -219,7 +219,7 @@ def test_bn_pool_head_adam():
     gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
     y = torch.empty_like(xd)
     L.check(lib.sd_bn_apply(xd.data_ptr(), y.data_ptr(), M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(), bet.data_ptr(),
-                            nhwc(res).data_ptr(), 1, L.stream()))
+                            nhwc(res).data_ptr(), 1, 0, L.stream()))
     close(from_nhwc(y), yr.detach(), 1e-5)
     close(rm.cpu(), bn.running_mean, 1e-5); close(rv.cpu(), bn.running_var, 1e-5)
     dx = torch.empty_like(xd); gout = torch.empty_like(xd); dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
@@ -227,6 +227,18 @@ def test_bn_pool_head_adam():
                           bet.data_ptr(), dx.data_ptr(), gout.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
     close(from_nhwc(dx), xr.grad, 2e-5); close(from_nhwc(gout), rr.grad, 1e-6)
     close(dg.cpu(), bn.weight.grad, 2e-5); close(db.cpu(), bn.bias.grad, 2e-5)
+    # mask bytes (relu mode 3): sd_bn_apply also writes one byte per four elements, the backward reads those instead of y
+    mask = torch.empty(M * Cc // 4, dtype=torch.uint8, device=DEV)
+    y3 = torch.empty_like(xd)
+    L.check(lib.sd_bn_apply(xd.data_ptr(), y3.data_ptr(), M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                            nhwc(res).data_ptr(), 1, mask.data_ptr(), L.stream()))
+    assert torch.equal(y3, y)
+    bits = (y > 0).view(-1, 4).to(torch.uint8)
+    assert torch.equal(mask, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3))
+    dx3 = torch.empty_like(xd); gout3 = torch.empty_like(xd); dg3 = torch.empty(Cc, device=DEV); db3 = torch.empty(Cc, device=DEV)
+    L.check(lib.sd_bn_bwd(nhwc(dy).data_ptr(), xd.data_ptr(), mask.data_ptr(), 3, M, Cc, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(),
+                          bet.data_ptr(), dx3.data_ptr(), gout3.data_ptr(), dg3.data_ptr(), db3.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    assert torch.equal(dx3, dx) and torch.equal(gout3, gout) and torch.equal(dg3, dg) and torch.equal(db3, db)
     # mask recomputed from x (relu mode 2): relu(bn(x)) without residual, y is never read
     xr2 = x.clone().requires_grad_(True); bn.zero_grad()
     F.relu(bn(xr2)).backward(dy)

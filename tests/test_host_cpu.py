@@ -170,7 +170,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.sd_conv2d_fwd(16, 16, 16, C.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1 and b"Cin" in lib.sd_last_error()
     d.Cin, d.Ho = 64, 7
     assert lib.sd_conv2d_fwd(16, 16, 16, C.byref(d), 0, 0, 0, 0, 0, 0, 0, 0) == -1 and b"geometry" in lib.sd_last_error()
-    assert lib.sd_bn_apply(16, 16, 100, 6, 16, 16, 16, 16, 0, 1, 0) == -1                                  # C % 4 != 0
+    assert lib.sd_bn_apply(16, 16, 100, 6, 16, 16, 16, 16, 0, 1, 0, 0) == -1                                  # C % 4 != 0
     # workspace queries
     assert lib.sd_decode_workspace_bytes(64, 2, 1, 128, 128, 20, 40) >= 64 * 3 * 128 * 128 * 8
     assert lib.sd_decode_packed_words(64, 20, 40) == 64 * (6 * 20 + 11 * 40)
