@@ -886,7 +886,7 @@ static int red_rows(int64_t M) {
     return r;
 }
 
-static int fold_rows(int rows) { return rows > 512 ? cdiv(rows, std::max(16, rows / 128)) : 0; }
+static int fold_rows(int rows) { return rows > 2048 ? cdiv(rows, std::max(16, rows / 128)) : 0; }      // (<= 2048 rows: one finalize launch is faster)
 
 // [nb partial rows][2][C] + the two per-channel means of the backward + the slab sums of the two-level finish
 size_t sd_col_reduce_workspace_bytes(int64_t M, int C) {
