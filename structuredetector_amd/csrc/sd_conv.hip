@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs0[BN * LDK];
     __shared__ __attribute__((aligned(16))) float Bs1[BN * LDK];
     __shared__ int orow[BM];               // output pixel of each tile row, -1 = none
+    __shared__ int rrow[BM];               // its row in a half-size residual map (res_up2), -1 = no residual for this pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Nn / BN;
@@ -184,6 +185,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             atx##i = ox * p.mul + p.off;                                                          \
             aptr##i = px_ + (int64_t)b * img_stride;                                              \
             pix = (b * p.Ho + oy) * p.Wo + ox;                                                    \
+            if ((tid & 7) == 0)      /* once per tile row instead of a div/mod chain per output element */ \
+                rrow[srow + 32 * i] = (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1); \
         }                                                                                         \
         if ((tid & 7) == 0) orow[srow + 32 * i] = pix;                                            \
     }
@@ -451,17 +454,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];   // output pixel index
+                const int trow = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int m = orow[trow];   // output pixel index
                 if (m < 0) continue;
                 float v = acc[mi][ni][e] * sc + sh;
                 if (p.res) {
-                    int64_t rm = m;
-                    bool has = true;
-                    if (p.res_up2) {       // 1: nearest-neighbour x2 upsample of the coarser map (network.py:10,19)
-                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;      // 2: half-size map added at even (y, x) only
-                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-                        has = p.res_up2 == 1 || !((ox | oy) & 1);
-                    }
+                    // res_up2 1: nearest-neighbour x2 upsample of the coarser map (network.py:10,19); 2: half-size map at even (y, x) only
+                    const int64_t rm = p.res_up2 ? rrow[trow] : m;
+                    const bool has = rm >= 0;
                     if (has) v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
@@ -491,9 +491,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 }
 
 // Epilogue of the 256-row tile kernels: y = [relu](acc * scale + shift [+ residual]) and the fused BatchNorm column sums (see
-// k_conv_igemm): one partial row per tile.  row_to_m maps a tile row to its output pixel (-1 = none).
-template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, typename RowMap>
-__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, int tid, int wave, int fr,
+// k_conv_igemm): one partial row per tile.  row_to_m maps a tile row to its output pixel (-1 = none), row_to_res to its row in a
+// half-size residual map (res_up2).
+template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, typename RowMap, typename ResMap>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, ResMap row_to_res, int tid, int wave, int fr,
                                               int fh, int wm0, int wn0, int n0, int tile_m) {
     const bool fwd_stat = !BF16 && FWD && p.stat && !p.bn_x;
     const bool bwd_red = !BF16 && p.stat && p.bn_x;
@@ -522,17 +523,13 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = row_to_m(wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh);
+                const int trow = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int m = row_to_m(trow);
                 if (m < 0) continue;
                 float v = acc[mi][ni][e] * sc + sh;
                 if (p.res) {
-                    int64_t rm = m;
-                    bool has = true;
-                    if (p.res_up2) {
-                        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-                        rm = ((int64_t)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-                        has = p.res_up2 == 1 || !((ox | oy) & 1);
-                    }
+                    const int64_t rm = p.res_up2 ? row_to_res(trow, m) : m;      // half-size residual map: its row, -1 = none here
+                    const bool has = rm >= 0;
                     if (has) v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
                 }
                 if (p.relu) v = fmaxf(v, 0.f);
@@ -638,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs1[B_ST];
     __shared__ __attribute__((aligned(16))) float Bs2[B_ST];
     __shared__ int orow[BMB];
+    __shared__ int rrow[BMB];              // row in a half-size residual map (res_up2), -1 = none
     const float* const px_ = reinterpret_cast<const float*>(p.x);
     const float* const pw_ = reinterpret_cast<const float*>(p.w);
 
@@ -674,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     {
         SD_BIG_PIXEL(tid, b, oy, ox, ok)
         orow[tid] = ok ? (b * p.Ho + oy) * p.Wo + ox : -1;
+        rrow[tid] = (!ok || (p.res_up2 == 2 && ((ox | oy) & 1))) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
     }
 
     // ---- staging: wave w owns A pieces 4w .. 4w+3 and B pieces PBW*w ..; lane -> row (lane / 4) of the piece, slot lane % 4.
@@ -809,7 +808,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_MFMA
 #undef SD_BIG_ISSUE
 
-    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0>(p, acc, [&](int row) { return orow[row]; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
+    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0>(p, acc, [&](int row) { return orow[row]; }, [&](int row, int) { return rrow[row]; }, tid, wave, fr, fh,
+                                                 wm0, wn0, n0, tile_m);
 }
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution (forward, and data-gradient with the taps flipped) with PATCH STAGING: the nine taps of
@@ -1013,7 +1013,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #undef PT_ISSUE_B
 #undef PT_OWN
 #undef PT_PATCH
-    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16>(p, acc, [&](int row) { return m0 + row; }, tid, wave, fr, fh, wm0, wn0, n0, tile_m);
+    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16>(
+        p, acc, [&](int row) { return m0 + row; },
+        [&](int, int m) {      // half-size residual map (not on this kernel's hot uses: 3x3 / stride 1 layers join full-size residuals)
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+        },
+        tid, wave, fr, fh, wm0, wn0, n0, tile_m);
 }
 
 #undef SD_BNRED_TERM
