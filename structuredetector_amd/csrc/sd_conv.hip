@@ -440,6 +440,44 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
+    if (!BF16 && !bwd_red) {
+        // 16-byte epilogue: a 32x32 MFMA accumulator holds 16 ROWS of one column per lane, so the direct form stores (and reads
+        // the residual) 4 bytes per lane -- 64 + 64 vector-memory instructions per lane and tile, which is what bounds the 1x1
+        // convs (FPN lateral with its upsample-add: 773 us vs 343 us for the plain conv).  The wave tile goes through the
+        // (now idle) LDS stage buffers once -- each wave has a 64 x BN/2 float region of its own, no block barrier -- and comes
+        // back as rows: 16 + 16 instructions of 16 bytes per lane.
+        constexpr int TWC = BN / 2;                    // wave tile columns
+        float* T = reinterpret_cast<float*>(BN == 128 ? (wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? Bs0 : Bs1)
+                                                      : (wave == 0 ? Bs0 : wave == 1 ? Bs1 : wave == 2 ? As0 : As1));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * TWC + ni * 32 + fr] = acc[mi][ni][e];
+        constexpr int LPR = TWC / 4, RPI = 64 / LPR;   // lanes per row, rows per pass
+        const int c4 = (lane % LPR) * 4, n = n0 + wn0 + c4;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
+        if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll 4
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int m = orow[wm0 + row];
+            if (m < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(T + row * TWC + c4);
+            v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+            if (p.res) {
+                const int64_t rm = p.res_up2 ? rrow[wm0 + row] : m;
+                if (rm >= 0) {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+        }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -471,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             }
         }
     }
+    }
     if (fwd_stat || bwd_red) {
         __shared__ float statred[2][BN];
 #pragma unroll
@@ -493,9 +532,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 // Epilogue of the 256-row tile kernels: y = [relu](acc * scale + shift [+ residual]) and the fused BatchNorm column sums (see
 // k_conv_igemm): one partial row per tile.  row_to_m maps a tile row to its output pixel (-1 = none), row_to_res to its row in a
 // half-size residual map (res_up2).
-template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, typename RowMap, typename ResMap>
+// T0 / T1 (VEC): two 32-row x 64-float LDS regions private to the wave (idle stage buffers) for the 16-byte form of the epilogue
+// (see k_conv_igemm); the caller guarantees that no LDS-DMA is still landing in them.
+template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, bool VEC = false, typename RowMap, typename ResMap>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, ResMap row_to_res, int tid, int wave, int fr,
-                                              int fh, int wm0, int wn0, int n0, int tile_m) {
+                                              int fh, int wm0, int wn0, int n0, int tile_m, float* T0 = nullptr, float* T1 = nullptr) {
     const bool fwd_stat = !BF16 && FWD && p.stat && !p.bn_x;
     const bool bwd_red = !BF16 && p.stat && p.bn_x;
     float sv[NTW], qv[NTW];
@@ -509,6 +550,42 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                 for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
+    const int lane = tid & 63;
+    if (VEC && !BF16 && NTW == 2 && !bwd_red) {
+        const int c4 = (lane & 15) * 4, n = n0 + wn0 + c4;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
+        if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+#pragma unroll
+        for (int h = 0; h < MT / 2; ++h) {            // 64 rows of the wave tile at a time
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    T0[r * 64 + ni * 32 + fr] = acc[2 * h][ni][e];
+                    T1[r * 64 + ni * 32 + fr] = acc[2 * h + 1][ni][e];
+                }
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = it * 4 + (lane >> 4);                      // 0 .. 63 inside this half
+                const int trow = wm0 + h * 64 + rl;
+                const int m = row_to_m(trow);
+                if (m < 0) continue;
+                float4 v = *reinterpret_cast<const float4*>((rl < 32 ? T0 : T1) + (rl & 31) * 64 + c4);
+                v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+                if (p.res) {
+                    const int64_t rm = p.res_up2 ? (int64_t)row_to_res(trow, m) : (int64_t)m;
+                    if (rm >= 0) {
+                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+            }
+        }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -538,6 +615,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                 if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
             }
         }
+    }
     }
     if (fwd_stat || bwd_red) {
         static_assert(WM == 2 || BN != 128, "two wave rows are combined");
@@ -808,8 +886,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_MFMA
 #undef SD_BIG_ISSUE
 
-    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0>(p, acc, [&](int row) { return orow[row]; }, [&](int row, int) { return rrow[row]; }, tid, wave, fr, fh,
-                                                 wm0, wn0, n0, tile_m);
+    // 16-byte epilogue through the idle stage buffers (BN = 128: three 16 KB A stages for waves 0..2, two 8 KB B stages for wave 3);
+    // the barrier makes sure no other wave's (past-the-end) DMA is still landing in them
+    __syncthreads();
+    float* T0 = wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? As2 : Bs0;
+    float* T1 = wave == 3 ? Bs1 : T0 + 32 * 64;
+    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0, false, BN == 128>(p, acc, [&](int row) { return orow[row]; }, [&](int row, int) { return rrow[row]; },
+                                                                   tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, T1);
 }
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution (forward, and data-gradient with the taps flipped) with PATCH STAGING: the nine taps of
@@ -1013,13 +1096,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #undef PT_ISSUE_B
 #undef PT_OWN
 #undef PT_PATCH
-    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16>(
+    // 16-byte epilogue through the idle patch / weight buffers (fp32, BN = 128: 16 KB per wave); the barrier makes sure no other
+    // wave's (past-the-end) DMA is still landing in them
+    __syncthreads();
+    float* T0 = wave < 3 ? Pt + wave * 4096 : Bs;
+    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16, (BN == 128 && !BF16)>(
         p, acc, [&](int row) { return m0 + row; },
         [&](int, int m) {      // half-size residual map (not on this kernel's hot uses: 3x3 / stride 1 layers join full-size residuals)
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
         },
-        tid, wave, fr, fh, wm0, wn0, n0, tile_m);
+        tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, T0 + 2048);
 }
 
 #undef SD_BNRED_TERM
