@@ -1472,18 +1472,36 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = ni * 32 + fr;
-        const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+    {
+        // 16-byte epilogue (see k_conv_igemm): the wave's 32 x 64 tile goes through the idle patch LDS and comes back as rows
+        __syncthreads();                                 // every wave is done with the patch / weight LDS
+        float* T = lds + wave * 2048;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int ox = ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
+            T[r * 64 + fr] = acc0[e];
+            T[r * 64 + 32 + fr] = acc1[e];
+        }
+        const int c4 = (lane & 15) * 4;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + c4);
+        if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + c4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int ox = ox0 + wave * 32 + r;
             if (ox >= p.Wo) continue;
-            float v = (ni ? acc1[e] : acc0[e]) * sc + sh;
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (p.out_bf16) reinterpret_cast<uint16_t*>(p.y)[(row0 + ox) * 64 + n] = f2bf(v);
-            else p.y[(row0 + ox) * 64 + n] = v;
+            float4 v = *reinterpret_cast<const float4*>(T + r * 64 + c4);
+            v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.out_bf16) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (row0 + ox) * 64 + c4) = pk;
+            } else {
+                *reinterpret_cast<float4*>(p.y + (row0 + ox) * 64 + c4) = v;
+            }
         }
     }
     if (p.stat) {
@@ -1496,8 +1514,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
         }
         s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
-        __syncthreads();                                 // every wave is done with the patch / weight LDS
-        float* red = lds;                                // [4 waves][2][64]
+        float* red = lds + 4 * 2048;                     // [4 waves][2][64], behind the epilogue's tile regions
         if (fh == 0) {
             red[(wave * 2 + 0) * 64 + fr] = s0; red[(wave * 2 + 0) * 64 + 32 + fr] = s1;
             red[(wave * 2 + 1) * 64 + fr] = q0; red[(wave * 2 + 1) * 64 + 32 + fr] = q1;
