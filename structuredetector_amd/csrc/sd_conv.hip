@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
-    if (!BF16 && !bwd_red) {
-        // 16-byte epilogue: a 32x32 MFMA accumulator holds 16 ROWS of one column per lane, so the direct form stores (and reads
+    if (!bwd_red) {
+        // 16-byte epilogue (bf16 output: 8 bytes = four values per lane): a 32x32 MFMA accumulator holds 16 ROWS of one column per lane, so the direct form stores (and reads
         // the residual) 4 bytes per lane -- 64 + 64 vector-memory instructions per lane and tile, which is what bounds the 1x1
         // convs (FPN lateral with its upsample-add: 773 us vs 343 us for the plain conv).  The wave tile goes through the
         // (now idle) LDS stage buffers once -- each wave has a 64 x BN/2 float region of its own, no block barrier -- and comes
@@ -470,12 +470,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             if (p.res) {
                 const int64_t rm = p.res_up2 ? rrow[wm0 + row] : m;
                 if (rm >= 0) {
-                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    if (BF16) {
+                        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + rm * p.Nn + n);
+                        v.x += bf2f((uint16_t)(r.x & 0xffff)); v.y += bf2f((uint16_t)(r.x >> 16));
+                        v.z += bf2f((uint16_t)(r.y & 0xffff)); v.w += bf2f((uint16_t)(r.y >> 16));
+                    } else {
+                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
                 }
             }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+            if (BF16) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (int64_t)m * p.Nn + n) = pk;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+            }
         }
     } else {
 #pragma unroll
@@ -551,7 +564,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         }
     }
     const int lane = tid & 63;
-    if (VEC && !BF16 && NTW == 2 && !bwd_red) {
+    if (VEC && NTW == 2 && !bwd_red) {
         const int c4 = (lane & 15) * 4, n = n0 + wn0 + c4;
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
@@ -577,12 +590,25 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                 if (p.res) {
                     const int64_t rm = p.res_up2 ? (int64_t)row_to_res(trow, m) : (int64_t)m;
                     if (rm >= 0) {
-                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
-                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        if (BF16) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + rm * p.Nn + n);
+                            v.x += bf2f((uint16_t)(r.x & 0xffff)); v.y += bf2f((uint16_t)(r.x >> 16));
+                            v.z += bf2f((uint16_t)(r.y & 0xffff)); v.w += bf2f((uint16_t)(r.y >> 16));
+                        } else {
+                            const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
                     }
                 }
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+                if (BF16) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (int64_t)m * p.Nn + n) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+                }
             }
         }
     } else {
@@ -1096,11 +1122,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #undef PT_ISSUE_B
 #undef PT_OWN
 #undef PT_PATCH
-    // 16-byte epilogue through the idle patch / weight buffers (fp32, BN = 128: 16 KB per wave); the barrier makes sure no other
+    // 16-byte epilogue through the idle patch / weight buffers (BN = 128: 16 KB per wave); the barrier makes sure no other
     // wave's (past-the-end) DMA is still landing in them
     __syncthreads();
     float* T0 = wave < 3 ? Pt + wave * 4096 : Bs;
-    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16, (BN == 128 && !BF16)>(
+    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16, BN == 128>(
         p, acc, [&](int row) { return m0 + row; },
         [&](int, int m) {      // half-size residual map (not on this kernel's hot uses: 3x3 / stride 1 layers join full-size residuals)
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
