@@ -412,16 +412,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 
     // ---- epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (e&3) + 8*(e>>2) + 4*(lane>>5)
     if (MODE == 0 && p.splits > 1) {
+        // split-K partial tile, stored as rows through the wave's LDS region (16-byte stores, see the epilogue below)
         float* dst = p.part + (int64_t)blockIdx.y * p.M * p.Nn;
+        constexpr int TWC = BN / 2;
+        float* T = reinterpret_cast<float*>(BN == 128 ? (wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? Bs0 : Bs1)
+                                                      : (wave == 0 ? Bs0 : wave == 1 ? Bs1 : wave == 2 ? As0 : As1));
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = orow[wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                    if (m >= 0) dst[(int64_t)m * p.Nn + n0 + wn0 + ni * 32 + fr] = acc[mi][ni][e];
-                }
+                for (int e = 0; e < 16; ++e) T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * TWC + ni * 32 + fr] = acc[mi][ni][e];
+        constexpr int LPR = TWC / 4, RPI = 64 / LPR;
+        const int c4 = (lane % LPR) * 4;
+#pragma unroll 4
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int m = orow[wm0 + row];
+            if (m >= 0) *reinterpret_cast<float4*>(dst + (int64_t)m * p.Nn + n0 + wn0 + c4) = *reinterpret_cast<const float4*>(T + row * TWC + c4);
+        }
         return;
     }
     // Column sums for a BatchNorm that is fused with this launch (p.stat): forward = statistics of the raw conv output, from
