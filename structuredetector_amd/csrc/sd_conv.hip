@@ -1357,26 +1357,42 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
             lds_dma16(src, (X) + q * 256);                                                                        \
         }                                                                                                         \
     }
-    // 16 pixel pairs x 9 taps; operands of pair kk+1 are read while the MFMAs of pair kk run
+    // 16 pixel pairs x 9 taps in four batches of four pairs.  A lane's B operand for (pair kk, tap r, s) is X[r][2 kk + s] (+ its
+    // pixel parity in the base address): neighbouring pairs overlap, so a batch needs 3 x 9 X values + 4 dY values (31 LDS
+    // reads for 36 MFMAs instead of 40), and the NEXT batch's operands are read while the current batch's MFMAs run -- with a
+    // one-pair prefetch distance hipcc merged the reads into ds_read2 pairs that the very next MFMA group consumed, and put
+    // an `s_waitcnt lgkmcnt(0)` in front of every other group (LDS latency exposed once per 18 MFMAs).
+#define W9_LOAD(AV, XV, bb)                                                                                       \
+    {                                                                                                             \
+        constexpr int kk0_ = 4 * (bb), prow_ = (2 * kk0_) / ROWW, pcol_ = (2 * kk0_) % ROWW;                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AV[i] = da[(2 * (kk0_ + i)) * 64];                          \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                             \
+            _Pragma("unroll") for (int q = 0; q < 9; ++q) XV[r][q] = xb[((r + prow_) * W9_PX + pcol_ + q) * 64];  \
+    }
+#define W9_MFMAS(AV, XV)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                             \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i], XV[t / 3][2 * i + t % 3], acc[t], 0, 0, 0);
 #define W9_COMPUTE(D, X)                                                                                          \
     {                                                                                                             \
         const float* da = (D) + fh * 64 + wn0 + fr;                                                               \
         const float* xb = (X) + fh * 64 + wc0 + fr;                                                               \
-        float na = da[0], nb[9];                                                                                  \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) nb[t] = xb[((t / 3) * W9_PX + (t % 3)) * 64];               \
-        _Pragma("unroll") for (int kk = 0; kk < 16; ++kk) {                                                       \
-            const float a = na;                                                                                   \
-            float bv[9];                                                                                          \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) bv[t] = nb[t];                                          \
-            if (kk + 1 < 16) {                                                                                    \
-                na = da[(2 * kk + 2) * 64];                                                                       \
-                _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                     \
-                    nb[t] = xb[((t / 3 + (2 * kk + 2) / ROWW) * W9_PX + (t % 3) + (2 * kk + 2) % ROWW) * 64];     \
-            }                                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            _Pragma("unroll") for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-        }                                                                                                         \
+        float a0[4], x0[3][9], a1[4], x1[3][9];                                                                   \
+        W9_LOAD(a0, x0, 0)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_LOAD(a1, x1, 1)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_LOAD(a0, x0, 2)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_MFMAS(a1, x1)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_LOAD(a1, x1, 3)                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        W9_MFMAS(a1, x1)                                                                                          \
     }
 #define W9_ITER(CUR)                                                                                              \
     {                                                                                                             \
@@ -1394,6 +1410,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
     }
 #undef W9_ITER
 #undef W9_COMPUTE
+#undef W9_MFMAS
+#undef W9_LOAD
 #undef W9_STAGE
     float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
 #pragma unroll
