@@ -129,6 +129,9 @@ def main():
                     help="run the weight-gradient GEMMs on a side stream (+3.5 %% images/s; per-kernel durations then overlap)")
     ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
                     help="gradient all-reduce binding for --gpus > 1: torch.distributed's RCCL (default) or the C-ABI sd_allreduce_*")
+    ap.add_argument("--fuse-bn-bwd", dest="fuse_bn_bwd", action="store_true", default=None,
+                    help="BatchNorm-backward reductions inside the data-gradient epilogues (experiment switch; default: the engine's)")
+    ap.add_argument("--no-fuse-bn-bwd", dest="fuse_bn_bwd", action="store_false")
     ap.add_argument("--zero-input", action="store_true",
                     help="experiment: all-zero images (every activation is then zero): same kernels at lower MFMA power -> DVFS headroom")
     ap.add_argument("--extras", action="store_true",
@@ -166,6 +169,8 @@ def main():
     step = TrainStep(net, args, exchange=a.exchange)
     step.sync_parameters()
     net._engine.overlap_wgrad = bool(a.overlap_wgrad)
+    if a.fuse_bn_bwd is not None:
+        net._engine.fuse_bn_bwd = bool(a.fuse_bn_bwd)
     enc = Encode(args)
     rng = np.random.default_rng(926354916 + rank)        # per-rank data
     gen = torch.Generator(device=dev).manual_seed(926354916 + rank)
@@ -286,7 +291,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[2]: train step bs={B}/GPU {img}x{img} fp32, 2 labels / 1 part, K=20 P=40, "
                                    "render targets + fwd + MSE/L1 loss + bwd + Adam; random-init ResNet-34+FPN",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad), **({"zero_input": True} if a.zero_input else {}),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad), "fuse_bn_bwd": bool(net._engine.fuse_bn_bwd), **({"zero_input": True} if a.zero_input else {}),
                        "exchange": "sd_allreduce (RCCL via C ABI)" if step.rccl is not None else (f"torch.distributed {dist.get_backend()}" if world > 1 else "none")},
             "train_tflops_per_gpu": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3, 2),
             "train_frac_of_mfma_peak": round(B * TRAIN_GFLOP_PER_IMG * a.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -109,6 +109,40 @@ __device__ __forceinline__ float f4c(const float4& v, int t) { return t == 0 ? v
 // NOTE on style: the staging registers are individual named variables filled by macros, not arrays written
 // inside lambdas -- hipcc left such arrays in scratch memory (scratch_store after every global_load and a
 // vmcnt(0) wait per load), which serialised the prefetch.
+// float4 form of the fused BatchNorm-backward reduction term for one row (m) and four consecutive channels (n .. n+3)
+struct BnRed4 { float4 mu, is, ga, be, s, q; };
+__device__ __forceinline__ void bnred4_init(BnRed4& b, const ConvArgs& p, int n) {
+    b.mu = *reinterpret_cast<const float4*>(p.bn_mean + n); b.is = *reinterpret_cast<const float4*>(p.bn_invstd + n);
+    b.ga = b.be = b.s = b.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bn_relu == 2) { b.ga = *reinterpret_cast<const float4*>(p.bn_gamma + n); b.be = *reinterpret_cast<const float4*>(p.bn_beta + n); }
+}
+__device__ __forceinline__ void bnred4_add(BnRed4& b, const ConvArgs& p, float4 g, int64_t m, int n) {
+    const int64_t i = m * p.Nn + n;
+    const float4 xv = *reinterpret_cast<const float4*>(p.bn_x + i);
+    const float4 xh = make_float4((xv.x - b.mu.x) * b.is.x, (xv.y - b.mu.y) * b.is.y, (xv.z - b.mu.z) * b.is.z, (xv.w - b.mu.w) * b.is.w);
+    if (p.bn_relu == 1) {
+        const float4 yy = *reinterpret_cast<const float4*>(p.bn_y + i);
+        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    } else if (p.bn_relu == 3) {
+        const uint8_t mb = reinterpret_cast<const uint8_t*>(p.bn_y)[i >> 2];
+        g.x = (mb & 1) ? g.x : 0.f; g.y = (mb & 2) ? g.y : 0.f; g.z = (mb & 4) ? g.z : 0.f; g.w = (mb & 8) ? g.w : 0.f;
+    } else if (p.bn_relu == 2) {
+        g.x = (xh.x * b.ga.x + b.be.x) > 0.f ? g.x : 0.f; g.y = (xh.y * b.ga.y + b.be.y) > 0.f ? g.y : 0.f;
+        g.z = (xh.z * b.ga.z + b.be.z) > 0.f ? g.z : 0.f; g.w = (xh.w * b.ga.w + b.be.w) > 0.f ? g.w : 0.f;
+    }
+    b.s.x += g.x; b.s.y += g.y; b.s.z += g.z; b.s.w += g.w;
+    b.q.x += g.x * xh.x; b.q.y += g.y * xh.y; b.q.z += g.z * xh.z; b.q.w += g.w * xh.w;
+}
+// sum over the lanes that share a column group (lane % LPR), result valid in lanes 0 .. LPR-1
+template <int LPR>
+__device__ __forceinline__ void bnred4_wave_sum(BnRed4& b) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        b.s.x += __shfl_xor(b.s.x, o); b.s.y += __shfl_xor(b.s.y, o); b.s.z += __shfl_xor(b.s.z, o); b.s.w += __shfl_xor(b.s.w, o);
+        b.q.x += __shfl_xor(b.q.x, o); b.q.y += __shfl_xor(b.q.y, o); b.q.z += __shfl_xor(b.q.z, o); b.q.w += __shfl_xor(b.q.w, o);
+    }
+}
+
 // Epilogue helpers shared by k_conv_igemm and k_conv_igemm_big.
 // SD_BNRED_TERM: contribution of one stored value v at (m, n) to the fused BatchNorm-backward reduction.
 #define SD_BNRED_TERM(v, m, n, S, Q)                                                               \
@@ -449,7 +483,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
-    if (!bwd_red) {
+    bool red_done = false;
+    __shared__ float statred[2][BN];
+    {
         // 16-byte epilogue (bf16 output: 8 bytes = four values per lane): a 32x32 MFMA accumulator holds 16 ROWS of one column per lane, so the direct form stores (and reads
         // the residual) 4 bytes per lane -- 64 + 64 vector-memory instructions per lane and tile, which is what bounds the 1x1
         // convs (FPN lateral with its upsample-add: 773 us vs 343 us for the plain conv).  The wave tile goes through the
@@ -469,6 +505,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
         if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+        BnRed4 br;
+        if (bwd_red) bnred4_init(br, p, n);
 #pragma unroll 4
         for (int it = 0; it < 64 / RPI; ++it) {
             const int row = it * RPI + lane / LPR;
@@ -497,9 +535,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (int64_t)m * p.Nn + n) = pk;
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+                if (bwd_red) bnred4_add(br, p, v, m, n);
             }
         }
-    } else {
+        if (bwd_red) {      // BatchNorm-backward reduction: lanes -> wave (64 rows) -> the two wave rows -> one partial row per tile
+            bnred4_wave_sum<LPR>(br);
+            if ((wave >> 1) == 1 && lane < LPR) {
+                *reinterpret_cast<float4*>(&statred[0][wn0 + c4]) = br.s; *reinterpret_cast<float4*>(&statred[1][wn0 + c4]) = br.q;
+            }
+            __syncthreads();
+            if ((wave >> 1) == 0 && lane < LPR) {
+                float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n;
+                const float4 a = *reinterpret_cast<const float4*>(&statred[0][wn0 + c4]), bq = *reinterpret_cast<const float4*>(&statred[1][wn0 + c4]);
+                *reinterpret_cast<float4*>(dst) = make_float4(br.s.x + a.x, br.s.y + a.y, br.s.z + a.z, br.s.w + a.w);
+                *reinterpret_cast<float4*>(dst + p.Nn) = make_float4(br.q.x + bq.x, br.q.y + bq.y, br.q.z + bq.z, br.q.w + bq.w);
+            }
+            red_done = true;
+        }
+    }
+    if (false) {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         const int n = n0 + wn0 + ni * 32 + fr;
@@ -532,8 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         }
     }
     }
-    if (fwd_stat || bwd_red) {
-        __shared__ float statred[2][BN];
+    if (fwd_stat || (bwd_red && !red_done)) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32);
@@ -573,11 +626,15 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         }
     }
     const int lane = tid & 63;
-    if (VEC && NTW == 2 && !bwd_red) {
+    bool red_done = false;
+    __shared__ float statred[2][BN];
+    if (VEC && NTW == 2) {
         const int c4 = (lane & 15) * 4, n = n0 + wn0 + c4;
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
         if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+        BnRed4 br;
+        if (bwd_red) bnred4_init(br, p, n);
 #pragma unroll
         for (int h = 0; h < MT / 2; ++h) {            // 64 rows of the wave tile at a time
 #pragma unroll
@@ -617,8 +674,30 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (int64_t)m * p.Nn + n) = pk;
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
+                    if (bwd_red) bnred4_add(br, p, v, m, n);
                 }
             }
+        }
+        if (bwd_red) {      // lanes -> wave -> wave rows 1 .. WM-1 into LDS in a fixed order -> wave row 0 writes the partial row
+            bnred4_wave_sum<16>(br);
+            if (tid < 2 * BN) statred[tid / BN][tid % BN] = 0.f;
+            __syncthreads();
+            for (int wr = 1; wr < WM; ++wr) {
+                if (wave / WN == wr && lane < 16) {
+                    float4* a = reinterpret_cast<float4*>(&statred[0][wn0 + c4]);
+                    float4* bq = reinterpret_cast<float4*>(&statred[1][wn0 + c4]);
+                    *a = make_float4(a->x + br.s.x, a->y + br.s.y, a->z + br.s.z, a->w + br.s.w);
+                    *bq = make_float4(bq->x + br.q.x, bq->y + br.q.y, bq->z + br.q.z, bq->w + br.q.w);
+                }
+                __syncthreads();
+            }
+            if (wave / WN == 0 && lane < 16) {
+                float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n;
+                const float4 a = *reinterpret_cast<const float4*>(&statred[0][wn0 + c4]), bq = *reinterpret_cast<const float4*>(&statred[1][wn0 + c4]);
+                *reinterpret_cast<float4*>(dst) = make_float4(br.s.x + a.x, br.s.y + a.y, br.s.z + a.z, br.s.w + a.w);
+                *reinterpret_cast<float4*>(dst + p.Nn) = make_float4(br.q.x + bq.x, br.q.y + bq.y, br.q.z + bq.z, br.q.w + bq.w);
+            }
+            red_done = true;
         }
     } else {
 #pragma unroll
@@ -652,9 +731,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         }
     }
     }
-    if (fwd_stat || bwd_red) {
+    if (fwd_stat || (bwd_red && !red_done)) {
         static_assert(WM == 2 || BN != 128, "two wave rows are combined");
-        __shared__ float statred[2][BN];
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
         // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes

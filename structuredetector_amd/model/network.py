@@ -122,10 +122,10 @@ class _Engine:
         # overlap was measured too: slower than no overlap, the HBM-bound passes slow the wgrad they run under.)
         self.overlap_wgrad = False
         self._side = None
-        # BatchNorm-backward reduction inside the data-gradient epilogue (sd_conv2d_dgrad_bn_reduce).  Measured at bs=64: the
-        # separate reduce passes drop from 3.0 to 0.8 ms per step, but the 4-byte epilogue reads of bn_x / bn_y cost the conv
-        # kernels 4.0 ms (a 32x32 MFMA accumulator holds 16 ROWS of one column per lane: no 16-byte access along channels),
-        # so the step gets 1.7 ms slower.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
+        # BatchNorm-backward reduction inside the data-gradient epilogue (sd_conv2d_dgrad_bn_reduce).  Measured at bs=64: with the
+        # first (4-byte) epilogue it cost the conv kernels 4.0 ms to save 2.2 ms of reduce passes; with the 16-byte epilogue
+        # (float4 reads of the BatchNorm input, mask bytes) it is exactly neutral (815.7 vs 815.4 img/s): the reduce passes it
+        # removes run at HBM speed anyway.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
         self.fuse_bn_bwd = False
 
     def _kname(self, d, which):
