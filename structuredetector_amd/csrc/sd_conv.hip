@@ -553,39 +553,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             red_done = true;
         }
     }
-    if (false) {
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + fr;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f;
-        if (bwd_red) {
-            bmu = p.bn_mean[n]; bis = p.bn_invstd[n];
-            if (p.bn_relu == 2) { bga = p.bn_gamma[n]; bbe = p.bn_beta[n]; }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int trow = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int m = orow[trow];   // output pixel index
-                if (m < 0) continue;
-                float v = acc[mi][ni][e] * sc + sh;
-                if (p.res) {
-                    // res_up2 1: nearest-neighbour x2 upsample of the coarser map (network.py:10,19); 2: half-size map at even (y, x) only
-                    const int64_t rm = p.res_up2 ? rrow[trow] : m;
-                    const bool has = rm >= 0;
-                    if (has) v += BF16 ? bf2f(reinterpret_cast<const uint16_t*>(p.res)[rm * p.Nn + n]) : reinterpret_cast<const float*>(p.res)[rm * p.Nn + n];
-                }
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (BF16) reinterpret_cast<uint16_t*>(p.y)[(int64_t)m * p.Nn + n] = f2bf(v);
-                else if (!SD_ABLATE_STORE || v == 123.456f) reinterpret_cast<float*>(p.y)[(int64_t)m * p.Nn + n] = v;
-                if (bwd_red) SD_BNRED_TERM(v, m, n, sv[ni], qv[ni])
-            }
-        }
-    }
-    }
     if (fwd_stat || (bwd_red && !red_done)) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
