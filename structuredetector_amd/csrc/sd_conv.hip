@@ -1951,7 +1951,8 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
     SD_REQUIRE(x && w && y, SD_ERR_INVALID, "sd_conv2d_fwd: null pointer");
     SD_REQUIRE(d->Cin % 32 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %d, %d)",
                d->Cin, d->Cout);
-    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd: pointers must be 16-byte aligned");
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(residual), SD_ERR_ALIGN,
+               "sd_conv2d_fwd: pointers must be 16-byte aligned");
     SD_REQUIRE(!res_up2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd: res_up2 needs even Ho, Wo");
     ConvArgs a{};
     fill_fwd(a, d);
@@ -2028,7 +2029,8 @@ int sd_conv2d_fwd_bf16(const void* x, const void* w, void* y, const sd_conv_desc
     SD_REQUIRE(x && w && y, SD_ERR_INVALID, "sd_conv2d_fwd_bf16: null pointer");
     SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd_bf16: needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)",
                d->Cin, d->Cout);
-    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd_bf16: pointers must be 16-byte aligned");
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(residual), SD_ERR_ALIGN,
+               "sd_conv2d_fwd_bf16: pointers must be 16-byte aligned");
     SD_REQUIRE(!res_up2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd_bf16: res_up2 needs even Ho, Wo");
     ConvArgs a{};
     a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual;
@@ -2113,7 +2115,8 @@ int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const
     SD_REQUIRE(dy && w_t && dx && residual_half, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: null pointer");
     SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: needs Cout %% 32 == 0 and Cin %% 64 == 0");
     SD_REQUIRE(d->Hi % 2 == 0 && d->Wi % 2 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_half_res: needs even Hi, Wi");
-    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad_half_res: pointers must be 16-byte aligned");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx) && aligned16(residual_half), SD_ERR_ALIGN,
+               "sd_conv2d_dgrad_half_res: pointers must be 16-byte aligned");
     ConvArgs a{};
     fill_dgrad(a, d);
     a.x = dy; a.w = w_t; a.y = dx; a.res = residual_half; a.res_up2 = 2;
@@ -2124,7 +2127,7 @@ int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_
     if (int e = check_conv("sd_conv2d_dgrad", d)) return e;
     SD_REQUIRE(dy && w_t && dx, SD_ERR_INVALID, "sd_conv2d_dgrad: null pointer");
     SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad: needs Cout %% 32 == 0 and Cin %% 64 == 0");
-    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad: pointers must be 16-byte aligned");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx) && aligned16(residual), SD_ERR_ALIGN, "sd_conv2d_dgrad: pointers must be 16-byte aligned");
     ConvArgs a{};
     fill_dgrad(a, d);
     a.x = dy; a.w = w_t; a.y = dx; a.res = residual;
@@ -2272,7 +2275,8 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
     SD_REQUIRE(relu >= 0 && relu <= 3 && ((relu != 1 && relu != 3) || bn_y) && (relu != 2 || beta), SD_ERR_INVALID,
                "sd_conv2d_dgrad_bn_reduce: relu must be 0, 1 / 3 (need bn_y) or 2 (needs beta)");
     SD_REQUIRE(d->Cout % 32 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_bn_reduce: needs Cout %% 32 == 0 and Cin %% 64 == 0");
-    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx), SD_ERR_ALIGN, "sd_conv2d_dgrad_bn_reduce: pointers must be 16-byte aligned");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx) && aligned16(residual) && aligned16(bn_x) && aligned16(bn_y) && aligned16(mean) &&
+               aligned16(invstd) && aligned16(gamma) && aligned16(beta), SD_ERR_ALIGN, "sd_conv2d_dgrad_bn_reduce: pointers must be 16-byte aligned");
     SD_REQUIRE(workspace_bytes >= sd_conv2d_dgrad_bn_reduce_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_dgrad_bn_reduce: workspace too small");
     ConvArgs a{};
     fill_dgrad(a, d);
