@@ -1478,10 +1478,12 @@ constexpr int STEM_K = 147;   // 7 * 7 * 3
 // ---------------------------------------------------------------------------------------------
 constexpr int SP_PITCH = 264, SP_ROWS = 21, SP_USED = 261;
 constexpr int STEM_KPAD = 148;
+constexpr int STEM_KB = 160, STEM_WROW = 168;    // bf16 MFMA path: K padded to 10 steps of 16; LDS weight row of 168 bf16 (336 B, bank-spread)
 
 struct StemArgs {
     const float* x;       // NCHW image
     const float* wt;      // [147][64] transposed weights (forward)
+    const float* w;       // [64][147] weights as stored (forward on the bf16 MFMA)
     const float* dy;      // [M][64] (weight gradient)
     float* y;             // [M][64] forward output / partial dW [blocks][64][147]
     const float* scale;
@@ -1521,16 +1523,34 @@ __device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* patch,
     }
 }
 
+// BF16MM: the product runs on the bf16 MFMA (inference with the bf16 backbone): image patch and weights are rounded to bf16 on the
+// way into the MFMA operands (eight reduction indices per lane and step), accumulation stays fp32 -- 20 MFMAs per wave instead of 148.
+template <bool BF16MM>
 __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* patch = lds;                              // [21][264]
-    float* wl = lds + SP_ROWS * SP_PITCH;            // [148][64], row 147 = 0
+    float* wl = lds + SP_ROWS * SP_PITCH;            // fp32: [148][64], row 147 = 0;  bf16: [64][STEM_WROW] bf16, k >= 147 zero
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
     const int ox0 = tx * 128;
     stem_load_patch(p, patch, b, oy, ox0);
-    {
+    if (BF16MM) {
+        // weights [64][147] fp32 (original layout, k = (r*7 + s)*3 + ci) -> LDS [64][STEM_WROW] bf16
+        uint16_t* wlb = reinterpret_cast<uint16_t*>(wl);
+        constexpr int NE = 64 * STEM_KB / 256;                    // 40 elements per thread
+        float wv[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = tid + 256 * j, n = i / STEM_KB, k = i - n * STEM_KB;
+            wv[j] = (k < STEM_K) ? p.w[n * STEM_K + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = tid + 256 * j, n = i / STEM_KB, k = i - n * STEM_KB;
+            wlb[n * STEM_WROW + k] = f2bf(wv[j]);
+        }
+    } else {
         constexpr int NW = (STEM_KPAD * 64 / 4 + 255) / 256;      // 10 float4 per thread
         float4 wv[NW];
 #pragma unroll
@@ -1553,6 +1573,24 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    if (BF16MM) {
+        const uint16_t* wb = reinterpret_cast<const uint16_t*>(wl) + fr * STEM_WROW + 8 * fh;
+#pragma unroll
+        for (int step = 0; step < STEM_KB / 16; ++step) {
+            uint16_t ah[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {       // lane half fh supplies k = 16 step + 8 fh + j (indices past 146 meet zero weights)
+                const int k0 = 16 * step + j < STEM_K ? 16 * step + j : STEM_K - 1;
+                const int k1 = 16 * step + 8 + j < STEM_K ? 16 * step + 8 + j : STEM_K - 1;
+                ah[j] = f2bf(pa[fh ? stem_koff(k1) : stem_koff(k0)]);
+            }
+            const bf16x8 a = __builtin_bit_cast(bf16x8, ah);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + 16 * step);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 32 * STEM_WROW + 16 * step);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+        }
+    } else {
     // operands of step kk+1 are read while the MFMAs of step kk run
     float na = pa[fh ? stem_koff(1) : stem_koff(0)], nb0 = pb[0], nb1 = pb[32];
 #pragma unroll
@@ -1568,6 +1606,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
     {
@@ -2061,10 +2100,13 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
         a.x = x_nchw; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift; a.relu = relu; a.out_bf16 = out_bf16;
         stem_args(a, d);
         const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
-        // one-time, thread-safe (C++11 static initialisation): allow > 64 KB of dynamic LDS for this kernel
-        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr_once;
-        hipLaunchKernelGGL(k_stem_fwd, dim3(a.ntiles), dim3(256), lds, st, a);
+        // one-time, thread-safe (C++11 static initialisation): allow > 64 KB of dynamic LDS for these kernels
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const hipError_t attr_once_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr_once; (void)attr_once_b;
+        a.w = w;
+        if (out_bf16) hipLaunchKernelGGL(k_stem_fwd<true>, dim3(a.ntiles), dim3(256), lds, st, a);     // bf16 backbone: bf16 MFMA, bf16 output
+        else hipLaunchKernelGGL(k_stem_fwd<false>, dim3(a.ntiles), dim3(256), lds, st, a);
         SD_LAUNCH_CHECK();
         return 0;
     }
@@ -2101,9 +2143,9 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
     a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
     stem_args(a, d);
     const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
-    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr_once;
-    hipLaunchKernelGGL(k_stem_fwd, dim3(a.ntiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_stem_fwd<false>, dim3(a.ntiles), dim3(256), lds, st, a);
     SD_LAUNCH_CHECK();
     return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
                                 partial + (size_t)a.ntiles * 128, stream);

@@ -73,6 +73,26 @@ def test_conv3x3_patch_kernel_bf16(case):
     close(y.float().permute(0, 3, 1, 2).cpu(), ref, 6e-3)
 
 
+def test_stem_conv_on_the_bf16_mfma():
+    """sd_conv2d_stem_fwd(out_bf16=1): image and weights rounded to bf16, fp32 accumulation, folded affine + ReLU, bf16 NHWC output."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    for (B, H, W) in ((2, 64, 96), (1, 32, 320)):
+        g = torch.Generator().manual_seed(H * 3 + W)
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+        scale = torch.rand(64, generator=g) + 0.5; shift = torch.randn(64, generator=g) * 0.2
+        d = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+        y = torch.empty(B, d.Ho, d.Wo, 64, dtype=torch.bfloat16, device=DEV)
+        ws = torch.empty(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+        xd, wd = x.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+        sc, sh = scale.to(DEV), shift.to(DEV)
+        L.check(lib.sd_conv2d_stem_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), sc.data_ptr(), sh.data_ptr(), 1, 1, ws.data_ptr(),
+                                       ws.numel(), L.stream()))
+        ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, 2, 3) * scale[None, :, None, None] + shift[None, :, None, None])
+        close(y.float().permute(0, 3, 1, 2).cpu(), ref, 6e-3)
+
+
 def _pair(M=2, N=1, seed=0):
     from structuredetector_amd.model import Network
     ref = O.build_reference_network(M, N, seed=seed)
