@@ -1478,6 +1478,7 @@ constexpr int STEM_K = 147;   // 7 * 7 * 3
 // ---------------------------------------------------------------------------------------------
 constexpr int SP_PITCH = 264, SP_ROWS = 21, SP_USED = 261;
 constexpr int STEM_KPAD = 148;
+constexpr size_t STEM_FWD_LDS_BYTES = (size_t)(21 * 264 + 148 * 64 + 4 * 1024 + 512) * sizeof(float);   // patch + weights + T + red = 78.5 KB
 constexpr int STEM_KB = 160, STEM_WROW = 168;    // bf16 MFMA path: K padded to 10 steps of 16; LDS weight row of 168 bf16 (336 B, bank-spread)
 
 struct StemArgs {
@@ -1527,14 +1528,15 @@ __device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* patch,
 // way into the MFMA operands (eight reduction indices per lane and step), accumulation stays fp32 -- 20 MFMAs per wave instead of 148.
 template <bool BF16MM>
 __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
+    // Persistent blocks (two per CU): the 7x7 weights are staged ONCE per block, then the block walks its 128-pixel tiles --
+    // re-staging 37 KB of weights for every 32 KB of output was as expensive as the MFMAs.
+    // LDS: [patch 21 x 264][weights][T: 4 waves x 16 rows x 64][red 4 x 2 x 64]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* patch = lds;                              // [21][264]
     float* wl = lds + SP_ROWS * SP_PITCH;            // fp32: [148][64], row 147 = 0;  bf16: [64][STEM_WROW] bf16, k >= 147 zero
+    float* Tall = wl + STEM_KPAD * 64;               // (the bf16 weight image is smaller than the fp32 one)
+    float* red = Tall + 4 * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
-    const int ox0 = tx * 128;
-    stem_load_patch(p, patch, b, oy, ox0);
     if (BF16MM) {
         // weights [64][147] fp32 (original layout, k = (r*7 + s)*3 + ci) -> LDS [64][STEM_WROW] bf16
         uint16_t* wlb = reinterpret_cast<uint16_t*>(wl);
@@ -1565,103 +1567,110 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             if (i < STEM_KPAD * 64 / 4) reinterpret_cast<float4*>(wl)[i] = wv[j];
         }
     }
-    __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
     const int px = wave * 32 + fr;
     const float* pa = patch + 2 * px;
     const float* pb = wl + fh * 64 + fr;
-    f32x16 acc0, acc1;
+    const int c4 = (lane & 15) * 4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + c4);
+    if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + c4);
+    float* T = Tall + wave * 1024;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
+        const int ox0 = tx * 128;
+        stem_load_patch(p, patch, b, oy, ox0);
+        __syncthreads();                                 // patch (and, the first time, the weights) staged
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-    if (BF16MM) {
-        const uint16_t* wb = reinterpret_cast<const uint16_t*>(wl) + fr * STEM_WROW + 8 * fh;
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        if (BF16MM) {
+            const uint16_t* wb = reinterpret_cast<const uint16_t*>(wl) + fr * STEM_WROW + 8 * fh;
 #pragma unroll
-        for (int step = 0; step < STEM_KB / 16; ++step) {
-            uint16_t ah[8];
+            for (int step = 0; step < STEM_KB / 16; ++step) {
+                uint16_t ah[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {       // lane half fh supplies k = 16 step + 8 fh + j (indices past 146 meet zero weights)
-                const int k0 = 16 * step + j < STEM_K ? 16 * step + j : STEM_K - 1;
-                const int k1 = 16 * step + 8 + j < STEM_K ? 16 * step + 8 + j : STEM_K - 1;
-                ah[j] = f2bf(pa[fh ? stem_koff(k1) : stem_koff(k0)]);
+                for (int j = 0; j < 8; ++j) {       // lane half fh supplies k = 16 step + 8 fh + j (indices past 146 meet zero weights)
+                    const int k0 = 16 * step + j < STEM_K ? 16 * step + j : STEM_K - 1;
+                    const int k1 = 16 * step + 8 + j < STEM_K ? 16 * step + 8 + j : STEM_K - 1;
+                    ah[j] = f2bf(pa[fh ? stem_koff(k1) : stem_koff(k0)]);
+                }
+                const bf16x8 a = __builtin_bit_cast(bf16x8, ah);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + 16 * step);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 32 * STEM_WROW + 16 * step);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
             }
-            const bf16x8 a = __builtin_bit_cast(bf16x8, ah);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + 16 * step);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 32 * STEM_WROW + 16 * step);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
-        }
-    } else {
-    // operands of step kk+1 are read while the MFMAs of step kk run
-    float na = pa[fh ? stem_koff(1) : stem_koff(0)], nb0 = pb[0], nb1 = pb[32];
+        } else {
+            // operands of step kk+1 are read while the MFMAs of step kk run
+            float na = pa[fh ? stem_koff(1) : stem_koff(0)], nb0 = pb[0], nb1 = pb[32];
 #pragma unroll
-    for (int kk = 0; kk < STEM_KPAD / 2; ++kk) {
-        const float a = na, b0 = nb0, b1 = nb1;
-        if (kk + 1 < STEM_KPAD / 2) {
-            const int k0 = 2 * kk + 2, k1 = (2 * kk + 3 < STEM_K) ? 2 * kk + 3 : STEM_K - 1;   // k = 147 multiplies a zero weight row
-            na = pa[fh ? stem_koff(k1) : stem_koff(k0)];
-            nb0 = pb[(2 * kk + 2) * 64];
-            nb1 = pb[(2 * kk + 2) * 64 + 32];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    }
-    const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
-    {
-        // 16-byte epilogue (see k_conv_igemm): the wave's 32 x 64 tile goes through the idle patch LDS and comes back as rows
-        __syncthreads();                                 // every wave is done with the patch / weight LDS
-        float* T = lds + wave * 2048;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
-            T[r * 64 + fr] = acc0[e];
-            T[r * 64 + 32 + fr] = acc1[e];
-        }
-        const int c4 = (lane & 15) * 4;
-        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + c4);
-        if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + c4);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = it * 4 + (lane >> 4);
-            const int ox = ox0 + wave * 32 + r;
-            if (ox >= p.Wo) continue;
-            float4 v = *reinterpret_cast<const float4*>(T + r * 64 + c4);
-            v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.out_bf16) {
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (row0 + ox) * 64 + c4) = pk;
-            } else {
-                *reinterpret_cast<float4*>(p.y + (row0 + ox) * 64 + c4) = v;
+            for (int kk = 0; kk < STEM_KPAD / 2; ++kk) {
+                const float a = na, b0 = nb0, b1 = nb1;
+                if (kk + 1 < STEM_KPAD / 2) {
+                    const int k0 = 2 * kk + 2, k1 = (2 * kk + 3 < STEM_K) ? 2 * kk + 3 : STEM_K - 1;   // k = 147 multiplies a zero weight row
+                    na = pa[fh ? stem_koff(k1) : stem_koff(k0)];
+                    nb0 = pb[(2 * kk + 2) * 64];
+                    nb1 = pb[(2 * kk + 2) * 64 + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
-    if (p.stat) {
-        // BatchNorm statistics of the raw conv output (tile pixels past the row end still see real image columns through the
-        // 7-wide window, so they are masked): column sums per wave (32 pixels), the four waves combined through LDS in a fixed
-        // order, one partial row per tile
-        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        // 16-byte epilogue (see k_conv_igemm): the wave's 32 x 64 tile goes through its LDS region 16 rows at a time and comes back as rows
+        const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * h + e8;                         // (e >> 2) in {2h, 2h+1}: rows 16h .. 16h+15
+                const int rl = (e & 3) + 8 * ((e >> 2) - 2 * h) + 4 * fh;
+                T[rl * 64 + fr] = acc0[e];
+                T[rl * 64 + 32 + fr] = acc1[e];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 4 + (lane >> 4);
+                const int ox = ox0 + wave * 32 + 16 * h + rl;
+                if (ox >= p.Wo) continue;
+                float4 v = *reinterpret_cast<const float4*>(T + rl * 64 + c4);
+                v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.out_bf16) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.y) + (row0 + ox) * 64 + c4) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(p.y + (row0 + ox) * 64 + c4) = v;
+                }
+            }
         }
-        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
-        float* red = lds + 4 * 2048;                     // [4 waves][2][64], behind the epilogue's tile regions
-        if (fh == 0) {
-            red[(wave * 2 + 0) * 64 + fr] = s0; red[(wave * 2 + 0) * 64 + 32 + fr] = s1;
-            red[(wave * 2 + 1) * 64 + fr] = q0; red[(wave * 2 + 1) * 64 + 32 + fr] = q1;
+        if (p.stat) {
+            // BatchNorm statistics of the raw conv output (tile pixels past the row end still see real image columns through the
+            // 7-wide window, so they are masked): column sums per wave (32 pixels), the four waves combined through LDS in a fixed
+            // order, one partial row per tile
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+            }
+            s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+            if (fh == 0) {
+                red[(wave * 2 + 0) * 64 + fr] = s0; red[(wave * 2 + 0) * 64 + 32 + fr] = s1;
+                red[(wave * 2 + 1) * 64 + fr] = q0; red[(wave * 2 + 1) * 64 + 32 + fr] = q1;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int which = tid >> 6, n = tid & 63;
+                const float v = (red[(0 * 2 + which) * 64 + n] + red[(1 * 2 + which) * 64 + n]) + (red[(2 * 2 + which) * 64 + n] + red[(3 * 2 + which) * 64 + n]);
+                p.stat[(int64_t)tile * 128 + which * 64 + n] = v;
+            }
         }
-        __syncthreads();
-        if (tid < 128) {
-            const int which = tid >> 6, n = tid & 63;
-            const float v = (red[(0 * 2 + which) * 64 + n] + red[(1 * 2 + which) * 64 + n]) + (red[(2 * 2 + which) * 64 + n] + red[(3 * 2 + which) * 64 + n]);
-            p.stat[(int64_t)tile * 128 + which * 64 + n] = v;
-        }
+        __syncthreads();                                 // every wave is done with the patch (and `red`) before the next tile's load
     }
 }
 
@@ -2099,14 +2108,14 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
         StemArgs a{};
         a.x = x_nchw; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift; a.relu = relu; a.out_bf16 = out_bf16;
         stem_args(a, d);
-        const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
+        const size_t lds = STEM_FWD_LDS_BYTES;
         // one-time, thread-safe (C++11 static initialisation): allow > 64 KB of dynamic LDS for these kernels
         static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         static const hipError_t attr_once_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)attr_once; (void)attr_once_b;
         a.w = w;
-        if (out_bf16) hipLaunchKernelGGL(k_stem_fwd<true>, dim3(a.ntiles), dim3(256), lds, st, a);     // bf16 backbone: bf16 MFMA, bf16 output
-        else hipLaunchKernelGGL(k_stem_fwd<false>, dim3(a.ntiles), dim3(256), lds, st, a);
+        if (out_bf16) hipLaunchKernelGGL(k_stem_fwd<true>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);     // bf16 backbone: bf16 MFMA, bf16 output
+        else hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
         SD_LAUNCH_CHECK();
         return 0;
     }
@@ -2142,10 +2151,10 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
     StemArgs a{};
     a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
     stem_args(a, d);
-    const size_t lds = (size_t)(SP_ROWS * SP_PITCH + STEM_KPAD * 64) * sizeof(float);
+    const size_t lds = STEM_FWD_LDS_BYTES;
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr_once;
-    hipLaunchKernelGGL(k_stem_fwd<false>, dim3(a.ntiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
     SD_LAUNCH_CHECK();
     return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
                                 partial + (size_t)a.ntiles * 128, stream);
