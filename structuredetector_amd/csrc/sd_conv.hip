@@ -602,20 +602,30 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
         BnRed4 br;
         if (bwd_red) bnred4_init(br, p, n);
-#pragma unroll
-        for (int h = 0; h < MT / 2; ++h) {            // 64 rows of the wave tile at a time
+        // passes of 64 rows (two 32-row LDS regions per wave) or, when the caller only has 8 KB per wave (T1 == nullptr), of 32 rows
+        const bool two = T1 != nullptr;
+        const int npass = two ? MT / 2 : MT, rpp = two ? 64 : 32;
+        for (int h = 0; h < npass; ++h) {
 #pragma unroll
             for (int ni = 0; ni < NTW; ++ni)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    T0[r * 64 + ni * 32 + fr] = acc[2 * h][ni][e];
-                    T1[r * 64 + ni * 32 + fr] = acc[2 * h + 1][ni][e];
+                    // (static accumulator indices: select by pass)
+                    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) {
+                        if (two ? mi == 2 * h : mi == h) v0 = acc[mi][ni][e];
+                        if (two && mi == 2 * h + 1) v1 = acc[mi][ni][e];
+                    }
+                    T0[r * 64 + ni * 32 + fr] = v0;
+                    if (two) T1[r * 64 + ni * 32 + fr] = v1;
                 }
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int rl = it * 4 + (lane >> 4);                      // 0 .. 63 inside this half
-                const int trow = wm0 + h * 64 + rl;
+                if (it * 4 >= rpp) break;
+                const int rl = it * 4 + (lane >> 4);                      // row inside this pass
+                const int trow = wm0 + h * rpp + rl;
                 const int m = row_to_m(trow);
                 if (m < 0) continue;
                 float4 v = *reinterpret_cast<const float4*>((rl < 32 ? T0 : T1) + (rl & 31) * 64 + c4);
@@ -1179,14 +1189,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     // 16-byte epilogue through the idle patch / weight buffers (BN = 128: 16 KB per wave); the barrier makes sure no other
     // wave's (past-the-end) DMA is still landing in them
     __syncthreads();
-    float* T0 = wave < 3 ? Pt + wave * 4096 : Bs;
-    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16, BN == 128>(
+    float* T0 = BN == 128 ? (wave < 3 ? Pt + wave * 4096 : Bs) : Pt + wave * 2048;      // BN = 64: 8 KB per wave, 32-row passes
+    tile_epilogue<BN, WM, WN, MT, NTW, true, BF16, true>(
         p, acc, [&](int row) { return m0 + row; },
         [&](int, int m) {      // half-size residual map (not on this kernel's hot uses: 3x3 / stride 1 layers join full-size residuals)
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
         },
-        tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, T0 + 2048);
+        tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, BN == 128 ? T0 + 2048 : nullptr);
 }
 
 #undef SD_BNRED_TERM
