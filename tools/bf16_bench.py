@@ -13,6 +13,9 @@ from structuredetector_amd.model import Network  # noqa: E402
 
 dev = torch.device("cuda")
 import os
+if os.environ.get("SD_PATCH_BN64"):       # A/B switch: 64-channel layers through the patch-staging kernel too
+    from structuredetector_amd import _lib as _L
+    _L.check(_L.lib().sd_set_option(b"conv_patch_bn64", 1))
 if os.environ.get("SD_NO_PATCH"):          # A/B switch: the layers the patch-staging kernel would take run the generic igemm kernels
     from structuredetector_amd import _lib as _L
     _L.check(_L.lib().sd_set_option(b"conv_patch_min_tiles", 1 << 30))
