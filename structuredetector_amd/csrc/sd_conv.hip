@@ -1873,7 +1873,8 @@ static int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_op
 // k_conv3x3_patch applies: unit-stride 3x3 with pad 1 (fwd: rsign +1, off -1; dgrad: rsign -1, off +1), map width 16..128 (power
 // of two), images that are whole 256-pixel tiles, no split-K, and a grid that fills the chip.  Fills the geometry fields.
 static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false) {
-    if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64 && !bf16) || mode != 0 || a.R != 3      // (bf16: 64-channel tiles gain 2 %) || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+    // (64-channel tiles: on for bf16, where they gain 2 %; opt-in for fp32)
+    if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64 && !bf16) || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
     if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % (bf16 ? 32 : BKB)) return false;
     int l2 = 0;
