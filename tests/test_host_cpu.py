@@ -177,3 +177,24 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     d.Ho = 8
     assert lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d)) >= 64 * 9 * 64 * 4
     assert lib.sd_loss_workspace_bytes(64, 2, 1, 128, 128) > 0
+
+
+def test_set_option_is_host_only_and_rejects_unknown_names():
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    assert lib.sd_set_option(b"conv_patch_min_tiles", 512) == 0
+    assert lib.sd_set_option(b"conv_patch_bn64", 0) == 0
+    assert lib.sd_set_option(b"no_such_option", 1) == -1
+    assert b"no_such_option" in lib.sd_last_error()
+    # kernel choice is host arithmetic on the descriptor: a 3x3 / 1 / 1 conv with a chip-filling grid takes the patch kernel,
+    # a strided one the 256-row tile kernel, a small one the 128-row tiles
+    d = L.ConvDesc()
+    d.B, d.Hi, d.Wi, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad, d.Ho, d.Wo = 64, 64, 64, 128, 128, 3, 3, 1, 1, 64, 64
+    import ctypes as C
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<128, false>"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<128, false>"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
+    d.stride, d.Ho, d.Wo = 2, 32, 32
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2>"
+    d.B, d.stride, d.Ho, d.Wo = 1, 1, 64, 64
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm<128, 0, false>"
