@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void k_nms_tile(Group g0, Group g1, int h, int
         m = fmaxf(m, Hm[r + 4][cc]);
         const float v = S[r + HALO][cc + HALO];
         const bool inside = (y < h) && (x < w);
-        const bool keep = inside && (v == m) && (MODE == 0 || v > min_score);
+        // min_score = fp32(conf) in the annotations-only mode: `>=` keeps a score EQUAL to fp32(conf), which the reference still
+        // emits as a part-less object when double(score) > conf (decoders.py:115-117, e.g. conf = 0.4 -> fp32 0.4000000060);
+        // the fp32 `score > conf` mask of the association stage and the host's double compare decide from there
+        const bool keep = inside && (v == m) && (MODE == 0 || v >= min_score);
         if (MODE == 0) {
             if (inside) dense_out[(((int64_t)b * g0.C + c) * h + y) * w + x] = keep ? v : 0.0f;
         } else if (keep) {

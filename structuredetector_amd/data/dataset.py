@@ -37,6 +37,7 @@ class CropDataset:
         import numpy as np
         from PIL import Image
 
+        from ..utils.misc import clip_annotation
         from ..utils.types import ImageAnnotation
         ann = ImageAnnotation.from_json(self.files[index], self.args.anchor_name)
         path = ann.image_path if ann.image_path.is_absolute() else self.files[index].parent / ann.image_path.name
@@ -44,6 +45,9 @@ class CropDataset:
         ann.img_size = img.size
         W, H = self.args.width, self.args.height
         ann.resize(img.size, (W, H))                                   # Resize transform, transforms.py:47-60
+        # the reference's pipeline ends with Encode, which clips the annotation IN PLACE to the network input
+        # (transforms.py:154, utils.py:364-381) before the Evaluator / the loss see it
+        clip_annotation(ann, (W, H))
         arr = np.asarray(img.resize((W, H), Image.BILINEAR), np.float32) / 255.0
         arr = (arr - np.asarray(_MEAN, np.float32)) / np.asarray(_STD, np.float32)
         return torch.from_numpy(arr).permute(2, 0, 1).contiguous(), ann

@@ -124,6 +124,19 @@ class StepLR:
         self.step_obj.lr = self.base * self.gamma ** (self.epoch // self.step_size)
 
 
+def shard_indices(n, batch, rank, world, seed):
+    """Per-rank batches of sample indices for one epoch of data-parallel training over a real dataset.
+    Every rank draws the SAME permutation (shared seed = base seed + epoch), truncates it to whole global batches
+    (drop_last=True, trainer.py:69, applied to the global batch `batch * world`) and takes the strided shard
+    `[rank::world]`: shards are disjoint, cover the truncated permutation and have the same number of steps on every
+    rank, so the bucketed all-reduces of all ranks pair up step by step."""
+    import numpy as np
+    order = np.random.default_rng(seed).permutation(n)
+    usable = (n // (batch * world)) * batch * world
+    mine = order[:usable][rank::world]
+    return [mine[i:i + batch] for i in range(0, len(mine), batch)]
+
+
 class Trainer:
     """Epoch loop around TrainStep with the reference's knobs (src/sdnet/model/trainer.py:23-237): Adam(lr),
     StepLR(step_size=args.lr_step), validation every second epoch with the Decoder + Evaluator + Loss and the four
@@ -141,6 +154,7 @@ class Trainer:
         from .network import Network
         self.args = args
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.epoch = 0
         self.net = Network(args, pretrained=True)
         if args.pretrained_model:
             self.net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu"))
@@ -171,9 +185,8 @@ class Trainer:
                 images = torch.randn(B, 3, a.height, a.width, device=a.device, generator=gen)
                 yield images, self.encode.render(self.encode.plan(a.width, a.height, *flat), a.device)
         else:
-            order = self.rng.permutation(len(self.dataset))[self.rank::world]
-            for i in range(0, len(order) - B + 1, B):                  # drop_last=True, trainer.py:69
-                items = [self.dataset[int(j)] for j in order[i:i + B]]
+            for idx in shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch):
+                items = [self.dataset[int(j)] for j in idx]
                 images = torch.stack([im for im, _ in items]).to(a.device, non_blocking=True)
                 yield images, self.encode.batch((a.width, a.height), [an for _, an in items], a.device)
 
@@ -219,6 +232,7 @@ class Trainer:
     def train(self):
         steps = 0
         for epoch in range(self.args.epochs):
+            self.epoch = epoch
             running, n = torch.zeros(4, device=self.args.device), 0
             for images, targets in self.batches():
                 running += self.step(images, targets)

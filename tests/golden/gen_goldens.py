@@ -233,6 +233,152 @@ def gen_evaluator(rng):
     print("evaluator:", ev.anchor_eval.reduce(), "|", ev.csi_eval.reduce())
 
 
+def _store_decode(out, md, args, n_img):
+    names = ["score", "ind", "cls", "y", "x"]
+    for nm, v in zip(names, md["topk_anchor"]):
+        out[f"dec_anchor_{nm}"] = v.numpy()
+    for nm, v in zip(names, md["topk_kp"]):
+        out[f"dec_part_{nm}"] = v.numpy()
+    out["dec_embeddings"] = md["embeddings"].numpy()
+    for b in range(n_img):
+        o, p = annotation_to_arrays(args, md["annotation"][b])
+        out[f"ann{b}_objs"] = o; out[f"ann{b}_parts"] = p
+        out[f"raw{b}"] = np.array([[args.parts[k.kind], k.x, k.y, k.score] for k in md["raw_parts"][b]],
+                                  np.float64).reshape(-1, 4)
+
+
+def gen_thresholds(rng):
+    """Threshold edge cases of Decoder.__call__ (decoders.py:78,83,100,115-117,153) with thresholds that
+    fp32 cannot represent: conf 0.4 (fp32 0.4000000060) and dist 0.1 * 64 = 6.4 (fp32 6.4000000954).
+      A1 / P2: score == fp32(0.4) exactly -> masked on the device (fp32 `>`), yet the anchor is still emitted as a
+               part-less object (double(score) > 0.4) and the part stays in raw_parts (double(score) < 0.4 is False);
+      P0: origin exactly fp32(6.4) from anchor A0 -> NOT attached (fp32 `<`); P1: one ulp closer -> attached;
+      P3: sits on the masked anchor A1 -> unattached (A1 is at the +1e6 sentinel); P4: ordinary attachment to A2."""
+    M, N, K, P, hw = 2, 1, 6, 8, 64
+    args = make_args(M, N, K, P)
+    conf, dist = 0.4, 0.1
+    f32 = np.float32
+    c32 = f32(conf)
+    x0 = f32(np.log(0.4 / 0.6))
+    cands = [x0]
+    for _ in range(40):
+        cands.append(np.nextafter(cands[-1], f32(1)))
+    lo = x0
+    for _ in range(40):
+        lo = np.nextafter(lo, f32(-1)); cands.append(lo)
+    cands = np.array(sorted(cands), f32)
+    sig = RU.clamped_sigmoid(torch.from_numpy(cands)).numpy()
+    hits = cands[sig == c32]
+    assert len(hits), "no fp32 logit whose reference sigmoid is exactly fp32(0.4)"
+    l04 = hits[len(hits) // 2]
+    head = np.zeros((1, M + N + 4, hw, hw), f32)
+    head[0, :M + N] = -8.0 + 0.3 * rng.standard_normal((M + N, hw, hw)).astype(f32)
+    d32 = f32(dist * hw)
+    below = np.nextafter(d32, f32(0))
+    anchors = [(0, 0, 10, 3.0), (1, 30, 30, l04), (0, 50, 50, 2.0), (1, 20, 50, -1.0)]          # (class, x, y, logit)
+    parts = [(8, 10, 2.5, d32 - f32(8), f32(0)), (8, 16, 2.4, below - f32(8), f32(-6)), (40, 30, l04, f32(0), f32(0)),
+             (31, 36, 2.2, f32(-1), f32(-6)), (52, 44, 2.1, f32(-2), f32(6))]                  # (x, y, logit, ex, ey)
+    for (c, x, y, lg) in anchors:
+        head[0, c, max(y - 3, 0):y + 4, max(x - 3, 0):x + 4] = -12.0
+        head[0, c, y, x] = lg
+    for (x, y, lg, ex, ey) in parts:
+        head[0, M, max(y - 3, 0):y + 4, max(x - 3, 0):x + 4] = -12.0
+        head[0, M, y, x] = lg
+        head[0, M + N + 2, y, x] = ex; head[0, M + N + 3, y, x] = ey
+    th = torch.from_numpy(head)
+    outputs = {"anchor_hm": th[:, :M], "part_hm": th[:, M:M + N], "offsets": th[:, M + N:M + N + 2], "embeddings": th[:, M + N + 2:]}
+    md = Decoder(args)(outputs, conf_thresh=conf, dist_thresh=dist, return_metadata=True)
+    out = {"meta": META, "cfg": np.array([hw * 4, hw * 4, M, N, K, P], np.int64), "head": head, "conf": np.float64(conf),
+           "dist": np.float64(dist), "planted_cells": np.array([[1, 30, 30], [M, 40, 30]], np.int64), "l04": l04}
+    _store_decode(out, md, args, 1)
+    check_margins(np.sort(RU.nms(md["anchor_hm_sig"])[0].numpy().ravel())[::-1][:K + 1], "thresholds anchors")
+    check_margins(np.sort(RU.nms(md["part_hm_sig"])[0].numpy().ravel())[::-1][:P + 1], "thresholds parts")
+    # the construction must really hit the edges in the reference's own arithmetic
+    ann = md["annotation"][0]
+    by_xy = {(round(o.x / 4), round(o.y / 4)): o for o in ann.objects}
+    assert set(by_xy) == {(0, 10), (30, 30), (50, 50)}, set(by_xy)
+    assert by_xy[(30, 30)].anchor.score == float(c32) and by_xy[(30, 30)].parts == []          # emitted, part-less
+    assert [round(p.y / 4) for p in by_xy[(0, 10)].parts] == [16]                                # P1 attached, P0 (== thresh) not
+    assert len(by_xy[(50, 50)].parts) == 1
+    assert any(k.score == float(c32) for k in md["raw_parts"][0])                                # P2 kept in raw_parts
+    assert (md["topk_anchor"][0] == -1).sum() == K - 2 and (md["topk_kp"][0] > 0).sum() == 4     # masked scores
+    np.savez_compressed(HERE / "decode_thresholds.npz", **out)
+    print("thresholds: objects", [(round(o.x / 4), round(o.y / 4), len(o.parts)) for o in ann.objects])
+
+
+def gen_evaluate16():
+    """BASELINE configs[0]: `evaluate` on 16 synthetic 512x512-input samples stored as PNG + JSON, 2 labels / 1 part,
+    anchor_name=stem.  The reference side of the pipeline is run here exactly as cli/evaluate.py:20-45 composes it, minus
+    the torchvision image ops (absent; the image content does not influence anything below because the head tensors are
+    planted): ImageAnnotation.from_json -> img_size = image size (dataset.py:41-44) -> Resize's annotation.resized
+    (transforms.py:58) -> Encode (clips the annotation in place, transforms.py:154) -> Decoder(return_metadata=True) on a
+    head synthesised from the encoded targets -> Evaluator.accumulate(prediction, annotation, raw_parts, True, True).
+    Stored: the scenes (in ORIGINAL image pixels, incl. out-of-frame keypoints and an empty image), the image sizes, the
+    per-image head seeds + sha256 of every head, and the Evaluator's counters / accuracy lists / CSV."""
+    import hashlib
+    import tempfile
+    M, N, K, P, img = 2, 1, 20, 40, 512
+    args = make_args(M, N, K, P)
+    args.labels = {"bean": 0, "maize": 1}; args.parts = {"leaf": 0}
+    args._r_labels = {0: "bean", 1: "maize"}; args._r_parts = {0: "leaf"}
+    args.width = args.height = img; args.dist_threshold = 0.05; args.csi_threshold = 0.75
+    ev = Evaluator(args)
+    dec_ref, enc_ref = Decoder(args), Encode(args)
+    sizes = [(512, 512), (640, 480), (800, 608), (512, 384)]
+    out = {"meta": META, "cfg": np.array([img, img, M, N, K, P], np.int64), "noise": np.float64(0.5), "reg_noise": np.float64(0.4)}
+    tmp = Path(tempfile.mkdtemp())
+    for n in range(16):
+        rng = np.random.default_rng(7000 + n)
+        iw, ih = sizes[n % 4]
+        objs = O.synthetic_scene(rng, iw, ih, M, N, 4, 10, 0, 3)
+        if n == 3:
+            objs.append((0, -7.5, ih + 3.0, [(0, iw + 12.0, 5.0)]))          # out of frame: clipped by Encode before the Evaluator
+        if n == 5:
+            objs = []
+        js = {"image_path": str(tmp / f"img_{n:02d}.png"), "img_size": [iw, ih],
+              "objects": [{"label": args._r_labels[l], "box": None,
+                           "parts": [{"kind": "stem", "location": {"x": x, "y": y}}]
+                           + [{"kind": args._r_parts[k], "location": {"x": px, "y": py}} for (k, px, py) in ps]}
+                          for (l, x, y, ps) in objs]}
+        f = tmp / f"img_{n:02d}.json"
+        f.write_text(json.dumps(js))
+        ann = RU.ImageAnnotation.from_json(f, "stem")
+        ann.img_size = (iw, ih)                                                # dataset.py:43-44 (PIL image.size)
+        resized = ann.resized((iw, ih), (img, img))                            # transforms.py:58
+        e = enc_ref(torch.zeros(3, img, img), resized)                         # clips `resized` in place
+        enp = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in e.items()}
+        for attempt in range(20):                                              # re-draw the head noise until the ranking is tie-free
+            seed = 9000 + n + 100 * attempt
+            head = O.head_from_targets(np.random.default_rng(seed), enp, M, N, noise=0.5, reg_noise=0.4)
+            th = torch.from_numpy(head)[None]
+            md = dec_ref({"anchor_hm": th[:, :M], "part_hm": th[:, M:M + N], "offsets": th[:, M + N:M + N + 2],
+                          "embeddings": th[:, M + N + 2:]}, return_metadata=True)
+            try:
+                for grp, kk, sig in (("anchors", K, md["anchor_hm_sig"]), ("parts", P, md["part_hm_sig"])):
+                    top = np.sort(RU.nms(sig)[0].numpy().ravel())[::-1][:kk + 1]
+                    check_margins(top, f"evaluate16 {grp} img{n}")
+                    assert (np.abs(top - 0.5) > 1e-5).all(), f"img{n}: a {grp} score sits on the confidence threshold"
+                break
+            except AssertionError as err:
+                print("  re-drawing head", n, "->", err)
+        else:
+            raise AssertionError(f"no tie-free head for image {n}")
+        out[f"head{n}_seed"] = np.int64(seed)
+        ev.accumulate(md["annotation"][0], e["annotation"], md["raw_parts"][0], True, True)
+        so, sp = flat_scene(objs)
+        out[f"scene{n}_objs"] = so; out[f"scene{n}_parts"] = sp; out[f"size{n}"] = np.array([iw, ih], np.int64)
+        out[f"head{n}_sha256"] = np.array(hashlib.sha256(head.tobytes()).hexdigest())
+        out[f"n_pred{n}"] = np.array([len(md["annotation"][0].objects), len(md["raw_parts"][0])], np.int64)
+    for sec, evals in (("anchor", ev.anchor_eval), ("part", ev.part_eval), ("csi", ev.csi_eval), ("classif", ev.classification_eval)):
+        out[f"{sec}_labels"] = np.array(list(evals.labels))
+        out[f"{sec}_counts"] = np.array([[e.tp, e.npos, e.ndet] for _, e in evals.items()], np.int64)
+        for label, e in evals.items():
+            out[f"{sec}_acc_{label}"] = np.array(e.acc, np.float64)
+    out["csv"] = np.array(ev._csv_kps_str())
+    np.savez_compressed(HERE / "evaluate16.npz", **out)
+    print("evaluate16:", ev.anchor_eval.reduce(), "|", ev.part_eval.reduce(), "|", ev.csi_eval.reduce())
+
+
 def gen_fpn_head(rng):
     torch.manual_seed(1234)
     fpn = Fpn(16, 8).train(); head = Head(8, 7)
@@ -255,4 +401,6 @@ if __name__ == "__main__":
     gen_truncation(rng)
     gen_fpn_head(rng)
     gen_evaluator(np.random.default_rng(77))
+    gen_thresholds(np.random.default_rng(404))
+    gen_evaluate16()
     print("goldens written to", HERE)

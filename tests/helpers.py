@@ -21,3 +21,115 @@ def objects_to_arrays(objs):
 
 ENC_KEYS = ["anchor_hm", "part_hm", "anchor_inds", "part_inds", "anchor_offsets", "part_offsets",
             "embeddings", "anchor_mask", "part_mask"]
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[0]: 16 synthetic samples on disk (PNG + JSON, README.md:40-71 schema with "box": null)
+# ---------------------------------------------------------------------------------------------
+EVAL16_LABELS = {"bean": 0, "maize": 1}
+EVAL16_PARTS = {"leaf": 0}
+
+
+def write_evaluate16_dir(g, directory):
+    """Materialise the scenes of tests/golden/evaluate16.npz as img_NN.png + img_NN.json under `directory`
+    (image sizes as recorded; blocky seeded-noise content) and return the 16 planted head tensors (7, 128, 128),
+    rebuilt with the oracle from the same seeds and verified against the golden's sha256 digests."""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    from PIL import Image
+
+    from oracle import sdnet_oracle as O
+    directory = Path(directory)
+    directory.mkdir(parents=True, exist_ok=True)
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    rl = {v: k for k, v in EVAL16_LABELS.items()}
+    rp = {v: k for k, v in EVAL16_PARTS.items()}
+    heads = []
+    for n in range(16):
+        iw, ih = (int(v) for v in g[f"size{n}"])
+        objs = scene_from_flat(g[f"scene{n}_objs"], g[f"scene{n}_parts"])
+        rng = np.random.default_rng(100 + n)
+        small = rng.integers(0, 256, (ih // 16, iw // 16, 3), dtype=np.uint8)
+        Image.fromarray(np.repeat(np.repeat(small, 16, 0), 16, 1)).save(directory / f"img_{n:02d}.png")
+        js = {"image_path": str(directory / f"img_{n:02d}.png"), "img_size": [iw, ih],
+              "objects": [{"label": rl[l], "box": None,
+                           "parts": [{"kind": "stem", "location": {"x": x, "y": y}}]
+                           + [{"kind": rp[k], "location": {"x": px, "y": py}} for (k, px, py) in ps]}
+                          for (l, x, y, ps) in objs]}
+        (directory / f"img_{n:02d}.json").write_text(json.dumps(js))
+        # Resize (transforms.py:58) in double, then Encode (clip + x out/in) via the oracle
+        fx, fy = W / iw, H / ih
+        resized = [(l, x * fx, y * fy, [(k, px * fx, py * fy) for (k, px, py) in ps]) for (l, x, y, ps) in objs]
+        enc = O.encode(W, H, resized, M, N, K, P, 4.0, 0.1)
+        head = O.head_from_targets(np.random.default_rng(int(g[f"head{n}_seed"])), enc, M, N, noise=float(g["noise"]),
+                                   reg_noise=float(g["reg_noise"]))
+        assert hashlib.sha256(head.tobytes()).hexdigest() == str(g[f"head{n}_sha256"]), f"head {n} differs from the golden's"
+        heads.append(head)
+    return heads
+
+
+def assert_evaluator_equals_golden(ev, g):
+    for sec, evals in (("anchor", ev.anchor_eval), ("part", ev.part_eval), ("csi", ev.csi_eval), ("classif", ev.classification_eval)):
+        assert list(evals.labels) == list(g[f"{sec}_labels"])
+        counts = np.array([[e.tp, e.npos, e.ndet] for _, e in evals.items()], np.int64)
+        np.testing.assert_array_equal(counts, g[f"{sec}_counts"], err_msg=sec)
+        for label, e in evals.items():
+            np.testing.assert_array_equal(np.array(e.acc, np.float64), g[f"{sec}_acc_{label}"], err_msg=f"{sec} {label}")
+    assert ev._csv_kps_str() == str(g["csv"])
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder parity: HIP packed result vs oracle.decode_tensors
+# ---------------------------------------------------------------------------------------------
+def safe_ranks(es, rel=2e-6):
+    """Ranks whose score is separated from both neighbours by more than `rel` (relative): GPU and CPU sigmoids differ by a
+    few ulp, so only there is the rank -> peak mapping defined identically on both sides."""
+    es = np.asarray(es)
+    gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / np.maximum(es[:, 1:], 1e-30)
+    safe = np.ones_like(es, bool)
+    safe[:, 1:] &= gap > rel
+    safe[:, :-1] &= gap > rel
+    return safe
+
+
+def assert_decode_matches_oracle(got, t, conf, sig_tol):
+    """got = Decoder.split_packed(...) (numpy), t = oracle.decode_tensors(...).  Bit-exact where the ranking is defined:
+      * per safe rank: flat index, class, refined x / y (same fp32 adds), gathered embedding; scores to `sig_tol`;
+      * grouping, UNCONDITIONALLY for every safe part rank: the part is attached to the same anchor PEAK (class, flat index)
+        or to none on both sides -- comparing the anchor's identity instead of its rank keeps the assertion meaningful when
+        two near-tied anchors swap ranks;
+      * in images whose above-threshold anchors are all safe, additionally the raw `assign` rank array.
+    Returns (parts checked, parts total, images with the strict rank check)."""
+    conf32 = np.float32(conf)
+    safe = {}
+    for grp in ("anchor", "part"):
+        es = t[f"{grp}_out"][..., 2]
+        s = safe[grp] = safe_ranks(es)
+        np.testing.assert_array_equal(got[f"{grp}_ind"][s], t[f"{grp}_inds"][s])
+        for ch in (3, 0, 1):
+            np.testing.assert_array_equal(got[f"{grp}_out"][..., ch][s], t[f"{grp}_out"][..., ch][s])
+        np.testing.assert_allclose(got[f"{grp}_out"][..., 2], es, **sig_tol)
+    ps = safe["part"]
+    np.testing.assert_array_equal(got["part_emb"][ps], t["part_embeddings"][ps])
+    np.testing.assert_array_equal(got["part_out"][..., 4:6][ps], t["part_out"][..., 4:6][ps])
+    B, P = ps.shape
+    want_assign = np.where(t["valid"], t["min_inds"], -1)
+    bi = np.arange(B)[:, None]
+
+    def identity(assign, a_ind, a_cls):
+        a = np.maximum(assign, 0)
+        ident = a_cls[bi, a].astype(np.int64) * (1 << 32) + a_ind[bi, a].astype(np.int64)
+        return np.where(assign >= 0, ident, -1)
+
+    id_got = identity(got["assign"], got["anchor_ind"], got["anchor_out"][..., 3])
+    id_want = identity(want_assign, t["anchor_inds"], t["anchor_out"][..., 3])
+    np.testing.assert_array_equal(id_got[ps], id_want[ps])
+    strict = 0
+    for b in range(B):
+        live = t["anchor_out"][b, :, 2] > conf32
+        if safe["anchor"][b][live].all():
+            np.testing.assert_array_equal(got["assign"][b][ps[b]], want_assign[b][ps[b]])
+            strict += 1
+    return int(ps.sum()), int(ps.size), strict

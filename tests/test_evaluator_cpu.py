@@ -62,3 +62,38 @@ def test_evaluator_merge_is_associative(golden_dir):
     assert Evaluation(0, 0, 3).precision == 0 and Evaluation(0, 3, 0).recall == 0
     u = Evaluations(["a"]) | Evaluations(["b"])
     assert set(u.labels) == {"a", "b"}
+
+
+def test_evaluate16_directory_reader_and_evaluator_vs_reference(golden_dir, tmp_path):
+    """BASELINE configs[0] without the GPU: PNG + JSON on disk -> product CropDataset (resize + clip) -> ORACLE decode of
+    the planted heads -> product Evaluator == the reference's pipeline (tests/golden/evaluate16.npz: reference
+    from_json / Resize / Encode-clip / Decoder / Evaluator).  Pins the reader, the clip and the oracle's
+    decode + assembly on 16 more images; the GPU test runs the same directory through `evaluate` with the HIP decoder."""
+    from oracle import sdnet_oracle as O
+    from structuredetector_amd.data import CropDataset
+    from structuredetector_amd.model import Evaluator
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object
+    from tests.helpers import EVAL16_LABELS, EVAL16_PARTS, assert_evaluator_equals_golden, write_evaluate16_dir
+    g = np.load(golden_dir / "evaluate16.npz")
+    heads = write_evaluate16_dir(g, tmp_path / "valid")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    rl, rp = {v: k for k, v in EVAL16_LABELS.items()}, {v: k for k, v in EVAL16_PARTS.items()}
+    args = Namespace(labels=EVAL16_LABELS, parts=EVAL16_PARTS, width=W, height=H, dist_threshold=0.05, csi_threshold=0.75,
+                     anchor_name="stem")
+    ds = CropDataset(args, tmp_path / "valid")
+    assert len(ds) == 16
+    ev = Evaluator(args)
+    for n in range(16):
+        image, ann = ds[n]
+        assert tuple(image.shape) == (3, H, W) and tuple(ann.img_size) == tuple(int(v) for v in g[f"size{n}"])
+        assert all(0 <= o.x <= W - 1 and 0 <= o.y <= H - 1 for o in ann.objects)           # clipped like Encode does
+        h = heads[n][None]
+        t = O.decode_tensors(h[:, :M], h[:, M:M + N], h[:, M + N:M + N + 2], h[:, M + N + 2:], K, P, 0.5, 0.1)
+        objs = O.assemble_objects(t, 0, 0.5, 4.0, W // 4, H // 4)
+        pred = ImageAnnotation("batch_0", [Object(rl[l], Keypoint("stem", *a), [Keypoint(rp[k], x, y, s) for (k, x, y, s) in ps])
+                                           for (l, a, ps) in objs])
+        raw = [Keypoint(rp[k], x, y, s) for (k, x, y, s) in O.raw_parts(t, 0, 0.5, 4.0, W // 4, H // 4)]
+        assert [len(pred.objects), len(raw)] == list(g[f"n_pred{n}"])
+        ev.accumulate(pred, ann, raw, True, True)
+    assert_evaluator_equals_golden(ev, g)
+    assert ev.anchor_eval.reduce().ndet == 126 and ev.csi_eval.reduce().tp == 87

@@ -143,8 +143,8 @@ def test_stress_config_bf16_backbone_fp32_decode():
     got = dec.split_packed(packed.cpu().numpy(), 1, K, P)
     h = head.cpu().numpy()
     t = O.decode_tensors(h[:, :M], h[:, M:M + N], h[:, M + N:M + N + 2], h[:, M + N + 2:], K, P, 0.5, 0.1)
-    for grp in ("anchor", "part"):
-        es = t[f"{grp}_out"][..., 2]
-        gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / np.maximum(es[:, 1:], 1e-30)
-        safe = np.ones_like(es, bool); safe[:, 1:] &= gap > 2e-6; safe[:, :-1] &= gap > 2e-6
-        np.testing.assert_array_equal(got[f"{grp}_ind"][safe], t[f"{grp}_inds"][safe])
+    # indices on the safe ranks AND the grouping of every safe part, unconditionally (tests/helpers.py); the dense
+    # >= 64-object workload of this config is asserted in test_gpu_parity.py::test_decoder_dense_stress_scenes_grouping_vs_oracle
+    from tests.helpers import assert_decode_matches_oracle
+    checked, total, _ = assert_decode_matches_oracle(got, t, 0.5, dict(rtol=4e-7, atol=0))
+    assert checked >= 0.9 * total

@@ -64,3 +64,57 @@ def test_stress_config_shapes():
     assert int(tgt["anchor_mask"].sum()) >= 64
     anns = Decoder(args)(out)
     assert len(anns) == 1
+
+
+def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monkeypatch, capsys):
+    """BASELINE configs[0]: `evaluate` over a directory of 16 PNG + JSON samples (2 labels / 1 part, anchor_name=stem), read
+    by the product CropDataset, decoded by the HIP decoder, scored by the product Evaluator -- against the reference's own
+    from_json / Resize / Encode-clip / Decoder / Evaluator on the same head tensors (tests/golden/evaluate16.npz).  The head
+    tensors are planted (a stand-in Network returns them in file order: a random-init backbone has nothing to detect), so the
+    counters, accuracy lists and the CSV must match the reference EXACTLY; the real backbone then runs over the same directory
+    for the plumbing, and its first head is checked against the oracle network on the image the reader produced."""
+    from oracle import sdnet_oracle as O
+    from structuredetector_amd.cli import evaluate
+    from structuredetector_amd.data import CropDataset
+    from structuredetector_amd.model import Network
+    from tests.helpers import assert_evaluator_equals_golden, write_evaluate16_dir
+    g = np.load(golden_dir / "evaluate16.npz")
+    heads = write_evaluate16_dir(g, tmp_path / "valid")
+    (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
+    argv = ["--valid_dir", str(tmp_path / "valid"), "-s", "stem", "--labels", str(tmp_path / "labels.json"),
+            "--save_csv_eval", str(tmp_path / "kps.csv")]
+    seen = []
+
+    class PlantedNetwork(torch.nn.Module):
+        def __init__(self, args, *a, **kw):
+            super().__init__()
+            self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            assert tuple(x.shape) == (1, 3, 512, 512) and x.is_cuda
+            seen.append(x)
+            h = torch.from_numpy(heads[len(seen) - 1])[None].to(x.device)
+            return {"anchor_hm": h[:, :2], "part_hm": h[:, 2:3], "offsets": h[:, 3:5], "embeddings": h[:, 5:7]}
+
+    monkeypatch.setattr(evaluate, "Network", PlantedNetwork)
+    ev = evaluate.main(argv)
+    assert len(seen) == 16
+    assert_evaluator_equals_golden(ev, g)
+    assert (tmp_path / "kps.csv").read_text() == str(g["csv"])
+    out = capsys.readouterr().out
+    assert "Anchor Location" in out and "CSI" in out
+    monkeypatch.undo()
+
+    # the real network over the same directory (seeded random checkpoint through --load_model)
+    ref = O.build_reference_network(2, 1, seed=16)
+    torch.save(ref.state_dict(), tmp_path / "seeded.pth")
+    ev2 = evaluate.main(argv[:-2] + ["-o", str(tmp_path / "seeded.pth")])
+    assert ev2.anchor_eval.reduce().npos == ev.anchor_eval.reduce().npos == 110
+    args = evaluate.Arguments().parse(argv[:-2])
+    image, _ = CropDataset(args, tmp_path / "valid")[1]                    # a 640x480 PNG resized to 512x512 and normalised
+    net = Network(args, raw_output=True)
+    net.load_state_dict(torch.load(tmp_path / "seeded.pth", map_location="cpu"))
+    with torch.no_grad():
+        got = net.eval().to("cuda")(image[None].to("cuda")).cpu()
+        want = ref.eval()(image[None])
+    assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()

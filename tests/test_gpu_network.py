@@ -313,6 +313,23 @@ def test_network_eval_forward():
     assert out["part_hm"]._base is out["anchor_hm"]._base
 
 
+def test_network_eval_forward_bs1_512_vs_oracle():
+    """BASELINE configs[1] geometry end to end: batch 1, 512x512, eval mode -- every conv takes the split-K path (the tile grid
+    of one image cannot fill 256 CUs) -- whole network vs the oracle, 1e-4 of the output range (north_star), also as a
+    hipGraph replay and as the dict of views the Decoder consumes."""
+    ref, net = _pair(seed=7)
+    x = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        want = ref.eval()(x)
+        got = net.eval()(x.to(DEV))
+        assert got.shape == want.shape == (1, 7, 128, 128)
+        close(got.cpu(), want, 1e-4)
+        run = net.graphed(x.to(DEV))
+        close(run(x.to(DEV)).cpu(), want, 1e-4)
+        x2 = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(13))
+        close(run(x2.to(DEV)).cpu(), ref(x2), 1e-4)
+
+
 def test_network_train_forward_backward():
     ref, net = _pair(seed=3)
     g = torch.Generator().manual_seed(2)

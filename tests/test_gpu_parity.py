@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import sdnet_oracle as O
-from tests.helpers import ENC_KEYS, objects_to_arrays, scene_from_flat
+from tests.helpers import ENC_KEYS, assert_decode_matches_oracle, objects_to_arrays, safe_ranks, scene_from_flat
 from tests.test_host_cpu import make_args, to_annotation
 
 pytestmark = pytest.mark.gpu
@@ -145,20 +145,47 @@ def test_decoder_vs_oracle_random_scenes(B, img, M, N, K, P):
     packed, (b_, k_, p_, h, w) = dec.decode_packed(head_views(dev(head), M, N), 0.5, 0.1)
     got = dec.split_packed(packed.cpu().numpy(), B, K, P)
     t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
-    for grp, n in (("anchor", K), ("part", P)):
-        es = t[f"{grp}_out"][..., 2]
-        gap = np.abs(np.diff(es.astype(np.float64), axis=1)) / np.maximum(es[:, 1:], 1e-30)
-        safe = np.ones_like(es, bool)
-        safe[:, 1:] &= gap > 2e-6; safe[:, :-1] &= gap > 2e-6
-        np.testing.assert_array_equal(got[f"{grp}_ind"][safe], t[f"{grp}_inds"][safe])
-        np.testing.assert_array_equal(got[f"{grp}_out"][..., 3][safe], t[f"{grp}_out"][..., 3][safe])
-        np.testing.assert_array_equal(got[f"{grp}_out"][..., 0][safe], t[f"{grp}_out"][..., 0][safe])
-        np.testing.assert_array_equal(got[f"{grp}_out"][..., 1][safe], t[f"{grp}_out"][..., 1][safe])
-        np.testing.assert_allclose(got[f"{grp}_out"][..., 2], es, **SIG_TOL)
-        if safe.all():
-            assign = np.where(t["valid"], t["min_inds"], -1)
-            np.testing.assert_array_equal(got["assign"], assign)
-            np.testing.assert_array_equal(got["part_emb"], t["part_embeddings"])
+    checked, total, strict = assert_decode_matches_oracle(got, t, 0.5, SIG_TOL)
+    assert checked >= 0.9 * total and (t["valid"].sum() > 0 or K < 4)
+
+
+def test_decoder_dense_stress_scenes_grouping_vs_oracle():
+    """BASELINE configs[4] workload: 1024x1024, 8 labels / 8 parts, K=128, P=512, 64-96 objects per image (dense scenes:
+    >= 11 k NMS survivors per list -> the radix-select path), targets rendered by the product Encode, head synthesised from
+    them, sd_decode vs the oracle: indices on the safe ranks and the GROUPING of every safe part (no all-or-nothing guard)."""
+    from structuredetector_amd.data import Decoder, Encode
+    from structuredetector_amd.data.synthetic import synthetic_batch
+    B, img, M, N, K, P = 4, 1024, 8, 8, 128, 512
+    args = make_args(M, N, K, P, device=torch.device(DEV))
+    rng = np.random.default_rng(4096)
+    enc = Encode(args)
+    tgt = enc.render(enc.plan(img, img, *synthetic_batch(rng, B, img, img, M, N, 64, 96)), DEV)
+    tgt = {k: v.cpu().numpy() for k, v in tgt.items() if isinstance(v, torch.Tensor)}
+    assert tgt["anchor_mask"].sum(1).min() >= 64
+    head = np.stack([O.head_from_targets(rng, {k: v[b] for k, v in tgt.items()}, M, N, noise=0.3) for b in range(B)])
+    dec = Decoder(args)
+    t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+    packed, _ = dec.decode_packed(head_views(dev(head), M, N), 0.5, 0.1, exact_topk=True)
+    got = dec.split_packed(packed.cpu().numpy(), B, K, P)
+    checked, total, strict = assert_decode_matches_oracle(got, t, 0.5, SIG_TOL)
+    attached = int(t["valid"].sum())
+    assert checked >= 0.95 * total, (checked, total)
+    assert attached >= 64 * B, attached                           # really dense: hundreds of part -> anchor links asserted
+    assert strict >= 1, "no image had all its live anchors on safe ranks: raise B or lower the noise"
+    # Decoder.__call__ without metadata (fast selection: peaks below fp32(conf) never enter the sort) -> same objects
+    anns = dec(head_views(dev(head), M, N))
+    compared = 0
+    for b in range(B):
+        live_a, live_p = t["anchor_out"][b, :, 2] > np.float32(0.5), t["part_out"][b, :, 2] > np.float32(0.5)
+        if not (safe_ranks(t["anchor_out"][..., 2])[b][live_a].all() and safe_ranks(t["part_out"][..., 2])[b][live_p].all()):
+            continue                                              # a near-tie may swap two objects / parts in the lists
+        o, p = annotation_arrays(args, anns[b])
+        ro, rp = objects_to_arrays(O.assemble_objects(t, b, 0.5, 4.0, img // 4, img // 4))
+        assert o.shape == ro.shape and p.shape == rp.shape and len(o) >= 64
+        np.testing.assert_array_equal(o[:, :3], ro[:, :3]); np.testing.assert_allclose(o[:, 3], ro[:, 3], **SIG_TOL)
+        np.testing.assert_array_equal(p[:, :4], rp[:, :4]); np.testing.assert_allclose(p[:, 4], rp[:, 4], **SIG_TOL)
+        compared += 1
+    assert compared >= 1
 
 
 def test_decode_group_matches_fused():
@@ -354,3 +381,56 @@ def test_nms_idempotent_and_sorted_full_size():
     picked = n1.view(64, 3, -1)[torch.arange(64, device=DEV)[:, None], cls.long(), ind]
     assert torch.equal(picked, sc)                                   # (cls, ind) really address those scores
     assert torch.equal(ys * 128 + xs, ind.float())
+
+
+# ------------------------------------------------------------------------------------------ thresholds that fp32 cannot represent
+def test_decoder_thresholds_vs_golden(golden_dir):
+    """conf 0.4 (fp32 0.4000000060) / dist 0.1*64 (fp32 6.4000000954) with scores and distances planted exactly ON the
+    rounded thresholds (tests/golden/decode_thresholds.npz, produced by the reference's Decoder): the anchor whose score
+    equals fp32(conf) is masked for the association yet emitted as a part-less object, the part with that score stays in
+    raw_parts, the part exactly fp32(dist) away is not attached and the one an ulp closer is -- in BOTH selection modes
+    (`return_metadata=True`: exact top-k; plain call: peaks below fp32(conf) dropped before the sort, `>=` keeps equality)."""
+    from structuredetector_amd.data import Decoder
+    from structuredetector_amd.utils import clamped_sigmoid
+    g = np.load(golden_dir / "decode_thresholds.npz")
+    W, H, M, N, K, P = (int(v) for v in g["cfg"])
+    conf, dist = float(g["conf"]), float(g["dist"])
+    head = g["head"].copy()
+    c32 = np.float32(conf)
+    # the planted logit must give EXACTLY fp32(0.4) through the GPU's sigmoid too (it may differ from the CPU's by an ulp):
+    # pick, among the neighbouring fp32 logits, one for which the reference's CPU sigmoid and the HIP sigmoid both do
+    cands = [np.float32(g["l04"])]
+    for step in (1.0, -1.0):
+        v = np.float32(g["l04"])
+        for _ in range(12):
+            v = np.nextafter(v, np.float32(step)); cands.append(v)
+    cands = np.array(sorted(cands), np.float32)
+    both = (O.clamped_sigmoid(cands) == c32) & (clamped_sigmoid(dev(cands)).cpu().numpy() == c32)
+    assert both.any(), "no logit maps to fp32(0.4) under both sigmoids"
+    l04 = cands[both][both.sum() // 2]
+    for (c, x, y) in g["planted_cells"]:
+        assert head[0, c, y, x] == g["l04"]
+        head[0, c, y, x] = l04
+    args = make_args(M, N, K, P)
+    dec = Decoder(args)
+    md = dec(head_views(dev(head), M, N), conf_thresh=conf, dist_thresh=dist, return_metadata=True)
+    for grp, key in (("anchor", "topk_anchor"), ("part", "topk_kp")):
+        s, i, c, y, x = (t.cpu().numpy() for t in md[key])
+        ref_s = g[f"dec_{grp}_score"]
+        pos = ref_s > 0
+        np.testing.assert_array_equal(s > 0, pos)                                   # same masked / unmasked split (fp32 `>`)
+        np.testing.assert_array_equal(i[pos], g[f"dec_{grp}_ind"][pos])
+        np.testing.assert_array_equal(x[pos], g[f"dec_{grp}_x"][pos]); np.testing.assert_array_equal(y[pos], g[f"dec_{grp}_y"][pos])
+    fast = dec(head_views(dev(head), M, N), conf_thresh=conf, dist_thresh=dist)
+    for ann in (md["annotation"][0], fast[0]):
+        o, p = annotation_arrays(args, ann)
+        ro, rp = g["ann0_objs"], g["ann0_parts"]
+        assert o.shape == ro.shape and p.shape == rp.shape
+        np.testing.assert_array_equal(o[:, :3], ro[:, :3]); np.testing.assert_allclose(o[:, 3], ro[:, 3], **SIG_TOL)
+        np.testing.assert_array_equal(p[:, :4], rp[:, :4])
+        on_edge = o[:, 3] == float(c32)
+        assert on_edge.sum() == 1 and not (p[:, 0] == np.nonzero(on_edge)[0][0]).any()   # emitted, and without parts
+    r = np.array([[args.parts[k.kind], k.x, k.y, k.score] for k in md["raw_parts"][0]], np.float64).reshape(-1, 4)
+    assert r.shape == g["raw0"].shape
+    np.testing.assert_array_equal(r[:, :3], g["raw0"][:, :3])
+    assert (r[:, 3] == float(c32)).sum() == 1

@@ -198,3 +198,16 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2>"
     d.B, d.stride, d.Ho, d.Wo = 1, 1, 64, 64
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm<128, 0, false>"
+
+
+def test_network_parameter_count_matches_published_resnet34():
+    """a4 pin: the trunk the reference keeps from torchvision's resnet34 (network.py:43-50) has 21 797 672 - 513 000 (fc)
+    = 21 284 672 parameters; FPN + head bring the 2-label / 1-part network to 21 852 103 (21.852 M)."""
+    from structuredetector_amd.model import Network
+    net = Network(Namespace(labels={"bean": 0, "maize": 1}, parts={"leaf": 0}, fpn_depth=128), pretrained=False)
+    trunk = sum(p.numel() for name, p in net.named_parameters() if name.split(".")[0] in ("adpater", "down1", "down2", "down3", "down4"))
+    assert trunk == 21_284_672
+    assert sum(p.numel() for p in net.parameters()) == 21_852_103
+    from oracle import sdnet_oracle as O
+    ref = O.build_reference_network(2, 1)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}

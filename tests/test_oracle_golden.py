@@ -56,12 +56,15 @@ def test_encode_truncation(golden_dir):
             np.testing.assert_array_equal(e[k], g[f"{name}_{k}"], err_msg=f"{name} {k}")
 
 
-@pytest.mark.parametrize("tag", SCENES)
+@pytest.mark.parametrize("tag", SCENES + ["decode_thresholds"])
 def test_decode(golden_dir, tag):
+    """decode_thresholds: conf 0.4 / dist 0.1*64 are not fp32-representable and scores / distances are planted exactly ON
+    the rounded thresholds: fp32 `>` / `<` on the device side, double compares in the host assembly."""
     g = np.load(golden_dir / f"{tag}.npz")
     W, H, M, N, K, P = (int(v) for v in g["cfg"])
     head = g["head"]
-    t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+    conf, dist = (float(g["conf"]), float(g["dist"])) if "conf" in g else (0.5, 0.1)
+    t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, conf, dist)
     for grp, key_out, key_inds, key_sm, n in (("anchor", "anchor_out", "anchor_inds", "anchor_scores_masked", K),
                                               ("part", "part_out", "part_inds", "part_scores_masked", P)):
         gs = g[f"dec_{grp}_score"]          # masked scores (-1 where score <= conf)
@@ -76,11 +79,15 @@ def test_decode(golden_dir, tag):
     np.testing.assert_array_equal(t["part_embeddings"][pos], g["dec_embeddings"][pos])
     out_w, out_h = W // 4, H // 4
     for b in range(head.shape[0]):
-        o, p = objects_to_arrays(O.assemble_objects(t, b, 0.5, 4.0, out_w, out_h))
+        o, p = objects_to_arrays(O.assemble_objects(t, b, conf, 4.0, out_w, out_h))
         np.testing.assert_array_equal(o, g[f"ann{b}_objs"])
         np.testing.assert_array_equal(p, g[f"ann{b}_parts"])
-        r = np.array(O.raw_parts(t, b, 0.5, 4.0, out_w, out_h), np.float64).reshape(-1, 4)
+        r = np.array(O.raw_parts(t, b, conf, 4.0, out_w, out_h), np.float64).reshape(-1, 4)
         np.testing.assert_array_equal(r, g[f"raw{b}"])
+    if tag == "decode_thresholds":
+        o = g["ann0_objs"]
+        assert len(o) == 3 and (o[:, 3] == float(np.float32(0.4))).sum() == 1          # the part-less anchor ON the threshold
+        assert (g["raw0"][:, 3] == float(np.float32(0.4))).sum() == 1                 # the part ON the threshold stays in raw_parts
 
 
 @pytest.mark.parametrize("tag", SCENES)
@@ -117,8 +124,15 @@ def test_reference_network_schema():
     assert sd["up4.lateral.weight"].shape == (128, 64, 1, 1)
     assert sd["up3.conv.0.weight"].shape == (128, 128, 3, 3)
     assert sd["head.conv.weight"].shape == (7, 128, 1, 1)
+    # exact counts: torchvision's published resnet34 has 21 797 672 parameters, its fc layer 512*1000 + 1000 = 513 000;
+    # the trunk the reference keeps (network.py:43-50) is therefore 21 284 672, and FPN (up1 65 664 + up2 180 608 +
+    # up3 164 224 + up4 156 032) + head (7*128 + 7 = 903) bring the 2-label / 1-part network to 21 852 103
+    trunk = sum(p.numel() for name, p in net.named_parameters() if name.split(".")[0] in ("adpater", "down1", "down2", "down3", "down4"))
+    assert trunk == 21_797_672 - 513_000 == 21_284_672
     n_params = sum(p.numel() for p in net.parameters())
-    assert n_params == 21_852_295 or abs(n_params - 21.852e6) < 2e3
+    assert n_params == 21_852_103
+    per_stage = {k: sum(p.numel() for name, p in net.named_parameters() if name.startswith(k + ".")) for k in ("adpater", "down1", "down2", "down3", "down4")}
+    assert per_stage == {"adpater": 9_536, "down1": 221_952, "down2": 1_116_416, "down3": 6_822_400, "down4": 13_114_368}
     with torch.no_grad():
         y = net.eval()(torch.zeros(1, 3, 64, 64))
     assert y.shape == (1, 7, 16, 16)
