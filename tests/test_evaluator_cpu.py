@@ -96,4 +96,4 @@ def test_evaluate16_directory_reader_and_evaluator_vs_reference(golden_dir, tmp_
         assert [len(pred.objects), len(raw)] == list(g[f"n_pred{n}"])
         ev.accumulate(pred, ann, raw, True, True)
     assert_evaluator_equals_golden(ev, g)
-    assert ev.anchor_eval.reduce().ndet == 126 and ev.csi_eval.reduce().tp == 87
+    assert ev.anchor_eval.reduce().ndet == 125 and ev.csi_eval.reduce().tp == 88
