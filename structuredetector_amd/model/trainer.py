@@ -74,6 +74,7 @@ class TrainStep:
         self.ranges = net.stage_ranges()
         self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
         self.stats = LossStats()
+        self.exchange_enabled = True     # False: skip the all-reduce (bench.py measures the exposed communication time with it)
 
     def sync_parameters(self):
         """Identical initial weights on every rank (rank 0's)."""
@@ -81,6 +82,81 @@ class TrainStep:
             dist.broadcast(self.net.flat_params, 0, group=self.pg)
             for b in self.net.buffers():
                 dist.broadcast(b, 0, group=self.pg)
+
+    def _exchange_hooks(self):
+        """(on_stage, finish): on_stage(name) starts the all-reduce of one gradient bucket (called by the backward schedule as
+        soon as that parameter group's gradients are complete), finish() joins every bucket before the Adam launch."""
+        net = self.net
+        if self.world == 1 or not self.exchange_enabled:
+            return None, (lambda: None)
+        if self.rccl is not None:
+            return (lambda name: self.rccl.all_reduce(net.flat_grads, *self.ranges[name])), self.rccl.wait
+        works = []
+
+        def on_stage(name):
+            lo, hi = self.ranges[name]
+            works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
+
+        def finish():
+            for w in works:
+                w.wait()
+        return on_stage, finish
+
+    STAGES = ("fpn_head", "down4", "down3", "down2", "down1_stem")       # order in which the backward completes the buckets
+
+    def verify_exchange(self):
+        """Self-check of the data-parallel exchange THROUGH THE PATH THE STEP USES (same buckets, same binding, same streams):
+        every rank fills its flat gradient buffer with rank+1, the five buckets are summed, and every element must read
+        world*(world+1)/2 on every rank.  Returns the report bench.py prints; raises if a rank is missing from the sum."""
+        net, n = self.net, self.world
+        report = {"ranks": n, "exchange": self.exchange_name(), "buckets": {k: self.ranges[k][1] - self.ranges[k][0] for k in self.STAGES}}
+        if n == 1:
+            report["check"] = "single rank: no exchange"
+            return report
+        rank = dist.get_rank(self.pg)
+        net.flat_grads.fill_(float(rank + 1))
+        on_stage, finish = self._exchange_hooks()
+        for name in self.STAGES:
+            on_stage(name)
+        finish()
+        want = n * (n + 1) / 2
+        lo, hi = float(net.flat_grads.min()), float(net.flat_grads.max())
+        net.flat_grads.zero_()
+        if lo != want or hi != want:
+            raise L.SdError(f"gradient exchange check failed on rank {rank}: sum of (rank+1) over {n} ranks should be {want}, got [{lo}, {hi}]")
+        report["check"] = f"ok: sum(rank+1) == {want:g} in all {len(self.STAGES)} buckets on every rank"
+        return report
+
+    def exchange_name(self):
+        if self.world == 1:
+            return "none"
+        if self.rccl is not None:
+            return "sd_allreduce (RCCL via C ABI)"
+        return f"torch.distributed {dist.get_backend(self.pg)}"
+
+    def time_buckets(self, iters=5):
+        """Isolated duration of each bucket's all-reduce in microseconds (stream events around a blocking all-reduce of the
+        bucket, nothing else running; median of `iters`): what the overlap with the backward kernels has to hide."""
+        if self.world == 1:
+            return {}
+        net, out = self.net, {}
+        for name in self.STAGES:
+            lo, hi = self.ranges[name]
+            ts = []
+            for _ in range(iters + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if self.rccl is not None:
+                    self.rccl.all_reduce(net.flat_grads, lo, hi); self.rccl.wait()
+                else:
+                    dist.all_reduce(net.flat_grads[lo:hi], group=self.pg)
+                e1.record(); e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts = sorted(ts[1:])
+            out[name] = {"floats": hi - lo, "us": round(ts[len(ts) // 2], 1),
+                         "algbw_GBps": round((hi - lo) * 4 / (ts[len(ts) // 2] * 1e-6) / 1e9, 1)}
+        net.flat_grads.zero_()
+        return out
 
     def __call__(self, images, targets):
         """One optimizer step; returns the loss vector [total, hm, offset, embedding] as a device tensor."""
@@ -90,21 +166,9 @@ class TrainStep:
         cfg = loss_config(self.args, M, N, targets["anchor_inds"].shape[1], targets["part_inds"].shape[1])
         desc, keep, out8 = loss_forward(head, targets, cfg)
         dhead = loss_backward(desc, out8, self.one, tuple(head.shape))
-        works = []
-        if self.rccl is not None:
-            def on_stage(name):
-                self.rccl.all_reduce(net.flat_grads, *self.ranges[name])
-        elif self.world > 1:
-            def on_stage(name):
-                lo, hi = self.ranges[name]
-                works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
-        else:
-            on_stage = None
+        on_stage, finish = self._exchange_hooks()
         net.backward_from(tape, dhead, on_stage)
-        for w in works:
-            w.wait()
-        if self.rccl is not None:
-            self.rccl.wait()
+        finish()
         self.step_count += 1
         L.check(L.lib().sd_adam_step(net.flat_params.data_ptr(), net.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), net.flat_params.numel(), self.step_count, self.lr, self.betas[0],

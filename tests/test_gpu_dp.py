@@ -128,3 +128,69 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["exchange"] == "torch.distributed gloo" and "roofline" in rec
+    # the line evidences its own exchange: every rank was in the sum, per-bucket durations, exposed communication time
+    r = rec["rccl"]
+    assert r["ranks"] == 2 and r["check"].startswith("ok: sum(rank+1) == 3") and r["backend"] == "gloo"
+    assert set(r["buckets_isolated"]) == {"fpn_head", "down4", "down3", "down2", "down1_stem"}
+    assert sum(b["floats"] for b in r["buckets_isolated"].values()) * 4 == r["allreduce_bytes_per_step"] > 87_000_000
+    assert "exposed_comm_ms" in r and r["ms_per_step_without_exchange"] > 0
+
+
+def test_verify_exchange_detects_a_missing_rank(monkeypatch):
+    """TrainStep.verify_exchange on one rank reports 'no exchange'; with a world of 2 whose all-reduce does not happen (hooks
+    stubbed out) the buffer holds rank+1 = 1 instead of sum(rank+1) = 3 and the check raises."""
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.model import trainer
+    args, net, x, tgt = _setup(0)
+    step = trainer.TrainStep(net, args)
+    assert step.verify_exchange()["check"].startswith("single rank")
+    step.world = 2
+    monkeypatch.setattr(trainer.dist, "get_rank", lambda *a, **k: 0)
+    monkeypatch.setattr(trainer.dist, "get_backend", lambda *a, **k: "stub")
+    step._exchange_hooks = lambda: ((lambda name: None), (lambda: None))
+    with pytest.raises(L.SdError, match="exchange check failed"):
+        step.verify_exchange()
+
+
+def _nccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from structuredetector_amd.data import Encode
+        from structuredetector_amd.data.synthetic import synthetic_batch
+        from structuredetector_amd.model import Network
+        from structuredetector_amd.model.trainer import TrainStep
+        from tests.test_host_cpu import make_args
+        dev = torch.device("cuda", rank)
+        args = make_args(2, 1, 20, 40, device=dev, learning_rate=1e-3)
+        torch.manual_seed(0)
+        net = Network(args, pretrained=False).to(dev).train()
+        enc = Encode(args)
+        tgt = enc.render(enc.plan(128, 128, *synthetic_batch(np.random.default_rng(100 + rank), 2, 128, 128, 2, 1)), dev)
+        x = torch.randn(2, 3, 128, 128, device=dev, generator=torch.Generator(dev).manual_seed(200 + rank))
+        res = {}
+        for exchange in ("torch", "rccl"):
+            step = TrainStep(net, args, exchange=exchange)
+            step.sync_parameters()
+            res[exchange + "_check"] = step.verify_exchange()["check"]
+            step(x, tgt)
+            torch.cuda.synchronize()
+            res[exchange] = net.flat_params.cpu()
+            if step.rccl is not None:
+                step.rccl.close()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on boxes with >= 2 GPUs")
+def test_two_rank_step_over_rccl_when_two_gpus_are_present():
+    """The real exchange (torch.distributed 'nccl' = RCCL, and the C-ABI sd_allreduce_* binding) with one rank per GPU: both
+    self-checks pass and both ranks hold bit-identical weights after a step."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(world, port, out), nprocs=world, join=True)
+    for exchange in ("torch", "rccl"):
+        assert out[0][exchange + "_check"].startswith("ok") and out[1][exchange + "_check"].startswith("ok")
+        assert torch.equal(out[0][exchange], out[1][exchange]), f"ranks diverged with exchange={exchange}"
