@@ -594,9 +594,10 @@ class Network(nn.Module):
     def __init__(self, args, pretrained=True, raw_output: bool = False):
         super().__init__()
         self.raw_output = raw_output
-        # `--amp` (args.use_amp): the reference autocasts the TRAINING forward (trainer.py:115-121); here it selects the
-        # bf16 backbone for inference (BASELINE stress config).  Training always runs the fp32 kernels.
-        self.bf16_inference = bool(getattr(args, "use_amp", False))
+        # bf16 backbone for the eval-mode forward (BASELINE stress config: "bf16 backbone + fp32 decode"): `--bf16_inference`, or
+        # `--amp` -- the reference autocasts its validation forward under that flag too (trainer.py:141-155).  What `--amp` means
+        # for the TRAINING step (trainer.py:115-121) is decided by the Trainer, not here.
+        self.bf16_inference = bool(getattr(args, "use_amp", False) or getattr(args, "bf16_inference", False))
         self.label_count = len(args.labels)  # M
         self.part_count = len(args.parts)  # N
         self.out_channels = self.label_count + self.part_count + 4

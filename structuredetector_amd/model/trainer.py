@@ -20,6 +20,9 @@ from .. import _lib as L
 from .loss import LossStats, loss_backward, loss_config, loss_forward
 
 
+BF16_TRAINING = False      # flipped when the bf16 data- / weight-gradient kernels exist (autocast semantics of trainer.py:115-121)
+
+
 class RcclExchange:
     """Gradient sum straight through the C ABI (`sd_allreduce_*`, RCCL): what a host without torch.distributed would
     call.  The 128-byte RCCL id travels over the already initialised process group's store (any host channel works);
@@ -75,6 +78,23 @@ class TrainStep:
         self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
         self.stats = LossStats()
         self.exchange_enabled = True     # False: skip the all-reduce (bench.py measures the exposed communication time with it)
+
+    # ---- true resume: the reference saves weights only (trainer.py:226-237), so a run cannot continue --------
+    def state_dict(self):
+        """Optimizer state of the flat-buffer Adam: both moment buffers, the step count (bias correction) and the learning rate.
+        Tensors are copies on the host; `Network.state_dict()` carries the weights and BatchNorm buffers."""
+        return {"exp_avg": self.exp_avg.detach().cpu().clone(), "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(),
+                "step_count": int(self.step_count), "lr": float(self.lr), "betas": tuple(self.betas), "eps": float(self.eps),
+                "flat_numel": int(self.net.flat_params.numel())}
+
+    def load_state_dict(self, state):
+        if int(state["flat_numel"]) != self.net.flat_params.numel():
+            raise L.SdError(f"optimizer state is for a flat parameter buffer of {state['flat_numel']} floats, this network has "
+                            f"{self.net.flat_params.numel()} (different labels / parts / fpn_depth?)")
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.step_count, self.lr = int(state["step_count"]), float(state["lr"])
+        self.betas, self.eps = tuple(state["betas"]), float(state["eps"])
 
     def sync_parameters(self):
         """Identical initial weights on every rank (rank 0's)."""
@@ -187,6 +207,13 @@ class StepLR:
         self.epoch += 1
         self.step_obj.lr = self.base * self.gamma ** (self.epoch // self.step_size)
 
+    def state_dict(self):
+        return {"epoch": self.epoch, "base": self.base, "step_size": self.step_size, "gamma": self.gamma}
+
+    def load_state_dict(self, state):
+        self.epoch, self.base, self.step_size, self.gamma = int(state["epoch"]), float(state["base"]), int(state["step_size"]), float(state["gamma"])
+        self.step_obj.lr = self.base * self.gamma ** (self.epoch // self.step_size)
+
 
 def shard_indices(n, batch, rank, world, seed):
     """Per-rank batches of sample indices for one epoch of data-parallel training over a real dataset.
@@ -217,6 +244,11 @@ class Trainer:
         from ..data import CropDataset, Encode
         from .network import Network
         self.args = args
+        if getattr(args, "use_amp", False) and not BF16_TRAINING:
+            # the reference autocasts the training forward under --amp (trainer.py:115-121); silently training in fp32 under the
+            # same flag would be a different experiment with the same name
+            raise NotImplementedError("--amp: the bf16 training step is not built; train without --amp (fp32), or use "
+                                      "--bf16_inference to run only the validation / inference forward on the bf16 backbone")
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.epoch = 0
         self.net = Network(args, pretrained=True)
@@ -237,6 +269,9 @@ class Trainer:
         from .loss import Loss
         self.decoder, self.evaluator, self.loss = Decoder(args), Evaluator(args), Loss(args)
         self.valid_set = None if args.synthetic or not args.valid_dir else CropDataset(args, args.valid_dir)
+        self.start_epoch = 0
+        if getattr(args, "resume", None):
+            self.load_resume(args.resume)
 
     def batches(self):
         a, B = self.args, self.args.batch_size
@@ -293,9 +328,24 @@ class Trainer:
                     self.net.save(self.save_dir / f"model_best_{name}.pth")
         return stats
 
+    # ---- true resume: weights + BatchNorm buffers + Adam moments / step + StepLR epoch + best-so-far metrics + epoch counter ----
+    def save_resume(self, path):
+        torch.save({"model": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
+                    "optimizer": self.step.state_dict(), "scheduler": self.scheduler.state_dict(), "epoch": self.epoch,
+                    "best": {k: getattr(self, k) for k in ("best_loss", "best_csi", "best_classif", "best_kp_reg")}}, path)
+
+    def load_resume(self, path):
+        state = torch.load(path, map_location="cpu", weights_only=False)
+        self.net.load_state_dict(state["model"])
+        self.step.load_state_dict(state["optimizer"])
+        self.scheduler.load_state_dict(state["scheduler"])
+        self.start_epoch = int(state["epoch"]) + 1
+        for k, v in state["best"].items():
+            setattr(self, k, v)
+
     def train(self):
         steps = 0
-        for epoch in range(self.args.epochs):
+        for epoch in range(self.start_epoch, self.args.epochs):
             self.epoch = epoch
             running, n = torch.zeros(4, device=self.args.device), 0
             for images, targets in self.batches():
@@ -310,5 +360,8 @@ class Trainer:
             if epoch % 2 == 0:                                         # trainer.py:98-99
                 self.valid()
             self.scheduler.step()
+            if self.rank == 0:                                         # state at the END of the epoch: --resume continues with epoch + 1
+                self.save_dir.mkdir(parents=True, exist_ok=True)
+                self.save_resume(self.save_dir / "resume.pth")
             if self.args.steps and steps >= self.args.steps:
                 break

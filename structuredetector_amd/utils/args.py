@@ -48,6 +48,8 @@ _FLAGS = [
     # build-only additions (data-parallel launcher / synthetic input)
     (("--synthetic",), dict(type=int, default=0, help="Train/evaluate on N seeded synthetic scenes instead of a directory.")),
     (("--steps",), dict(type=int, default=0, help="Stop training after this many optimizer steps (0 = full epochs).")),
+    (("--bf16_inference",), dict(action="store_true", help="Eval-mode forward on the bf16 backbone (fp32 decode); training unaffected.")),
+    (("--resume",), dict(type=str, default=None, help="Continue a run from trainings/<stamp>/resume.pth (weights, Adam state, scheduler, epoch).")),
 ]
 
 _POSITIVE = ["in_channels", "fpn_depth", "batch_size", "epochs", "learning_rate", "down_ratio", "max_objects", "max_parts"]

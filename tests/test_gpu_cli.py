@@ -118,3 +118,71 @@ def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monk
         got = net.eval().to("cuda")(image[None].to("cuda")).cpu()
         want = ref.eval()(image[None])
     assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_resume_is_bit_identical_and_amp_training_is_refused(tmp_path, monkeypatch):
+    """f3 true resume: 4 optimizer steps == 2 steps + save (weights, BatchNorm buffers, Adam moments + step, StepLR epoch) + load
+    into a FRESH process-state + 2 steps, bit for bit (trainer.py:226-237 saves weights only).  And `train --amp` raises
+    instead of silently training fp32 under the reference's autocast flag."""
+    from structuredetector_amd.cli import train
+    from structuredetector_amd.data import Encode
+    from structuredetector_amd.data.synthetic import synthetic_batch
+    from structuredetector_amd.model import Network
+    from structuredetector_amd.model.trainer import StepLR, TrainStep
+    from tests.test_host_cpu import make_args
+    dev = torch.device("cuda")
+    args = make_args(2, 1, 20, 40, device=dev, learning_rate=1e-3)
+    enc = Encode(args)
+    batches = []
+    for i in range(4):
+        tgt = enc.render(enc.plan(128, 128, *synthetic_batch(np.random.default_rng(10 + i), 4, 128, 128, 2, 1)), dev)
+        batches.append((torch.randn(4, 3, 128, 128, device=dev, generator=torch.Generator(dev).manual_seed(20 + i)), tgt))
+
+    def fresh():
+        torch.manual_seed(3)
+        net = Network(args, pretrained=False).to(dev).train()
+        step = TrainStep(net, args)
+        return net, step, StepLR(step, 1)
+
+    net_a, step_a, sch_a = fresh()
+    for i, (x, t) in enumerate(batches):
+        step_a(x, t)
+        if i == 1:
+            sch_a.step()                                  # lr drops by 10x after the second step
+    net_b, step_b, sch_b = fresh()
+    for i, (x, t) in enumerate(batches[:2]):
+        step_b(x, t)
+    sch_b.step()
+    torch.save({"model": net_b.state_dict(), "optimizer": step_b.state_dict(), "scheduler": sch_b.state_dict()}, tmp_path / "resume.pth")
+    del net_b, step_b, sch_b
+    state = torch.load(tmp_path / "resume.pth", map_location="cpu", weights_only=False)
+    torch.manual_seed(99)                                 # a different init: everything must come from the file
+    net_c = Network(args, pretrained=False).to(dev).train()
+    net_c.load_state_dict(state["model"])
+    step_c = TrainStep(net_c, args)
+    sch_c = StepLR(step_c, 1)
+    step_c.load_state_dict(state["optimizer"]); sch_c.load_state_dict(state["scheduler"])
+    assert step_c.step_count == 2 and abs(step_c.lr - 1e-4) < 1e-12 and sch_c.epoch == 1
+    for x, t in batches[2:]:
+        step_c(x, t)
+    assert torch.equal(net_c.flat_params, net_a.flat_params)
+    assert torch.equal(step_c.exp_avg, step_a.exp_avg) and torch.equal(step_c.exp_avg_sq, step_a.exp_avg_sq)
+    for (ka, va), (kc, vc) in zip(net_a.state_dict().items(), net_c.state_dict().items()):
+        assert ka == kc and torch.equal(va, vc), ka        # running statistics and num_batches_tracked too
+    bad = dict(state["optimizer"], flat_numel=123)
+    from structuredetector_amd import _lib as L
+    with pytest.raises(L.SdError):
+        step_c.load_state_dict(bad)
+
+    # Trainer-level: resume.pth written next to the checkpoints, --resume continues at the next epoch; --amp refused
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
+    common = ["-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json"), "--synthetic", "8", "-b", "4"]
+    train.main(common + ["-e", "1"])
+    resume = list((tmp_path / "trainings").glob("*/resume.pth"))
+    assert len(resume) == 1
+    st = torch.load(resume[0], map_location="cpu", weights_only=False)
+    assert st["epoch"] == 0 and st["optimizer"]["step_count"] == 2 and st["scheduler"]["epoch"] == 1
+    train.main(common + ["-e", "2", "--resume", str(resume[0])])
+    with pytest.raises(NotImplementedError, match="--amp"):
+        train.main(common + ["-e", "1", "--amp"])

@@ -211,3 +211,26 @@ def test_network_parameter_count_matches_published_resnet34():
     from oracle import sdnet_oracle as O
     ref = O.build_reference_network(2, 1)
     assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+
+
+def test_steplr_matches_torch_scheduler():
+    """StepLR (trainer.py:54-56: torch.optim.lr_scheduler.StepLR(optimizer, step_size=args.lr_step), gamma 0.1) against torch's."""
+    import torch
+    from structuredetector_amd.model.trainer import StepLR
+
+    class _Step:
+        lr = 1e-3
+
+    for step_size in (1, 3, 33):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], 1e-3)
+        ref = torch.optim.lr_scheduler.StepLR(opt, step_size=step_size)
+        obj = _Step(); obj.lr = 1e-3
+        mine = StepLR(obj, step_size)
+        for epoch in range(100):
+            opt.step(); ref.step(); mine.step()
+            assert abs(obj.lr - opt.param_groups[0]["lr"]) <= 1e-12 * obj.lr, (step_size, epoch)
+        state = mine.state_dict()
+        other = StepLR(_Step(), 7)
+        other.load_state_dict(state)
+        assert other.epoch == 100 and abs(other.step_obj.lr - obj.lr) < 1e-30
