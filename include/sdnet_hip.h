@@ -39,6 +39,10 @@ typedef void* sd_stream_t;
 
 int         sd_version(void);
 const char* sd_last_error(void);
+/* Bit mask of timing-only experiment switches compiled into this library (csrc/sd_conv.hip SD_ABLATE_HOT = 1, _STORE = 2,
+ * _PATCH = 4: each makes the conv kernels compute WRONG results on purpose).  0 for every product build; the Python loader
+ * (structuredetector_amd/_lib.py) refuses a non-zero library.  No reference counterpart (build hygiene). */
+int         sd_build_flags(void);
 
 /* ---- tensor primitives: src/sdnet/utils/utils.py ------------------------------------------ */
 

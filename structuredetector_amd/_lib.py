@@ -51,6 +51,7 @@ _PEAK_OUT = [c_vp, c_vp, c_vp, c_vp, c_vp]
 _SIGNATURES = {
     "sd_version": (c_int, []),
     "sd_last_error": (C.c_char_p, []),
+    "sd_build_flags": (c_int, []),
     "sd_clamped_sigmoid": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sd_nms5": (c_int, _MAP + [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "sd_topk_workspace_bytes": (c_size, [c_int] * 5),
@@ -134,6 +135,11 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
+        flags = handle.sd_build_flags()
+        if flags and os.environ.get("SDNET_ALLOW_ABLATION") != "1":
+            raise SdError(f"{LIB_PATH} is a timing-only ablation build (sd_build_flags = {flags}: SD_ABLATE_* switches make the conv "
+                          "kernels compute wrong results on purpose); rebuild without EXTRA=-DSD_ABLATE_... "
+                          "(set SDNET_ALLOW_ABLATION=1 only for timing experiments)")
         _lib = handle
     return _lib
 

@@ -43,6 +43,13 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_ABLATE_PATCH
 #define SD_ABLATE_PATCH 0     // timing-only experiment: stage the A tile for ~1.6 of the 9 taps only (what patch staging would need) -- WRONG RESULTS
 #endif
+#if SD_ABLATE_HOT || SD_ABLATE_STORE || SD_ABLATE_PATCH
+#warning "timing-only ablation build: this libsdnet_hip.so computes WRONG RESULTS; the Python loader refuses it unless SDNET_ALLOW_ABLATION=1"
+#endif
+// Reported through the C ABI (sd_build_flags): the loader, build() and the CPU tests assert 0, so an experiment build can never
+// be mistaken for the product library.
+extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0); }
+
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
 #endif

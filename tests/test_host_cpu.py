@@ -43,6 +43,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in include/sdnet_hip.h but not exported"
     assert declared == set(L.declared_symbols()), declared ^ set(L.declared_symbols())
     assert handle.sd_version() >= 1
+    assert handle.sd_build_flags() == 0          # no SD_ABLATE_* (wrong-results timing switches) in the shipped library
 
 
 def test_ops_refuse_cpu_tensors():
