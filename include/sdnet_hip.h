@@ -90,6 +90,7 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
  *   anchor_ind   i32 (B,K)    flat y*w+x                        decoders.py:46
  *   part_ind     i32 (B,P)
  *   assign       i32 (B,P)    anchor rank, or -1 when min dist >= dist_px  decoders.py:98-100
+ *   status       i32 (B)      0 = ok; 1 = sd_decode_fused gave up waiting for a tile block (that image's results are invalid)
  * conf and dist_px are the fp32-rounded thresholds.
  * exact_topk = 1: every slot equals the reference's top-k, including peaks below conf (needed by return_metadata=True);
  * exact_topk = 0: peaks with score <= conf are dropped at compaction -- the assembled annotations are identical (the
@@ -103,6 +104,29 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
               const float* embeddings, int64_t e_sb, int64_t e_sc,
               int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk,
               void* packed, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* The same decoder in ONE launch (no second kernel, no memset): the last tile block to arrive for an image runs the selection
+ * and association for it.  Results are bit-identical to sd_decode.  max_objects and max_parts up to 512, B up to 256.
+ * `state`: sd_decode_state_bytes(B) bytes of device memory owned by the caller and used by nothing else, which must be ZERO
+ * before the first call; every call leaves it zero again (so back-to-back calls and hipGraph replays need no memset).  After a
+ * failed or aborted launch re-zero it.  `workspace`: sd_decode_fused_workspace_bytes() bytes of scratch (per-tile candidate
+ * slots and counts; contents need no initialisation).  Images whose (M+N) x tiles bookkeeping does not fit 64 KB of LDS
+ * (e.g. 2048x2048 inputs with 16 maps) are rejected with SD_ERR_INVALID: use sd_decode for those.
+ * Replaces decoders.py:41-100 like sd_decode; exists because bs = 1 inference is launch-latency-bound. */
+size_t sd_decode_state_bytes(int B, int M, int N, int h, int w);
+int    sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P);   /* 1 when sd_decode_fused accepts this geometry */
+size_t sd_decode_fused_workspace_bytes(int B, int M, int N, int h, int w, int K, int P);
+int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
+                    const float* part_hm, int64_t p_sb, int64_t p_sc,
+                    const float* offsets, int64_t o_sb, int64_t o_sc,
+                    const float* embeddings, int64_t e_sb, int64_t e_sc,
+                    int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk,
+                    void* packed, void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
+/* Explicit host wait for everything queued on `stream` (hipStreamSynchronize): the ONE blocking call of the decoder's host side,
+ * after which a `packed` buffer that lives in pinned, device-mapped host memory may be read (decoders.py:103-139 reads its
+ * tensors through ~200 implicit synchronisations instead).  No other function of this library blocks. */
+int sd_stream_synchronize(sd_stream_t stream);
 
 /* D4-D5 alone (decoders.py:49-100) from already selected peaks (outputs of sd_decode_peaks):
  * same `packed` layout as sd_decode. */

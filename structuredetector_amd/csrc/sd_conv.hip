@@ -48,7 +48,12 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #endif
 // Reported through the C ABI (sd_build_flags): the loader, build() and the CPU tests assert 0, so an experiment build can never
 // be mistaken for the product library.
-extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0); }
+#ifdef SD_DECODE_TRACE
+#define SD_TRACE_FLAG 8       // csrc/sd_decode.hip compiled with in-kernel timestamps (slower, extra global stores)
+#else
+#define SD_TRACE_FLAG 0
+#endif
+extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG; }
 
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)

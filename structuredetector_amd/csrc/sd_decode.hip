@@ -143,8 +143,17 @@ __global__ __launch_bounds__(256) void k_dense_keys(const float* __restrict__ sc
 //                   key, collect the k keys >= it, bitonic sort those.
 // Slots beyond min(n,k) are left as key 0 (filled by the caller).
 // ---------------------------------------------------------------------------------------------
-constexpr int SEL_THREADS = 512;      // threads of one selection "team" (8 waves)
+constexpr int SEL_THREADS = 512;      // threads of one selection "team" (8 waves) in the two-launch kernels
 constexpr int SORT_CAP = 4096;
+
+// Candidate keys written by OTHER workgroups of the SAME launch (k_decode_fused) are read with agent-scope relaxed atomic
+// loads (global_load_dwordx2 sc1: bypasses this CU's L1, which is never refreshed by another CU's stores -- guide, Guideline 16);
+// lists written by an earlier launch are read with plain loads.
+template <bool COH>
+__device__ __forceinline__ uint64_t ldkey(const uint64_t* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 
 // One team = SEL_THREADS threads working on one candidate list.  k_select_group runs two teams in one
 // 1024-thread block (anchors and parts side by side): every team executes the SAME sequence of block barriers
@@ -155,6 +164,7 @@ struct Team {
     int* hist;          // [2][256]  (double-buffered by radix pass)
     int* misc;          // [4]
     int* flags;         // [SD_MAX_TOPK]
+    uint64_t* out;      // [out_keys(k_max)]: the selected keys of an LDS-resident radix select before they replace buf[0..k)
     int team;           // index of this team inside the block
     int* alive;         // [2], shared by ALL teams of the block: 1 while a team still needs radix passes
 };
@@ -162,9 +172,11 @@ struct Team {
 // In-place descending bitonic sort of buf[0..np2).  Each wave owns a contiguous range of R elements; stages
 // whose compare distance stays inside a range need no block barrier (LDS operations of one wave execute in
 // order), only the few long-distance stages synchronise the whole block: 6 instead of 66 barriers for 2048 keys.
-__device__ void bitonic_desc(const Team& T, int np2) {
+template <int NT>
+__device__ void bitonic_desc(const Team& T, uint64_t* buf, int np2) {
+    constexpr int NW = NT / 64;
     const int lane = T.tid & 63, wave = T.tid >> 6;
-    const int R = max(np2 >> 3, 128);                 // elements per wave range
+    const int R = max(np2 / NW, 128);                 // elements per wave range
     const int half_pairs = min(R, np2) >> 1;          // compare-exchange pairs per range and stage
     const bool active = wave * R < np2;
     bool local_dirty = false;                         // wave-local stages since the last block barrier
@@ -175,18 +187,18 @@ __device__ void bitonic_desc(const Team& T, int np2) {
                     const int base = wave * R;
                     for (int t = lane; t < half_pairs; t += 64) {
                         const int i = base + 2 * t - (t & (j - 1)), l = i + j;
-                        const uint64_t a = T.buf[i], bb = T.buf[l];
-                        if ((a < bb) == ((i & k) == 0)) { T.buf[i] = bb; T.buf[l] = a; }
+                        const uint64_t a = buf[i], bb = buf[l];
+                        if ((a < bb) == ((i & k) == 0)) { buf[i] = bb; buf[l] = a; }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-level ordering of the LDS traffic
                 local_dirty = true;
             } else {
                 if (local_dirty) { __syncthreads(); local_dirty = false; }
-                for (int t = T.tid; t < (np2 >> 1); t += SEL_THREADS) {
+                for (int t = T.tid; t < (np2 >> 1); t += NT) {
                     const int i = 2 * t - (t & (j - 1)), l = i + j;
-                    const uint64_t a = T.buf[i], bb = T.buf[l];
-                    if ((a < bb) == ((i & k) == 0)) { T.buf[i] = bb; T.buf[l] = a; }
+                    const uint64_t a = buf[i], bb = buf[l];
+                    if ((a < bb) == ((i & k) == 0)) { buf[i] = bb; buf[l] = a; }
                 }
                 __syncthreads();
             }
@@ -195,50 +207,145 @@ __device__ void bitonic_desc(const Team& T, int np2) {
     __syncthreads();
 }
 
+// Descending sort of buf[0..np2) by ranking (np2 <= RANK_CAP, buf holds >= 2 * np2 keys): every thread counts the keys that
+// precede its own (LDS broadcast reads, no barrier inside) and drops it at that rank.  Two block barriers -- the bitonic network
+// needs 15-28 dependent LDS round trips for 32-128 keys (3-5 us measured in the one-launch decoder), this one pass.
+// Equal keys (only the zero padding) are ordered by index.
+constexpr int RANK_CAP = 256;
+template <int NT>
+__device__ void rank_sort_desc(const Team& T, uint64_t* buf, int np2) {
+    for (int i = T.tid; i < np2; i += NT) {
+        const uint64_t key = buf[i];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < np2; j += 2) {
+            const uint64_t a = buf[j], bb = buf[j + 1];
+            rank += (a > key || (a == key && j < i)) ? 1 : 0;
+            rank += (bb > key || (bb == key && j + 1 < i)) ? 1 : 0;
+        }
+        buf[np2 + rank] = key;
+    }
+    __syncthreads();
+    for (int i = T.tid; i < np2; i += NT) buf[i] = buf[np2 + i];
+    __syncthreads();
+}
+
+// keys the `out` buffer of a team must hold for selections of up to k_max keys
+__host__ __device__ constexpr int out_keys(int np2k) { return np2k <= RANK_CAP ? 2 * np2k : np2k; }
+
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
     return p;
 }
 
-// Exact top-k of n unique keys (descending) into T.buf[0..k).  use_radix / np2 are team-uniform AND identical for
-// all teams of the block.  !use_radix: n <= SORT_CAP, everything is sorted in LDS (np2 >= max(n, k)).
-// use_radix: MSB-first 8-bit radix select over the global list finds the k-th largest key, the k keys >= it are
-// collected and sorted (np2 >= k).  Slots beyond min(n, k) are left as key 0 (filled by the caller).
-__device__ void team_select_topk(const Team& T, const uint64_t* __restrict__ cand, int n, int k, bool use_radix, int np2) {
-    const int tid = T.tid;
-    if (!use_radix) {
-        for (int i = tid; i < np2; i += SEL_THREADS) T.buf[i] = (i < n) ? cand[i] : 0ull;
-        __syncthreads();
-        bitonic_desc(T, np2);
-        return;
+// Key sources of the selection.  FlatSrc: one contiguous list (k_nms_tile<1>'s append buffer).  TiledSrc: one fixed region of
+// TILE_CAP slots per NMS tile plus per-tile counts (k_decode_fused: no global append counter on the tile blocks' critical path).
+template <int NT, bool COH>
+struct FlatSrc {
+    const uint64_t* p;
+    int n;
+    template <class F>
+    __device__ __forceinline__ void for_each(int tid, F f) const {          // key loads batched four deep
+        for (int base = tid; base < n; base += 4 * NT) {
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) key[u] = (base + u * NT < n) ? ldkey<COH>(p + base + u * NT) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * NT < n) f(key[u]);
+        }
     }
-    // MSB-first 8-bit radix select.  Two block barriers per pass (histograms double-buffered by pass parity, bucket scan by
-    // one wave), key loads batched four deep, and the passes stop as soon as the boundary bucket is taken whole in EVERY team
-    // of the block (unique keys: usually after the score bytes) -- `alive` is block-wide so that all teams leave together.
+    __device__ __forceinline__ void fill(int tid, uint64_t* buf, int np2) const {
+        for (int i = tid; i < np2; i += NT) buf[i] = (i < n) ? ldkey<COH>(p + i) : 0ull;
+    }
+};
+
+constexpr int TILE_CAP = TW * TH;     // candidate slots of one tile: every pixel of a plateau survives the NMS
+constexpr int SPEC = 6;               // keys of a tile that travel INSIDE its 64-byte hand-off record (count word + 6 keys): one round trip
+constexpr int SPEC_TILES = 256;       // ... captured in LDS for the first SPEC_TILES tiles of the image (the others re-read them from the slots)
+
+template <int NT>
+struct TiledSrc {
+    const uint64_t* base;   // slot 0 of the list's first tile (global; written by other workgroups of this launch -> sc1 loads)
+    const int* cnt;         // LDS: candidates of each tile of the list
+    const int* off;         // LDS: exclusive prefix of cnt within the list
+    const uint64_t* spec;   // LDS: the first SPEC keys of the tiles that were loaded speculatively (image-wide tile index)
+    int tile0;              // image-wide index of the list's first tile
+    int ntiles, n;
+    __device__ __forceinline__ uint64_t key_at(int t, int j) const {
+        const int ti = tile0 + t;
+        if (j < SPEC && ti < SPEC_TILES) return spec[ti * SPEC + j];
+        return ldkey<true>(base + (int64_t)t * TILE_CAP + j);
+    }
+    // candidate g of the list (0 <= g < n) -> (tile, slot): binary search in the exclusive prefix `off`
+    __device__ __forceinline__ uint64_t key_of(int gidx) const {
+        int lo = 0, hi = ntiles - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= gidx) lo = mid; else hi = mid - 1;
+        }
+        return key_at(lo, gidx - off[lo]);
+    }
+    template <class F>
+    __device__ __forceinline__ void for_each(int tid, F f) const {          // all threads busy, loads batched four deep
+        for (int base = tid; base < n; base += 4 * NT) {
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) key[u] = (base + u * NT < n) ? key_of(base + u * NT) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * NT < n) f(key[u]);
+        }
+    }
+    __device__ __forceinline__ void fill(int tid, uint64_t* buf, int np2) const {
+        for (int i = n + tid; i < np2; i += NT) buf[i] = 0ull;
+        for (int base = tid; base < n; base += 4 * NT) {
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) key[u] = (base + u * NT < n) ? key_of(base + u * NT) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * NT < n) buf[base + u * NT] = key[u];
+        }
+    }
+};
+
+// keys already resident in LDS (second stage of the selection)
+template <int NT>
+struct LdsSrc {
+    const uint64_t* p;
+    int n;
+    template <class F>
+    __device__ __forceinline__ void for_each(int tid, F f) const {
+        for (int i = tid; i < n; i += NT) f(p[i]);
+    }
+};
+
+// MSB-first 8-bit radix select of the k largest of the source's n unique keys into dst[0..np2k) (zero padded), then sorted
+// descending.  Two block barriers per pass (histograms double-buffered by pass parity, bucket scan by one wave); the passes stop
+// as soon as the boundary bucket is taken whole in EVERY team of the block (unique keys: usually after the score bytes) --
+// `alive` is block-wide so that all teams leave together.  dst holds out_keys(np2k) keys and must not alias the source.
+template <int NT, class Src>
+__device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64_t* dst, int np2k) {
+    const int tid = T.tid;
+    const int n = src.n;
     uint64_t prefix = 0, mask = 0;
     int remaining = min(k, n);
     bool done = remaining == 0;
     if (done) prefix = ~0ull;
-    static_assert(SEL_THREADS == 512, "one thread per entry of the double-buffered histogram");
-    T.hist[tid] = 0;
+    for (int i = tid; i < 512; i += NT) T.hist[i] = 0;          // double-buffered histogram
     if (tid == 0) T.alive[T.team] = done ? 0 : 1;
     __syncthreads();
     for (int pass = 7; pass >= 0; --pass) {
         int* hcur = T.hist + (pass & 1) * 256;
         int* hnext = T.hist + ((pass & 1) ^ 1) * 256;
         const int shift = pass * 8;
-        if (!done) {
-            for (int base = tid; base < n; base += 4 * SEL_THREADS) {
-                uint64_t key[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) key[u] = (base + u * SEL_THREADS < n) ? cand[base + u * SEL_THREADS] : 0ull;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (base + u * SEL_THREADS < n && (key[u] & mask) == prefix) atomicAdd(&hcur[(int)((key[u] >> shift) & 255ull)], 1);
-            }
-        }
-        if (tid < 256) hnext[tid] = 0;
+        if (!done)
+            src.for_each(tid, [&](uint64_t key) {
+                if ((key & mask) == prefix) atomicAdd(&hcur[(int)((key >> shift) & 255ull)], 1);
+            });
+        for (int i = tid; i < 256; i += NT) hnext[i] = 0;
         __syncthreads();
         if (!done && tid < 64) {          // one wave: lane l owns digits 255-4l .. 252-4l (descending)
             const int c0 = hcur[255 - 4 * tid], c1 = hcur[254 - 4 * tid], c2 = hcur[253 - 4 * tid], c3 = hcur[252 - 4 * tid];
@@ -270,31 +377,70 @@ __device__ void team_select_topk(const Team& T, const uint64_t* __restrict__ can
         if ((T.alive[0] | T.alive[1]) == 0) break;
     }
     // keys are unique, so exactly min(k, n) keys are >= prefix
-    for (int i = tid; i < np2; i += SEL_THREADS) T.buf[i] = 0ull;
+    for (int i = tid; i < np2k; i += NT) dst[i] = 0ull;
     if (tid == 0) T.misc[2] = 0;
     __syncthreads();
-    for (int base = tid; base < n; base += 4 * SEL_THREADS) {
-        uint64_t key[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = (base + u * SEL_THREADS < n) ? cand[base + u * SEL_THREADS] : 0ull;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (base + u * SEL_THREADS < n && key[u] >= prefix) {
-                const int slot = atomicAdd(&T.misc[2], 1);
-                if (slot < np2) T.buf[slot] = key[u];
-            }
-    }
+    src.for_each(tid, [&](uint64_t key) {
+        if (key >= prefix) {
+            const int slot = atomicAdd(&T.misc[2], 1);
+            if (slot < np2k) dst[slot] = key;
+        }
+    });
     __syncthreads();
-    bitonic_desc(T, np2);
+    if (np2k <= RANK_CAP) rank_sort_desc<NT>(T, dst, np2k);
+    else bitonic_desc<NT>(T, dst, np2k);
+}
+
+// Exact top-k of the source's n unique keys (descending) into T.buf[0..k).  The path depends only on (n_max, k_max, cap), the
+// longest list / largest k of ALL teams of the block and the key capacity of T.buf, so every team runs the same barriers:
+//   A  everything fits the ranking sort (<= RANK_CAP keys): load, rank, done -- the annotations-only mode (tens of peaks);
+//   B  the list fits T.buf: load it ONCE into LDS, radix-select the k largest from LDS into T.out, sort those, move them to
+//      T.buf[0..k) -- a bitonic sort of 2048 keys took 30 us per image (exact top-k at 512x512), this takes a tenth;
+//   C  longer lists: the same radix select reading the source (global memory) once per pass, selected keys straight into T.buf.
+// Slots beyond min(n, k) are left as key 0 (filled by the caller).
+template <int NT, class Src>
+__device__ void team_select_topk(const Team& T, const Src& src, int k, int n_max, int k_max, int cap) {
+    const int tid = T.tid;
+    const int np2_all = max(next_pow2(max(n_max, k_max)), 2);
+    if (np2_all <= RANK_CAP) {
+        src.fill(tid, T.buf, np2_all);
+        __syncthreads();
+        rank_sort_desc<NT>(T, T.buf, np2_all);
+        return;
+    }
+    const int np2k = max(next_pow2(k_max), 2);
+    if (n_max <= cap) {
+        src.fill(tid, T.buf, src.n);
+        __syncthreads();
+        radix_select_sorted<NT>(T, LdsSrc<NT>{T.buf, src.n}, k, T.out, np2k);
+        for (int i = tid; i < k; i += NT) T.buf[i] = T.out[i];
+        __syncthreads();
+        return;
+    }
+    radix_select_sorted<NT>(T, src, k, T.buf, np2k);
 }
 
 // Suppressed pixels have score exactly 0; when fewer than k peaks exist the reference's remaining top-k slots
 // are zeros (utils.py:451 on the NMS'ed map).  Fill them with the lowest class-major flat indices that are not
 // peaks (stable order).  Always executes two block barriers (team-uniform control flow).
+template <int NT>
 __device__ void fill_zero_slots(const Team& T, int npos, int k) {
     const int tid = T.tid;
+    if (k <= 64) {                                    // one wave: unused flat indices ranked with a ballot (the default K = 20 / P = 40)
+        if (npos < k && tid < 64) {
+            int used = 0;
+            for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~T.buf[j]) == (uint32_t)tid);
+            const bool flag = tid < k && !used;
+            const unsigned long long m = __ballot(flag);
+            const int rank = __popcll(m & ((1ull << tid) - 1ull));
+            if (flag && npos + rank < k) T.buf[npos + rank] = make_key(0.0f, (uint32_t)tid);
+        }
+        __syncthreads();
+        __syncthreads();                              // (same barrier count as the general path: teams may take different paths)
+        return;
+    }
     if (npos < k) {
-        for (int f = tid; f < k; f += SEL_THREADS) {
+        for (int f = tid; f < k; f += NT) {
             int used = 0;
             for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~T.buf[j]) == (uint32_t)f);
             T.flags[f] = used ? 0 : 1;
@@ -302,7 +448,7 @@ __device__ void fill_zero_slots(const Team& T, int npos, int k) {
     }
     __syncthreads();
     if (npos < k) {
-        for (int f = tid; f < k; f += SEL_THREADS) {
+        for (int f = tid; f < k; f += NT) {
             if (!T.flags[f]) continue;
             int rank = 0;
             for (int j = 0; j < f; ++j) rank += T.flags[j];
@@ -333,11 +479,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_peaks(const uint64_t* __
     const int n = counters ? counters[b * counter_stride] : fixed_n;
     if (threadIdx.x < 2) alive[threadIdx.x] = 0;
     __syncthreads();
-    const Team T{(int)threadIdx.x, buf, hist, misc, flags, 0, alive};
-    const bool use_radix = n > SORT_CAP;
-    const int np2 = max(next_pow2(use_radix ? k : max(n, k)), 2);
-    team_select_topk(T, cand + (int64_t)b * cap, n, k, use_radix, np2);
-    if (do_fill) fill_zero_slots(T, min(n, k), k);
+    __shared__ uint64_t outb[SD_MAX_TOPK];
+    const Team T{(int)threadIdx.x, buf, hist, misc, flags, outb, 0, alive};
+    team_select_topk<SEL_THREADS>(T, FlatSrc<SEL_THREADS, false>{cand + (int64_t)b * cap, n}, k, n, k, SORT_CAP);
+    if (do_fill) fill_zero_slots<SEL_THREADS>(T, min(n, k), k);
     for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
         const uint64_t key = buf[i];
         const uint32_t flat = ~(uint32_t)key;
@@ -364,6 +509,7 @@ struct PackedLayout {
     int* anchor_ind;     // (B,K)
     int* part_ind;       // (B,P)
     int* assign;         // (B,P)
+    int* status;         // (B)   0 = ok, 1 = sd_decode_fused gave up waiting for a tile block (results of that image invalid)
 };
 
 __host__ __device__ inline PackedLayout packed_layout(void* packed, int B, int K, int P) {
@@ -376,7 +522,8 @@ __host__ __device__ inline PackedLayout packed_layout(void* packed, int B, int K
     L.part_smask = f;                 f += (int64_t)B * P;
     L.anchor_ind = reinterpret_cast<int*>(f);  f += (int64_t)B * K;
     L.part_ind = reinterpret_cast<int*>(f);    f += (int64_t)B * P;
-    L.assign = reinterpret_cast<int*>(f);
+    L.assign = reinterpret_cast<int*>(f);      f += (int64_t)B * P;
+    L.status = reinterpret_cast<int*>(f);
     return L;
 }
 
@@ -436,6 +583,7 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         L.part_ind[(int64_t)b * P + p] = ind;
         L.assign[(int64_t)b * P + p] = (best < dist_px) ? best_a : -1;   // decoders.py:100
     }
+    if (tid == 0) L.status[b] = 0;
 }
 
 // fused: select anchors and parts side by side (two teams), then associate (2nd and last launch of sd_decode)
@@ -452,16 +600,15 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t
     __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
     const int b = blockIdx.x, hw = h * w;
     const int team = threadIdx.x >> 9, tid = threadIdx.x & (SEL_THREADS - 1);
-    const Team T{tid, buf[team], hist[team], misc[team], flags[team], team, alive};
+    __shared__ uint64_t outb[2][SD_MAX_TOPK];
+    const Team T{tid, buf[team], hist[team], misc[team], flags[team], outb[team], team, alive};
 
     const int n0 = counters[(b * 2 + 0) * CNT_STRIDE], n1 = counters[(b * 2 + 1) * CNT_STRIDE];
-    // identical barrier sequence for both teams: the path and the sort size come from the larger list
-    const bool use_radix = max(n0, n1) > SORT_CAP;
-    const int np2 = max(next_pow2(use_radix ? max(K, P) : max(max(n0, n1), max(K, P))), 2);
+    // identical barrier sequence for both teams: the path comes from the longer list and the larger k
     const int n = team ? n1 : n0, k = team ? P : K;
     const uint64_t* cand = team ? cand1 + (int64_t)b * N * hw : cand0 + (int64_t)b * M * hw;
-    team_select_topk(T, cand, n, k, use_radix, np2);
-    fill_zero_slots(T, min(n, k), k);
+    team_select_topk<SEL_THREADS>(T, FlatSrc<SEL_THREADS, false>{cand, n}, k, max(n0, n1), max(K, P), SORT_CAP);
+    fill_zero_slots<SEL_THREADS>(T, min(n, k), k);
     float* os = team ? ps_ : as_;
     int* oi = team ? pi_ : ai_;
     int* oc = team ? pc_ : ac_;
@@ -474,6 +621,273 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t
     __syncthreads();
     const PackedLayout L = packed_layout(packed, B, K, P);
     block_group(b, K, P, w, conf, dist_px, rm, as_, ai_, ac_, ps_, pi_, pc_, posx, posy, L);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// ONE-launch decoder (sd_decode_fused): NMS tile blocks + one SELECTOR block per image in the same grid.  bs = 1 inference is
+// latency-bound (199 KB of algorithmic traffic): what counts is the number of DEPENDENT global round trips (~2 us each across
+// XCDs) and of same-address atomics (~0.15-0.2 us EACH, serialised at the memory side: a per-image arrival counter bumped by
+// every tile block cost 7 us at 48 tiles and 200 us at 1024 -- measured, first version of this kernel).  So:
+//   * no second launch, no counter memset, no atomic read-modify-write anywhere;
+//   * a tile block's chain is load -> NMS -> stores: every tile owns TILE_CAP candidate slots in the scratch workspace and a
+//     64-byte hand-off RECORD {valid | count, first SPEC keys} in the caller's zero-initialised state buffer;
+//   * the selector blocks are the LAST blocks of the (linear) grid, so every tile block has been dispatched before a selector
+//     starts to wait (at most B selectors spin; the launcher caps B far below the number of resident block slots);
+//     thread t polls record t (one round trip: count word + 6 keys), takes a record when the valid bit is set and the keys it
+//     announces are non-zero (self-validating granules: guide, Guideline 16 R2 -- the loads of one poll are not ordered among
+//     themselves), zeroes it again (state left zero: back-to-back calls and hipGraph replays need no memset), fetches the keys
+//     beyond SPEC from the tile's slots (published BEFORE the record: sc1 stores, s_waitcnt vmcnt(0), barrier, then the
+//     record's count word), sorts in LDS, gathers offsets / embeddings, writes the packed result.
+// All hand-off stores / loads are agent-scope relaxed atomics (sc1: written through, never read from a stale L1 line).
+// A bounded spin: after ~2^21 polls a selector gives up and reports status 1 for its image instead of hanging the GPU.
+// 256 threads; dynamic LDS sized by the host from K, P and the tile count (cfg: ~22 KB).
+// Results are bit-identical to sd_decode (same keys, same total order, same block_group arithmetic).
+// ---------------------------------------------------------------------------------------------
+#ifdef SD_DECODE_TRACE
+// timing experiment (not in product builds; reported by sd_build_flags bit 3): 100 MHz timestamps of the stages of k_decode_fused
+__device__ unsigned long long sd_trace[8192];
+#define SD_TRACE(slot) do { if (threadIdx.x == 0 && (slot) >= 0 && (slot) < 8192) sd_trace[(slot)] = wall_clock64(); } while (0)
+#else
+#define SD_TRACE(slot) do { } while (0)
+#endif
+constexpr int FUSED_THREADS = 256;
+constexpr int FUSED_TEAM = 128;               // the selector works on the anchor list and the part list side by side: 2 teams x 2 waves
+// keys per team sorted in LDS (longer lists take the radix select), chosen by the launcher: the LDS of the selector is paid by
+// every tile block of the grid (occupancy), and the two selection modes see very different list lengths -- annotations-only:
+// only peaks >= conf (tens); exact top-k: every NMS survivor (~4 % of all pixels on noisy maps)
+constexpr int FUSED_CAP_FAST = 512, FUSED_CAP_EXACT = 2048;
+constexpr int FUSED_MAX_TOPK = 512;
+constexpr int REC_WORDS = 16;                 // one 64-byte record per tile: word 0 = 0x80000000 | count, bytes 8..55 = SPEC keys
+constexpr unsigned REC_VALID = 0x80000000u;
+constexpr int POLL_LIMIT = 1 << 21;
+
+struct FusedLds {       // byte offsets into the dynamic LDS block of the selector
+    int buf, spec, tcnt, toff, hist, flags, out, outk, as_, ps_, posx, posy, ai_, ac_, pi_, pc_, total;
+};
+__host__ __device__ inline FusedLds fused_lds(int K, int P, int ntiles_img, int sort_cap) {
+    FusedLds L;
+    int o = 0;
+    auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
+    L.buf = take(2 * sort_cap * 8);
+    L.spec = take((ntiles_img < SPEC_TILES ? ntiles_img : SPEC_TILES) * SPEC * 8);
+    L.tcnt = take(ntiles_img * 4);
+    L.toff = take((ntiles_img + 1) * 4);
+    L.hist = take(2 * 512 * 4);
+    L.flags = take(2 * (K > P ? K : P) * 4);
+    {
+        int np2k = 2;
+        while (np2k < (K > P ? K : P)) np2k <<= 1;
+        L.outk = out_keys(np2k);
+        L.out = take(2 * L.outk * 8);
+    }
+    L.as_ = take(K * 4); L.posx = take(K * 4); L.posy = take(K * 4); L.ai_ = take(K * 4); L.ac_ = take(K * 4);
+    L.ps_ = take(P * 4); L.pi_ = take(P * 4); L.pc_ = take(P * 4);
+    const int nms = (LH * LW + LH * TW) * 4;
+    L.total = o > nms ? o : nms;
+    return L;
+}
+
+__global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group g1, int h, int w, int tiles_x, int tiles, float min_score,
+                                                                 uint64_t* cand, unsigned* records, int K, int P, int sort_cap,
+                                                                 float conf, float dist_px, RegMaps rm, void* packed, int B) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int keep_n;
+    __shared__ int misc[2][4];
+    __shared__ int alive[2];
+    __shared__ int wave_tot[FUSED_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int C = g0.C + g1.C;
+    const int nti = C * tiles;                                 // tiles of one image
+    const int64_t blk = blockIdx.x;
+
+    if (blk < (int64_t)B * nti) {
+        // ================= tile block: clamped sigmoid + 5x5 NMS of one 64x16 tile ==========================================
+        float (*S)[LW] = reinterpret_cast<float(*)[LW]>(smem);
+        float (*Hm)[TW] = reinterpret_cast<float(*)[TW]>(smem + sizeof(float) * LH * LW);
+        const int b = (int)(blk / nti);
+        const int rem = (int)(blk - (int64_t)b * nti);
+        const int m = rem / tiles, tile = rem - m * tiles;     // map of the image: anchors 0..M-1, parts M..M+N-1
+        const int grp = (m >= g0.C) ? 1 : 0;
+        const Group g = grp ? g1 : g0;
+        const int c = grp ? m - g0.C : m;
+        const int tx0 = (tile % tiles_x) * TW;
+        const int ty0 = (tile / tiles_x) * TH;
+        const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
+        uint64_t* mine = cand + blk * TILE_CAP;
+        unsigned* rec = records + blk * REC_WORDS;
+        SD_TRACE(blk < 1024 ? blk * 4 + 0 : -1);
+        if (tid == 0) keep_n = 0;
+        constexpr int NLD = (LH * LW + FUSED_THREADS - 1) / FUSED_THREADS;
+        float ld[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * FUSED_THREADS;
+            const int r = i / LW, cc = i - r * LW;
+            const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
+            const bool ok = i < LH * LW && y >= 0 && y < h && x >= 0 && x < w;
+            ld[j] = plane[ok ? (int64_t)y * w + x : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * FUSED_THREADS;
+            const int r = i / LW, cc = i - r * LW;
+            const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
+            const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+            if (i < LH * LW) S[r][cc] = ok ? clamped_sigmoid(ld[j]) : -INFINITY;
+        }
+        __syncthreads();
+        SD_TRACE(blk < 1024 ? blk * 4 + 1 : -1);
+        for (int i = tid; i < LH * TW; i += FUSED_THREADS) {
+            const int r = i / TW, cc = i - r * TW;
+            float mx = fmaxf(fmaxf(S[r][cc], S[r][cc + 1]), fmaxf(S[r][cc + 2], S[r][cc + 3]));
+            Hm[r][cc] = fmaxf(mx, S[r][cc + 4]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (TW * TH) / FUSED_THREADS; ++j) {
+            const int i = tid + j * FUSED_THREADS;
+            const int r = i / TW, cc = i - r * TW;
+            const int y = ty0 + r, x = tx0 + cc;
+            float mx = fmaxf(fmaxf(Hm[r][cc], Hm[r + 1][cc]), fmaxf(Hm[r + 2][cc], Hm[r + 3][cc]));
+            mx = fmaxf(mx, Hm[r + 4][cc]);
+            const float v = S[r + HALO][cc + HALO];
+            if ((y < h) && (x < w) && (v == mx) && (v >= min_score)) {        // `>=`: see k_nms_tile
+                const int slot = atomicAdd(&keep_n, 1);
+                const uint64_t key = make_key(v, (uint32_t)(c * h * w + y * w + x));
+                __hip_atomic_store(mine + slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < SPEC)
+                    __hip_atomic_store(reinterpret_cast<uint64_t*>(rec + 2) + slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // publish: every wave drains its write-through stores, then ONE lane sets the record's count word
+        SD_TRACE(blk < 1024 ? blk * 4 + 2 : -1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(rec, REC_VALID | (unsigned)keep_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SD_TRACE(blk < 1024 ? blk * 4 + 3 : -1);
+        return;
+    }
+
+    // ================= selector block of image b: wait for the image's records, exact top-K / top-P, association ============
+    const int b = (int)(blk - (int64_t)B * nti);
+    const FusedLds Lo = fused_lds(K, P, nti, sort_cap);
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem + Lo.buf);
+    uint64_t* spec = reinterpret_cast<uint64_t*>(smem + Lo.spec);
+    int* tcnt = reinterpret_cast<int*>(smem + Lo.tcnt);
+    int* toff = reinterpret_cast<int*>(smem + Lo.toff);
+    int* hist = reinterpret_cast<int*>(smem + Lo.hist);
+    int* flags = reinterpret_cast<int*>(smem + Lo.flags);
+    float* as_ = reinterpret_cast<float*>(smem + Lo.as_);
+    float* ps_ = reinterpret_cast<float*>(smem + Lo.ps_);
+    float* posx = reinterpret_cast<float*>(smem + Lo.posx);
+    float* posy = reinterpret_cast<float*>(smem + Lo.posy);
+    int* ai_ = reinterpret_cast<int*>(smem + Lo.ai_);
+    int* ac_ = reinterpret_cast<int*>(smem + Lo.ac_);
+    int* pi_ = reinterpret_cast<int*>(smem + Lo.pi_);
+    int* pc_ = reinterpret_cast<int*>(smem + Lo.pc_);
+    unsigned* rec_img = records + (int64_t)b * nti * REC_WORDS;
+    const uint64_t* cand_img = cand + (int64_t)b * nti * TILE_CAP;
+    const PackedLayout L = packed_layout(packed, B, K, P);
+    SD_TRACE(4096 + b * 8 + 0);
+    if (tid < 2) alive[tid] = 0;
+    {
+        // thread t owns tiles t, t + 256, ...; `pending` = owned tiles whose record has not been taken yet
+        int pending = 0;
+        for (int t = tid; t < nti; t += FUSED_THREADS) ++pending;
+        unsigned taken = 0;                                    // bit i: owned tile number i taken (nti <= 32 * 256 checked by the host)
+        int polls = 0;
+        while (true) {
+            int i = 0;
+            for (int t = tid; t < nti; t += FUSED_THREADS, ++i) {
+                if (taken & (1u << i)) continue;
+                unsigned* rec = rec_img + (int64_t)t * REC_WORDS;
+                const unsigned word = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint64_t k6[SPEC];
+#pragma unroll
+                for (int u = 0; u < SPEC; ++u) k6[u] = ldkey<true>(reinterpret_cast<uint64_t*>(rec + 2) + u);
+                if (!(word & REC_VALID)) continue;
+                const int cnt = (int)(word & ~REC_VALID);
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < SPEC; ++u) ok = ok && (u >= cnt || k6[u] != 0ull);
+                if (!ok) continue;
+                tcnt[t] = cnt;
+                if (t < SPEC_TILES) {
+#pragma unroll
+                    for (int u = 0; u < SPEC; ++u) spec[t * SPEC + u] = k6[u];
+                }
+                __hip_atomic_store(rec, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // state left zero
+#pragma unroll
+                for (int u = 0; u < SPEC; ++u)
+                    if (u < cnt) __hip_atomic_store(reinterpret_cast<uint64_t*>(rec + 2) + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                taken |= 1u << i;
+                --pending;
+            }
+            if (__syncthreads_or(pending) == 0) break;
+            if (++polls > POLL_LIMIT) {                         // never hang the GPU: report and leave (block-uniform decision)
+                if (tid == 0) L.status[b] = 1;
+                return;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    SD_TRACE(4096 + b * 8 + 1);
+    // exclusive prefix of the tile counts over the whole image (anchor tiles first): thread t owns a contiguous chunk
+    {
+        const int chunk = (nti + FUSED_THREADS - 1) / FUSED_THREADS;
+        const int lo = min(tid * chunk, nti), hi = min(lo + chunk, nti);
+        int sum = 0;
+        for (int t = lo; t < hi; ++t) sum += tcnt[t];
+        int incl = sum;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < wave; ++q) before += wave_tot[q];
+        int run = before + incl - sum;
+        for (int t = lo; t < hi; ++t) { toff[t] = run; run += tcnt[t]; }
+        if (tid == FUSED_THREADS - 1) toff[nti] = run;
+    }
+    __syncthreads();
+    const int split = g0.C * tiles;                            // first part tile
+    const int n0 = toff[split], n1 = toff[nti] - n0;
+    __syncthreads();
+    for (int t = split + tid; t < nti; t += FUSED_THREADS) toff[t] -= n0;   // part offsets relative to the part list
+    const int hw = h * w;
+    SD_TRACE(4096 + b * 8 + 2);
+    {
+        // anchors on waves 0-1, parts on waves 2-3; both teams run the same barrier sequence (path and sort size from the longer list)
+        const int team = tid / FUSED_TEAM, ttid = tid - team * FUSED_TEAM;
+        const int maxkp = K > P ? K : P;
+        const Team T{ttid, buf + team * sort_cap, hist + team * 512, misc[team], flags + team * maxkp,
+                     reinterpret_cast<uint64_t*>(smem + Lo.out) + team * Lo.outk, team, alive};
+        const int n = team ? n1 : n0, k = team ? P : K;
+        const int t0 = team ? split : 0;
+        const TiledSrc<FUSED_TEAM> src{cand_img + (int64_t)t0 * TILE_CAP, tcnt + t0, toff + t0, spec, t0, team ? nti - split : split, n};
+        team_select_topk<FUSED_TEAM>(T, src, k, max(n0, n1), maxkp, sort_cap);
+        SD_TRACE(4096 + b * 8 + 3);
+        fill_zero_slots<FUSED_TEAM>(T, min(n, k), k);
+        SD_TRACE(4096 + b * 8 + 4);
+        float* os = team ? ps_ : as_;
+        int* oi = team ? pi_ : ai_;
+        int* oc = team ? pc_ : ac_;
+        for (int i = ttid; i < k; i += FUSED_TEAM) {
+            const uint64_t key = T.buf[i];
+            const uint32_t flat = ~(uint32_t)key;
+            const int cls = flat / hw;
+            os[i] = ord2f((uint32_t)(key >> 32)); oi[i] = flat - cls * hw; oc[i] = cls;
+        }
+    }
+    __syncthreads();
+    block_group(b, K, P, w, conf, dist_px, rm, as_, ai_, ac_, ps_, pi_, pc_, posx, posy, L);
+    __syncthreads();
+    SD_TRACE(4096 + b * 8 + 7);
 }
 
 // association from externally supplied peaks (sd_decode_group)
@@ -661,7 +1075,7 @@ size_t sd_decode_workspace_bytes(int B, int M, int N, int h, int w, int K, int P
     return carve(nullptr, B, M, N, h, w).bytes;
 }
 
-size_t sd_decode_packed_words(int B, int K, int P) { return (size_t)B * (6 * (size_t)K + 11 * (size_t)P); }
+size_t sd_decode_packed_words(int B, int K, int P) { return (size_t)B * (6 * (size_t)K + 11 * (size_t)P + 1); }
 
 int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* part_hm, int64_t p_sb, int64_t p_sc,
               const float* offsets, int64_t o_sb, int64_t o_sc, const float* embeddings, int64_t e_sb, int64_t e_sc, int B, int M,
@@ -686,6 +1100,86 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
     hipLaunchKernelGGL(k_select_group, dim3(B), dim3(2 * SEL_THREADS), 0, st, ws.cand0, ws.cand1, ws.counters, M, N, h, w, K, P, conf,
                        dist_px, rm, packed, B);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+constexpr int FUSED_LDS_LIMIT = 96 * 1024;    // dynamic LDS the launcher asks for at most (gfx950: 160 KB per CU)
+static int next_pow2_host(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static size_t fused_tiles(int h, int w) { return (size_t)cdiv(w, TW) * cdiv(h, TH); }
+
+size_t sd_decode_state_bytes(int B, int M, int N, int h, int w) {
+    return align_up((size_t)std::max(B, 1) * (M + N) * fused_tiles(h, w) * REC_WORDS * sizeof(unsigned), 256);
+}
+
+size_t sd_decode_fused_workspace_bytes(int B, int M, int N, int h, int w, int K, int P) {
+    (void)K; (void)P;
+    return align_up((size_t)B * (M + N) * fused_tiles(h, w) * TILE_CAP * 8, 256);
+}
+
+#ifdef SD_DECODE_TRACE
+int sd_debug_read_trace(unsigned long long* out, int n) {
+    SD_HIP(hipDeviceSynchronize());
+    SD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::sd_trace), sizeof(unsigned long long) * (size_t)n));
+    return 0;
+}
+#endif
+
+int sd_stream_synchronize(sd_stream_t stream) {
+    SD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P) {
+    if (B <= 0 || M <= 0 || N <= 0 || h <= 0 || w <= 0 || K <= 0 || P <= 0) return 0;
+    const int64_t nti = (int64_t)(M + N) * fused_tiles(h, w);
+    return K <= FUSED_MAX_TOPK && P <= FUSED_MAX_TOPK && B <= 256 && nti <= 32 * FUSED_THREADS && (int64_t)B * nti + B < (1ll << 31) &&
+           fused_lds(K, P, (int)nti, std::max(FUSED_CAP_EXACT, 2 * next_pow2_host(std::max(K, P)))).total <= FUSED_LDS_LIMIT;
+}
+
+int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* part_hm, int64_t p_sb, int64_t p_sc,
+                    const float* offsets, int64_t o_sb, int64_t o_sc, const float* embeddings, int64_t e_sb, int64_t e_sc, int B,
+                    int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk, void* packed, void* state,
+                    size_t state_bytes, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_map("sd_decode_fused(anchor_hm)", anchor_hm, a_sb, a_sc, B, M, h, w)) return e;
+    if (int e = check_map("sd_decode_fused(part_hm)", part_hm, p_sb, p_sc, B, N, h, w)) return e;
+    if (int e = check_map("sd_decode_fused(offsets)", offsets, o_sb, o_sc, B, 2, h, w)) return e;
+    if (int e = check_map("sd_decode_fused(embeddings)", embeddings, e_sb, e_sc, B, 2, h, w)) return e;
+    SD_REQUIRE(K > 0 && K <= FUSED_MAX_TOPK && (int64_t)K <= (int64_t)M * h * w, SD_ERR_INVALID,
+               "sd_decode_fused: max_objects=%d out of range (1..%d; use sd_decode beyond)", K, FUSED_MAX_TOPK);
+    SD_REQUIRE(P > 0 && P <= FUSED_MAX_TOPK && (int64_t)P <= (int64_t)N * h * w, SD_ERR_INVALID,
+               "sd_decode_fused: max_parts=%d out of range (1..%d; use sd_decode beyond)", P, FUSED_MAX_TOPK);
+    // at most B selector blocks wait inside the grid: keep them far below the resident block slots of the chip (256 CUs x >= 2)
+    SD_REQUIRE(B <= 256, SD_ERR_INVALID, "sd_decode_fused: batch %d > 256 (selector blocks must stay resident); use sd_decode", B);
+    SD_REQUIRE(packed && workspace && state, SD_ERR_INVALID, "sd_decode_fused: null pointer");
+    const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+    const int tiles = tiles_x * tiles_y;
+    const int64_t nti = (int64_t)(M + N) * tiles;
+    SD_REQUIRE(nti <= 32 * FUSED_THREADS, SD_ERR_INVALID, "sd_decode_fused: %lld tiles per image > %d; use sd_decode", (long long)nti,
+               32 * FUSED_THREADS);
+    SD_REQUIRE((int64_t)B * nti + B < (1ll << 31), SD_ERR_INVALID, "sd_decode_fused: grid too large");
+    SD_REQUIRE(state_bytes >= sd_decode_state_bytes(B, M, N, h, w), SD_ERR_WORKSPACE, "sd_decode_fused: state %zu < %zu bytes", state_bytes,
+               sd_decode_state_bytes(B, M, N, h, w));
+    const size_t need = sd_decode_fused_workspace_bytes(B, M, N, h, w, K, P);
+    SD_REQUIRE(workspace_bytes >= need, SD_ERR_WORKSPACE, "sd_decode_fused: workspace %zu < %zu", workspace_bytes, need);
+    // rank sort needs 2 * np2 <= cap with np2 >= max(K, P): never below 2 * next_pow2(max(K, P))
+    int sort_cap = exact_topk ? FUSED_CAP_EXACT : FUSED_CAP_FAST;
+    while (sort_cap < 2 * std::max(K, P)) sort_cap *= 2;
+    const FusedLds lds = fused_lds(K, P, (int)nti, sort_cap);
+    SD_REQUIRE(lds.total <= FUSED_LDS_LIMIT, SD_ERR_INVALID, "sd_decode_fused: %d maps x %d tiles need %d bytes of LDS (> %d); use sd_decode",
+               M + N, tiles, lds.total, FUSED_LDS_LIMIT);
+    if (lds.total > 48 * 1024) {
+        static thread_local bool raised = false;      // per host thread: cheap, idempotent
+        if (!raised) {
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fused), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_LIMIT));
+            raised = true;
+        }
+    }
+    Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
+    RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
+    hipLaunchKernelGGL(k_decode_fused, dim3((unsigned)(B * nti + B)), dim3(FUSED_THREADS), (size_t)lds.total, (hipStream_t)stream, g0, g1,
+                       h, w, tiles_x, tiles, exact_topk ? 0.f : conf, reinterpret_cast<uint64_t*>(workspace),
+                       reinterpret_cast<unsigned*>(state), K, P, sort_cap, conf, dist_px, rm, packed, B);
     SD_LAUNCH_CHECK();
     return 0;
 }

@@ -24,11 +24,15 @@ class Decoder:
         self.down_ratio = args.down_ratio
         self.max_objects = args.max_objects  # K
         self.max_parts = args.max_parts  # P
+        self._state = {}
+        self._plans = {}
+        self._thresholds = {}
 
     # ------------------------------------------------------------------ device stage
-    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True):
-        """Run sd_decode; returns (packed int32 device buffer, (B, K, P, h, w)).
-        exact_topk=False drops peaks with score <= conf before the selection: same annotations, fewer candidates."""
+    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None):
+        """Run the device stage; returns (packed int32 device buffer, (B, K, P, h, w)).
+        exact_topk=False drops peaks with score < fp32(conf) before the selection: same annotations, fewer candidates.
+        fused: None = one-launch sd_decode_fused whenever K, P allow it; False = the two-launch sd_decode (bit-identical)."""
         a, a_p, a_sb, a_sc = L.map_view(outputs["anchor_hm"])
         p, p_p, p_sb, p_sc = L.map_view(outputs["part_hm"])
         o, o_p, o_sb, o_sc = L.map_view(outputs["offsets"])
@@ -39,12 +43,40 @@ class Decoder:
         K, P = self.max_objects, self.max_parts
         lib = L.lib()
         packed = torch.empty(lib.sd_decode_packed_words(B, K, P), dtype=torch.int32, device=a.device)
-        ws = L.workspace(lib.sd_decode_workspace_bytes(B, M, N, h, w, K, P), a.device)
         conf32 = float(np.float32(conf_thresh))                       # tensor-vs-scalar compares run in fp32
         dist32 = float(np.float32(dist_thresh * min(w, h)))           # decoders.py:100
-        L.check(lib.sd_decode(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
-                              conf32, dist32, int(bool(exact_topk)), packed.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_decode")
+        if fused is None:
+            # one launch for image geometries up to 256 tiles (512x512 with 2 + 1 maps = 48): the selector's LDS is paid by every
+            # tile block of the grid, and with the bookkeeping of ~1000 tiles per image (stress config) it halves the occupancy
+            # of the 16 k tile blocks -- there the NMS launch + select launch pair is faster
+            # (measured device span per call, 512x512 2+1 maps: bs=1 13.5 us vs 21.7 us for the launch pair; bs=64 23.1 vs 25.9;
+            #  exact top-k at bs=64: 39.0 vs 31.3 -- its 2 x 2048-key sort buffers cost the tile blocks occupancy -> launch pair)
+            tiles = (M + N) * (-(-w // 64)) * (-(-h // 16))
+            fused = tiles <= 256 and (not exact_topk or B <= 8) and bool(lib.sd_decode_fused_supported(B, M, N, h, w, K, P))
+        if fused:
+            ws = L.workspace(lib.sd_decode_fused_workspace_bytes(B, M, N, h, w, K, P), a.device)
+            state = self._fused_state(a.device, lib.sd_decode_state_bytes(B, M, N, h, w))
+            try:
+                L.check(lib.sd_decode_fused(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
+                                            conf32, dist32, int(bool(exact_topk)), packed.data_ptr(), state.data_ptr(), state.numel(),
+                                            ws.data_ptr(), ws.numel(), L.stream()), "sd_decode_fused")
+            except L.SdError:
+                state.zero_()                                         # contract: re-zero the state after a failed call
+                raise
+        else:
+            ws = L.workspace(lib.sd_decode_workspace_bytes(B, M, N, h, w, K, P), a.device)
+            L.check(lib.sd_decode(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
+                                  conf32, dist32, int(bool(exact_topk)), packed.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_decode")
         return packed, (B, K, P, h, w)
+
+    def _fused_state(self, device, need):
+        """Hand-off records of sd_decode_fused: zero once, left zero by every call; one buffer per (device, stream)."""
+        key = (device.index if device.index is not None else torch.cuda.current_device(), L.stream())
+        buf = self._state.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.zeros(max(need, 1 << 14), dtype=torch.uint8, device=device)
+            self._state[key] = buf
+        return buf
 
     @staticmethod
     def split_packed(packed, B, K, P):
@@ -53,7 +85,7 @@ class Decoder:
         sizes = [("anchor_out", B * K * 4, (B, K, 4), True), ("part_out", B * P * 6, (B, P, 6), True),
                  ("part_emb", B * P * 2, (B, P, 2), True), ("anchor_smask", B * K, (B, K), True),
                  ("part_smask", B * P, (B, P), True), ("anchor_ind", B * K, (B, K), False),
-                 ("part_ind", B * P, (B, P), False), ("assign", B * P, (B, P), False)]
+                 ("part_ind", B * P, (B, P), False), ("assign", B * P, (B, P), False), ("status", B, (B,), False)]
         out, off = {}, 0
         for name, n, shape, is_f in sizes:
             src = f if is_f else packed
@@ -62,14 +94,90 @@ class Decoder:
         return out
 
     # ------------------------------------------------------------------ reference entry point
+    def _call_low_latency(self, outputs, conf_thresh, dist_thresh):
+        """Decoder.__call__ without metadata on the one-launch kernel, trimmed for bs = 1 latency: the kernel writes its packed
+        result straight into pinned (device-mapped) host memory -- no device buffer, no copy launch -- the host waits on the
+        stream once and assembles the objects from plain Python lists.  Same values as the general path (tests assert it).
+        Returns None when the geometry is not served by sd_decode_fused (caller falls back)."""
+        a, a_p, a_sb, a_sc = L.map_view(outputs["anchor_hm"])
+        p, p_p, p_sb, p_sc = L.map_view(outputs["part_hm"])
+        o, o_p, o_sb, o_sc = L.map_view(outputs["offsets"])
+        e, e_p, e_sb, e_sc = L.map_view(outputs["embeddings"])
+        if not (a.is_cuda and p.is_cuda and o.is_cuda and e.is_cuda):
+            L.require_cuda(a, p, o, e)
+        B, M, h, w = a.shape
+        N = p.shape[1]
+        K, P = self.max_objects, self.max_parts
+        stream = L.stream()
+        key = (a.device.index, stream, B, M, N, h, w)           # per stream: scratch and hand-off state must not be shared in flight
+        plan = self._plans.get(key)
+        lib = L.lib()
+        if plan is None:
+            tiles = (M + N) * (-(-w // 64)) * (-(-h // 16))
+            if not (tiles <= 256 and lib.sd_decode_fused_supported(B, M, N, h, w, K, P)):
+                self._plans[key] = False
+                return None
+            host = torch.empty(lib.sd_decode_packed_words(B, K, P), dtype=torch.int32, pin_memory=True)
+            # scratch and hand-off state owned by the plan (the shared grow-only workspace may be re-allocated by other ops)
+            ws = torch.empty(lib.sd_decode_fused_workspace_bytes(B, M, N, h, w, K, P), dtype=torch.uint8, device=a.device)
+            state = torch.zeros(lib.sd_decode_state_bytes(B, M, N, h, w), dtype=torch.uint8, device=a.device)
+            views = self.split_packed(host.numpy(), B, K, P)
+            plan = (host.data_ptr(), views["anchor_out"], views["part_out"], views["assign"], views["status"], ws.data_ptr(), ws.numel(),
+                    state.data_ptr(), state.numel(), (host, ws, state))
+            self._plans[key] = plan
+        elif plan is False:
+            return None
+        host_ptr, v_anchor, v_part, v_assign, v_status, ws_ptr, ws_n, st_ptr, st_n, keep = plan
+        th = self._thresholds.get((conf_thresh, dist_thresh, w, h))
+        if th is None:
+            th = self._thresholds[(conf_thresh, dist_thresh, w, h)] = (float(np.float32(conf_thresh)), float(np.float32(dist_thresh * min(w, h))))
+        rc = lib.sd_decode_fused(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
+                                 th[0], th[1], 0, host_ptr, st_ptr, st_n, ws_ptr, ws_n, stream)
+        if rc == 0:
+            rc = lib.sd_stream_synchronize(stream)                                     # the one host wait
+        status = v_status.tolist()
+        if rc or any(status):
+            keep[2].zero_()                                                            # contract: re-zero the state after a failed call
+            L.check(rc, "sd_decode_fused")
+            raise L.SdError(f"sd_decode_fused: the selector of image(s) {[i for i, v in enumerate(status) if v]} gave up waiting for a tile block")
+        in_h, in_w = int(self.down_ratio * h), int(self.down_ratio * w)                # decoders.py:41
+        sx, sy = in_w / w, in_h / h                                                    # utils.py:19-26
+        anchor_all, part_all, assign_all = v_anchor.tolist(), v_part.tolist(), v_assign.tolist()
+        label_map, part_map, anchor_name = self.label_map, self.part_map, self.anchor_name
+        annotations = []
+        for b in range(B):                                                             # decoders.py:104-139
+            parts_b = part_all[b]
+            by_anchor = {}
+            for i, an in enumerate(assign_all[b]):
+                if an >= 0:
+                    by_anchor.setdefault(an, []).append(i)
+            ann = ImageAnnotation(f"batch_{b}")
+            objs = ann.objects
+            for an, (ax, ay, asc, alab) in enumerate(anchor_all[b]):
+                if asc > conf_thresh:                                                  # skip score <= conf (double compare)
+                    parts = [Keypoint(part_map[int(parts_b[i][3])], parts_b[i][0] * sx, parts_b[i][1] * sy, parts_b[i][2])
+                             for i in by_anchor.get(an, ())]
+                    objs.append(Object(name=label_map[int(alab)], anchor=Keypoint(anchor_name, ax * sx, ay * sy, asc), parts=parts))
+            annotations.append(ann)
+        return annotations
+
     def __call__(self, outputs, conf_thresh=None, dist_thresh=None, return_metadata=False):
         conf_thresh = conf_thresh if conf_thresh is not None else self.args.conf_threshold
         dist_thresh = dist_thresh if dist_thresh is not None else self.args.decoder_dist_thresh
+
+        if not return_metadata:
+            fast = self._call_low_latency(outputs, conf_thresh, dist_thresh)
+            if fast is not None:
+                return fast
 
         # the metadata exposes every top-k slot (also peaks below the threshold): exact selection only when it is asked for
         packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=return_metadata)
         in_h, in_w = int(self.down_ratio * out_h), int(self.down_ratio * out_w)       # decoders.py:41
         host = self.split_packed(packed.cpu().numpy(), B, K, P)                        # the one D2H (+ sync)
+        if host["status"].any():
+            for st in self._state.values():
+                st.zero_()
+            raise L.SdError(f"sd_decode_fused: the selector of image(s) {np.nonzero(host['status'])[0].tolist()} gave up waiting for a tile block")
         sx, sy = in_w / out_w, in_h / out_h                                            # utils.py:19-26
 
         anchor_out = host["anchor_out"].astype(np.float64)        # float(np.float32) == tensor.item()

@@ -436,3 +436,50 @@ def test_decoder_thresholds_vs_golden(golden_dir):
     assert r.shape == g["raw0"].shape
     np.testing.assert_array_equal(r[:, :3], g["raw0"][:, :3])
     assert (r[:, 3] == float(c32)).sum() == 1
+
+
+# ------------------------------------------------------------------------------------------ one-launch decoder
+@pytest.mark.parametrize("B,img,M,N,K,P,kind", [(1, 512, 2, 1, 20, 40, "scene"), (64, 512, 2, 1, 20, 40, "scene"), (5, 256, 3, 2, 12, 24, "noise"),
+                                                (3, 1024, 8, 8, 128, 512, "scene"), (2, 512, 8, 8, 128, 512, "noise"), (2, 132, 1, 1, 3, 2, "flat")])
+def test_fused_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, kind):
+    """sd_decode_fused (one launch; the last tile block of an image selects and associates; self-cleaning counters) against
+    sd_decode (NMS launch + select launch + memset): the packed result must be identical bit for bit, in both selection modes,
+    on repeated calls (state left zero), for lists that take the LDS sort and for lists that take the radix select."""
+    from structuredetector_amd.data import Decoder
+    rng = np.random.default_rng(B * 31 + img + K)
+    h = img // 4
+    if kind == "noise":
+        head = (2 * rng.standard_normal((B, M + N + 4, h, h))).astype(np.float32)               # ~4 % of all pixels are candidates
+    elif kind == "flat":
+        head = np.full((B, M + N + 4, h, h), -20.0, np.float32)                                 # one plateau: every pixel survives, all tied
+        head[:, :, 5, 7] = 3.0
+    else:
+        n_max = 96 if K > 20 else 12
+        head = np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N, n_max // 2, n_max), M, N, K, P, 4.0, 0.1),
+                                             M, N, noise=0.3) for _ in range(B)])
+    views = head_views(dev(head), M, N)
+    dec = Decoder(make_args(M, N, K, P))
+    for exact in (True, False, True):
+        want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+        for _ in range(3):                                                                       # back-to-back: no memset in between
+            got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=True)
+            assert torch.equal(got, want), f"exact_topk={exact}"
+    state = next(iter(dec._state.values()))
+    assert int(state.view(torch.int32).abs().sum()) == 0                                        # counters left zero
+    if kind == "scene":
+        t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+        got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=True)                             # default path = fused
+        assert_decode_matches_oracle(dec.split_packed(got.cpu().numpy(), B, K, P), t, 0.5, SIG_TOL)
+
+
+def test_fused_decoder_limits_and_fallback():
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.data import Decoder
+    head = dev((2 * np.random.default_rng(0).standard_normal((1, 6, 64, 64))).astype(np.float32))
+    assert L.lib().sd_decode_fused_supported(1, 2, 1, 128, 128, 20, 40) == 1 and L.lib().sd_decode_fused_supported(300, 2, 1, 128, 128, 20, 40) == 0
+    dec = Decoder(make_args(1, 1, 600, 700))                      # beyond sd_decode_fused's 512: the two-launch path is taken
+    a, _ = dec.decode_packed(head_views(head, 1, 1), 0.5, 0.1)
+    b, _ = dec.decode_packed(head_views(head, 1, 1), 0.5, 0.1, fused=False)
+    assert torch.equal(a, b) and not dec._state
+    with pytest.raises(L.SdError, match="out of range"):
+        dec.decode_packed(head_views(head, 1, 1), 0.5, 0.1, fused=True)

@@ -174,7 +174,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.sd_bn_apply(16, 16, 100, 6, 16, 16, 16, 16, 0, 1, 0, 0) == -1                                  # C % 4 != 0
     # workspace queries
     assert lib.sd_decode_workspace_bytes(64, 2, 1, 128, 128, 20, 40) >= 64 * 3 * 128 * 128 * 8
-    assert lib.sd_decode_packed_words(64, 20, 40) == 64 * (6 * 20 + 11 * 40)
+    assert lib.sd_decode_packed_words(64, 20, 40) == 64 * (6 * 20 + 11 * 40 + 1)
     d.Ho = 8
     assert lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d)) >= 64 * 9 * 64 * 4
     assert lib.sd_loss_workspace_bytes(64, 2, 1, 128, 128) > 0

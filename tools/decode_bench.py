@@ -23,19 +23,37 @@ for B in (64, 1):
     head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
                       0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
     outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
-    res = {}
-    for exact in (True, False):
-        for _ in range(5):
-            packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(50):
-            packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact)
+    for fused in (False, True):
+        res = {}
+        for exact in (True, False):
+            for _ in range(5):
+                packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact, fused=fused)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(200):
+                packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact, fused=fused)
+            torch.cuda.synchronize()
+            res[exact] = (time.perf_counter() - t0) / 200
+        print(f"B={B} {'fused (1 launch)' if fused else 'two-launch     '}: exact top-k {res[True] * 1e6:6.1f} us/batch, annotations-only "
+              f"{res[False] * 1e6:6.1f} us/batch = {res[False] / B * 1e6:.3f} us/img = {B * 199008 / res[False] / 1e9:.0f} GB/s")
+    if B == 1:
+        import cProfile, pstats, io
+        for _ in range(20):
+            dec(outs)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dec(outs)
+        print(f"B=1 end to end (launch + D2H + host objects): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us")
+        t0 = time.perf_counter()
+        for _ in range(200):
+            packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=False)
         torch.cuda.synchronize()
-        res[exact] = (time.perf_counter() - t0) / 50
-    dt = res[True]
-    print(f"B={B}: exact top-k {res[True] * 1e6:.1f} us/batch, annotations-only mode {res[False] * 1e6:.1f} us/batch = {res[False] / B * 1e6:.2f} us/img")
-    packed, _ = dec.decode_packed(outs, 0.5, 0.1, exact_topk=True)
-    import ctypes
-    from structuredetector_amd import _lib as L
-    cnt = L.workspace(1, dev)[:B * 2 * 128].view(torch.int32).cpu().numpy().reshape(B, 2, 32)[:, :, 0]
-    print(f"B={B}: device {dt * 1e6:.1f} us/batch = {dt / B * 1e6:.2f} us/img; candidates per image (anchor, part): mean {cnt.mean(0)}, max {cnt.max(0)}")
+        print(f"B=1 decode_packed host time: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us")
+        t0 = time.perf_counter()
+        for _ in range(200):
+            host = packed.cpu()
+        print(f"B=1 packed.cpu(): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us")
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(500):
+            dec(outs)
+        pr.disable()
+        st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14); print(st.getvalue()[:3500])
