@@ -147,6 +147,21 @@ int sd_decode_group(const float* a_score, const int64_t* a_ind, const float* a_c
 int sd_render_targets(const int32_t* cx, const int32_t* cy, const int32_t* chan_ptr,
                       int B, int C, int h, int w, float two_sigma2, float* out, sd_stream_t stream);
 
+/* ---- input pipeline: src/sdnet/data/transforms.py:9-35,47-60,108-118 (flips, Resize, Normalize) ------------------------ */
+
+/* Batched Resize (PIL bilinear, bit-identical bytes: Pillow's 22-bit fixed-point separable resampling, horizontal pass first)
+ * + optional horizontal / vertical flip of the RESIZED image (transforms.py:217-226 order) + to_tensor + Normalize.
+ * images: (B, Hin, Win, 3) u8 on the device; out: (B, 3, Hout, Wout) fp32 NCHW.  h_bounds / h_kk (Wout x {first source
+ * column, count} and Wout x h_ksize fixed-point weights) and v_bounds / v_kk (per output row) are the coefficient tables of
+ * Pillow's precompute_coeffs + normalize_coeffs_8bpc, computed by the host (structuredetector_amd/data/augment.py) and
+ * resident on the device; flips: B bytes (bit 0 = horizontal, bit 1 = vertical) or NULL; mean3 / std3: HOST pointers to
+ * three floats.  workspace: sd_preprocess_workspace_bytes() bytes (the 8-bit intermediate of the horizontal pass). */
+size_t sd_preprocess_workspace_bytes(int B, int Hin, int Win, int Wout);
+int sd_preprocess_images(const uint8_t* images, int B, int Hin, int Win, int Hout, int Wout,
+                         const int* h_bounds, const int* h_kk, int h_ksize, const int* v_bounds, const int* v_kk, int v_ksize,
+                         const uint8_t* flips, const float* mean3, const float* std3, float* out,
+                         void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
 /* ---- loss: src/sdnet/model/loss.py:17-64,91-117 ------------------------------------------- */
 
 #define SD_HM_MSE   0

@@ -1,0 +1,185 @@
+"""GPU input pipeline: the reference's per-sample PIL / torchvision chain
+`Resize -> [ColorJitter] -> RandomHorizontalFlip -> RandomVerticalFlip -> Normalize` (src/sdnet/data/transforms.py:217-234,
+validation :255-261) for a whole batch in two HIP launches (`sd_preprocess_images`), with the annotation transforms of
+src/sdnet/utils/utils.py:384-415 on the host and the per-epoch multi-scale shapes of transforms.py:237-244.
+
+Resize parity: `F.resize` of a PIL image is Pillow's separable 8-bit fixed-point resampling; `pil_bilinear_coeffs` reproduces
+Pillow's coefficient tables (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc) and the kernels its integer
+arithmetic, so the resized bytes equal `Image.resize(size, BILINEAR)` and the normalised tensor equals the reference's bit for bit.
+ColorJitter (transforms.py:37-44: random photometric noise from torchvision) is not reproduced: with `--no_augmentation` the two
+pipelines are identical; with augmentation this one applies the geometric part (flips + multi-scale) only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..utils.misc import clip_annotation, hflip_annotation, vflip_annotation
+
+PRECISION_BITS = 32 - 8 - 2
+_MEAN = (0.485, 0.456, 0.406)
+_STD = (0.229, 0.224, 0.225)
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs (triangle filter, support 1.0 scaled by max(in/out, 1)) + normalize_coeffs_8bpc for one axis.
+    Returns (bounds int32 (out, 2) = first source index and tap count, kk int32 (out, ksize) 22-bit fixed-point weights, ksize).
+    Plain Python floats are C doubles and int() truncates like a C cast, so every intermediate matches Pillow's."""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ww = 0.0
+        k = []
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                k[x] /= ww
+            v = k[x] * (1 << PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + v) if k[x] < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+class _Tables:
+    """Device-resident coefficient tables, one entry per (in_size, out_size) pair seen (a handful per run)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, in_size, out_size, device):
+        key = (in_size, out_size, device.index)
+        t = self.cache.get(key)
+        if t is None:
+            bounds, kk, ksize = pil_bilinear_coeffs(in_size, out_size)
+            t = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
+            self.cache[key] = t
+        return t
+
+
+_tables = _Tables()
+
+
+def preprocess_images(images: torch.Tensor, out_size, flips=None, mean=_MEAN, std=_STD) -> torch.Tensor:
+    """images: (B, Hin, Win, 3) uint8 on the GPU; out_size = (width, height); flips: (B,) uint8 (bit 0 horizontal, bit 1 vertical)
+    or None.  Returns (B, 3, height, width) fp32 = Normalize(to_tensor(flip(resize(image)))) of transforms.py."""
+    L.require_cuda(images)
+    if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
+        raise L.SdError(f"preprocess_images expects (B, H, W, 3) uint8, got {tuple(images.shape)} {images.dtype}")
+    images = images.contiguous()
+    B, Hin, Win, _ = images.shape
+    Wout, Hout = int(out_size[0]), int(out_size[1])
+    hb, hk, hks = _tables.get(Win, Wout, images.device)
+    vb, vk, vks = _tables.get(Hin, Hout, images.device)
+    out = torch.empty((B, 3, Hout, Wout), dtype=torch.float32, device=images.device)
+    lib = L.lib()
+    ws = L.workspace(lib.sd_preprocess_workspace_bytes(B, Hin, Win, Wout), images.device)
+    fl = None
+    if flips is not None:
+        fl = torch.as_tensor(flips, dtype=torch.uint8).to(images.device)
+        if fl.numel() != B:
+            raise L.SdError("flips must have one entry per image")
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    L.check(lib.sd_preprocess_images(images.data_ptr(), B, Hin, Win, Hout, Wout, hb.data_ptr(), hk.data_ptr(), hks, vb.data_ptr(),
+                                     vk.data_ptr(), vks, fl.data_ptr() if fl is not None else 0, m3, s3, out.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), L.stream()), "sd_preprocess_images")
+    return out
+
+
+class ValidationAugmentation:
+    """transforms.py:255-261 for a batch: Resize((width, height)) + Normalize (+ the clip Encode applies, transforms.py:154)."""
+
+    def __init__(self, args):
+        self.args = args
+        self.size = (args.width, args.height)
+
+    def flips_for(self, n):
+        return None
+
+    def __call__(self, images, annotations):
+        """images: list of (H, W, 3) uint8 arrays / tensors (any sizes) or one (B, H, W, 3) tensor; annotations: list of
+        ImageAnnotation in ORIGINAL image pixels (modified in place like the reference's Resize / flips / Encode clip do on their
+        copies).  Returns ((B, 3, height, width) fp32 device tensor, annotations in network-input pixels)."""
+        dev = self.args.device
+        W, H = self.size
+        if isinstance(images, torch.Tensor) and images.dim() == 4:
+            groups = {tuple(images.shape[1:3]): (list(range(images.shape[0])), images)}
+        else:
+            by_size = {}
+            for i, im in enumerate(images):
+                t = im if isinstance(im, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(im))
+                by_size.setdefault(tuple(t.shape[:2]), []).append((i, t))
+            groups = {k: ([i for i, _ in v], torch.stack([t for _, t in v])) for k, v in by_size.items()}
+        n = sum(len(idx) for idx, _ in groups.values())
+        flips = self.flips_for(n)
+        out = torch.empty((n, 3, H, W), dtype=torch.float32, device=dev)
+        for (hin, win), (idx, stack) in groups.items():
+            f = None if flips is None else [flips[i] for i in idx]
+            res = preprocess_images(stack.to(dev, non_blocking=True), (W, H), f)
+            if len(groups) == 1:
+                out = res
+            else:
+                out[torch.as_tensor(idx, device=dev)] = res
+            for i in idx:
+                ann = annotations[i]
+                ann.img_size = ann.img_size or (win, hin)
+                ann.resize((win, hin), (W, H))                       # transforms.py:58
+                if flips is not None and flips[i] & 1:
+                    hflip_annotation(ann, (W, H))                    # transforms.py:15 (on the resized image)
+                if flips is not None and flips[i] & 2:
+                    vflip_annotation(ann, (W, H))                    # transforms.py:28
+                clip_annotation(ann, (W, H))                         # transforms.py:154
+        return out, annotations
+
+
+class TrainAugmentation(ValidationAugmentation):
+    """transforms.py:211-247: Resize + RandomHorizontalFlip + RandomVerticalFlip + Normalize, and the per-epoch multi-scale
+    `trigger_random_resize` (ratios 0.75 .. 1.25 in steps of 1/16, sizes rounded down to multiples of 32).  Random decisions are
+    drawn like the reference draws them -- `torch.randn(1).item() < prob` (transforms.py:14,27: a normal, not a uniform, draw:
+    the flip probability is Phi(0.5) = 0.69) and `torch.randint` for the ratio -- from torch's global generator."""
+
+    ratios = (0.75, 0.8125, 0.875, 0.9375, 1, 1.0625, 1.125, 1.1875, 1.25)
+
+    def __init__(self, args, prob=0.5):
+        super().__init__(args)
+        self.prob = prob
+
+    def flips_for(self, n):
+        if self.args.no_augmentation:
+            return None
+        out = []
+        for _ in range(n):
+            h = torch.randn(1).item() < self.prob
+            v = torch.randn(1).item() < self.prob
+            out.append(int(h) | (int(v) << 1))
+        return out
+
+    def trigger_random_resize(self):
+        if self.args.no_augmentation:
+            return self.size
+        ratio = self.ratios[torch.randint(len(self.ratios), (1,)).item()]
+        self.size = (int(ratio * self.args.width / 32) * 32, int(ratio * self.args.height / 32) * 32)
+        return self.size

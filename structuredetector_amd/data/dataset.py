@@ -24,10 +24,16 @@ _STD = (0.229, 0.224, 0.225)
 
 
 class CropDataset:
-    def __init__(self, args, directories):
+    """raw=False: items are (normalised (3, height, width) fp32 CPU tensor, annotation in network-input pixels) -- resize and
+    normalisation on the host with PIL (the reference's ValidationAugmentation minus Encode).
+    raw=True: items are ((H, W, 3) uint8 CPU tensor, annotation in ORIGINAL pixels): decode only; resize / flips / normalisation
+    then run for the whole batch on the GPU (data/augment.py)."""
+
+    def __init__(self, args, directories, raw=False):
         from pathlib import Path
         dirs = [directories] if isinstance(directories, (str, Path)) else list(directories)
         self.args = args
+        self.raw = raw
         self.files = sorted(f for d in dirs for f in Path(d).iterdir() if f.suffix == ".json")
 
     def __len__(self):
@@ -43,6 +49,8 @@ class CropDataset:
         path = ann.image_path if ann.image_path.is_absolute() else self.files[index].parent / ann.image_path.name
         img = Image.open(path).convert("RGB")
         ann.img_size = img.size
+        if self.raw:
+            return torch.from_numpy(np.asarray(img, np.uint8).copy()), ann
         W, H = self.args.width, self.args.height
         ann.resize(img.size, (W, H))                                   # Resize transform, transforms.py:47-60
         # the reference's pipeline ends with Encode, which clips the annotation IN PLACE to the network input
@@ -51,3 +59,27 @@ class CropDataset:
         arr = np.asarray(img.resize((W, H), Image.BILINEAR), np.float32) / 255.0
         arr = (arr - np.asarray(_MEAN, np.float32)) / np.asarray(_STD, np.float32)
         return torch.from_numpy(arr).permute(2, 0, 1).contiguous(), ann
+
+
+class PredictionDataset:
+    """src/sdnet/data/dataset.py:166-181 + PredictionTransformation (transforms.py:265-280): every `.jpg` of a directory, resized to
+    the network input and ImageNet-normalised; items are {"img": (3,H,W) tensor, "img_size": (w, h) of the original}."""
+
+    def __init__(self, directory, args):
+        from pathlib import Path
+        self.images = sorted(f for f in Path(directory).iterdir() if f.suffix == ".jpg")
+        self.args = args
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, index):
+        import numpy as np
+        from PIL import Image
+        if index >= len(self.images):
+            raise IndexError(index)
+        img = Image.open(self.images[index]).convert("RGB")
+        size = img.size
+        arr = np.asarray(img.resize((self.args.width, self.args.height), Image.BILINEAR), np.float32) / 255.0
+        arr = (arr - np.asarray(_MEAN, np.float32)) / np.asarray(_STD, np.float32)
+        return {"img": torch.from_numpy(arr).permute(2, 0, 1).contiguous(), "img_size": size}

@@ -221,3 +221,52 @@ class Decoder:
             "raw_embeddings": outputs["embeddings"],
             "raw_offsets": outputs["offsets"],
         }
+
+
+class RawDecoder:
+    """src/sdnet/cli/convert_coreml.py:12-18: the part of the decoder that the reference bakes into its exported model --
+    `cat(nms(clamped_sigmoid(x[:, :nb_hms])), x[:, nb_hms:])`.  Here ONE tile kernel pass (`sd_nms5` with the sigmoid
+    fused: the logits are read once) writes the heatmap channels of the output; the regression channels are copied."""
+
+    def __init__(self, nb_hms: int) -> None:
+        self.nb_hms = nb_hms
+
+    def __call__(self, input: torch.Tensor) -> torch.Tensor:
+        L.require_cuda(input)
+        x = input if input.dtype == torch.float32 else input.float()
+        B, C, h, w = x.shape
+        if not 0 < self.nb_hms <= C:
+            raise L.SdError(f"RawDecoder: nb_hms={self.nb_hms} does not fit a {C}-channel output")
+        out = torch.empty((B, C, h, w), dtype=torch.float32, device=x.device)
+        t, p, sb, sc = L.map_view(x[:, :self.nb_hms])
+        # the NMS output plane (b, c) lives at out[b, c]: channel stride h*w, batch stride C*h*w -> write through a dense scratch
+        hm = out[:, :self.nb_hms] if B == 1 else torch.empty((B, self.nb_hms, h, w), dtype=torch.float32, device=x.device)
+        L.check(L.lib().sd_nms5(p, sb, sc, hm.data_ptr(), B, self.nb_hms, h, w, 1, L.stream()), "sd_nms5")
+        if B != 1:
+            out[:, :self.nb_hms] = hm
+        out[:, self.nb_hms:] = x[:, self.nb_hms:]
+        return out
+
+
+class FusedOutputDecoder(Decoder):
+    """Decoder for the output of a model with the sigmoid + NMS embedded (reference: `CoreMLDecoder`,
+    src/sdnet/data/decoders.py:182-342): top-k directly on the already suppressed heatmaps (`sd_topk`), then the same gather +
+    association kernel (`sd_decode_group`) and the same host assembly as `Decoder`."""
+
+    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None):
+        from ..utils.ops import topk
+        a_s, a_i, a_c, _, _ = topk(outputs["anchor_hm"], self.max_objects)
+        p_s, p_i, p_c, _, _ = topk(outputs["part_hm"], self.max_parts)
+        o, o_p, o_sb, o_sc = L.map_view(outputs["offsets"])
+        e, e_p, e_sb, e_sc = L.map_view(outputs["embeddings"])
+        B, _, h, w = o.shape
+        K, P = self.max_objects, self.max_parts
+        lib = L.lib()
+        packed = torch.empty(lib.sd_decode_packed_words(B, K, P), dtype=torch.int32, device=o.device)
+        L.check(lib.sd_decode_group(a_s.data_ptr(), a_i.data_ptr(), a_c.data_ptr(), p_s.data_ptr(), p_i.data_ptr(), p_c.data_ptr(),
+                                    o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, h, w, K, P, float(np.float32(conf_thresh)),
+                                    float(np.float32(dist_thresh * min(w, h))), packed.data_ptr(), L.stream()), "sd_decode_group")
+        return packed, (B, K, P, h, w)
+
+    def _call_low_latency(self, outputs, conf_thresh, dist_thresh):
+        return None                                   # (the one-launch kernel starts from logits; this class starts from NMS'ed maps)

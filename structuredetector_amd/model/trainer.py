@@ -260,7 +260,10 @@ class Trainer:
         self.scheduler = StepLR(self.step, args.lr_step)
         self.encode = Encode(args)
         self.rng = np.random.default_rng(926354916 + self.rank)
-        self.dataset = None if args.synthetic else CropDataset(args, args.train_dir)
+        # directory data: decode on the host (PIL), resize + flips + normalisation for the whole batch on the GPU
+        from ..data.augment import TrainAugmentation
+        self.dataset = None if args.synthetic else CropDataset(args, args.train_dir, raw=True)
+        self.augment = TrainAugmentation(args)
         self.save_dir = Path("trainings") / f"{datetime.now():%Y-%m-%d_%H-%M-%S}"
         self.best_loss = float("inf")
         self.best_csi = self.best_classif = self.best_kp_reg = 0.0
@@ -286,8 +289,8 @@ class Trainer:
         else:
             for idx in shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch):
                 items = [self.dataset[int(j)] for j in idx]
-                images = torch.stack([im for im, _ in items]).to(a.device, non_blocking=True)
-                yield images, self.encode.batch((a.width, a.height), [an for _, an in items], a.device)
+                images, anns = self.augment([im for im, _ in items], [an for _, an in items])
+                yield images, self.encode.batch(self.augment.size, anns, a.device)
 
     def valid_samples(self):
         if self.valid_set is not None:
@@ -360,6 +363,7 @@ class Trainer:
             if epoch % 2 == 0:                                         # trainer.py:98-99
                 self.valid()
             self.scheduler.step()
+            self.augment.trigger_random_resize()                       # trainer.py:135: a new input size (multiple of 32) per epoch
             if self.rank == 0:                                         # state at the END of the epoch: --resume continues with epoch + 1
                 self.save_dir.mkdir(parents=True, exist_ok=True)
                 self.save_resume(self.save_dir / "resume.pth")

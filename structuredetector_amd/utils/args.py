@@ -13,7 +13,7 @@ from pathlib import Path
 
 import torch
 
-from .misc import set_seed
+from .misc import get_unique_color_map, set_seed
 
 # (flags, kwargs)
 _FLAGS = [
@@ -99,6 +99,8 @@ def finalize(args):
         raise IOError(f"'hm_loss_fn' should either be 'focal' or 'mse', not {args.hm_loss_fn}.")
     args._r_labels = {v: k for k, v in args.labels.items()}
     args._r_parts = {v: k for k, v in args.parts.items()}
+    args._label_color_map = get_unique_color_map(args.labels)          # args.py:264-267
+    args._part_color_map = get_unique_color_map(args.parts)
     return args
 
 

@@ -29,3 +29,38 @@ def clip_annotation(annotation, img_size):
             b = obj.box
             b.x_min, b.x_max, b.y_min, b.y_max = cx(b.x_min), cx(b.x_max), cy(b.y_min), cy(b.y_max)
     return annotation
+
+
+def hflip_annotation(annotation, img_size):
+    """utils.py:384-398: mirror every x about the image width, in place (boxes keep x_min <= x_max)."""
+    w, _ = img_size
+    for obj in annotation.objects:
+        obj.x = w - obj.x - 1
+        for p in obj.parts:
+            p.x = w - p.x - 1
+        if obj.box is not None:
+            obj.box.x_min, obj.box.x_max = w - obj.box.x_max - 1, w - obj.box.x_min - 1
+    return annotation
+
+
+def vflip_annotation(annotation, img_size):
+    """utils.py:401-415."""
+    _, h = img_size
+    for obj in annotation.objects:
+        obj.y = h - obj.y - 1
+        for p in obj.parts:
+            p.y = h - p.y - 1
+        if obj.box is not None:
+            obj.box.y_min, obj.box.y_max = h - obj.box.y_max - 1, h - obj.box.y_min - 1
+    return annotation
+
+
+def get_unique_color_map(labels):
+    """utils.py:476-479: a stable RGB triple per name (first three bytes of its xxh64 digest)."""
+    from xxhash import xxh64_digest
+    return {n: (*xxh64_digest(n.encode())[:3],) for n in labels}
+
+
+def files_with_extension(folder, extension: str):
+    """utils.py:327-328."""
+    return [f for f in Path(folder).iterdir() if f.suffix == extension]

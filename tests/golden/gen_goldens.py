@@ -395,6 +395,38 @@ def gen_evaluate16():
     print("evaluate16:", ev.anchor_eval.reduce(), "|", ev.part_eval.reduce(), "|", ev.csi_eval.reduce())
 
 
+def gen_annotation_transforms(rng):
+    """Annotation side of the augmentations (utils.py:364-415: clip, hflip, vflip incl. boxes) and the colour map (utils.py:476-479)."""
+    out = {"meta": META}
+    objs = []
+    for i in range(5):
+        x, y = float(rng.uniform(-5, 210)), float(rng.uniform(-5, 110))
+        box = RU.Box(x - 10.5, y - 7.25, x + 12.0, y + 9.5) if i % 2 == 0 else None
+        kps = [RU.Keypoint("leaf", float(rng.uniform(0, 200)), float(rng.uniform(0, 100))) for _ in range(i % 3)]
+        objs.append(RU.Object("bean" if i % 2 else "maize", RU.Keypoint("stem", x, y), kps, box))
+    ann = RU.ImageAnnotation("a.jpg", objs)
+
+    def flat(a):
+        rows = []
+        for o in a.objects:
+            b = o.box
+            rows.append([o.x, o.y] + ([b.x_min, b.y_min, b.x_max, b.y_max] if b is not None else [np.nan] * 4) + [len(o.parts)])
+            rows += [[k.x, k.y, np.nan, np.nan, np.nan, np.nan, -1] for k in o.parts]
+        return np.array(rows, np.float64)
+
+    import copy
+    out["input"] = flat(ann)
+    out["hflip"] = flat(RU.hflip_annotation(copy.deepcopy(ann), (200, 100)))
+    out["vflip"] = flat(RU.vflip_annotation(copy.deepcopy(ann), (200, 100)))
+    out["hvflip"] = flat(RU.vflip_annotation(RU.hflip_annotation(copy.deepcopy(ann), (200, 100)), (200, 100)))
+    out["clip"] = flat(RU.clip_annotation(copy.deepcopy(ann), (200, 100)))
+    out["resized"] = flat(copy.deepcopy(ann).resize((200, 100), (512, 384)))
+    names = ["bean", "maize", "leaf", "stem", "haricot"]
+    out["color_names"] = np.array(names)
+    out["colors"] = np.array([RU.get_unique_color_map(names)[n] for n in names], np.int64)
+    np.savez_compressed(HERE / "annotation_transforms.npz", **out)
+
+
 def gen_fpn_head(rng):
     torch.manual_seed(1234)
     fpn = Fpn(16, 8).train(); head = Head(8, 7)
@@ -418,5 +450,6 @@ if __name__ == "__main__":
     gen_fpn_head(rng)
     gen_evaluator(np.random.default_rng(77))
     gen_thresholds(np.random.default_rng(404))
+    gen_annotation_transforms(np.random.default_rng(31))
     gen_evaluate16()
     print("goldens written to", HERE)

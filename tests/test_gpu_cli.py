@@ -186,3 +186,67 @@ def test_resume_is_bit_identical_and_amp_training_is_refused(tmp_path, monkeypat
     train.main(common + ["-e", "2", "--resume", str(resume[0])])
     with pytest.raises(NotImplementedError, match="--amp"):
         train.main(common + ["-e", "1", "--amp"])
+
+
+def test_fused_inference_export_and_detect(tmp_path, monkeypatch):
+    """f4: RawDecoder (convert_coreml.py:12-18) = cat(nms(clamped_sigmoid(hm)), regs) in one tile pass; FusedInferenceModel
+    (network + that stage, also as one hipGraph) + FusedOutputDecoder give the same annotations as Network + Decoder;
+    save / load round trip; `detect` over a folder of .jpg writes predictions/<name>.json + the drawn image."""
+    from PIL import Image
+    from oracle import sdnet_oracle as O
+    from structuredetector_amd.cli import detect
+    from structuredetector_amd.data import Decoder, FusedOutputDecoder, RawDecoder
+    from structuredetector_amd.model import FusedInferenceModel, Network
+    from structuredetector_amd.utils import ImageAnnotation, clamped_sigmoid, nms
+    from tests.test_host_cpu import make_args
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(8)
+    M, N, K, P, img = 2, 1, 20, 40, 256
+    args = make_args(M, N, K, P, device=dev)
+    # RawDecoder against the (golden-pinned) primitives and the oracle, batch 1 and batch 3, views and copies
+    for B in (1, 3):
+        head = torch.from_numpy(np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N), M, N, K, P, 4.0, 0.1),
+                                                              M, N, noise=0.3) for _ in range(B)])).to(dev)
+        raw = RawDecoder(M + N)(head)
+        want = torch.cat([nms(clamped_sigmoid(head[:, :M + N])), head[:, M + N:]], 1)
+        assert torch.equal(raw, want)
+        ref = O.nms(O.clamped_sigmoid(head[:, :M + N].cpu().numpy()))
+        np.testing.assert_array_equal(raw[:, :M + N].cpu().numpy() > 0, ref > 0)
+        np.testing.assert_allclose(raw[:, :M + N].cpu().numpy(), ref, rtol=4e-7, atol=0)
+        # decoding the fused output == decoding the logits
+        v = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
+        f = {"anchor_hm": raw[:, :M], "part_hm": raw[:, M:M + N], "offsets": raw[:, M + N:M + N + 2], "embeddings": raw[:, M + N + 2:]}
+        a1, a2 = Decoder(args)(v), FusedOutputDecoder(args)(f)
+        for x, y in zip(a1, a2):
+            assert [(o.name, o.x, o.y, o.anchor.score, [(p.kind, p.x, p.y, p.score) for p in o.parts]) for o in x.objects] == \
+                   [(o.name, o.x, o.y, o.anchor.score, [(p.kind, p.x, p.y, p.score) for p in o.parts]) for o in y.objects]
+        assert sum(len(a) for a in a1) >= 3 * B
+    # the exported module: network + sigmoid/NMS, eager and as one hipGraph, and through save / load
+    net = Network(args, pretrained=False).to(dev).eval()
+    fused = FusedInferenceModel(net, args)
+    x = torch.randn(1, 3, 128, 160, device=dev)
+    with torch.no_grad():
+        out = fused(x)
+        logits = net(x)
+    assert out.shape == (1, M + N + 4, 32, 40)
+    assert torch.equal(out, RawDecoder(M + N)(logits)) and torch.equal(out[:, M + N:], logits[:, M + N:])
+    run = fused.graphed(x)
+    assert torch.equal(run(x), out)
+    fused.save(tmp_path / "fused.pt")
+    again = FusedInferenceModel.load(tmp_path / "fused.pt")
+    with torch.no_grad():
+        assert torch.equal(again(x), out)
+    assert set(fused.split(out)) == {"anchor_hm", "part_hm", "offsets", "embeddings"}
+    # detect CLI
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
+    (tmp_path / "imgs").mkdir()
+    for i, size in enumerate([(320, 240), (200, 200)]):
+        Image.fromarray(rng.integers(0, 255, (size[1], size[0], 3), dtype=np.uint8)).save(tmp_path / "imgs" / f"p{i}.jpg")
+    torch.save(O.build_reference_network(2, 1, seed=4).state_dict(), tmp_path / "w.pth")
+    written = detect.main(["--valid_dir", str(tmp_path / "imgs"), "-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json"),
+                           "-o", str(tmp_path / "w.pth"), "-t", "0.3"])
+    assert [w.name for w in written] == ["p0.json", "p1.json"]
+    ann = ImageAnnotation.from_json(tmp_path / "predictions" / "p0.json", "stem")
+    assert list(ann.img_size) == [320, 240] and all(np.isfinite([o.x, o.y, o.anchor.score]).all() for o in ann.objects)
+    assert Image.open(tmp_path / "predictions" / "p0.jpg").size == (320, 240)

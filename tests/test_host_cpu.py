@@ -235,3 +235,96 @@ def test_steplr_matches_torch_scheduler():
         other = StepLR(_Step(), 7)
         other.load_state_dict(state)
         assert other.epoch == 100 and abs(other.step_obj.lr - obj.lr) < 1e-30
+
+
+def test_draw_marks_anchors_parts_and_links():
+    """utils/visualization.py::draw (reference visualization.py:13-50): discs of 1 % of the short side in the xxh64-derived colours
+    (args.py:264-267), a white link per part."""
+    from PIL import Image
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object, draw, draw_keypoints, get_unique_color_map
+    args = Namespace(labels={"bean": 0, "maize": 1}, parts={"leaf": 0})
+    args._label_color_map = get_unique_color_map(args.labels)
+    args._part_color_map = get_unique_color_map(args.parts)
+    assert args._label_color_map["bean"] == (28, 48, 154) and args._part_color_map["leaf"] == (148, 24, 183)   # first 3 bytes of xxh64(name)
+    ann = ImageAnnotation("x.jpg", [Object("bean", Keypoint("stem", 50.0, 60.0, 0.9), [Keypoint("leaf", 150.0, 60.0, 0.8)]),
+                                    Object("maize", Keypoint("stem", 100.0, 150.0, 0.7), [])])
+    base = Image.new("RGB", (200, 300), (0, 0, 0))
+    out = draw(base, ann, args)
+    assert out.size == (200, 300) and base.getpixel((50, 60)) == (0, 0, 0)                 # the input image is not modified
+    assert out.getpixel((50, 60)) == args._label_color_map["bean"] and out.getpixel((100, 150)) == args._label_color_map["maize"]
+    assert out.getpixel((150, 60)) == args._part_color_map["leaf"] and out.getpixel((100, 60)) == (255, 255, 255)   # link
+    assert out.getpixel((50, 64)) == (0, 0, 0)                                              # radius = int(200 * 1 / 100) = 2
+    kp = draw_keypoints(base, [Keypoint("maize", 20, 20), Keypoint("leaf", 40, 40)], args)
+    assert kp.getpixel((20, 20)) == args._label_color_map["maize"] and kp.getpixel((40, 40)) == args._part_color_map["leaf"]
+    import torch
+    t = torch.zeros(3, 40, 60)                                                             # normalised tensor input: un-normalised first
+    img = draw(t, ImageAnnotation("t", []), args)
+    assert img.size == (60, 40) and img.getpixel((5, 5)) == (124, 116, 104)                # round(255 * ImageNet mean)
+
+
+def test_annotation_transforms_vs_reference(golden_dir):
+    """clip / hflip / vflip / resize of annotations incl. boxes (utils.py:19-26,364-415) and the colour map (utils.py:476-479) against
+    the reference's own functions (tests/golden/annotation_transforms.npz)."""
+    import copy
+    from structuredetector_amd.utils import (Box, ImageAnnotation, Keypoint, Object, clip_annotation, get_unique_color_map,
+                                             hflip_annotation, vflip_annotation)
+    g = np.load(golden_dir / "annotation_transforms.npz")
+
+    def build(rows):
+        objs, i = [], 0
+        while i < len(rows):
+            x, y, b0, b1, b2, b3, n = rows[i]
+            n = int(n)
+            parts = [Keypoint("leaf", rows[i + 1 + j][0], rows[i + 1 + j][1]) for j in range(n)]
+            objs.append(Object("bean", Keypoint("stem", x, y), parts, None if np.isnan(b0) else Box(b0, b1, b2, b3)))
+            i += 1 + n
+        return ImageAnnotation("a.jpg", objs)
+
+    def flat(a):
+        rows = []
+        for o in a.objects:
+            b = o.box
+            rows.append([o.x, o.y] + ([b.x_min, b.y_min, b.x_max, b.y_max] if b is not None else [np.nan] * 4) + [len(o.parts)])
+            rows += [[k.x, k.y, np.nan, np.nan, np.nan, np.nan, -1] for k in o.parts]
+        return np.array(rows, np.float64)
+
+    ann = build(g["input"])
+    np.testing.assert_array_equal(flat(ann), g["input"])
+    np.testing.assert_array_equal(flat(hflip_annotation(copy.deepcopy(ann), (200, 100))), g["hflip"])
+    np.testing.assert_array_equal(flat(vflip_annotation(copy.deepcopy(ann), (200, 100))), g["vflip"])
+    np.testing.assert_array_equal(flat(vflip_annotation(hflip_annotation(copy.deepcopy(ann), (200, 100)), (200, 100))), g["hvflip"])
+    np.testing.assert_array_equal(flat(clip_annotation(copy.deepcopy(ann), (200, 100))), g["clip"])
+    np.testing.assert_array_equal(flat(copy.deepcopy(ann).resize((200, 100), (512, 384))), g["resized"])
+    cm = get_unique_color_map([str(n) for n in g["color_names"]])
+    assert [list(cm[str(n)]) for n in g["color_names"]] == g["colors"].tolist()
+
+
+def test_pil_bilinear_coefficient_tables_reproduce_pillow():
+    """The host half of the GPU Resize: coefficient tables of Pillow's separable 8-bit resampling (data/augment.py) applied with
+    numpy must give exactly the bytes of Image.resize(BILINEAR) -- up-scaling, antialiased down-scaling, identity passes."""
+    from PIL import Image
+    from structuredetector_amd.data.augment import PRECISION_BITS, pil_bilinear_coeffs
+
+    def resample(img, Wout, Hout):
+        Hin, Win, _ = img.shape
+        hb, hk, _ = pil_bilinear_coeffs(Win, Wout)
+        vb, vk, _ = pil_bilinear_coeffs(Hin, Hout)
+        clip8 = lambda v: np.clip(v >> PRECISION_BITS, 0, 255).astype(np.uint8)
+        tmp = np.zeros((Hin, Wout, 3), np.uint8)
+        for x in range(Wout):
+            acc = np.full((Hin, 3), 1 << (PRECISION_BITS - 1), np.int64)
+            for t in range(hb[x, 1]):
+                acc += img[:, hb[x, 0] + t].astype(np.int64) * int(hk[x, t])
+            tmp[:, x] = clip8(acc)
+        out = np.zeros((Hout, Wout, 3), np.uint8)
+        for y in range(Hout):
+            acc = np.full((Wout, 3), 1 << (PRECISION_BITS - 1), np.int64)
+            for t in range(vb[y, 1]):
+                acc += tmp[vb[y, 0] + t].astype(np.int64) * int(vk[y, t])
+            out[y] = clip8(acc)
+        return out
+
+    rng = np.random.default_rng(0)
+    for (Hin, Win, Hout, Wout) in [(48, 64, 32, 32), (30, 50, 64, 96), (37, 41, 32, 64), (100, 80, 100, 32), (64, 64, 64, 64), (75, 33, 24, 24)]:
+        img = rng.integers(0, 256, (Hin, Win, 3), dtype=np.uint8)
+        np.testing.assert_array_equal(resample(img, Wout, Hout), np.asarray(Image.fromarray(img).resize((Wout, Hout), Image.BILINEAR)))
