@@ -280,6 +280,31 @@ int sd_conv2d_fwd_bf16(const void* x_nhwc_bf16, const void* w_krsc_bf16, void* y
                        const float* scale, const float* shift, const void* residual_bf16, int res_up2, int relu,
                        void* workspace, size_t workspace_bytes, sd_stream_t stream);
 int sd_maxpool3x3s2_fwd_bf16(const void* x_bf16, void* y_bf16, int B, int Hi, int Wi, int C, sd_stream_t stream);
+
+/* ---- mixed-precision training: the step the reference runs under `--amp` (src/sdnet/model/trainer.py:115-121: the forward and
+ * the loss inside torch.autocast, backward in the dtypes the forward used, fp32 master weights updated by Adam).  Activations and
+ * the weights handed to the convs are bf16, every accumulation (MFMA, BatchNorm statistics, gradients of parameters) is fp32.
+ * BatchNorm statistics are those of the bf16-ROUNDED conv output (the tensor that is normalised, as under autocast). */
+int sd_cast_bf16_to_f32(const void* x_bf16, float* y, int64_t n, sd_stream_t stream);
+size_t sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_fwd_bf16_bn_stats(const void* x_nhwc_bf16, const void* w_krsc_bf16, void* y_nhwc_bf16, const sd_conv_desc* d, float eps,
+                                float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                                void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* dx = dgrad(dy) [+ residual]: bf16 dy / transposed weights [Cin][R][S][Cout] / dx; res_mode 0 none, 1 bf16 tensor of dx's shape,
+ * 2 bf16 half-size map added at the even pixels (the 1x1 / stride-2 downsample branch). */
+int sd_conv2d_dgrad_bf16(const void* dy_bf16, const void* w_t_bf16, void* dx_bf16, const sd_conv_desc* d, const void* residual_bf16,
+                         int res_mode, sd_stream_t stream);
+/* sd_bn_apply / sd_bn_bwd / sd_col_sum / sd_upsample2x_bwd on bf16 activations (parameters, statistics and parameter gradients fp32;
+ * arithmetic in fp32, one rounding at the store). */
+int sd_bn_apply_bf16(const void* x, void* y, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, const void* residual, int relu, uint8_t* relu_mask_out, sd_stream_t stream);
+int sd_bn_bwd_bf16(const void* dy, const void* x, const void* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, void* dx, void* g_out, float* dgamma, float* dbeta, int accumulate,
+                   void* workspace, size_t workspace_bytes, sd_stream_t stream);
+int sd_bn_train_stats_bf16(const void* x, int64_t M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* invstd, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+int sd_col_sum_bf16(const void* x, int64_t M, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+int sd_upsample2x_bwd_bf16(const void* dy, const void* add, void* dx, int B, int H, int W, int C, sd_stream_t stream);
 int sd_head_fwd_bf16(const void* x_nhwc_bf16, const float* w, const float* bias, float* y_nchw, int B, int HW, int C,
                      int Co, sd_stream_t stream);
 /* dX = conv_transpose(dY, W): same kernel with the inverted coordinate map; w_t = weights

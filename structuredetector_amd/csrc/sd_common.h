@@ -48,6 +48,24 @@ __device__ __forceinline__ float clamped_sigmoid(float x) {
     return fminf(fmaxf(sigmoid_raw(x), kClampLo), kClampHi);
 }
 
+// bf16 <-> fp32 (round to nearest even: v_cvt_pk_bf16_f32) and four-element activation accessors used by the kernels that exist
+// for both activation types (fp32, and bf16 for the mixed-precision training path: i indexes groups of four elements)
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ float4 ld4(const uint16_t* p, int64_t i) {
+    const uint2 r = reinterpret_cast<const uint2*>(p)[i];
+    return make_float4(bf16_to_f32((uint16_t)(r.x & 0xffff)), bf16_to_f32((uint16_t)(r.x >> 16)), bf16_to_f32((uint16_t)(r.y & 0xffff)),
+                       bf16_to_f32((uint16_t)(r.y >> 16)));
+}
+__device__ __forceinline__ void st4(float* p, int64_t i, const float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+__device__ __forceinline__ void st4(uint16_t* p, int64_t i, const float4 v) {
+    uint2 pk;
+    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    reinterpret_cast<uint2*>(p)[i] = pk;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

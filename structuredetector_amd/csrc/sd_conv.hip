@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     // Column sums for a BatchNorm that is fused with this launch (p.stat): forward = statistics of the raw conv output, from
     // the accumulators (rows past M staged zeros: they add nothing); data-gradient = the BatchNorm-backward reduction over
     // the values being stored.  Per wave over its 64 rows, the two wave rows combined through LDS, one partial row per tile.
-    const bool fwd_stat = !BF16 && MODE == 0 && p.stat && !p.bn_x;
+    // (bf16 output: the statistics are those of the ROUNDED values, i.e. of the tensor the BatchNorm will normalise)
+    const bool fwd_stat = MODE == 0 && p.stat && !p.bn_x;
     const bool bwd_red = !BF16 && p.stat && p.bn_x;
     float sv[NT], qv[NT];
 #pragma unroll
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
+                for (int e = 0; e < 16; ++e) { const float a = BF16 ? bf2f(f2bf(acc[mi][ni][e])) : acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
     bool red_done = false;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
 template <int BN, int WM, int WN, int MT, int NTW, bool FWD, bool BF16 = false, bool VEC = false, typename RowMap, typename ResMap>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[MT][NTW], RowMap row_to_m, ResMap row_to_res, int tid, int wave, int fr,
                                               int fh, int wm0, int wn0, int n0, int tile_m, float* T0 = nullptr, float* T1 = nullptr) {
-    const bool fwd_stat = !BF16 && FWD && p.stat && !p.bn_x;
+    const bool fwd_stat = FWD && p.stat && !p.bn_x;
     const bool bwd_red = !BF16 && p.stat && p.bn_x;
     float sv[NTW], qv[NTW];
 #pragma unroll
@@ -601,7 +602,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
+                for (int e = 0; e < 16; ++e) { const float a = BF16 ? bf2f(f2bf(acc[mi][ni][e])) : acc[mi][ni][e]; sv[ni] += a; qv[ni] += a * a; }
         }
     }
     const int lane = tid & 63;
@@ -1945,9 +1946,16 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
             return 0;
         }
     }
-    if (bf16) {                            // inference forward only (MODE 0)
-        if (BN == 128) launch_one<128, 0, true>(a, tiles, lds, st);
-        else launch_one<64, 0, true>(a, tiles, lds, st);
+    if (bf16) {                            // forward (MODE 0) and, for mixed-precision training, the data-gradient modes
+        if (BN == 128) {
+            if (mode == 0) launch_one<128, 0, true>(a, tiles, lds, st);
+            else if (mode == 2) launch_one<128, 2, true>(a, tiles, lds, st);
+            else launch_one<128, 3, true>(a, tiles, lds, st);
+        } else {
+            if (mode == 0) launch_one<64, 0, true>(a, tiles, lds, st);
+            else if (mode == 2) launch_one<64, 2, true>(a, tiles, lds, st);
+            else launch_one<64, 3, true>(a, tiles, lds, st);
+        }
     } else
     if (mode == 1) launch_one<64, 1>(a, tiles, lds, st);
     else if (BN == 128) {
@@ -2038,13 +2046,14 @@ int sd_conv2d_fwd(const float* x, const float* w, float* y, const sd_conv_desc* 
 }
 
 // rows of the statistics partial buffer the forward kernel of this geometry writes (0 = the split-K path: no fused statistics)
-static int fwd_stat_rows(const sd_conv_desc* d) {
+static int fwd_stat_rows(const sd_conv_desc* d, bool bf16 = false) {
     ConvArgs a{};
     fill_fwd(a, d);
+    if (bf16) { a.kchunks = d->Cin / 64; a.nk = d->R * d->S * a.kchunks; a.splits = fwd_splits(d, 64); }
     if (a.splits > 1) return 0;
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     ConvArgs t = a;
-    return (conv_patch_geometry(t, BN, 0) || igemm_big_tiles(a, BN, 0)) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+    return (conv_patch_geometry(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
 size_t sd_conv2d_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d) {
@@ -2114,6 +2123,56 @@ int sd_conv2d_fwd_bf16(const void* x, const void* w, void* y, const sd_conv_desc
         if (workspace && workspace_bytes >= sd_conv2d_fwd_bf16_workspace_bytes(d)) a.part = (float*)workspace;
         else a.splits = 1;
     }
+    return launch_igemm(a, false, (hipStream_t)stream, true);
+}
+
+// ---- mixed-precision training (bf16 activations and weights, fp32 accumulation; trainer.py:115-121 autocast) -----------------
+size_t sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 64 || d->Cout % 64) return 0;
+    const int rows = fwd_stat_rows(d, true);
+    const size_t fused = (size_t)(rows + sd_bn_finalize_scratch_rows(rows)) * 2 * d->Cout * sizeof(float);
+    const size_t split = sd_conv2d_fwd_bf16_workspace_bytes(d) + sd_col_reduce_workspace_bytes((int64_t)d->B * d->Ho * d->Wo, d->Cout);
+    return std::max(std::max(fused, split), (size_t)256);
+}
+
+int sd_conv2d_fwd_bf16_bn_stats(const void* x, const void* w, void* y, const sd_conv_desc* d, float eps, float momentum, float* running_mean,
+                                float* running_var, float* mean, float* invstd, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_fwd_bf16_bn_stats", d)) return e;
+    SD_REQUIRE(x && w && y && mean && invstd && workspace, SD_ERR_INVALID, "sd_conv2d_fwd_bf16_bn_stats: null pointer");
+    SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_fwd_bf16_bn_stats: needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)",
+               d->Cin, d->Cout);
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SD_ERR_ALIGN, "sd_conv2d_fwd_bf16_bn_stats: pointers must be 16-byte aligned");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_fwd_bf16_bn_stats: workspace too small");
+    const int rows = fwd_stat_rows(d, true);
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    if (rows == 0) {        // small batch (split-K): plain conv, then the separate statistics pass over the bf16 output
+        const size_t cw = sd_conv2d_fwd_bf16_workspace_bytes(d);
+        if (int e = sd_conv2d_fwd_bf16(x, w, y, d, nullptr, nullptr, nullptr, 0, 0, workspace, cw, stream)) return e;
+        return sd_bn_train_stats_bf16(y, M, d->Cout, eps, momentum, running_mean, running_var, mean, invstd, (char*)workspace + cw,
+                                      workspace_bytes - cw, stream);
+    }
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = y; a.stat = (float*)workspace;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / 64; a.nk = d->R * d->S * a.kchunks; a.splits = 1;
+    if (int e = launch_igemm(a, false, (hipStream_t)stream, true)) return e;
+    return sd_bn_finalize_stats((const float*)workspace, rows, M, d->Cout, eps, momentum, running_mean, running_var, mean, invstd,
+                                (float*)workspace + (size_t)rows * 2 * d->Cout, stream);
+}
+
+// data-gradient with bf16 dy / transposed weights / dx (+ bf16 residual: res_mode 0 none, 1 same size, 2 half-size map added at even pixels)
+int sd_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, const sd_conv_desc* d, const void* residual, int res_mode, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_dgrad_bf16", d)) return e;
+    SD_REQUIRE(dy && w_t && dx && (res_mode == 0 || residual), SD_ERR_INVALID, "sd_conv2d_dgrad_bf16: null pointer");
+    SD_REQUIRE(res_mode >= 0 && res_mode <= 2, SD_ERR_INVALID, "sd_conv2d_dgrad_bf16: res_mode must be 0, 1 or 2");
+    SD_REQUIRE(d->Cout % 64 == 0 && d->Cin % 64 == 0, SD_ERR_INVALID, "sd_conv2d_dgrad_bf16: needs Cout %% 64 == 0 and Cin %% 64 == 0");
+    SD_REQUIRE(res_mode != 2 || (d->Hi % 2 == 0 && d->Wi % 2 == 0), SD_ERR_INVALID, "sd_conv2d_dgrad_bf16: a half-size residual needs even Hi, Wi");
+    SD_REQUIRE(aligned16(dy) && aligned16(w_t) && aligned16(dx) && aligned16(residual), SD_ERR_ALIGN, "sd_conv2d_dgrad_bf16: pointers must be 16-byte aligned");
+    ConvArgs a{};
+    fill_dgrad(a, d);
+    a.kchunks = d->Cout / 64; a.nk = d->R * d->S * a.kchunks;
+    a.x = dy; a.w = w_t; a.y = dx; a.res = res_mode ? residual : nullptr; a.res_up2 = res_mode == 2 ? 2 : 0;
     return launch_igemm(a, false, (hipStream_t)stream, true);
 }
 

@@ -18,8 +18,8 @@ constexpr int RED_ROWS_PER_BLOCK = 256;
 // MODE 0: sum x, sum x^2                      (BN statistics)
 // MODE 1: sum g, sum g*xhat  with g = dy * [y > 0 if relu]   (BN backward)
 // MODE 2: sum x                               (bias gradient)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
+template <int MODE, typename T = float>
+__global__ __launch_bounds__(256) void k_col_reduce(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ y,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                      int64_t M, int C, float* __restrict__ partial, int rpb) {
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
     if (rl < lanes) {
 #pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += lanes) {
-            const float4 v = reinterpret_cast<const float4*>(a + r * C)[col];
+            const float4 v = ld4(a, r * cols + col);
             if (MODE == 0) {
                 s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
                 s1.x += v.x * v.x; s1.y += v.y * v.y; s1.z += v.z * v.z; s1.w += v.w * v.w;
@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
                 s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
             } else {
                 float4 g = v;
-                const float4 xv = reinterpret_cast<const float4*>(b + r * C)[col];
+                const float4 xv = ld4(b, r * cols + col);
                 if (relu == 1) {            // mask from the saved post-activation (layers with a residual input)
-                    const float4 yy = reinterpret_cast<const float4*>(y + r * C)[col];
+                    const float4 yy = ld4(y, r * cols + col);
                     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
                 } else if (relu == 2) {     // mask recomputed from x (same expression as k_bn_apply): one tensor read less
@@ -165,28 +165,29 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
 }
 
 // y = [relu]( (x - mean) * invstd * gamma + beta [+ res] )
-__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y, int64_t n4, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, T* __restrict__ y, int64_t n4, int C,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
+                                                   const T* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int col = (int)(i % cols);
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 v = ld4(x, i);
         const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
         const float4 g = reinterpret_cast<const float4*>(gamma)[col], b = reinterpret_cast<const float4*>(beta)[col];
         float4 o;
         o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
         o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
         if (res) {
-            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            const float4 r = ld4(res, i);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         // one mask byte per float4 (bit j = element j is positive): the backward of a residual layer reads 1/16 of the bytes of y
         if (mask) mask[i] = (uint8_t)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        reinterpret_cast<float4*>(y)[i] = o;
+        st4(y, i, o);
     }
 }
 
@@ -201,21 +202,22 @@ __global__ __launch_bounds__(256) void k_bn_fold(const float* gamma, const float
 }
 
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * [y > 0];  optionally g_out = g
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                        int relu, int64_t n4, int C, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ mg,
-                                                       const float* __restrict__ mgx, float* __restrict__ dx, float* __restrict__ g_out) {
+                                                       const float* __restrict__ mgx, T* __restrict__ dx, T* __restrict__ g_out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int col = (int)(i % cols);
-        float4 g = reinterpret_cast<const float4*>(dy)[i];
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 g = ld4(dy, i);
+        const float4 xv = ld4(x, i);
         const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
         const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
         if (relu == 1) {
-            const float4 yy = reinterpret_cast<const float4*>(y)[i];
+            const float4 yy = ld4(y, i);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         } else if (relu == 3) {
             const uint8_t mb = reinterpret_cast<const uint8_t*>(y)[i];
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         o.y = ga.y * is.y * (g.y - a.y - (xv.y - mu.y) * is.y * b.y);
         o.z = ga.z * is.z * (g.z - a.z - (xv.z - mu.z) * is.z * b.z);
         o.w = ga.w * is.w * (g.w - a.w - (xv.w - mu.w) * is.w * b.w);
-        reinterpret_cast<float4*>(dx)[i] = o;
-        if (g_out) reinterpret_cast<float4*>(g_out)[i] = g;
+        st4(dx, i, o);
+        if (g_out) st4(g_out, i, g);
     }
 }
 
@@ -566,7 +568,8 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_apply(const float* __restri
 }
 
 // backward of nearest x2 upsample: dx[b,y,x,c] = sum of the 2x2 block of dy (+ add, nullable)
-__global__ __launch_bounds__(256) void k_up2_bwd(const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dx, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void k_up2_bwd(const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx, int B,
                                                   int H, int W, int C) {
     const int cols = C >> 2;
     const int64_t n4 = (int64_t)B * H * W * cols;
@@ -577,16 +580,16 @@ __global__ __launch_bounds__(256) void k_up2_bwd(const float* __restrict__ dy, c
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H);
     const int b = (int)(t / H);
-    const float* base = dy + (((int64_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C;
-    const float4 v0 = reinterpret_cast<const float4*>(base)[col], v1 = reinterpret_cast<const float4*>(base + C)[col];
-    const float4 v2 = reinterpret_cast<const float4*>(base + (int64_t)2 * W * C)[col];
-    const float4 v3 = reinterpret_cast<const float4*>(base + (int64_t)2 * W * C + C)[col];
+    const T* base = dy + (((int64_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C;
+    const float4 v0 = ld4(base, col), v1 = ld4(base + C, col);
+    const float4 v2 = ld4(base + (int64_t)2 * W * C, col);
+    const float4 v3 = ld4(base + (int64_t)2 * W * C + C, col);
     float4 o = make_float4(v0.x + v1.x + v2.x + v3.x, v0.y + v1.y + v2.y + v3.y, v0.z + v1.z + v2.z + v3.z, v0.w + v1.w + v2.w + v3.w);
     if (add) {
-        const float4 a = reinterpret_cast<const float4*>(add)[i];
+        const float4 a = ld4(add, i);
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
-    reinterpret_cast<float4*>(dx)[i] = o;
+    st4(dx, i, o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -788,6 +791,11 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_cast_f32(const uint16_t* __restrict__ x, float* __restrict__ y, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) st4(y, i, ld4(x, i));
+}
+
 __global__ __launch_bounds__(256) void k_maxpool_fwd_bf16(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int B, int Hi, int Wi,
                                                            int Ho, int Wo, int C) {
     const int cols = C >> 3;                       // 8 bf16 = 16 bytes per thread
@@ -928,6 +936,24 @@ int sd_bn_train_stats(const float* x, int64_t M, int C, float eps, float momentu
     return 0;
 }
 
+int sd_bn_train_stats_bf16(const void* x, int64_t M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* invstd, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_train_stats_bf16", M, C)) return e;
+    SD_REQUIRE(x && mean && invstd && workspace, SD_ERR_INVALID, "sd_bn_train_stats_bf16: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_train_stats_bf16: workspace too small");
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_col_reduce<0, uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace, rpb);
+    SD_LAUNCH_CHECK();
+    int rows = nb;
+    const float* fin = fold_partials((const float*)workspace, rows, C, (float*)workspace + ((size_t)nb + 1) * 2 * C, st);
+    hipLaunchKernelGGL(k_col_finalize<0>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, eps, momentum,
+                       mean, invstd, running_mean, running_var, (float*)nullptr, (float*)nullptr, 0);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
 // rows of `scratch` the two-level finish of `rows` partial rows needs (0 = single level)
 int sd_bn_finalize_scratch_rows(int rows) { return fold_rows(rows); }
 
@@ -951,7 +977,7 @@ int sd_bn_apply(const float* x, float* y, int64_t M, int C, const float* mean, c
     if (int e = check_mc("sd_bn_apply", M, C)) return e;
     SD_REQUIRE(x && y && mean && invstd && gamma && beta, SD_ERR_INVALID, "sd_bn_apply: null pointer");
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, mean, invstd, gamma, beta, residual, relu,
+    hipLaunchKernelGGL(k_bn_apply<float>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, n4, C, mean, invstd, gamma, beta, residual, relu,
                        relu_mask_out);
     SD_LAUNCH_CHECK();
     return 0;
@@ -986,7 +1012,7 @@ int sd_bn_bwd(const float* dy, const float* x, const float* y, int relu, int64_t
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
                        (const float*)mg, (const float*)mgx, dx, g_out);
     SD_LAUNCH_CHECK();
     return 0;
@@ -1015,7 +1041,7 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
     SD_REQUIRE(dy && x && mean && invstd && gamma && means && dx && ((relu != 1 && relu != 3) || y) && (relu != 2 || beta), SD_ERR_INVALID,
                "sd_bn_bwd_apply: null pointer");
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, y, relu, n4, C, mean, invstd, gamma, beta,
                        means, means + C, dx, g_out);
     SD_LAUNCH_CHECK();
     return 0;
@@ -1103,7 +1129,7 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream) {
     SD_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_upsample2x_bwd: bad arguments");
     const int64_t n4 = (int64_t)B * H * W * C / 4;
-    hipLaunchKernelGGL(k_up2_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, add, dx, B, H, W, C);
+    hipLaunchKernelGGL(k_up2_bwd<float>, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, dy, add, dx, B, H, W, C);
     SD_LAUNCH_CHECK();
     return 0;
 }
@@ -1111,6 +1137,80 @@ int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H
 int sd_cast_f32_to_bf16(const float* x, void* y, int64_t n, sd_stream_t stream) {
     SD_REQUIRE(x && y && n > 0 && n % 4 == 0 && aligned16(x), SD_ERR_INVALID, "sd_cast_f32_to_bf16: bad arguments (n %% 4 == 0, 16-byte aligned source)");
     hipLaunchKernelGGL(k_cast_bf16, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n / 4);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_cast_bf16_to_f32(const void* x, float* y, int64_t n, sd_stream_t stream) {
+    SD_REQUIRE(x && y && n > 0 && n % 4 == 0 && aligned16(y) && (reinterpret_cast<uintptr_t>(x) & 7u) == 0, SD_ERR_INVALID,
+               "sd_cast_bf16_to_f32: bad arguments (n %% 4 == 0, 8-byte aligned source, 16-byte aligned destination)");
+    hipLaunchKernelGGL(k_cast_f32, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, y, n / 4);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- bf16 activations (mixed-precision training): the same kernels with 2-byte loads / stores, all arithmetic in fp32 --------
+int sd_bn_apply_bf16(const void* x, void* y, int64_t M, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const void* residual, int relu, uint8_t* relu_mask_out, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_apply_bf16", M, C)) return e;
+    SD_REQUIRE(x && y && mean && invstd && gamma && beta, SD_ERR_INVALID, "sd_bn_apply_bf16: null pointer");
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_bn_apply<uint16_t>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n4, C, mean,
+                       invstd, gamma, beta, (const uint16_t*)residual, relu, relu_mask_out);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_bn_bwd_bf16(const void* dy, const void* x, const void* y, int relu, int64_t M, int C, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, void* dx, void* g_out, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                   size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_bn_bwd_bf16", M, C)) return e;
+    SD_REQUIRE(relu >= 0 && relu <= 3, SD_ERR_INVALID, "sd_bn_bwd_bf16: relu must be 0 (none), 1 (mask from y), 2 (mask recomputed from x) or 3 (mask bytes)");
+    SD_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && ((relu != 1 && relu != 3) || y) && (relu != 2 || beta),
+               SD_ERR_INVALID, "sd_bn_bwd_bf16: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_bn_bwd_bf16: workspace too small");
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* mg = partial + (size_t)nb * 2 * C;
+    float* mgx = mg + C;
+    hipLaunchKernelGGL((k_col_reduce<1, uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y, mean,
+                       invstd, gamma, beta, relu, M, C, partial, rpb);
+    SD_LAUNCH_CHECK();
+    int rows = nb;
+    const float* fin = fold_partials(partial, rows, C, mgx + C, st);
+    hipLaunchKernelGGL(k_col_finalize<1>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, dgamma, dbeta,
+                       (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(k_bn_bwd_apply<uint16_t>, dim3(ew_grid(n4)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y,
+                       relu, n4, C, mean, invstd, gamma, beta, (const float*)mg, (const float*)mgx, (uint16_t*)dx, (uint16_t*)g_out);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_col_sum_bf16(const void* x, int64_t M, int C, float* out, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_mc("sd_col_sum_bf16", M, C)) return e;
+    SD_REQUIRE(x && out && workspace, SD_ERR_INVALID, "sd_col_sum_bf16: null pointer");
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_col_sum_bf16: workspace too small");
+    const int rpb = red_rows(M), nb = cdiv(M, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_col_reduce<2, uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, M, C, (float*)workspace, rpb);
+    SD_LAUNCH_CHECK();
+    int rows = nb;
+    const float* fin = fold_partials((const float*)workspace, rows, C, (float*)workspace + ((size_t)nb + 1) * 2 * C, st);
+    hipLaunchKernelGGL(k_col_finalize<2>, dim3(cdiv(C, 4)), dim3(256), 0, st, fin, rows, C, (double)M, 0.f, 0.f, out,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_upsample2x_bwd_bf16(const void* dy, const void* add, void* dx, int B, int H, int W, int C, sd_stream_t stream) {
+    SD_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID, "sd_upsample2x_bwd_bf16: bad arguments");
+    const int64_t n4 = (int64_t)B * H * W * C / 4;
+    hipLaunchKernelGGL(k_up2_bwd<uint16_t>, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (const uint16_t*)add,
+                       (uint16_t*)dx, B, H, W, C);
     SD_LAUNCH_CHECK();
     return 0;
 }

@@ -145,8 +145,38 @@ class _Engine:
     def _ws(self, nbytes, dev):
         return L.workspace(max(int(nbytes), 256), dev)
 
-    def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
+    # ---- mixed precision (`--amp`, trainer.py:115-121): bf16 activations / conv weights, fp32 accumulation and master weights ----
+    def _to_bf16(self, t):
+        out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        L.check(self.lib.sd_cast_f32_to_bf16(t.data_ptr(), out.data_ptr(), t.numel(), L.stream()), "sd_cast_f32_to_bf16")
+        return out
+
+    def _to_f32(self, t):
+        out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        L.check(self.lib.sd_cast_bf16_to_f32(t.data_ptr(), out.data_ptr(), t.numel(), L.stream()), "sd_cast_bf16_to_f32")
+        return out
+
+    def refresh_bf16_weights(self):
+        """One cast of the whole flat fp32 parameter buffer per step; every conv weight is then a view at its fp32 offset."""
+        net = self.net
+        if net.flat_params_bf16 is None:
+            net.flat_params_bf16 = torch.empty(net.flat_params.numel(), dtype=torch.bfloat16, device=net.flat_params.device)
+        L.check(self.lib.sd_cast_f32_to_bf16(net.flat_params.data_ptr(), net.flat_params_bf16.data_ptr(), net.flat_params.numel(), L.stream()),
+                "sd_cast_f32_to_bf16")
+
+    def _w16(self, conv):
+        off, n = self.net._flat_off[id(conv.weight)]
+        return self.net.flat_params_bf16[off:off + n]                 # physical [Cout][R][S][Cin] order, 8-byte aligned slots (off % 4 == 0)
+
+    def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False, amp=False):
         d = _desc(B, Hi, Wi, conv)
+        if amp:
+            y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
+            flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+            self._timed("bf16:" + self._kname(d, 0), flops, lambda: L.check(
+                self.lib.sd_conv2d_fwd_bf16(x.data_ptr(), self._w16(conv).data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
+                                            _ptr(res), int(res_up2), int(relu), 0, 0, L.stream()), "sd_conv2d_fwd_bf16"))
+            return y, d
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         nws = self.lib.sd_conv2d_fwd_workspace_bytes(C.byref(d))          # > 0 only for small batches (split-K)
@@ -157,14 +187,23 @@ class _Engine:
             "sd_conv2d_fwd"))
         return y, d
 
-    def conv_stats(self, x, conv, B, Hi, Wi, bn: BNParams, update_running=True):
+    def conv_stats(self, x, conv, B, Hi, Wi, bn: BNParams, update_running=True, amp=False):
         """Training forward of conv -> BatchNorm: the conv launch also produces the batch statistics of its output
         (sd_conv2d_fwd_bn_stats), so bn_train(..., stats=...) only has the apply pass left."""
         d = _desc(B, Hi, Wi, conv)
-        y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16 if amp else torch.float32, device=x.device)
         mean = torch.empty(conv.cout, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        if amp:
+            ws = self._ws(self.lib.sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(C.byref(d)), x.device)
+            self._timed("bf16:" + self._kname(d, 0), flops, lambda: L.check(
+                self.lib.sd_conv2d_fwd_bf16_bn_stats(x.data_ptr(), self._w16(conv).data_ptr(), y.data_ptr(), C.byref(d), BN_EPS, BN_MOMENTUM,
+                                                     bn.running_mean.data_ptr() if update_running else 0,
+                                                     bn.running_var.data_ptr() if update_running else 0,
+                                                     mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()),
+                "sd_conv2d_fwd_bf16_bn_stats"))
+            return y, d, (mean, invstd)
         ws = self._ws(self.lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), x.device)
         self._timed(self._kname(d, 0), flops, lambda: L.check(
             self.lib.sd_conv2d_fwd_bn_stats(x.data_ptr(), conv.weight.data_ptr(), y.data_ptr(), C.byref(d), BN_EPS, BN_MOMENTUM,
@@ -189,8 +228,9 @@ class _Engine:
         y = torch.empty_like(x)
         # residual layers: the backward needs the ReLU mask of y; one byte per four elements instead of re-reading y twice
         mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device) if want_mask else None
-        L.check(self.lib.sd_bn_apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
-                                     bn.bias.data_ptr(), _ptr(res), int(relu), _ptr(mask), L.stream()), "sd_bn_apply")
+        apply = self.lib.sd_bn_apply_bf16 if x.dtype == torch.bfloat16 else self.lib.sd_bn_apply
+        L.check(apply(x.data_ptr(), y.data_ptr(), Mrows, Cc, mean.data_ptr(), invstd.data_ptr(), bn.weight.data_ptr(),
+                      bn.bias.data_ptr(), _ptr(res), int(relu), _ptr(mask), L.stream()), "sd_bn_apply")
         if update_running:
             self._nbt.append(bn.num_batches_tracked)
         return (y, mean, invstd, mask) if want_mask else (y, mean, invstd)
@@ -207,8 +247,12 @@ class _Engine:
         return scale, shift
 
     # ---- forward -------------------------------------------------------------------------
-    def forward(self, x, training, tape=None):
+    def forward(self, x, training, tape=None, amp=False):
         net, lib = self.net, self.lib
+        if amp:
+            if not training:
+                raise L.SdError("amp=True is the mixed-precision TRAINING forward; inference uses forward_bf16")
+            self.refresh_bf16_weights()
         if x.dim() != 4 or x.shape[1] != 3:
             raise L.SdError(f"Network expects (B, 3, H, W) input, got {tuple(x.shape)}")
         L.require_cuda(x)
@@ -245,7 +289,9 @@ class _Engine:
             m0 = i0 = None
             L.check(lib.sd_maxpool3x3s2_fwd(s0.data_ptr(), p1.data_ptr(), pidx.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
         if rec:
-            tape["x"], tape["stem"] = x, (d0, s0, m0, i0, pidx)
+            tape["x"], tape["stem"], tape["amp"] = x, (d0, s0, m0, i0, pidx), bool(amp)
+        if amp:
+            p1 = self._to_bf16(p1)          # the stem (2.7 % of the MACs) stays fp32; everything behind the max-pool is bf16
 
         # trunk (network.py:47-50)
         feats, cur, Hc, Wc = [], p1, Hp, Wp
@@ -253,11 +299,11 @@ class _Engine:
         for layer in (net.down1, net.down2, net.down3, net.down4):
             for blk in layer:
                 if training:
-                    c1, d1, st1 = self.conv_stats(cur, blk.conv1, B, Hc, Wc, blk.bn1)
+                    c1, d1, st1 = self.conv_stats(cur, blk.conv1, B, Hc, Wc, blk.bn1, amp=amp)
                     a1, m1, i1 = self.bn_train(c1, blk.bn1, stats=st1)
-                    c2, d2, st2 = self.conv_stats(a1, blk.conv2, B, d1.Ho, d1.Wo, blk.bn2)
+                    c2, d2, st2 = self.conv_stats(a1, blk.conv2, B, d1.Ho, d1.Wo, blk.bn2, amp=amp)
                     if blk.downsample is not None:
-                        cd, dd, std_ = self.conv_stats(cur, blk.downsample[0], B, Hc, Wc, blk.downsample[1])
+                        cd, dd, std_ = self.conv_stats(cur, blk.downsample[0], B, Hc, Wc, blk.downsample[1], amp=amp)
                         idt, md, idd = self.bn_train(cd, blk.downsample[1], relu=False, stats=std_)
                     else:
                         cd = dd = md = idd = None
@@ -280,12 +326,12 @@ class _Engine:
         (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
 
         # FPN (network.py:52-55,6-19): lateral 1x1 (+bias) with the x2-upsampled coarser map added in the epilogue
-        f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias)
+        f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias, amp=amp)
         fpn_tape = []
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
-            t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
+            t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True, amp=amp)
             if training:
-                c, dc, stf = self.conv_stats(t, fpn.conv[0], B, Hs, Ws, fpn.conv[1])
+                c, dc, stf = self.conv_stats(t, fpn.conv[0], B, Hs, Ws, fpn.conv[1], amp=amp)
                 fn, mf, if_ = self.bn_train(c, fpn.conv[1], stats=stf)
                 if rec:
                     fpn_tape.append((fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn))
@@ -297,8 +343,9 @@ class _Engine:
         # head (network.py:57): NHWC -> NCHW
         hc = net.head.conv
         out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
-        L.check(lib.sd_head_fwd(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
-                                L.stream()), "sd_head_fwd")
+        head_fwd = lib.sd_head_fwd_bf16 if amp else lib.sd_head_fwd       # (the head's output and the loss stay fp32)
+        L.check(head_fwd(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
+                         L.stream()), "sd_head_fwd")
         if rec:
             tape.update(blocks=blocks_tape, fpn=fpn_tape, p5=(p5, H5, W5), f1=f, B=B, hw=(H2, W2))
         if self._nbt:
@@ -374,20 +421,28 @@ class _Engine:
         return out
 
     # ---- backward ------------------------------------------------------------------------
-    def _wt(self, conv):
-        """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient."""
+    def _wt(self, conv, amp=False):
+        """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient (amp: transposed in fp32, then one cast to bf16)."""
         wt = torch.empty(conv.cin * conv.k * conv.k * conv.cout, dtype=torch.float32, device=conv.weight.device)
         L.check(self.lib.sd_conv2d_transpose_weights(conv.weight.data_ptr(), wt.data_ptr(), conv.cout, conv.k * conv.k, conv.cin, L.stream()),
                 "transpose_weights")
-        return wt
+        return self._to_bf16(wt) if amp else wt
 
     def _dgrad(self, dy, conv, d, res=None, bn_next=None, res_half=False):
         """dx = dgrad(dy) [+ res].  bn_next = (x, y, relu, bn, mean, invstd) of the BatchNorm whose output gradient dx is:
         the launch then also does that BatchNorm's backward reduction (sd_conv2d_dgrad_bn_reduce) and the per-channel means
         come back for _bn_bwd(..., means=...), which only has the apply pass left."""
-        dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=torch.float32, device=dy.device)
-        wt = self._wt(conv)
+        amp = dy.dtype == torch.bfloat16
+        dx = torch.empty((d.B, d.Hi, d.Wi, conv.cin), dtype=dy.dtype, device=dy.device)
+        wt = self._wt(conv, amp)
         flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        if amp:
+            assert bn_next is None, "fuse_bn_bwd is an fp32-path experiment"
+            mode = 2 if res_half else (1 if res is not None else 0)
+            self._timed("bf16:" + self._kname(d, 1), flops, lambda: L.check(
+                self.lib.sd_conv2d_dgrad_bf16(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), mode, L.stream()),
+                "sd_conv2d_dgrad_bf16"), phase="dgrad")
+            return dx
         if bn_next is None:
             if res_half:
                 fn = lambda: L.check(self.lib.sd_conv2d_dgrad_half_res(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), res.data_ptr(),
@@ -430,6 +485,10 @@ class _Engine:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def _wgrad_now(self, dy, x, conv, d):
+        if dy.dtype == torch.bfloat16:
+            # bf16 operands widened to fp32 (exact) and multiplied on the fp32 MFMA: same products and fp32 accumulation as a bf16
+            # MFMA would give; a weight-gradient kernel that reads bf16 directly (transposed LDS reads) is the next step for speed
+            dy, x = self._to_f32(dy), self._to_f32(x)
         g = self.net.grad_of(conv.weight)
         nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = self._ws(nbytes, dy.device)
@@ -441,7 +500,8 @@ class _Engine:
     def _bias_grad(self, dy, conv):
         Mrows, Cc = dy.numel() // dy.shape[-1], dy.shape[-1]
         ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), dy.device)
-        L.check(self.lib.sd_col_sum(dy.data_ptr(), Mrows, Cc, self.net.grad_of(conv.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()),
+        col_sum = self.lib.sd_col_sum_bf16 if dy.dtype == torch.bfloat16 else self.lib.sd_col_sum
+        L.check(col_sum(dy.data_ptr(), Mrows, Cc, self.net.grad_of(conv.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()),
                 "sd_col_sum")
 
     def _bn_bwd(self, dy, x, y, relu, bn, mean, invstd, want_g=False, means=None):
@@ -455,7 +515,8 @@ class _Engine:
             return dx, g
         ws = self._ws(self.lib.sd_col_reduce_workspace_bytes(Mrows, Cc), x.device)
         # relu: False/0 = none, True/1 = mask from y, 3 = y holds the mask bytes of sd_bn_apply (residual layers), 2 = mask recomputed from x
-        L.check(self.lib.sd_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) in (1, 3) else 0, int(relu), Mrows, Cc, mean.data_ptr(),
+        bn_bwd = self.lib.sd_bn_bwd_bf16 if x.dtype == torch.bfloat16 else self.lib.sd_bn_bwd
+        L.check(bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y) if int(relu) in (1, 3) else 0, int(relu), Mrows, Cc, mean.data_ptr(),
                                    invstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), dx.data_ptr(), _ptr(g),
                                    self.net.grad_of(bn.weight).data_ptr(),
                                    self.net.grad_of(bn.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_bn_bwd")
@@ -470,12 +531,17 @@ class _Engine:
         H2, W2 = tape["hw"]
         dhead = dhead.contiguous().float()
         hc = net.head.conv
-        f1 = tape["f1"]
+        amp = bool(tape.get("amp"))
+        if amp and self.fuse_bn_bwd:
+            raise L.SdError("fuse_bn_bwd is an fp32-path experiment; switch it off for mixed-precision training")
+        f1 = self._to_f32(tape["f1"]) if amp else tape["f1"]      # the 7-channel head runs in fp32 on both paths (HBM-bound, 0.4 % of a step)
         df = torch.empty_like(f1)
         ws = self._ws(lib.sd_head_bwd_workspace_bytes(B, H2 * W2, hc.cin, hc.cout), dhead.device)
         L.check(lib.sd_head_bwd(dhead.data_ptr(), f1.data_ptr(), hc.weight.data_ptr(), df.data_ptr(), net.grad_of(hc.weight).data_ptr(),
                                 net.grad_of(hc.bias).data_ptr(), B, H2 * W2, hc.cin, hc.cout, 0, ws.data_ptr(), ws.numel(), L.stream()),
                 "sd_head_bwd")
+        if amp:
+            df = self._to_bf16(df)
 
         # FPN, finest level first.  The lateral 1x1 data-gradients are deferred until the trunk's own
         # gradient for that tensor exists, so the sum of the two is the dgrad kernel's residual epilogue.
@@ -487,8 +553,9 @@ class _Engine:
             self._wgrad(dt, sc_t, fpn.lateral, dl)
             self._bias_grad(dt, fpn.lateral)
             lateral_grad[sc_t.data_ptr()] = (dt, fpn.lateral, dl)
-            dfp = torch.empty((B, Hs // 2, Ws // 2, fpn.lateral.cout), dtype=torch.float32, device=dt.device)
-            L.check(lib.sd_upsample2x_bwd(dt.data_ptr(), 0, dfp.data_ptr(), B, Hs // 2, Ws // 2, fpn.lateral.cout, L.stream()), "up2_bwd")
+            dfp = torch.empty((B, Hs // 2, Ws // 2, fpn.lateral.cout), dtype=dt.dtype, device=dt.device)
+            up2_bwd = lib.sd_upsample2x_bwd_bf16 if amp else lib.sd_upsample2x_bwd
+            L.check(up2_bwd(dt.data_ptr(), 0, dfp.data_ptr(), B, Hs // 2, Ws // 2, fpn.lateral.cout, L.stream()), "up2_bwd")
             df = dfp
         p5, H5, W5 = tape["p5"]
         d5 = _desc(B, H5, W5, net.up1)
@@ -558,6 +625,8 @@ class _Engine:
         # stem
         d0, s0, m0, i0, pidx = tape["stem"]
         bn0 = net.adpater[1]
+        if amp:
+            dcur = self._to_f32(dcur)           # the stem tail (max-pool / ReLU / BatchNorm backward, 7x7 weight gradient) is the fp32 one
         ds0 = torch.empty_like(s0)
         ws = self._ws(lib.sd_col_reduce_workspace_bytes(B * d0.Ho * d0.Wo, 64), s0.device)
         L.check(lib.sd_maxpool_bn_relu_bwd(dcur.data_ptr(), pidx.data_ptr(), s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(),
@@ -620,7 +689,7 @@ class Network(nn.Module):
         # The reference downloads ImageNet weights here (network.py:41); there is no network access and no
         # torchvision in this environment, so `pretrained` selects nothing: load a checkpoint with --load_model.
         self.reset_parameters(seed=0)
-        self.flat_params = self.flat_grads = None
+        self.flat_params = self.flat_grads = self.flat_params_bf16 = None
         self._flat_order, self._flat_off = [], {}
         self._folded = {}        # eval-mode (scale, shift) per BN, valid until the parameters can have changed
         self._engine = None
@@ -672,7 +741,7 @@ class Network(nn.Module):
                 view.copy_(p.data)
                 p.data = view
                 self._flat_off[id(p)] = (off, n)
-        self.flat_params, self.flat_grads = flat, grads
+        self.flat_params, self.flat_grads, self.flat_params_bf16 = flat, grads, None
         self._folded = {}
         self._engine = _Engine(self)
 
@@ -742,10 +811,11 @@ class Network(nn.Module):
         return run
 
     # ---- explicit (autograd-free) training path used by the trainer / bench ----------------
-    def forward_train(self, x):
-        """Forward in training mode recording the tape; returns (head tensor, tape)."""
+    def forward_train(self, x, amp=False):
+        """Forward in training mode recording the tape; returns (head tensor, tape).  amp=True: the mixed-precision step of the
+        reference's `--amp` (trainer.py:115-121) -- bf16 activations and conv weights, fp32 accumulation, statistics and master weights."""
         tape = {}
-        return self._engine.forward(x, True, tape), tape
+        return self._engine.forward(x, True, tape, amp=amp), tape
 
     def backward_from(self, tape, dhead, on_stage=None):
         """Backward of `forward_train`: fills `flat_grads` in place."""

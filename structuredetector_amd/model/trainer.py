@@ -20,7 +20,7 @@ from .. import _lib as L
 from .loss import LossStats, loss_backward, loss_config, loss_forward
 
 
-BF16_TRAINING = False      # flipped when the bf16 data- / weight-gradient kernels exist (autocast semantics of trainer.py:115-121)
+BF16_TRAINING = True       # `--amp`: bf16 activations / conv weights, fp32 accumulation + master weights (autocast semantics of trainer.py:115-121)
 
 
 class RcclExchange:
@@ -77,6 +77,7 @@ class TrainStep:
         self.ranges = net.stage_ranges()
         self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
         self.stats = LossStats()
+        self.amp = bool(getattr(args, "use_amp", False))      # mixed-precision step (trainer.py:115-121)
         self.exchange_enabled = True     # False: skip the all-reduce (bench.py measures the exposed communication time with it)
 
     # ---- true resume: the reference saves weights only (trainer.py:226-237), so a run cannot continue --------
@@ -181,7 +182,7 @@ class TrainStep:
     def __call__(self, images, targets):
         """One optimizer step; returns the loss vector [total, hm, offset, embedding] as a device tensor."""
         net = self.net
-        head, tape = net.forward_train(images)
+        head, tape = net.forward_train(images, amp=self.amp)
         M, N = net.label_count, net.part_count
         cfg = loss_config(self.args, M, N, targets["anchor_inds"].shape[1], targets["part_inds"].shape[1])
         desc, keep, out8 = loss_forward(head, targets, cfg)

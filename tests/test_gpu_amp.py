@@ -1,0 +1,224 @@
+"""Mixed-precision training (`--amp`, reference src/sdnet/model/trainer.py:115-121): bf16 activations / conv weights with fp32
+accumulation, statistics, loss and master weights.  Kernel level: against PyTorch references of the same op on bf16-rounded
+operands; whole step: against the CPU oracle under torch.autocast(cpu, bfloat16) with an fp64 run as the yardstick."""
+import copy
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sdnet_oracle as O
+from tests.test_gpu_network import close, make_desc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc16(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+
+
+def back(t):
+    return t.float().permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("case", [(4, 16, 24, 64, 64, 3, 1, 1), (2, 20, 12, 64, 128, 3, 2, 1), (4, 12, 12, 64, 128, 1, 2, 0), (2, 16, 16, 512, 512, 3, 1, 1),
+                                  (64, 32, 32, 128, 128, 3, 1, 1), (16, 64, 64, 64, 128, 3, 2, 1), (2, 6, 10, 512, 128, 1, 1, 0)])
+def test_conv_bf16_forward_statistics_and_data_gradient(case):
+    """sd_conv2d_fwd_bf16_bn_stats (output bf16 + BatchNorm batch statistics of the ROUNDED output, fused or via the small-batch
+    path) and sd_conv2d_dgrad_bf16 (stride 1 / stride-2 parity classes / strided 1x1, plain, + residual, + half-size residual)."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16().float()
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    xd, wd = nhwc16(x), nhwc16(w)
+    y = torch.empty(B, d.Ho, d.Wo, cout, dtype=torch.bfloat16, device=DEV)
+    mean = torch.empty(cout, device=DEV); invstd = torch.empty(cout, device=DEV)
+    rm = torch.zeros(cout, device=DEV); rv = torch.ones(cout, device=DEV)
+    ws = torch.empty(lib.sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_conv2d_fwd_bf16_bn_stats(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+    ref = F.conv2d(x, w, None, stride, pad)
+    close(back(y), ref, 6e-3)
+    yr = back(y).double()                                            # statistics of the tensor that was stored
+    m_ref = yr.mean((0, 2, 3)); v_ref = yr.var((0, 2, 3), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(v_ref + 1e-5)).numpy(), rtol=1e-4)
+    n = yr.numel() / cout
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * v_ref * n / (n - 1)).numpy(), rtol=1e-4)
+    # data gradient
+    dy = torch.randn(B, cout, d.Ho, d.Wo, generator=g).bfloat16().float()
+    wt = w.permute(1, 2, 3, 0).contiguous().to(DEV).to(torch.bfloat16)       # [Cin][R][S][Cout]
+    dyd = nhwc16(dy)
+    xg = x.clone().requires_grad_(True)
+    F.conv2d(xg, w, None, stride, pad).backward(dy)
+    dx_ref = xg.grad
+    dx = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), 0, 0, L.stream()))
+    close(back(dx), dx_ref, 8e-3)
+    res = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    resd = nhwc16(res)
+    L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), resd.data_ptr(), 1, L.stream()))
+    close(back(dx), dx_ref + res, 8e-3)
+    if H % 2 == 0 and W % 2 == 0:
+        half = torch.randn(B, cin, H // 2, W // 2, generator=g).bfloat16().float()
+        full = torch.zeros(B, cin, H, W); full[:, :, ::2, ::2] = half
+        L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc16(half).data_ptr(), 2, L.stream()))
+        close(back(dx), dx_ref + full, 8e-3)
+
+
+def test_bn_kernels_on_bf16_activations_equal_the_fp32_kernels_rounded():
+    """sd_bn_apply_bf16 / sd_bn_bwd_bf16 / sd_col_sum_bf16 / sd_upsample2x_bwd_bf16 / casts: the same arithmetic as the fp32 kernels
+    on the widened operands, ONE rounding at the store -> bit-identical to round_bf16(fp32 kernel(float(x)))."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(DEV).manual_seed(3)
+    M, Cc = 4 * 24 * 16, 128
+    x16 = torch.randn(M, Cc, device=DEV, generator=g).bfloat16()
+    res16 = torch.randn(M, Cc, device=DEV, generator=g).bfloat16()
+    dy16 = torch.randn(M, Cc, device=DEV, generator=g).bfloat16()
+    gamma = torch.rand(Cc, device=DEV, generator=g) + 0.5; beta = torch.randn(Cc, device=DEV, generator=g) * 0.3
+    mean = torch.randn(Cc, device=DEV, generator=g) * 0.1; invstd = torch.rand(Cc, device=DEV, generator=g) + 0.7
+    # casts round-trip
+    f = torch.empty(M, Cc, device=DEV)
+    L.check(lib.sd_cast_bf16_to_f32(x16.data_ptr(), f.data_ptr(), f.numel(), L.stream()))
+    assert torch.equal(f, x16.float())
+    b = torch.empty(M, Cc, dtype=torch.bfloat16, device=DEV)
+    r32 = torch.randn(M, Cc, device=DEV, generator=g)
+    L.check(lib.sd_cast_f32_to_bf16(r32.data_ptr(), b.data_ptr(), b.numel(), L.stream()))
+    assert torch.equal(b, r32.bfloat16())
+    for relu, with_res, want_mask in ((1, False, False), (1, True, True), (0, False, False)):
+        y16 = torch.empty_like(x16); y32 = torch.empty(M, Cc, device=DEV)
+        m16 = torch.empty(M * Cc // 4, dtype=torch.uint8, device=DEV); m32 = torch.empty_like(m16)
+        x32, res32 = x16.float(), res16.float()
+        L.check(lib.sd_bn_apply_bf16(x16.data_ptr(), y16.data_ptr(), M, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     res16.data_ptr() if with_res else 0, relu, m16.data_ptr() if want_mask else 0, L.stream()))
+        L.check(lib.sd_bn_apply(x32.data_ptr(), y32.data_ptr(), M, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                res32.data_ptr() if with_res else 0, relu, m32.data_ptr() if want_mask else 0, L.stream()))
+        assert torch.equal(y16, y32.bfloat16())
+        if want_mask:
+            assert torch.equal(m16, m32)
+        # backward: relu mode 2 (mask recomputed from x) for plain layers, 3 (mask bytes) for residual layers, 0 for none
+        mode = 0 if relu == 0 else (3 if want_mask else 2)
+        wsb = torch.empty(lib.sd_col_reduce_workspace_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+        dx16 = torch.empty_like(x16); g16 = torch.empty_like(x16); dx32 = torch.empty(M, Cc, device=DEV); g32 = torch.empty(M, Cc, device=DEV)
+        dg16 = torch.empty(Cc, device=DEV); db16 = torch.empty(Cc, device=DEV); dg32 = torch.empty(Cc, device=DEV); db32 = torch.empty(Cc, device=DEV)
+        dy32 = dy16.float()
+        L.check(lib.sd_bn_bwd_bf16(dy16.data_ptr(), x16.data_ptr(), m16.data_ptr() if mode == 3 else 0, mode, M, Cc, mean.data_ptr(), invstd.data_ptr(),
+                                   gamma.data_ptr(), beta.data_ptr(), dx16.data_ptr(), g16.data_ptr(), dg16.data_ptr(), db16.data_ptr(), 0,
+                                   wsb.data_ptr(), wsb.numel(), L.stream()))
+        L.check(lib.sd_bn_bwd(dy32.data_ptr(), x32.data_ptr(), m32.data_ptr() if mode == 3 else 0, mode, M, Cc, mean.data_ptr(), invstd.data_ptr(),
+                              gamma.data_ptr(), beta.data_ptr(), dx32.data_ptr(), g32.data_ptr(), dg32.data_ptr(), db32.data_ptr(), 0,
+                              wsb.data_ptr(), wsb.numel(), L.stream()))
+        assert torch.equal(dx16, dx32.bfloat16()) and torch.equal(g16, g32.bfloat16())
+        assert torch.equal(dg16, dg32) and torch.equal(db16, db32)
+    # bias-gradient column sums and the upsample backward
+    wsb = torch.empty(lib.sd_col_reduce_workspace_bytes(M, Cc), dtype=torch.uint8, device=DEV)
+    s16 = torch.empty(Cc, device=DEV); s32 = torch.empty(Cc, device=DEV)
+    L.check(lib.sd_col_sum_bf16(dy16.data_ptr(), M, Cc, s16.data_ptr(), 0, wsb.data_ptr(), wsb.numel(), L.stream()))
+    x32 = dy16.float()
+    L.check(lib.sd_col_sum(x32.data_ptr(), M, Cc, s32.data_ptr(), 0, wsb.data_ptr(), wsb.numel(), L.stream()))
+    assert torch.equal(s16, s32)
+    up = torch.randn(2, 16, 24, 64, device=DEV, generator=g).bfloat16()
+    o16 = torch.empty(2, 8, 12, 64, dtype=torch.bfloat16, device=DEV); o32 = torch.empty(2, 8, 12, 64, device=DEV)
+    up32 = up.float()
+    L.check(lib.sd_upsample2x_bwd_bf16(up.data_ptr(), 0, o16.data_ptr(), 2, 8, 12, 64, L.stream()))
+    L.check(lib.sd_upsample2x_bwd(up32.data_ptr(), 0, o32.data_ptr(), 2, 8, 12, 64, L.stream()))
+    assert torch.equal(o16, o32.bfloat16())
+
+
+def _pair(seed=0):
+    from argparse import Namespace
+    from structuredetector_amd.model import Network
+    ref = O.build_reference_network(2, 1, seed=seed)
+    args = Namespace(labels={"l0": 0, "l1": 1}, parts={"p0": 0}, fpn_depth=128)
+    net = Network(args, pretrained=False, raw_output=True)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.to(DEV)
+
+
+def test_amp_training_step_vs_oracle_under_autocast():
+    """Forward + backward of the mixed-precision step against the oracle network under torch.autocast(cpu, bfloat16) -- the
+    reference's own `--amp` mechanism (trainer.py:40-42,115-121).  bf16 rounding makes the two implementations differ by far more
+    than 1e-4 from each other, so the yardstick is an fp64 run of the same network: the HIP step must be as close to the fp64 truth
+    as the autocast oracle is (error populations over all parameter tensors within a factor 2)."""
+    ref, net = _pair(seed=13)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 3, 128, 128, generator=g)
+    dy = torch.randn(8, 7, 32, 32, generator=g) * 0.1
+    ref.train(); net.train()
+    ref64 = copy.deepcopy(ref).double()
+    ref_ac = copy.deepcopy(ref)
+    out64 = ref64(x.double()); out64.backward(dy.double())
+    with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+        out_ac = ref_ac(x)
+    out_ac.float().backward(dy)
+    out, tape = net.forward_train(x.to(DEV), amp=True)
+    assert out.dtype == torch.float32 and tape["amp"] is True and tape["f1"].dtype == torch.bfloat16
+    net.backward_from(tape, dy.to(DEV))
+    scale = out64.abs().max().item()
+    e_fwd_gpu = (out.cpu().double() - out64.detach()).abs().max().item() / scale
+    e_fwd_ac = (out_ac.detach().double() - out64.detach()).abs().max().item() / scale
+    assert e_fwd_gpu <= 2 * e_fwd_ac + 1e-3, (e_fwd_gpu, e_fwd_ac)
+    g64, gac = dict(ref64.named_parameters()), dict(ref_ac.named_parameters())
+    e_gpu, e_ac = [], []
+    for name, p in net.named_parameters():
+        truth = g64[name].grad
+        s = truth.abs().max().item() + 1e-30
+        e_gpu.append((net.grad_of(p).cpu().double() - truth).abs().max().item() / s)
+        e_ac.append((gac[name].grad.double() - truth).abs().max().item() / s)
+    e_gpu, e_ac = np.array(e_gpu), np.array(e_ac)
+    assert np.isfinite(e_gpu).all()
+    assert np.median(e_gpu) <= 2 * np.median(e_ac) + 1e-3, (np.median(e_gpu), np.median(e_ac))
+    assert np.mean(e_gpu) <= 2 * np.mean(e_ac) + 1e-3, (np.mean(e_gpu), np.mean(e_ac))
+    assert e_gpu.max() <= 2 * e_ac.max() + 1e-2, (e_gpu.max(), e_ac.max())
+    # running statistics were updated from the (rounded) batch statistics: as close to the fp64 buffers as the autocast oracle's are
+    b64, bac = dict(ref64.named_buffers()), dict(ref_ac.named_buffers())
+    eb_gpu, eb_ac = [], []
+    for name, b in net.named_buffers():
+        if b.dtype == torch.long:
+            assert int(b) == int(b64[name]) == 1, name
+            continue
+        s = b64[name].abs().max().item() + 1e-30
+        eb_gpu.append((b.cpu().double() - b64[name]).abs().max().item() / s)
+        eb_ac.append((bac[name].double() - b64[name]).abs().max().item() / s)
+    assert np.median(eb_gpu) <= 2 * np.median(eb_ac) + 1e-3 and max(eb_gpu) <= 2 * max(eb_ac) + 1e-2, (np.median(eb_gpu), np.median(eb_ac), max(eb_gpu), max(eb_ac))
+
+
+def test_amp_training_reduces_loss_and_cli(tmp_path, monkeypatch, capsys):
+    from structuredetector_amd.cli import train
+    from structuredetector_amd.data import Encode
+    from structuredetector_amd.data.synthetic import synthetic_batch
+    from structuredetector_amd.model import Network
+    from structuredetector_amd.model.trainer import TrainStep
+    from tests.test_host_cpu import make_args
+    dev = torch.device(DEV)
+    args = make_args(2, 1, 20, 40, device=dev, learning_rate=1e-3, use_amp=True)
+    torch.manual_seed(0)
+    net = Network(args, pretrained=False).to(dev).train()
+    step = TrainStep(net, args)
+    assert step.amp
+    enc = Encode(args)
+    tgt = enc.render(enc.plan(128, 128, *synthetic_batch(np.random.default_rng(0), 8, 128, 128, 2, 1)), dev)
+    x = torch.randn(8, 3, 128, 128, device=dev)
+    losses = [float(step(x, tgt)[0]) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+    assert net.flat_params.dtype == torch.float32 and net.flat_params_bf16.dtype == torch.bfloat16      # fp32 master weights
+    # deterministic: same state -> same step, bit for bit
+    a = net.flat_params.clone(); m1 = step.exp_avg.clone(); m2 = step.exp_avg_sq.clone(); sc = step.step_count
+    l1 = step(x, tgt).clone(); p1 = net.flat_params.clone()
+    net.flat_params.copy_(a); step.exp_avg.copy_(m1); step.exp_avg_sq.copy_(m2); step.step_count = sc
+    l2 = step(x, tgt).clone()
+    assert torch.equal(l1, l2) and torch.equal(p1, net.flat_params)
+    # `train --amp` end to end (validation runs the bf16 inference forward, as the reference's autocast validation does)
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
+    train.main(["-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json"), "--synthetic", "16", "-b", "8", "-e", "2", "--amp"])
+    out = capsys.readouterr().out
+    assert "epoch 1: total" in out and "validation (" in out
