@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--fuse-bn-bwd", dest="fuse_bn_bwd", action="store_true", default=None,
                     help="BatchNorm-backward reductions inside the data-gradient epilogues (experiment switch; default: the engine's)")
     ap.add_argument("--no-fuse-bn-bwd", dest="fuse_bn_bwd", action="store_false")
+    ap.add_argument("--amp", action="store_true",
+                    help="time the mixed-precision training step instead (reference `--amp`: bf16 activations / conv weights, fp32 "
+                         "accumulation and master weights); the default line is the fp32 step BASELINE.json names")
     ap.add_argument("--zero-input", action="store_true",
                     help="experiment: all-zero images (every activation is then zero): same kernels at lower MFMA power -> DVFS headroom")
     ap.add_argument("--no-extras", dest="extras", action="store_false", default=True,
@@ -232,6 +235,7 @@ def main():
 
     M, N, K, P, B, img = 2, 1, 20, 40, a.batch, a.size
     args = make_args(dev, M, N, K, P)
+    args.use_amp = bool(a.amp)
     torch.manual_seed(926354916)                         # args.py:257; identical init on every rank (+ broadcast)
     net = Network(args, pretrained=False).to(dev).train()
     step = TrainStep(net, args, exchange=a.exchange)
@@ -375,6 +379,14 @@ def main():
             net.bf16_inference = False
             net.invalidate_folded()
         net.train()
+        if not a.amp:
+            # the same training step under `--amp` (trainer.py:115-121): bf16 activations / conv weights, fp32 accumulation + master weights
+            step.amp = True
+            t_amp = timed(lambda: run_step(0), 5, warm=2)
+            step.amp = False
+            ns["train_step_amp_bf16"] = {"batch": B, "ms_per_step": round(t_amp * 1e3, 3), "images_per_sec": round(B / t_amp, 1),
+                                         "speedup_vs_fp32_step": round((dt / a.steps) / t_amp, 2),
+                                         "note": "weight gradients still run on the fp32 MFMA from widened bf16 operands"}
         # BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, K=128, P=512, dense scenes (64-96 objects), bf16 backbone + fp32 decode
         try:
             Ms = Nn = 8; Ks, Ps, Bs, S = 128, 512, 16, 1024
@@ -426,7 +438,8 @@ def main():
         line = {
             "metric": "images/sec (train fwd+bwd) and decode us/img at 512x512", "value": round(imgs_per_s, 2), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (fp32 accumulate / master weights)" if a.amp else "f32",
+            "data": "synthetic",
             "config": {"workload": f"configs[2]: train step bs={B}/GPU {img}x{img} fp32, 2 labels / 1 part, K=20 P=40, "
                                    "render targets + fwd + MSE/L1 loss + bwd + Adam; random-init ResNet-34+FPN",
                        "global_batch": B * world, "parallelism": f"dp{world}", "overlap_wgrad": bool(a.overlap_wgrad), "fuse_bn_bwd": bool(net._engine.fuse_bn_bwd), **({"zero_input": True} if a.zero_input else {}),
