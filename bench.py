@@ -386,7 +386,8 @@ def main():
             step.amp = False
             ns["train_step_amp_bf16"] = {"batch": B, "ms_per_step": round(t_amp * 1e3, 3), "images_per_sec": round(B / t_amp, 1),
                                          "speedup_vs_fp32_step": round((dt / a.steps) / t_amp, 2),
-                                         "note": "weight gradients still run on the fp32 MFMA from widened bf16 operands"}
+                                         "note": "bf16 MFMA forward / data-gradient / 3x3 weight-gradient (transposed LDS reads); stem, head and the "
+                                                 "strided / 1x1 weight gradients in fp32"}
         # BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, K=128, P=512, dense scenes (64-96 objects), bf16 backbone + fp32 decode
         try:
             Ms = Nn = 8; Ks, Ps, Bs, S = 128, 512, 16, 1024

@@ -294,6 +294,11 @@ int sd_conv2d_fwd_bf16_bn_stats(const void* x_nhwc_bf16, const void* w_krsc_bf16
  * 2 bf16 half-size map added at the even pixels (the 1x1 / stride-2 downsample branch). */
 int sd_conv2d_dgrad_bf16(const void* dy_bf16, const void* w_t_bf16, void* dx_bf16, const sd_conv_desc* d, const void* residual_bf16,
                          int res_mode, sd_stream_t stream);
+/* dW (fp32, into the flat gradient buffer) from bf16 dy and bf16 x: 3x3 / stride 1 / pad 1 layers on the bf16 MFMA (transposed LDS
+ * reads, all nine taps per block), the strided and 1x1 convs through the fp32 kernels on widened operands. */
+size_t sd_conv2d_wgrad_bf16_workspace_bytes(const sd_conv_desc* d);
+int sd_conv2d_wgrad_bf16(const void* dy_bf16, const void* x_nhwc_bf16, float* dw_krsc, const sd_conv_desc* d, int accumulate,
+                         void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* sd_bn_apply / sd_bn_bwd / sd_col_sum / sd_upsample2x_bwd on bf16 activations (parameters, statistics and parameter gradients fp32;
  * arithmetic in fp32, one rounding at the store). */
 int sd_bn_apply_bf16(const void* x, void* y, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,

@@ -1491,6 +1491,138 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient of a 3x3 / stride 1 / pad 1 conv (mixed-precision training): the all-taps tiling of k_wgrad3x3 on the
+// bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 partial sums).  The reduction index is the PIXEL, but both
+// operands are stored pixel-major ([pixel][n] and [pixel][c], channels contiguous), while a lane of the 32x32x16 MFMA holds
+// EIGHT CONSECUTIVE reduction indices of one row / column: the operands have to be transposed on the way LDS -> registers.
+// gfx950's ds_read_b64_tr_b16 does that for free: per 16-lane group it reads a 4 (pixels) x 16 (channels) block and hands lane i
+// the four pixels of channel i -- two reads per operand and 16-pixel step.  The nine taps reuse the dY operand; the X operand of
+// tap (r, s) is the same patch read at row offset r, pixel offset s (row addresses are per lane, so the one-pixel shifts need
+// no aligned copies).  20 transposed reads per 9 MFMAs.
+// LDS images (LDS-DMA, 1 KB pieces = 8 pixel rows of 64 bf16 = 128 B): the 32-byte column slot t of pixel row i lives at slot
+// t ^ (i & 3), so the four rows of a transposed read (any four CONSECUTIVE rows: distinct i & 3, and rows two apart differ in
+// bit 1) and the two column halves of a 32-lane half fall on 8 disjoint bank groups -- conflict-free at every tap offset.
+// The swizzle is applied to the SOURCE address of the DMA (the LDS side of global_load_lds is lane-linear).
+// ---------------------------------------------------------------------------------------------
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+struct alignas(16) TrPair { v4i16 lo, hi; };
+
+__device__ __forceinline__ v4i16 lds_tr16(const uint16_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)p);
+#else
+    (void)p; return v4i16{0, 0, 0, 0};
+#endif
+}
+
+struct WgradArgs16 {
+    const uint16_t* dy;   // [M][Nn] bf16
+    const uint16_t* x;    // NHWC [B][Hi][Wi][Ck] bf16
+    float* part;          // [splits][Nn][9][Ck] fp32
+    int B, Hi, Wi, Ck, Ho, Wo, Nn;
+    int M, splits, m_per_split;
+};
+
+template <int ROWW>
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
+    constexpr int PX = ROWW + 2, ROWS = 32 / ROWW + 2;
+    constexpr int XPIX = ROWS * PX;                                  // patch pixels: 102 / 72
+    constexpr int XPIECES = ((XPIX + 7) / 8 + 3) / 4 * 4;            // 1 KB pieces of 8 pixel rows, a multiple of 4: 16 / 12
+    __shared__ __attribute__((aligned(16))) uint16_t Ds0[32 * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t Ds1[32 * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t Xs0[XPIECES * 512];
+    __shared__ __attribute__((aligned(16))) uint16_t Xs1[XPIECES * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;
+    const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
+    const int nchunks = (m_end - m_beg + 31) / 32;
+    const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const uint16_t* const zero16 = reinterpret_cast<const uint16_t*>(g_zero_line);
+
+    // DMA source of this lane inside an 8-row piece: row lane / 8, logical 16-byte chunk (lane % 8) ^ ((row & 3) << 1)
+    const int srow = lane >> 3;
+    const int schunk = ((lane & 7) ^ ((srow & 3) << 1)) * 8;          // element offset inside the 64-channel row
+#define W16_STAGE(ch, D, X)                                                                                       \
+    {                                                                                                             \
+        const int m0 = m_beg + (ch) * 32;                                                                         \
+        const int ox0 = m0 % p.Wo, t_ = m0 / p.Wo, oy = t_ % p.Ho, b = t_ / p.Ho;                                 \
+        {                                                                                                         \
+            const int row = wave * 8 + srow;                    /* pixel of the chunk: 4 pieces, one per wave */   \
+            const uint16_t* src = (m0 < m_end) ? p.dy + (int64_t)(m0 + row) * p.Nn + tn0 + schunk : zero16;       \
+            lds_dma16(src, reinterpret_cast<float*>((D) + wave * 512));                                           \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < XPIECES / 4; ++j) {                                                 \
+            const int q = wave + 4 * j;                                                                           \
+            const int idx = q * 8 + srow;                       /* patch pixel: row idx / PX, column idx % PX */   \
+            const int r = idx / PX, px = idx - r * PX;                                                            \
+            const int iy = oy - 1 + r, ix = ox0 - 1 + px;                                                         \
+            const bool ok = m0 < m_end && idx < XPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
+            const uint16_t* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + tc0 + schunk : zero16; \
+            lds_dma16(src, reinterpret_cast<float*>((X) + q * 512));                                              \
+        }                                                                                                         \
+    }
+    // transposed-read geometry of this lane: 16-lane group g = lane / 16 -> column half g & 1, 8-pixel half g >> 1 of the 16-pixel
+    // step; lane 4q + pp of the group addresses row q, columns 4 pp .. 4 pp + 3 of the group's 4 x 16 block
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int a_slot = (wn0 >> 4) + (g & 1), b_slot = (wc0 >> 4) + (g & 1);
+    const int khalf = (g >> 1) * 8 + q4;                             // pixel of the 16-pixel step this lane addresses (first read; +4 second)
+    auto rd = [&](const uint16_t* base, int row, int slot) -> v4i16 {
+        return lds_tr16(base + row * 64 + ((slot ^ (row & 3)) << 4) + pp * 4);
+    };
+#define W16_COMPUTE(D, X)                                                                                         \
+    {                                                                                                             \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                        \
+            const int prow = ROWW == 32 ? 0 : kb, pcol = ROWW == 32 ? kb * 16 : 0;                                \
+            TrPair ap;                                                                                            \
+            ap.lo = rd((D), kb * 16 + khalf, a_slot);                                                             \
+            ap.hi = rd((D), kb * 16 + khalf + 4, a_slot);                                                         \
+            const bf16x8 av = __builtin_bit_cast(bf16x8, ap);                                                     \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                         \
+                _Pragma("unroll") for (int s2 = 0; s2 < 3; ++s2) {                                                \
+                    const int row0 = (prow + r) * PX + pcol + s2 + khalf;                                         \
+                    TrPair bp;                                                                                    \
+                    bp.lo = rd((X), row0, b_slot);                                                                \
+                    bp.hi = rd((X), row0 + 4, b_slot);                                                            \
+                    acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bp), acc[r * 3 + s2], 0, 0, 0); \
+                }                                                                                                 \
+        }                                                                                                         \
+    }
+#define W16_ITER(CUR)                                                                                             \
+    {                                                                                                             \
+        if (ch + 1 < nchunks) { W16_STAGE(ch + 1, (CUR) ? Ds0 : Ds1, (CUR) ? Xs0 : Xs1) }                         \
+        W16_COMPUTE((CUR) ? Ds1 : Ds0, (CUR) ? Xs1 : Xs0)                                                         \
+        __syncthreads();                                                                                          \
+        ++ch;                                                                                                     \
+    }
+    if (nchunks > 0) { W16_STAGE(0, Ds0, Xs0) }
+    __syncthreads();
+    int ch = 0;
+    while (ch < nchunks) {
+        W16_ITER(0)
+        if (ch < nchunks) W16_ITER(1)
+    }
+#undef W16_ITER
+#undef W16_COMPUTE
+#undef W16_STAGE
+    float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+        }
+}
+
 constexpr int STEM_K = 147;   // 7 * 7 * 3
 
 // ---------------------------------------------------------------------------------------------
@@ -2346,6 +2478,49 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     SD_LAUNCH_CHECK();
     if (a.splits >= 16) hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
     else hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- mixed-precision weight gradient: dY and X bf16, dW fp32.  3x3 / stride 1 layers (32 of the 42 weight-gradient launches of a
+// step, 97 % of the flops) run k_wgrad3x3_bf16; the strided and 1x1 convs widen their operands to fp32 in the workspace and take
+// the fp32 kernels (exact: a bf16 value is an fp32 value).
+size_t sd_conv2d_wgrad_bf16_workspace_bytes(const sd_conv_desc* d) {
+    if (!d || d->Cin % 64 || d->Cout % 64) return 0;
+    const size_t base = align_up(sd_conv2d_wgrad_workspace_bytes(d), 256);
+    if (wgrad_all_taps(d)) return base;
+    return base + align_up((size_t)d->B * d->Ho * d->Wo * d->Cout * 4, 256) + align_up((size_t)d->B * d->Hi * d->Wi * d->Cin * 4, 256);
+}
+
+int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                         size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_wgrad_bf16", d)) return e;
+    SD_REQUIRE(dy && x && dw && workspace, SD_ERR_INVALID, "sd_conv2d_wgrad_bf16: null pointer");
+    SD_REQUIRE(d->Cin % 64 == 0 && d->Cout % 64 == 0, SD_ERR_INVALID, "sd_conv2d_wgrad_bf16: needs Cin, Cout %% 64 == 0");
+    SD_REQUIRE(aligned16(dy) && aligned16(x), SD_ERR_ALIGN, "sd_conv2d_wgrad_bf16: pointers must be 16-byte aligned");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_wgrad_bf16_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_wgrad_bf16: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (!wgrad_all_taps(d)) {
+        const size_t base = align_up(sd_conv2d_wgrad_workspace_bytes(d), 256);
+        const int64_t ndy = (int64_t)d->B * d->Ho * d->Wo * d->Cout, nx = (int64_t)d->B * d->Hi * d->Wi * d->Cin;
+        float* dy32 = reinterpret_cast<float*>((char*)workspace + base);
+        float* x32 = reinterpret_cast<float*>((char*)workspace + base + align_up((size_t)ndy * 4, 256));
+        if (int e = sd_cast_bf16_to_f32(dy, dy32, ndy, stream)) return e;
+        if (int e = sd_cast_bf16_to_f32(x, x32, nx, stream)) return e;
+        return sd_conv2d_wgrad(dy32, x32, dw, d, accumulate, workspace, base, stream);
+    }
+    const int tiles = (d->Cout / 64) * (d->Cin / 64);
+    WgradArgs16 a{};
+    a.dy = (const uint16_t*)dy; a.x = (const uint16_t*)x; a.part = (float*)workspace;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout;
+    a.M = d->B * d->Ho * d->Wo;
+    a.splits = wgrad_splits(d, tiles);
+    a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
+    const int64_t n4 = (int64_t)d->Cout * 9 * d->Cin / 4;
+    if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3_bf16<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_wgrad3x3_bf16<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
     SD_LAUNCH_CHECK();
     return 0;
 }

@@ -485,14 +485,18 @@ class _Engine:
             torch.cuda.current_stream().wait_stream(self._side)
 
     def _wgrad_now(self, dy, x, conv, d):
-        if dy.dtype == torch.bfloat16:
-            # bf16 operands widened to fp32 (exact) and multiplied on the fp32 MFMA: same products and fp32 accumulation as a bf16
-            # MFMA would give; a weight-gradient kernel that reads bf16 directly (transposed LDS reads) is the next step for speed
-            dy, x = self._to_f32(dy), self._to_f32(x)
         g = self.net.grad_of(conv.weight)
+        flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        if dy.dtype == torch.bfloat16:
+            # mixed precision: bf16 operands, fp32 accumulation, fp32 gradient (3x3 / stride 1 layers on the bf16 MFMA through
+            # transposed LDS reads; the strided and 1x1 convs widen their operands in the workspace and take the fp32 kernels)
+            ws = self._ws(self.lib.sd_conv2d_wgrad_bf16_workspace_bytes(C.byref(d)), dy.device)
+            self._timed("bf16:" + self._kname(d, 2), flops, lambda: L.check(
+                self.lib.sd_conv2d_wgrad_bf16(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
+                "sd_conv2d_wgrad_bf16"), phase="wgrad")
+            return
         nbytes = self.lib.sd_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = self._ws(nbytes, dy.device)
-        flops = 2.0 * d.B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         self._timed(self._kname(d, 2), flops, lambda: L.check(
             self.lib.sd_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), g.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()),
             "sd_conv2d_wgrad"), phase="wgrad")

@@ -69,8 +69,40 @@ def test_conv_bf16_forward_statistics_and_data_gradient(case):
     if H % 2 == 0 and W % 2 == 0:
         half = torch.randn(B, cin, H // 2, W // 2, generator=g).bfloat16().float()
         full = torch.zeros(B, cin, H, W); full[:, :, ::2, ::2] = half
-        L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc16(half).data_ptr(), 2, L.stream()))
+        half16 = nhwc16(half)
+        L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), half16.data_ptr(), 2, L.stream()))
         close(back(dx), dx_ref + full, 8e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1, 1), (1, 16, 16, 128, 64, 3, 1, 1), (64, 128, 128, 64, 64, 3, 1, 1), (8, 64, 64, 128, 128, 3, 1, 1),
+                                  (4, 16, 16, 512, 512, 3, 1, 1), (3, 32, 64, 64, 128, 3, 1, 1), (2, 20, 12, 64, 128, 3, 2, 1), (4, 12, 12, 64, 128, 1, 2, 0),
+                                  (2, 8, 8, 128, 128, 1, 1, 0)])
+def test_conv_bf16_weight_gradient(case):
+    """sd_conv2d_wgrad_bf16: dW (fp32) from bf16 dy / x.  3x3 stride-1 layers take k_wgrad3x3_bf16 (bf16 MFMA fed by
+    ds_read_b64_tr_b16 transposed reads; 32-wide rows and the two-rows-of-16 form; one and several pixel splits; image borders),
+    the other geometries the fp32 kernels on widened operands.  Products of bf16 values are exact in fp32 and the accumulation
+    is fp32 on both sides, so only the summation order differs from the reference."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    lib = L.lib()
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    dy = torch.randn(B, cout, d.Ho, d.Wo, generator=g).bfloat16().float()
+    wz = torch.zeros(cout, cin, k, k, requires_grad=True)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    wg = wz.detach().to(DEV).requires_grad_(True)
+    F.conv2d(xd, wg, None, stride, pad).backward(dyd)                  # reference on the GPU (fp32, same operands)
+    ref = wg.grad.cpu()
+    dw = torch.full((cout, k, k, cin), float("nan"), device=DEV)
+    ws = torch.empty(lib.sd_conv2d_wgrad_bf16_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=DEV)
+    dy16, x16 = nhwc16(dy), nhwc16(x)                                   # (named: raw pointers of temporaries would alias)
+    L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), dw.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw.permute(0, 3, 1, 2).cpu(), ref, 2e-4)
+    base = torch.randn(cout, k, k, cin, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    acc = base.clone()
+    L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), acc.data_ptr(), C.byref(d), 1, ws.data_ptr(), ws.numel(), L.stream()))
+    close((acc - base).permute(0, 3, 1, 2).cpu(), ref, 2e-4)            # accumulate = 1 adds into dW
 
 
 def test_bn_kernels_on_bf16_activations_equal_the_fp32_kernels_rounded():
