@@ -27,7 +27,11 @@ for k, d in out.items():
         write = d["WRITE_SIZE"]["avg_kb"] * 1024
         res[k] = {"launches": d["FETCH_SIZE"]["launches"], "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
                   "hbm_bytes_per_launch": fetch + write}
+import hashlib
+res["_meta"] = {"sd_conv_hip_sha256": hashlib.sha256(open("structuredetector_amd/csrc/sd_conv.hip", "rb").read()).hexdigest(),
+                "workload": "tools/prof_train.py 2 (bs=64, 512x512 fp32 training steps)", "counters": "FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate passes"}
 json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 for k, v in res.items():
+    if k == "_meta": continue
     print(f"{k[:44]:44s} launches {v['launches']:4d}  read {v['hbm_read_bytes_per_launch']/1e6:9.1f} MB  write {v['hbm_write_bytes_per_launch']/1e6:8.1f} MB")
 PY

@@ -12,6 +12,7 @@ from structuredetector_amd.model import Network
 from structuredetector_amd.model.trainer import TrainStep
 dev = torch.device("cuda")
 args = make_args(dev)
+args.use_amp = len(sys.argv) > 2 and sys.argv[2] == "amp"      # prof_train.py <steps> amp: the mixed-precision step
 net = Network(args, pretrained=False).to(dev).train()
 step = TrainStep(net, args)
 enc = Encode(args)
