@@ -878,6 +878,159 @@ __global__ __launch_bounds__(256) void k_head_fwd_bf16(const uint16_t* __restric
     }
 }
 
+// ---- bf16 activations, 16 bytes per lane (8 elements): the mixed-precision training path's BatchNorm passes.  Same arithmetic
+// as the templated 4-element kernels above (fp32, one rounding at the store; results are bit-identical to them) -- only the
+// access width differs: 8-byte accesses left these HBM-bound passes at ~60 % of the rate of their fp32 (16-byte) versions.
+struct F8 { float4 a, b; };
+__device__ __forceinline__ F8 ld8(const uint16_t* p, int64_t i) {
+    const uint4 r = reinterpret_cast<const uint4*>(p)[i];
+    F8 v;
+    v.a = make_float4(bf16_to_f32((uint16_t)(r.x & 0xffff)), bf16_to_f32((uint16_t)(r.x >> 16)), bf16_to_f32((uint16_t)(r.y & 0xffff)), bf16_to_f32((uint16_t)(r.y >> 16)));
+    v.b = make_float4(bf16_to_f32((uint16_t)(r.z & 0xffff)), bf16_to_f32((uint16_t)(r.z >> 16)), bf16_to_f32((uint16_t)(r.w & 0xffff)), bf16_to_f32((uint16_t)(r.w >> 16)));
+    return v;
+}
+__device__ __forceinline__ void st8(uint16_t* p, int64_t i, const F8& v) {
+    uint4 r;
+    r.x = (uint32_t)f32_to_bf16(v.a.x) | ((uint32_t)f32_to_bf16(v.a.y) << 16); r.y = (uint32_t)f32_to_bf16(v.a.z) | ((uint32_t)f32_to_bf16(v.a.w) << 16);
+    r.z = (uint32_t)f32_to_bf16(v.b.x) | ((uint32_t)f32_to_bf16(v.b.y) << 16); r.w = (uint32_t)f32_to_bf16(v.b.z) | ((uint32_t)f32_to_bf16(v.b.w) << 16);
+    reinterpret_cast<uint4*>(p)[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply_bf16x8(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n8, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const uint16_t* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int cols = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const int col = (int)(i % cols);
+        const F8 v = ld8(x, i);
+        F8 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 mu = reinterpret_cast<const float4*>(mean)[2 * col + h], is = reinterpret_cast<const float4*>(invstd)[2 * col + h];
+            const float4 g = reinterpret_cast<const float4*>(gamma)[2 * col + h], b = reinterpret_cast<const float4*>(beta)[2 * col + h];
+            const float4 vv = h ? v.b : v.a;
+            float4 oo;
+            oo.x = (vv.x - mu.x) * is.x * g.x + b.x; oo.y = (vv.y - mu.y) * is.y * g.y + b.y;
+            oo.z = (vv.z - mu.z) * is.z * g.z + b.z; oo.w = (vv.w - mu.w) * is.w * g.w + b.w;
+            if (h) o.b = oo; else o.a = oo;
+        }
+        if (res) {
+            const F8 r = ld8(res, i);
+            o.a.x += r.a.x; o.a.y += r.a.y; o.a.z += r.a.z; o.a.w += r.a.w; o.b.x += r.b.x; o.b.y += r.b.y; o.b.z += r.b.z; o.b.w += r.b.w;
+        }
+        if (mask) {        // one byte per FOUR elements, as the 4-element kernels write it
+            const uint8_t m0 = (uint8_t)((o.a.x > 0.f ? 1 : 0) | (o.a.y > 0.f ? 2 : 0) | (o.a.z > 0.f ? 4 : 0) | (o.a.w > 0.f ? 8 : 0));
+            const uint8_t m1 = (uint8_t)((o.b.x > 0.f ? 1 : 0) | (o.b.y > 0.f ? 2 : 0) | (o.b.z > 0.f ? 4 : 0) | (o.b.w > 0.f ? 8 : 0));
+            reinterpret_cast<uchar2*>(mask)[i] = make_uchar2(m0, m1);
+        }
+        if (relu) {
+            o.a.x = fmaxf(o.a.x, 0.f); o.a.y = fmaxf(o.a.y, 0.f); o.a.z = fmaxf(o.a.z, 0.f); o.a.w = fmaxf(o.a.w, 0.f);
+            o.b.x = fmaxf(o.b.x, 0.f); o.b.y = fmaxf(o.b.y, 0.f); o.b.z = fmaxf(o.b.z, 0.f); o.b.w = fmaxf(o.b.w, 0.f);
+        }
+        st8(y, i, o);
+    }
+}
+
+// g = dy * relu mask (relu: 0 none, 2 recomputed from x, 3 mask bytes) for one float4 half
+__device__ __forceinline__ float4 bn_mask4(float4 g, const float4 xv, const float4 mu, const float4 is, const float4 ga, const float4 be, int relu, uint8_t mb) {
+    if (relu == 3) {
+        g.x = (mb & 1) ? g.x : 0.f; g.y = (mb & 2) ? g.y : 0.f; g.z = (mb & 4) ? g.z : 0.f; g.w = (mb & 8) ? g.w : 0.f;
+    } else if (relu == 2) {
+        g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
+        g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_bf16x8(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, const uint8_t* __restrict__ maskb,
+                                                              int relu, int64_t n8, int C, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ mg,
+                                                              const float* __restrict__ mgx, uint16_t* __restrict__ dx, uint16_t* __restrict__ g_out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int cols = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const int col = (int)(i % cols);
+        const F8 gy = ld8(dy, i), xv = ld8(x, i);
+        uchar2 mb = make_uchar2(0, 0);
+        if (relu == 3) mb = reinterpret_cast<const uchar2*>(maskb)[i];
+        F8 o, gm;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 mu = reinterpret_cast<const float4*>(mean)[2 * col + h], is = reinterpret_cast<const float4*>(invstd)[2 * col + h];
+            const float4 ga = reinterpret_cast<const float4*>(gamma)[2 * col + h];
+            float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (relu == 2) be = reinterpret_cast<const float4*>(beta)[2 * col + h];
+            const float4 xx = h ? xv.b : xv.a;
+            const float4 g = bn_mask4(h ? gy.b : gy.a, xx, mu, is, ga, be, relu, h ? mb.y : mb.x);
+            const float4 a = reinterpret_cast<const float4*>(mg)[2 * col + h], b = reinterpret_cast<const float4*>(mgx)[2 * col + h];
+            float4 oo;
+            oo.x = ga.x * is.x * (g.x - a.x - (xx.x - mu.x) * is.x * b.x);
+            oo.y = ga.y * is.y * (g.y - a.y - (xx.y - mu.y) * is.y * b.y);
+            oo.z = ga.z * is.z * (g.z - a.z - (xx.z - mu.z) * is.z * b.z);
+            oo.w = ga.w * is.w * (g.w - a.w - (xx.w - mu.w) * is.w * b.w);
+            if (h) { o.b = oo; gm.b = g; } else { o.a = oo; gm.a = g; }
+        }
+        st8(dx, i, o);
+        if (g_out) st8(g_out, i, gm);
+    }
+}
+
+// BatchNorm-backward reduction (k_col_reduce<1>) on bf16, 8 columns per lane: sum g, sum g * xhat per channel
+__global__ __launch_bounds__(256) void k_col_reduce_bwd_bf16x8(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, const uint8_t* __restrict__ maskb,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                                int64_t M, int C, float* __restrict__ partial, int rpb) {
+    __shared__ float4 red[4][256];
+    const int cols = C >> 3;                       // 8-element columns (cols <= 128 for C <= 1024)
+    const int lanes = 256 / cols;
+    const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = min(r0 + rpb, M);
+    float4 s0[2], s1[2], mu[2], is[2], ga[2], be[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        s0[h] = s1[h] = ga[h] = be[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mu[h] = reinterpret_cast<const float4*>(mean)[2 * col + h]; is[h] = reinterpret_cast<const float4*>(invstd)[2 * col + h];
+        if (relu == 2) { ga[h] = reinterpret_cast<const float4*>(gamma)[2 * col + h]; be[h] = reinterpret_cast<const float4*>(beta)[2 * col + h]; }
+    }
+    if (rl < lanes) {
+#pragma unroll 2
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const F8 gy = ld8(a, r * cols + col), xv = ld8(b, r * cols + col);
+            uchar2 mb = make_uchar2(0, 0);
+            if (relu == 3) mb = reinterpret_cast<const uchar2*>(maskb)[r * cols + col];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 xx = h ? xv.b : xv.a;
+                const float4 g = bn_mask4(h ? gy.b : gy.a, xx, mu[h], is[h], ga[h], be[h], relu, h ? mb.y : mb.x);
+                s0[h].x += g.x; s0[h].y += g.y; s0[h].z += g.z; s0[h].w += g.w;
+                s1[h].x += g.x * ((xx.x - mu[h].x) * is[h].x); s1[h].y += g.y * ((xx.y - mu[h].y) * is[h].y);
+                s1[h].z += g.z * ((xx.z - mu[h].z) * is[h].z); s1[h].w += g.w * ((xx.w - mu[h].w) * is[h].w);
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0[0]; red[1][threadIdx.x] = s0[1]; red[2][threadIdx.x] = s1[0]; red[3][threadIdx.x] = s1[1];
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 u = red[h][l * cols + col], w = red[2 + h][l * cols + col];
+                s0[h].x += u.x; s0[h].y += u.y; s0[h].z += u.z; s0[h].w += u.w;
+                s1[h].x += w.x; s1[h].y += w.y; s1[h].z += w.z; s1[h].w += w.w;
+            }
+        }
+        float* dst = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            reinterpret_cast<float4*>(dst)[2 * col + h] = s0[h];
+            reinterpret_cast<float4*>(dst + C)[2 * col + h] = s1[h];
+        }
+    }
+}
+
 static inline int ew_grid(int64_t n4) { return (int)std::min<int64_t>(cdiv(n4, 256), 256 * 16); }
 
 }  // namespace sd
@@ -1155,6 +1308,12 @@ int sd_bn_apply_bf16(const void* x, void* y, int64_t M, int C, const float* mean
     if (int e = check_mc("sd_bn_apply_bf16", M, C)) return e;
     SD_REQUIRE(x && y && mean && invstd && gamma && beta, SD_ERR_INVALID, "sd_bn_apply_bf16: null pointer");
     const int64_t n4 = M * C / 4;
+    if (C % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(residual)) {
+        hipLaunchKernelGGL(k_bn_apply_bf16x8, dim3(ew_grid(n4 / 2)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n4 / 2, C, mean,
+                           invstd, gamma, beta, (const uint16_t*)residual, relu, relu_mask_out);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_bn_apply<uint16_t>, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n4, C, mean,
                        invstd, gamma, beta, (const uint16_t*)residual, relu, relu_mask_out);
     SD_LAUNCH_CHECK();
@@ -1174,8 +1333,11 @@ int sd_bn_bwd_bf16(const void* dy, const void* x, const void* y, int relu, int64
     float* partial = (float*)workspace;
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
-    hipLaunchKernelGGL((k_col_reduce<1, uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y, mean,
-                       invstd, gamma, beta, relu, M, C, partial, rpb);
+    const bool wide = C % 8 == 0 && relu != 1 && aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(g_out);
+    if (wide) hipLaunchKernelGGL(k_col_reduce_bwd_bf16x8, dim3(nb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint8_t*)y, mean,
+                                 invstd, gamma, beta, relu, M, C, partial, rpb);
+    else hipLaunchKernelGGL((k_col_reduce<1, uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y, mean,
+                            invstd, gamma, beta, relu, M, C, partial, rpb);
     SD_LAUNCH_CHECK();
     int rows = nb;
     const float* fin = fold_partials(partial, rows, C, mgx + C, st);
@@ -1183,7 +1345,9 @@ int sd_bn_bwd_bf16(const void* dy, const void* x, const void* y, int relu, int64
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    hipLaunchKernelGGL(k_bn_bwd_apply<uint16_t>, dim3(ew_grid(n4)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y,
+    if (wide) hipLaunchKernelGGL(k_bn_bwd_apply_bf16x8, dim3(ew_grid(n4 / 2)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint8_t*)y,
+                                 relu, n4 / 2, C, mean, invstd, gamma, beta, (const float*)mg, (const float*)mgx, (uint16_t*)dx, (uint16_t*)g_out);
+    else hipLaunchKernelGGL(k_bn_bwd_apply<uint16_t>, dim3(ew_grid(n4)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (const uint16_t*)y,
                        relu, n4, C, mean, invstd, gamma, beta, (const float*)mg, (const float*)mgx, (uint16_t*)dx, (uint16_t*)g_out);
     SD_LAUNCH_CHECK();
     return 0;

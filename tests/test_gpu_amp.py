@@ -148,8 +148,13 @@ def test_bn_kernels_on_bf16_activations_equal_the_fp32_kernels_rounded():
         L.check(lib.sd_bn_bwd(dy32.data_ptr(), x32.data_ptr(), m32.data_ptr() if mode == 3 else 0, mode, M, Cc, mean.data_ptr(), invstd.data_ptr(),
                               gamma.data_ptr(), beta.data_ptr(), dx32.data_ptr(), g32.data_ptr(), dg32.data_ptr(), db32.data_ptr(), 0,
                               wsb.data_ptr(), wsb.numel(), L.stream()))
-        assert torch.equal(dx16, dx32.bfloat16()) and torch.equal(g16, g32.bfloat16())
-        assert torch.equal(dg16, dg32) and torch.equal(db16, db32)
+        # (the 16-byte bf16 reduction walks the rows in another order than the fp32 kernel: the per-channel sums agree to fp32
+        #  rounding, dx to one bf16 ulp where a mean moved in its last bit; the masked gradient g is elementwise -> exact)
+        assert torch.equal(g16, g32.bfloat16())
+        np.testing.assert_allclose(dg16.cpu().numpy(), dg32.cpu().numpy(), rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(db16.cpu().numpy(), db32.cpu().numpy(), rtol=2e-5, atol=1e-4)
+        diff = (dx16.float() - dx32.bfloat16().float()).abs()
+        assert (diff <= dx32.abs() * 2 ** -7 + 1e-6).all() and (diff > 0).float().mean().item() < 0.01
     # bias-gradient column sums and the upsample backward
     wsb = torch.empty(lib.sd_col_reduce_workspace_bytes(M, Cc), dtype=torch.uint8, device=DEV)
     s16 = torch.empty(Cc, device=DEV); s32 = torch.empty(Cc, device=DEV)
