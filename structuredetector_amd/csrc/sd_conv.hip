@@ -2374,6 +2374,29 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
                                 partial + (size_t)a.ntiles * 128, stream);
 }
 
+// the same stem launch with the product on the bf16 MFMA (image patch and weights rounded to bf16 on the way into the operands, fp32
+// accumulation, fp32 output + statistics): the mixed-precision training step (under autocast the reference's conv1 runs in bf16 too)
+int sd_conv2d_stem_fwd_bn_stats_bf16mm(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* mean, float* invstd, void* workspace,
+                                       size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_fwd_bn_stats_bf16mm", d)) return e;
+    SD_REQUIRE(x_nchw && w && y && mean && invstd && workspace, SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats_bf16mm: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats_bf16mm: the stem is a 7x7 / stride 2 / pad 3 conv, 3 -> 64 channels");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_fwd_bn_stats_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_fwd_bn_stats_bf16mm: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)((char*)workspace + align_up((size_t)STEM_K * 64 * sizeof(float), 256));
+    StemArgs a{};
+    a.x = x_nchw; a.w = w; a.y = y; a.stat = partial;
+    stem_args(a, d);
+    const size_t lds = STEM_FWD_LDS_BYTES;
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr_once;
+    hipLaunchKernelGGL(k_stem_fwd<true>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
+    SD_LAUNCH_CHECK();
+    return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+                                partial + (size_t)a.ntiles * 128, stream);
+}
+
 int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual_half,
                              sd_stream_t stream) {
     if (int e = check_conv("sd_conv2d_dgrad_half_res", d)) return e;

@@ -276,9 +276,10 @@ class _Engine:
             m0 = torch.empty(64, dtype=torch.float32, device=x.device)
             i0 = torch.empty_like(m0)
             ws = self._ws(lib.sd_conv2d_stem_fwd_bn_stats_workspace_bytes(C.byref(d0)), x.device)
-            L.check(lib.sd_conv2d_stem_fwd_bn_stats(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), BN_EPS, BN_MOMENTUM,
-                                                    bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(), m0.data_ptr(), i0.data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_fwd_bn_stats")
+            stem_fwd = lib.sd_conv2d_stem_fwd_bn_stats_bf16mm if amp else lib.sd_conv2d_stem_fwd_bn_stats      # amp: product on the bf16 MFMA
+            L.check(stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), BN_EPS, BN_MOMENTUM,
+                             bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(), m0.data_ptr(), i0.data_ptr(),
+                             ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_fwd_bn_stats")
             self._nbt.append(bn0.num_batches_tracked)
             L.check(lib.sd_bn_relu_maxpool_fwd(s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(), bn0.weight.data_ptr(),
                                                bn0.bias.data_ptr(), p1.data_ptr(), pidx.data_ptr(), L.stream()), "sd_bn_relu_maxpool_fwd")
@@ -291,7 +292,7 @@ class _Engine:
         if rec:
             tape["x"], tape["stem"], tape["amp"] = x, (d0, s0, m0, i0, pidx), bool(amp)
         if amp:
-            p1 = self._to_bf16(p1)          # the stem (2.7 % of the MACs) stays fp32; everything behind the max-pool is bf16
+            p1 = self._to_bf16(p1)          # the stem's output, statistics and tail stay fp32; everything behind the max-pool is bf16
 
         # trunk (network.py:47-50)
         feats, cur, Hc, Wc = [], p1, Hp, Wp
