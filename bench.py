@@ -346,50 +346,68 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / n
 
+    def guarded(ns, key, fn):
+        """A side figure must never cost the headline line: errors are reported in place of the figure."""
+        try:
+            ns[key] = fn()
+        except Exception as err:
+            ns[key] = {"error": repr(err)[:300]}
+
     if rank == 0 and a.extras and world == 1:
         ns = {}
-        net.eval()
-        with torch.no_grad():
+
+        def fig_fwd_fp32():
             # north_star target: ">= 60 % of the relevant roofline on the backbone forward at bs=64" (fp32 MFMA peak)
-            fwd = timed(lambda: net(images), 5)
-            ns["fwd_eval_fp32"] = {"batch": B, "ms": round(fwd * 1e3, 3), "tflops": round(B * FWD_GFLOP_PER_IMG / fwd / 1e3, 2),
-                                   "frac_of_fp32_mfma_peak": round(B * FWD_GFLOP_PER_IMG / fwd / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "target_frac": 0.60}
+            with torch.no_grad():
+                fwd = timed(lambda: net(images), 5)
+            return {"batch": B, "ms": round(fwd * 1e3, 3), "tflops": round(B * FWD_GFLOP_PER_IMG / fwd / 1e3, 2),
+                    "frac_of_fp32_mfma_peak": round(B * FWD_GFLOP_PER_IMG / fwd / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4), "target_frac": 0.60}
+
+        def fig_bs1():
             # BASELINE configs[1]: bs=1 inference = backbone forward + HIP decoder + host objects
             dec1 = Decoder(args)
             x1 = images[:1].contiguous()
-            f1 = timed(lambda: net(x1), 20, warm=3)
-            run1 = net.graphed(x1)
-            g1 = timed(lambda: run1(x1), 20, warm=3)
-            e2e = timed(lambda: dec1(net(x1)), 20, warm=3)
             Mn = M + N
+            with torch.no_grad():
+                f1 = timed(lambda: net(x1), 20, warm=3)
+                run1 = net.graphed(x1)
+                g1 = timed(lambda: run1(x1), 20, warm=3)
+                e2e = timed(lambda: dec1(net(x1)), 20, warm=3)
 
-            def graph_e2e():
-                o = run1(x1)
-                return dec1({"anchor_hm": o[:, :M], "part_hm": o[:, M:Mn], "offsets": o[:, Mn:Mn + 2], "embeddings": o[:, Mn + 2:Mn + 4]})
-            ge2e = timed(graph_e2e, 20, warm=3)
-            ns["infer_bs1_fp32"] = {"fwd_ms": round(f1 * 1e3, 3), "fwd_hipgraph_ms": round(g1 * 1e3, 3),
-                                    "fwd_decode_objects_ms": round(e2e * 1e3, 3), "hipgraph_fwd_decode_objects_ms": round(ge2e * 1e3, 3)}
-            del run1
+                def graph_e2e():
+                    o = run1(x1)
+                    return dec1({"anchor_hm": o[:, :M], "part_hm": o[:, M:Mn], "offsets": o[:, Mn:Mn + 2], "embeddings": o[:, Mn + 2:Mn + 4]})
+                ge2e = timed(graph_e2e, 20, warm=3)
+            return {"fwd_ms": round(f1 * 1e3, 3), "fwd_hipgraph_ms": round(g1 * 1e3, 3), "fwd_decode_objects_ms": round(e2e * 1e3, 3),
+                    "hipgraph_fwd_decode_objects_ms": round(ge2e * 1e3, 3)}
+
+        def fig_fwd_bf16():
             # bf16 backbone (inference), same network object: bs=64 512x512, against the dense bf16 MFMA peak
             net.bf16_inference = True
             net.invalidate_folded()
-            b16 = timed(lambda: net(images), 10, warm=3)
-            ns["fwd_eval_bf16"] = {"batch": B, "ms": round(b16 * 1e3, 3), "tflops": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3, 1),
-                                   "frac_of_bf16_mfma_peak": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4)}
-            net.bf16_inference = False
-            net.invalidate_folded()
-        net.train()
-        if not a.amp:
+            try:
+                with torch.no_grad():
+                    b16 = timed(lambda: net(images), 10, warm=3)
+            finally:
+                net.bf16_inference = False
+                net.invalidate_folded()
+            return {"batch": B, "ms": round(b16 * 1e3, 3), "tflops": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3, 1),
+                    "frac_of_bf16_mfma_peak": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4)}
+
+        def fig_amp():
             # the same training step under `--amp` (trainer.py:115-121): bf16 activations / conv weights, fp32 accumulation + master weights
             step.amp = True
-            t_amp = timed(lambda: run_step(0), 5, warm=2)
-            step.amp = False
-            ns["train_step_amp_bf16"] = {"batch": B, "ms_per_step": round(t_amp * 1e3, 3), "images_per_sec": round(B / t_amp, 1),
-                                         "speedup_vs_fp32_step": round((dt / a.steps) / t_amp, 2),
-                                         "note": "bf16 MFMA forward / data-gradient / 3x3 weight-gradient (transposed LDS reads); stem, head and the "
-                                                 "strided / 1x1 weight gradients in fp32"}
-        # BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, K=128, P=512, dense scenes (64-96 objects), bf16 backbone + fp32 decode
-        try:
+            try:
+                t_amp = timed(lambda: run_step(0), 5, warm=2)
+            finally:
+                step.amp = False
+            return {"batch": B, "ms_per_step": round(t_amp * 1e3, 3), "images_per_sec": round(B / t_amp, 1),
+                    "speedup_vs_fp32_step": round((dt / a.steps) / t_amp, 2),
+                    "note": "bf16 MFMA forward / data-gradient / 3x3 weight-gradient (transposed LDS reads); stem tail, head and the "
+                            "strided / 1x1 weight gradients in fp32"}
+
+        def fig_stress():
+            # BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, K=128, P=512, dense scenes (64-96 objects), bf16 backbone + fp32 decode
             Ms = Nn = 8; Ks, Ps, Bs, S = 128, 512, 16, 1024
             sargs = make_args(dev, Ms, Nn, Ks, Ps)
             sargs.use_amp = True
@@ -405,34 +423,42 @@ def main():
                 sf = timed(lambda: snet(simg), 5)
                 sd_ = timed(lambda: sdec.decode_packed(souts, 0.5, 0.1, exact_topk=True), 10)
                 sboth = timed(lambda: (snet(simg), sdec.decode_packed(souts, 0.5, 0.1, exact_topk=True)), 5)
-            ns["stress_1024_8x8_bf16"] = {"batch": Bs, "fwd_ms": round(sf * 1e3, 3), "fwd_tflops": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3, 1),
-                                          "fwd_frac_of_bf16_mfma_peak": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
-                                          "decode_us_per_img": round(sd_ / Bs * 1e6, 2),
-                                          "decode_GBps": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9, 1),
-                                          "fwd_plus_decode_ms": round(sboth * 1e3, 3), "objects_per_img": "64-96", "K": Ks, "P": Ps}
-            del snet, simg, stg, shm, shead, souts
-        except Exception as err:                          # a side figure must never cost the headline line
-            ns["stress_1024_8x8_bf16"] = {"error": repr(err)[:200]}
+            return {"batch": Bs, "fwd_ms": round(sf * 1e3, 3), "fwd_tflops": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3, 1),
+                    "fwd_frac_of_bf16_mfma_peak": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "decode_us_per_img": round(sd_ / Bs * 1e6, 2), "decode_GBps": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9, 1),
+                    "fwd_plus_decode_ms": round(sboth * 1e3, 3), "objects_per_img": "64-96", "K": Ks, "P": Ps}
+
+        net.eval()
+        guarded(ns, "fwd_eval_fp32", fig_fwd_fp32)
+        guarded(ns, "infer_bs1_fp32", fig_bs1)
+        guarded(ns, "fwd_eval_bf16", fig_fwd_bf16)
+        net.train()
+        if not a.amp:
+            guarded(ns, "train_step_amp_bf16", fig_amp)
+        guarded(ns, "stress_1024_8x8_bf16", fig_stress)
         extra["north_star"] = ns
     if rank == 0:
-        dec = Decoder(args)
-        tgt = enc.render_device(plans[0])
-        hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
-        head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
-                          0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
-        outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
-        d_dev = timed(lambda: dec.decode_packed(outs, 0.5, 0.1, exact_topk=False), 20, warm=3)   # what Decoder.__call__ runs without metadata
-        d_exact = timed(lambda: dec.decode_packed(outs, 0.5, 0.1, exact_topk=True), 20, warm=3)
-        one = {k: v[:1] for k, v in outs.items()}
-        d_one = timed(lambda: dec(one), 20, warm=3)                                             # launches + D2H + host assembly
-        extra["decode"] = {"device_us_per_img_bs%d" % B: round(d_dev / B * 1e6, 3), "device_us_per_batch": round(d_dev * 1e6, 1),
-                           "device_GBps_bs%d" % B: round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9, 1),
-                           "frac_of_hbm_peak": round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9 / PEAK_HBM_GBPS, 4),
-                           "exact_topk_us_per_img_bs%d" % B: round(d_exact / B * 1e6, 3),
-                           "e2e_us_per_img_bs1": round(d_one * 1e6, 1), "bytes_per_img": DECODE_BYTES_PER_IMG}
-        extra["decode_device_us_per_img_bs%d" % B] = extra["decode"]["device_us_per_img_bs%d" % B]     # (round-1 key names kept)
-        extra["decode_device_GBps_bs%d" % B] = extra["decode"]["device_GBps_bs%d" % B]
-        extra["decode_e2e_us_per_img_bs1"] = extra["decode"]["e2e_us_per_img_bs1"]
+        try:
+            dec = Decoder(args)
+            tgt = enc.render_device(plans[0])
+            hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
+            head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
+                              0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
+            outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
+            d_dev = timed(lambda: dec.decode_packed(outs, 0.5, 0.1, exact_topk=False), 20, warm=3)   # what Decoder.__call__ runs without metadata
+            d_exact = timed(lambda: dec.decode_packed(outs, 0.5, 0.1, exact_topk=True), 20, warm=3)
+            one = {k: v[:1] for k, v in outs.items()}
+            d_one = timed(lambda: dec(one), 20, warm=3)                                             # launches + D2H + host assembly
+            extra["decode"] = {"device_us_per_img_bs%d" % B: round(d_dev / B * 1e6, 3), "device_us_per_batch": round(d_dev * 1e6, 1),
+                               "device_GBps_bs%d" % B: round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9, 1),
+                               "frac_of_hbm_peak": round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9 / PEAK_HBM_GBPS, 4),
+                               "exact_topk_us_per_img_bs%d" % B: round(d_exact / B * 1e6, 3),
+                               "e2e_us_per_img_bs1": round(d_one * 1e6, 1), "bytes_per_img": DECODE_BYTES_PER_IMG}
+            extra["decode_device_us_per_img_bs%d" % B] = extra["decode"]["device_us_per_img_bs%d" % B]     # (round-1 key names kept)
+            extra["decode_device_GBps_bs%d" % B] = extra["decode"]["device_GBps_bs%d" % B]
+            extra["decode_e2e_us_per_img_bs1"] = extra["decode"]["e2e_us_per_img_bs1"]
+        except Exception as err:                      # never lose the headline line to a side figure
+            extra["decode"] = {"error": repr(err)[:300]}
 
     if rank == 0:
         imgs_per_s = B * world * a.steps / dt
@@ -453,7 +479,10 @@ def main():
         }
         line.update(extra)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(M, N, K, P, img)
+            try:
+                line["cpu_baseline"] = cpu_baseline(M, N, K, P, img)
+            except Exception as err:
+                line["cpu_baseline"] = {"error": repr(err)[:300]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
