@@ -1623,6 +1623,138 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient of the remaining geometries (strided 3x3, 1x1; mixed-precision training): ONE filter tap x 128 (n) x TC (c)
+// tile per block, split over pixel ranges, on the bf16 MFMA with the transposed operand reads of k_wgrad3x3_bf16.  A chunk is 32
+// consecutive output pixels: their dY rows (128 n = 256 B) and the input pixels the tap pairs them with (TC c; gathered per row by
+// the DMA's per-lane source address, padding reads the zero line).
+// LDS images: 256-byte rows keep their 32-byte slot t of row i at slot t ^ ((i & 3) << 1), 128-byte rows (TC = 64) at t ^ (i & 3):
+// the four rows x two column halves of a transposed read then cover all 64 banks once.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs16t {
+    const uint16_t* dy;   // [M][Nn] bf16
+    const uint16_t* x;    // NHWC [B][Hi][Wi][Ck] bf16
+    float* part;          // [splits][Nn][R*S][Ck] fp32
+    int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S, stride, pad;
+    int M, splits, m_per_split;
+};
+
+template <int TC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_tap_bf16(WgradArgs16t p) {
+    constexpr int TN = 128;
+    constexpr int NTC = TC / 64;                                     // 32-column MFMA tiles per wave along c (wave tile 64 x TC/2)
+    constexpr int XROWB = TC * 2;                                    // bytes per X row: 256 or 128
+    constexpr int XPIECES = 32 * XROWB / 1024;                       // 8 or 4
+    __shared__ __attribute__((aligned(16))) uint16_t Ds0[32 * TN];
+    __shared__ __attribute__((aligned(16))) uint16_t Ds1[32 * TN];
+    __shared__ __attribute__((aligned(16))) uint16_t Xs0[32 * TC];
+    __shared__ __attribute__((aligned(16))) uint16_t Xs1[32 * TC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck / TC, n_tiles = p.Nn / TN;
+    int t = blockIdx.y;
+    const int ct = t % c_tiles; t /= c_tiles;
+    const int nt = t % n_tiles; t /= n_tiles;
+    const int tap = t, r = tap / p.S, s = tap - r * p.S;
+    const int tn0 = nt * TN, tc0 = ct * TC;
+    const int m_beg = split * p.m_per_split, m_end = min(m_beg + p.m_per_split, p.M);
+    const int nchunks = (m_end - m_beg + 31) / 32;
+    const int wn0 = (wave >> 1) * 64, wc0 = (wave & 1) * (TC / 2);
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2][NTC];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const uint16_t* const zero16 = reinterpret_cast<const uint16_t*>(g_zero_line);
+
+    // DMA lane geometry: 256-byte rows -> 4 rows per 1 KB piece (row lane / 16, chunk lane % 16, swizzle (row & 3) << 2 on the chunk);
+    //                    128-byte rows -> 8 rows per piece (row lane / 8, chunk lane % 8, swizzle (row & 3) << 1)
+    const int d_row = lane >> 4, d_chunk = ((lane & 15) ^ ((d_row & 3) << 2)) * 8;
+    const int x_row = TC == 128 ? (lane >> 4) : (lane >> 3);
+    const int x_chunk = TC == 128 ? ((lane & 15) ^ ((x_row & 3) << 2)) * 8 : ((lane & 7) ^ ((x_row & 3) << 1)) * 8;
+    constexpr int XRPP = TC == 128 ? 4 : 8;                          // X rows per piece
+#define WT_STAGE(ch, D, X)                                                                                        \
+    {                                                                                                             \
+        const int m0 = m_beg + (ch) * 32;                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                 /* dY: 8 pieces of 4 rows, two per wave */ \
+            const int q = wave + 4 * j, row = q * 4 + d_row;                                                      \
+            const uint16_t* src = (m0 + row < m_end) ? p.dy + (int64_t)(m0 + row) * p.Nn + tn0 + d_chunk : zero16; \
+            lds_dma16(src, reinterpret_cast<float*>((D) + q * 512));                                              \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < XPIECES / 4; ++j) {                                                 \
+            const int q = wave + 4 * j, row = q * XRPP + x_row;                                                   \
+            const int m = m0 + row;                                                                               \
+            const int ox = m % p.Wo, t_ = m / p.Wo, oy = t_ % p.Ho, b = t_ / p.Ho;                                \
+            const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;                             \
+            const bool ok = m < m_end && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;          \
+            const uint16_t* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + tc0 + x_chunk : zero16; \
+            lds_dma16(src, reinterpret_cast<float*>((X) + q * 512));                                              \
+        }                                                                                                         \
+    }
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int khalf = (g >> 1) * 8 + q4;
+    auto rd_d = [&](const uint16_t* base, int row, int slot) -> v4i16 {          // 256-byte rows
+        return lds_tr16(base + row * 128 + ((slot ^ ((row & 3) << 1)) << 4) + pp * 4);
+    };
+    auto rd_x = [&](const uint16_t* base, int row, int slot) -> v4i16 {
+        if (TC == 128) return lds_tr16(base + row * 128 + ((slot ^ ((row & 3) << 1)) << 4) + pp * 4);
+        return lds_tr16(base + row * 64 + ((slot ^ (row & 3)) << 4) + pp * 4);
+    };
+#define WT_COMPUTE(D, X)                                                                                          \
+    {                                                                                                             \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                        \
+            const int row = kb * 16 + khalf;                                                                      \
+            bf16x8 av[2], bv[NTC];                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+                TrPair ap;                                                                                        \
+                const int slot = (wn0 >> 4) + 2 * i + (g & 1);                                                    \
+                ap.lo = rd_d((D), row, slot); ap.hi = rd_d((D), row + 4, slot);                                   \
+                av[i] = __builtin_bit_cast(bf16x8, ap);                                                           \
+            }                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < NTC; ++j) {                                                     \
+                TrPair bp;                                                                                        \
+                const int slot = (wc0 >> 4) + 2 * j + (g & 1);                                                    \
+                bp.lo = rd_x((X), row, slot); bp.hi = rd_x((X), row + 4, slot);                                   \
+                bv[j] = __builtin_bit_cast(bf16x8, bp);                                                           \
+            }                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < NTC; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);        \
+        }                                                                                                         \
+    }
+#define WT_ITER(CUR)                                                                                              \
+    {                                                                                                             \
+        if (ch + 1 < nchunks) { WT_STAGE(ch + 1, (CUR) ? Ds0 : Ds1, (CUR) ? Xs0 : Xs1) }                          \
+        WT_COMPUTE((CUR) ? Ds1 : Ds0, (CUR) ? Xs1 : Xs0)                                                          \
+        __syncthreads();                                                                                          \
+        ++ch;                                                                                                     \
+    }
+    if (nchunks > 0) { WT_STAGE(0, Ds0, Xs0) }
+    __syncthreads();
+    int ch = 0;
+    while (ch < nchunks) {
+        WT_ITER(0)
+        if (ch < nchunks) WT_ITER(1)
+    }
+#undef WT_ITER
+#undef WT_COMPUTE
+#undef WT_STAGE
+    float* out = p.part + (int64_t)split * p.Nn * p.R * p.S * p.Ck;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = tn0 + wn0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int c = tc0 + wc0 + j * 32 + fr;
+                out[((int64_t)n * p.R * p.S + tap) * p.Ck + c] = acc[i][j][e];
+            }
+}
+
 constexpr int STEM_K = 147;   // 7 * 7 * 3
 
 // ---------------------------------------------------------------------------------------------
@@ -2508,10 +2640,19 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
 // ---- mixed-precision weight gradient: dY and X bf16, dW fp32.  3x3 / stride 1 layers (32 of the 42 weight-gradient launches of a
 // step, 97 % of the flops) run k_wgrad3x3_bf16; the strided and 1x1 convs widen their operands to fp32 in the workspace and take
 // the fp32 kernels (exact: a bf16 value is an fp32 value).
+static bool wgrad_tap_bf16(const sd_conv_desc* d) { return !wgrad_all_taps(d) && d->Cout % 128 == 0 && d->Cin % 64 == 0; }
+static int wgrad_tap_bf16_tiles(const sd_conv_desc* d) { return d->R * d->S * (d->Cout / 128) * (d->Cin / (d->Cin % 128 == 0 ? 128 : 64)); }
+static int wgrad_tap_bf16_splits(const sd_conv_desc* d) {
+    // fill two blocks per CU (512 slots) with whole rounds, at least 8 chunks (256 pixels) per split
+    const int tiles = wgrad_tap_bf16_tiles(d), M = d->B * d->Ho * d->Wo;
+    return std::max(1, std::min(cdiv(1024, tiles), M / 256));
+}
+
 size_t sd_conv2d_wgrad_bf16_workspace_bytes(const sd_conv_desc* d) {
     if (!d || d->Cin % 64 || d->Cout % 64) return 0;
     const size_t base = align_up(sd_conv2d_wgrad_workspace_bytes(d), 256);
     if (wgrad_all_taps(d)) return base;
+    if (wgrad_tap_bf16(d)) return align_up((size_t)wgrad_tap_bf16_splits(d) * d->Cout * d->R * d->S * d->Cin * sizeof(float), 256);
     return base + align_up((size_t)d->B * d->Ho * d->Wo * d->Cout * 4, 256) + align_up((size_t)d->B * d->Hi * d->Wi * d->Cin * 4, 256);
 }
 
@@ -2523,7 +2664,25 @@ int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv
     SD_REQUIRE(aligned16(dy) && aligned16(x), SD_ERR_ALIGN, "sd_conv2d_wgrad_bf16: pointers must be 16-byte aligned");
     SD_REQUIRE(workspace_bytes >= sd_conv2d_wgrad_bf16_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_wgrad_bf16: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (!wgrad_all_taps(d)) {
+    if (wgrad_tap_bf16(d)) {
+        WgradArgs16t a{};
+        a.dy = (const uint16_t*)dy; a.x = (const uint16_t*)x; a.part = (float*)workspace;
+        a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+        a.stride = d->stride; a.pad = d->pad;
+        a.M = d->B * d->Ho * d->Wo;
+        a.splits = wgrad_tap_bf16_splits(d);
+        a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
+        const dim3 grid(a.splits, wgrad_tap_bf16_tiles(d));
+        if (d->Cin % 128 == 0) hipLaunchKernelGGL(k_wgrad_tap_bf16<128>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_wgrad_tap_bf16<64>, grid, dim3(256), 0, st, a);
+        SD_LAUNCH_CHECK();
+        const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
+        if (a.splits >= 16) hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+        else hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n4, 256)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!wgrad_all_taps(d)) {       // (Cout not a multiple of 128: no such layer in SDNet) widen to fp32 in the workspace, fp32 kernels
         const size_t base = align_up(sd_conv2d_wgrad_workspace_bytes(d), 256);
         const int64_t ndy = (int64_t)d->B * d->Ho * d->Wo * d->Cout, nx = (int64_t)d->B * d->Hi * d->Wi * d->Cin;
         float* dy32 = reinterpret_cast<float*>((char*)workspace + base);

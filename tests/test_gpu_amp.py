@@ -76,11 +76,11 @@ def test_conv_bf16_forward_statistics_and_data_gradient(case):
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1, 1), (1, 16, 16, 128, 64, 3, 1, 1), (64, 128, 128, 64, 64, 3, 1, 1), (8, 64, 64, 128, 128, 3, 1, 1),
                                   (4, 16, 16, 512, 512, 3, 1, 1), (3, 32, 64, 64, 128, 3, 1, 1), (2, 20, 12, 64, 128, 3, 2, 1), (4, 12, 12, 64, 128, 1, 2, 0),
-                                  (2, 8, 8, 128, 128, 1, 1, 0)])
+                                  (2, 8, 8, 128, 128, 1, 1, 0), (2, 16, 16, 256, 512, 3, 2, 1), (3, 16, 16, 512, 128, 1, 1, 0), (1, 17, 9, 128, 256, 1, 2, 0)])
 def test_conv_bf16_weight_gradient(case):
     """sd_conv2d_wgrad_bf16: dW (fp32) from bf16 dy / x.  3x3 stride-1 layers take k_wgrad3x3_bf16 (bf16 MFMA fed by
     ds_read_b64_tr_b16 transposed reads; 32-wide rows and the two-rows-of-16 form; one and several pixel splits; image borders),
-    the other geometries the fp32 kernels on widened operands.  Products of bf16 values are exact in fp32 and the accumulation
+    strided 3x3 and 1x1 convs k_wgrad_tap_bf16 (one tap per block, 128 x 64 / 128 x 128 tiles, ragged last chunk).  Products of bf16 values are exact in fp32 and the accumulation
     is fp32 on both sides, so only the summation order differs from the reference."""
     from structuredetector_amd import _lib as L
     B, H, W, cin, cout, k, stride, pad = case
