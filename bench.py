@@ -380,8 +380,18 @@ def main():
                     o = run1(x1)
                     return dec1({"anchor_hm": o[:, :M], "part_hm": o[:, M:Mn], "offsets": o[:, Mn:Mn + 2], "embeddings": o[:, Mn + 2:Mn + 4]})
                 ge2e = timed(graph_e2e, 20, warm=3)
+                del run1
+                net.bf16_inference = True                      # the same image through the bf16 backbone (fp32 decode)
+                net.invalidate_folded()
+                try:
+                    f1b = timed(lambda: net(x1), 20, warm=3)
+                    e2eb = timed(lambda: dec1(net(x1)), 20, warm=3)
+                finally:
+                    net.bf16_inference = False
+                    net.invalidate_folded()
             return {"fwd_ms": round(f1 * 1e3, 3), "fwd_hipgraph_ms": round(g1 * 1e3, 3), "fwd_decode_objects_ms": round(e2e * 1e3, 3),
-                    "hipgraph_fwd_decode_objects_ms": round(ge2e * 1e3, 3)}
+                    "hipgraph_fwd_decode_objects_ms": round(ge2e * 1e3, 3), "bf16_fwd_ms": round(f1b * 1e3, 3),
+                    "bf16_fwd_decode_objects_ms": round(e2eb * 1e3, 3)}
 
         def fig_fwd_bf16():
             # bf16 backbone (inference), same network object: bs=64 512x512, against the dense bf16 MFMA peak

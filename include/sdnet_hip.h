@@ -294,6 +294,8 @@ int sd_conv2d_fwd_bf16_bn_stats(const void* x_nhwc_bf16, const void* w_krsc_bf16
 int sd_conv2d_stem_fwd_bn_stats_bf16mm(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
                                        float* running_mean, float* running_var, float* mean, float* invstd,
                                        void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* [Cout][taps][Cin] fp32 -> [Cin][taps][Cout] bf16 in one pass (the data-gradient's weights under --amp). */
+int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, int taps, int Cin, sd_stream_t stream);
 /* dx = dgrad(dy) [+ residual]: bf16 dy / transposed weights [Cin][R][S][Cout] / dx; res_mode 0 none, 1 bf16 tensor of dx's shape,
  * 2 bf16 half-size map added at the even pixels (the 1x1 / stride-2 downsample branch). */
 int sd_conv2d_dgrad_bf16(const void* dy_bf16, const void* w_t_bf16, void* dx_bf16, const sd_conv_desc* d, const void* residual_bf16,

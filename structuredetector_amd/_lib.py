@@ -88,6 +88,7 @@ _SIGNATURES = {
     "sd_conv2d_fwd_bf16_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_wgrad_bf16_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_wgrad_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_transpose_weights_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_dgrad_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "sd_bn_apply_bf16": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "sd_bn_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_size, c_vp]),

@@ -2079,7 +2079,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // [N][T][C] -> [C][T][N]  (forward weights -> data-gradient weights, flipping nothing: the
 // dgrad coordinate map already walks the taps with rsign = -1)
-__global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w, float* __restrict__ wt, int N, int T, int C) {
+// (WT = uint16_t: the transposed copy is written as bf16 -- mixed-precision data-gradient weights in one pass)
+template <typename WT = float>
+__global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w, WT* __restrict__ wt, int N, int T, int C) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
     const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -2091,7 +2093,10 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, n = n0 + tx;
-        if (n < N && c < C) wt[((int64_t)c * T + tap) * N + n] = tile[tx][j];
+        if (n < N && c < C) {
+            if constexpr (sizeof(WT) == 2) wt[((int64_t)c * T + tap) * N + n] = f2bf(tile[tx][j]);
+            else wt[((int64_t)c * T + tap) * N + n] = tile[tx][j];
+        }
     }
 }
 
@@ -2449,7 +2454,7 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
     if (stem_is_7x7s2(d) && workspace && workspace_bytes >= sd_conv2d_stem_fwd_workspace_bytes(d)) {
         // LDS-patch kernel: weights are re-laid as [k][cout] once per call (37 KB)
         float* wt = (float*)workspace;
-        hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
+        hipLaunchKernelGGL(k_transpose_w<float>, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
         SD_LAUNCH_CHECK();
         StemArgs a{};
         a.x = x_nchw; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift; a.relu = relu; a.out_bf16 = out_bf16;
@@ -2492,7 +2497,7 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
     hipStream_t st = (hipStream_t)stream;
     float* wt = (float*)workspace;
     float* partial = (float*)((char*)workspace + align_up((size_t)STEM_K * 64 * sizeof(float), 256));
-    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
+    hipLaunchKernelGGL(k_transpose_w<float>, dim3(cdiv(STEM_K, 32), 2, 1), dim3(256), 0, st, w, wt, 64, 1, STEM_K);
     SD_LAUNCH_CHECK();
     StemArgs a{};
     a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
@@ -2556,7 +2561,15 @@ int sd_conv2d_dgrad(const float* dy, const float* w_t, float* dx, const sd_conv_
 
 int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, int Cin, sd_stream_t stream) {
     SD_REQUIRE(w && w_t && Cout > 0 && taps > 0 && Cin > 0, SD_ERR_INVALID, "sd_conv2d_transpose_weights: bad arguments");
-    hipLaunchKernelGGL(k_transpose_w, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, taps, Cin);
+    hipLaunchKernelGGL(k_transpose_w<float>, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w, w_t, Cout, taps, Cin);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, int taps, int Cin, sd_stream_t stream) {
+    SD_REQUIRE(w && w_t_bf16 && Cout > 0 && taps > 0 && Cin > 0, SD_ERR_INVALID, "sd_conv2d_transpose_weights_bf16: bad arguments");
+    hipLaunchKernelGGL(k_transpose_w<uint16_t>, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_t_bf16,
+                       Cout, taps, Cin);
     SD_LAUNCH_CHECK();
     return 0;
 }

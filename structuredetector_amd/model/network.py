@@ -423,11 +423,11 @@ class _Engine:
 
     # ---- backward ------------------------------------------------------------------------
     def _wt(self, conv, amp=False):
-        """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient (amp: transposed in fp32, then one cast to bf16)."""
-        wt = torch.empty(conv.cin * conv.k * conv.k * conv.cout, dtype=torch.float32, device=conv.weight.device)
-        L.check(self.lib.sd_conv2d_transpose_weights(conv.weight.data_ptr(), wt.data_ptr(), conv.cout, conv.k * conv.k, conv.cin, L.stream()),
-                "transpose_weights")
-        return self._to_bf16(wt) if amp else wt
+        """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient (amp: written as bf16 by the same pass)."""
+        wt = torch.empty(conv.cin * conv.k * conv.k * conv.cout, dtype=torch.bfloat16 if amp else torch.float32, device=conv.weight.device)
+        transpose = self.lib.sd_conv2d_transpose_weights_bf16 if amp else self.lib.sd_conv2d_transpose_weights
+        L.check(transpose(conv.weight.data_ptr(), wt.data_ptr(), conv.cout, conv.k * conv.k, conv.cin, L.stream()), "transpose_weights")
+        return wt
 
     def _dgrad(self, dy, conv, d, res=None, bn_next=None, res_half=False):
         """dx = dgrad(dy) [+ res].  bn_next = (x, y, relu, bn, mean, invstd) of the BatchNorm whose output gradient dx is:
