@@ -263,11 +263,14 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
 
 /* Process-wide tuning / test switches.  "conv_patch_min_tiles": smallest tile grid for which the 3x3 stride-1 convs take the
  * patch-staging kernel (default 512 = two resident blocks per CU; 1 = always, for tests; 1 << 30 = never);
- * "conv_patch_bn64": 1 = also for layers with 64 output channels (default 0: slower inside the training step). */
+ * "conv_patch_bn64": 1 = also for layers with 64 output channels (default 0: slower inside the training step);
+ * "conv_pp_min_tiles": smallest grid of 512-pixel x 128-channel tiles for which the bf16 3x3 stride-1 convs take the two-group
+ * kernel k_conv3x3_bf16_pp (default 200; 1 = always, for tests; 1 << 30 = never); "conv_fwd_split_k": 0 = the forward convs never
+ * split K over blocks (default 1: small grids do), so that tests can put small problems on the single-pass kernels. */
 int sd_set_option(const char* name, int value);
 
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
- * 2 = sd_conv2d_wgrad), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
+ * 2 = sd_conv2d_wgrad; 16 = sd_conv2d_fwd_bf16, 17 = sd_conv2d_dgrad_bf16), as rocprofv3 prints it without the sd:: namespace -- lets a profiler label its event timings
  * with the same names as the kernel trace.  Thread-local storage, valid until the next call on the thread. */
 const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass);
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_ABLATE_PATCH
 #define SD_ABLATE_PATCH 0     // timing-only experiment: stage the A tile for ~1.6 of the 9 taps only (what patch staging would need) -- WRONG RESULTS
 #endif
-#if SD_ABLATE_HOT || SD_ABLATE_STORE || SD_ABLATE_PATCH
+#if SD_ABLATE_HOT || SD_ABLATE_STORE || SD_ABLATE_PATCH || defined(SD_PP_ABL)
 #warning "timing-only ablation build: this libsdnet_hip.so computes WRONG RESULTS; the Python loader refuses it unless SDNET_ALLOW_ABLATION=1"
 #endif
 // Reported through the C ABI (sd_build_flags): the loader, build() and the CPU tests assert 0, so an experiment build can never
@@ -52,6 +52,10 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #define SD_TRACE_FLAG 8       // csrc/sd_decode.hip compiled with in-kernel timestamps (slower, extra global stores)
 #else
 #define SD_TRACE_FLAG 0
+#endif
+#ifdef SD_PP_TRACE
+#undef SD_TRACE_FLAG
+#define SD_TRACE_FLAG 8
 #endif
 extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG; }
 
@@ -722,7 +726,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     }
     }
     if (fwd_stat || (bwd_red && !red_done)) {
-        static_assert(WM == 2 || BN != 128, "two wave rows are combined");
+        static_assert(WM == 2 || WM == 4, "wave rows 1 .. WM-1 are combined into row 0");
 #pragma unroll
         for (int ni = 0; ni < NTW; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
         // wave rows 1 .. WM-1 add into LDS one after the other (fixed order -> deterministic), wave row 0 finishes
@@ -1145,7 +1149,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #define PT_TAP(t)                                                                                  \
     {                                                                                              \
         int n_iss = PBW;                                                                           \
-        PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
+        if (!BF16) {                                                                               \
+            PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
         if (rolling) {                                                                             \
             /* taps 0..3: rows 2, 3 of this chunk; taps 4..7: rows 0, 1 of the next one; even tap: slot 0, odd: slots 1 (+2) */ \
             if ((t) < 8) {                                                                         \
@@ -1162,6 +1167,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         } else if ((t) < 7 && cc + 1 < nchunks && PT_OWN(t)) {                                     \
             PT_PATCH(t, pt_nxt, (cc + 1) * KC) ++n_iss;                                            \
         }                                                                                          \
+        }                                                                                          \
         const int tapoff = ((t) / 3) * PW + ((t) % 3);      /* data-gradient: same walk, weight taps reversed */ \
         uint32_t aa[MT];                                                                           \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                        \
@@ -1177,6 +1183,27 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         f32x4 a12 = a10, a13 = a10;                                                                \
         if (MT == 4) { a12 = lds_read128_async<0>(aa[MT - 2] ^ 32u); a13 = lds_read128_async<0>(aa[MT - 1] ^ 32u); } \
         f32x4 b10 = lds_read128_async<0>(bb ^ 32u), b11 = lds_read128_async<TSTR>(bb ^ 32u);       \
+        /* bf16: a wave gets one LDS-DMA instruction out per ~66 cycles and waits at it in order, and a bf16 tap is only 512 MFMA \
+           cycles long -- the fragment reads go first (fp32 taps are 8x longer: the order does not matter there) */ \
+        if (BF16) {                                                                                \
+            PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
+        if (rolling) {                                                                             \
+            /* taps 0..3: rows 2, 3 of this chunk; taps 4..7: rows 0, 1 of the next one; even tap: slot 0, odd: slots 1 (+2) */ \
+            if ((t) < 8) {                                                                         \
+                const int row = (t) < 4 ? 2 + (t) / 2 : ((t) - 4) / 2;                             \
+                const int cch = (t) < 4 ? cc : cc + 1;                                             \
+                if (cch < nchunks) {                                                               \
+                    if (((t) & 1) == 0) { PT_PATCH(3 * row, Pt, cch * KC) ++n_iss; }               \
+                    else {                                                                         \
+                        if (PT_OWN(3 * row + 1)) { PT_PATCH(3 * row + 1, Pt, cch * KC) ++n_iss; }  \
+                        if (PT_OWN(3 * row + 2)) { PT_PATCH(3 * row + 2, Pt, cch * KC) ++n_iss; }  \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        } else if ((t) < 7 && cc + 1 < nchunks && PT_OWN(t)) {                                     \
+            PT_PATCH(t, pt_nxt, (cc + 1) * KC) ++n_iss;                                            \
+        }                                                                                          \
+        }                                                                                          \
         if (MT == 4) { SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01); } else { SD_LDS_WAIT4(4, a00, a01, b00, b01); } \
         PT_MFMA_GROUP(a00, a01, a02, a03, b00, b01)                                                \
         if (MT == 4) { SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11); } else { SD_LDS_WAIT4(0, a10, a11, b10, b11); } \
@@ -1210,6 +1237,228 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
             return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
         },
         tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, BN == 128 ? T0 + 2048 : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 3x3 / stride 1 / pad 1 convolution, TWO-GROUP form of the patch-staging kernel (forward and flipped-tap data-gradient).
+// Why: a bf16 tap is 16 MFMAs of 32 cycles per wave -- 8x shorter than the fp32 tap -- so in k_conv3x3_patch<128, true> the
+// per-tap barrier, the fragment reads and above all the 2-tap prefetch distance of the weight ring (shorter than one L2 round trip)
+// are exposed: 31 % of the MFMA peak.  Here ONE 512-thread block per CU holds two 256-pixel sub-tiles that share the weights:
+//   group g = wave / 4 owns sub-tile g (its own double-buffered patch) and runs exactly k_conv3x3_patch's 2 x 2 wave grid on it;
+//   the weight ring has 7 stages of one tap (8 KB), tap t + 5 is issued during tap t (all 8 waves, one 1 KB piece each):
+//     staged weight bytes per MFMA are half of the 256-pixel tile's and a piece has > 5 tap times to land;
+//   the groups run half a tap apart (group 1 does one extra s_barrier first, group 0 one last): every tap is
+//     LOAD [issue DMA, 12 ds_read_b128, counted vmcnt] - s_barrier - MFMA [16 x 32x32x16, raised priority] - s_barrier
+//     so that one group's LOAD always runs under the other group's MFMAs on the same SIMDs (2 waves per SIMD).
+//   Hazards (t = tap, interval = time between two barriers; group 0 LOADs tap t in interval 2t, group 1 in 2t + 1):
+//     RAW  a piece of tap t+1 is covered by its issuer's vmcnt wait in LOAD(t), which ends with a barrier every reader passes
+//          before its LOAD(t+1);
+//     WAR  stage (t+5) % 7 = stage of tap t-2, whose last reads (group 1, interval 2t-3) were waited for (lgkmcnt) in interval
+//          2t-2, two barriers before group 0 issues in interval 2t.  The next chunk's patch is written by its own group only.
+//   vmcnt: per tap a wave issues p(tap) patch pieces (2, 2, 2, 1, 0 ... of the NEXT chunk; non-existent pieces re-load piece
+//          wave % 4, past the last chunk the zero line: the count stays fixed) and then 1 weight piece;
+//          LOAD(t) needs the weight piece issued last in LOAD(t-4): N(t) = 4 + p(t) + p(t-1) + p(t-2) + p(t-3).
+//   LDS: 4 x 25 KB patches + 7 x 8 KB weights = 156 KB (dynamic) + 1 KB statistics; epilogue scratch = the same array.
+// ---------------------------------------------------------------------------------------------
+#ifdef SD_PP_TRACE
+// timing experiment (make SUFFIX=_pptrace EXTRA=-DSD_PP_TRACE): shader-clock time of the phases of every tap, summed per wave of block 0
+__device__ unsigned long long g_pp_trace[8][8];
+#define PP_T(v) const unsigned long long v = __builtin_readcyclecounter();
+#define PP_ACC(k, a, b) tr[k] += (b) - (a);
+#else
+#define PP_T(v)
+#define PP_ACC(k, a, b)
+#endif
+#ifndef SD_PP_ABL
+#define SD_PP_ABL 0          // timing experiments (WRONG RESULTS): 1 no fragment reads, 2 no DMA in the loop, 3 no MFMA, 4 no s_setprio, 5 no vmcnt wait, 6 DMA from the zero line only, 7 DMA only (no reads, no MFMA)
+#endif
+constexpr int PP_NST = 7, PP_D = 5;
+constexpr int PP_B_FLOATS = 128 * 16;                                            // one tap of 128 channels x 32 k (bf16) = 8 KB
+constexpr int PP_LDS_FLOATS = 4 * PT_STAGE_FLOATS + PP_NST * PP_B_FLOATS;        // 39936 floats = 159744 B
+constexpr int PP_BM = 512;
+
+__device__ __forceinline__ f32x4 pp_fake_read(uint32_t addr) { f32x4 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(addr)); v[1] = v[2] = v[3] = v[0]; return v; }
+__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
+    using T = uint16_t;
+    constexpr int BN = 128, EPS = 8, KC = 32, MT = 4, NTW = 2, NPP = 7;
+    extern __shared__ __attribute__((aligned(16))) float pp_lds[];
+    PP_T(tr_start)
+    const T* const px_ = reinterpret_cast<const T*>(p.x);
+    const T* const pw_ = reinterpret_cast<const T*>(p.w);
+    const T* const zero_ = reinterpret_cast<const T*>(g_zero_line);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wl = wave & 3;
+    const int n_tiles = p.Nn / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = tile / n_tiles;
+    const int n0 = (tile % n_tiles) * BN;
+    const int m0 = tile_m * PP_BM + grp * BMB;                  // this group's 256-pixel sub-tile
+    const int TWl = p.pt_tw_log2, TW = 1 << TWl, PW = p.pt_pw, TH = BMB >> TWl;
+    const int hw = p.Ho * p.Wo;
+    const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> TWl;
+    const int nchunks = p.Ck / KC;
+    float* const Pt = pp_lds + grp * (2 * PT_STAGE_FLOATS);
+    float* const Bs = pp_lds + 4 * PT_STAGE_FLOATS;
+
+    // ---- patch pieces of this wave: piece j = wl + 4 i (i < 7); a piece past the patch re-loads piece wl
+    const int prow = lane >> 2, pslot = lane & 3;
+    const T* pbase[NPP];
+    int pdst[NPP];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int j = (wl + 4 * i < p.pt_pieces) ? wl + 4 * i : wl;
+        const int pp = j * 16 + prow;
+        const int py = pp / PW, pxx = pp - py * PW;
+        const int iy = y0 - 1 + py, ix = pxx - 1;
+        const bool ok = py < TH + 2 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const int qe = (pslot ^ ((pp >> 2) & 3)) * EPS;
+        pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : zero_ + qe;
+        okmask |= (ok ? 1u : 0u) << i;
+        pdst[i] = j * 256;
+    }
+    const int wk = 9 * p.Ck;
+    const int qeb = (pslot ^ ((prow >> 2) & 3)) * EPS;
+    const T* const bbase = pw_ + (int64_t)(n0 + wave * 16 + prow) * wk + qeb;
+    const T* const zsrc = zero_ + qeb;
+
+    // patch piece i of chunk cch -> stage buffer dst (past the last chunk: the zero line)
+#define PP_PATCH(i, dst, cch) if (SD_PP_ABL == 6 && (cch) != 0) { lds_dma16(zsrc, (dst) + pdst[i]); } else if (SD_PP_ABL != 2 || (cch) == 0) { lds_dma16((((okmask >> (i)) & 1u) && (cch) < nchunks) ? pbase[i] + (cch) * KC : (((okmask >> (i)) & 1u) ? zero_ + (lane & 3) * EPS : pbase[i]), (dst) + pdst[i]); }
+    // weights of (chunk cci, tap ti) -> ring stage st
+#define PP_ISSUE_B(cci, ti, st)                                                                    \
+    {                                                                                              \
+        float* bd = Bs + (st) * PP_B_FLOATS + wave * 256;                                          \
+        if (SD_PP_ABL == 2 && pp_in_loop) {}                                                        \
+        else if (SD_PP_ABL == 6 && pp_in_loop) lds_dma16(zsrc, bd);                                \
+        else if ((cci) < nchunks) lds_dma16(bbase + ((p.pt_flip ? 8 - (ti) : (ti)) * p.Ck + (cci) * KC), bd); \
+        else lds_dma16(zsrc, bd);                                                                  \
+    }
+
+    // ---- MFMA side (inside the group: k_conv3x3_patch's 2 x 2 wave grid, wave tile 128 x 64)
+    const int wm0 = (wl >> 1) * 128, wn0 = (wl & 1) * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+    int bpp[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int ml = wm0 + mi * 32 + fr;
+        bpp[mi] = (ml >> TWl) * PW + (ml & (TW - 1));
+    }
+    const int rd_swz_b = (fr >> 2) & 3;
+    const uint32_t b_k0 = ((wn0 + fr) * BKB + ((fh ^ rd_swz_b) << 2)) * 4;
+    constexpr int TSTR = 32 * BKB * 4;
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // ---- prologue: the patch of chunk 0 and the weights of taps 0 .. PP_D-1
+    bool pp_in_loop = false; (void)pp_in_loop;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) PP_PATCH(i, Pt, 0)
+#pragma unroll
+    for (int t = 0; t < PP_D; ++t) PP_ISSUE_B(0, t, t)
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();               // group 1 runs half a tap behind
+
+    const uint32_t pt_base = lds_addr(Pt), bs_base = lds_addr(Bs);
+    int rp = 0, ip = PP_D;                                     // ring stage of the current tap / of the tap being issued
+    pp_in_loop = true;
+#if SD_PP_ABL == 1 || SD_PP_ABL == 7
+#define PP_RD(OFF, addr) pp_fake_read(addr)
+#else
+#define PP_RD(OFF, addr) lds_read128_async<OFF>(addr)
+#endif
+#if SD_PP_ABL == 3 || SD_PP_ABL == 7
+#define PP_MFMA(A, B, mi, ni) asm volatile("" :: "v"(A), "v"(B));
+#else
+#define PP_MFMA(A, B, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni], 0, 0, 0);
+#endif
+#define PP_TAP(t, NW)                                                                              \
+    {                                                                                              \
+        /* LOAD */                                                                                 \
+        PP_T(t0_)                                                                                  \
+        const int tapoff = ((t) / 3) * PW + ((t) % 3);                                             \
+        uint32_t aa[MT];                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                        \
+            const int pp = bpp[mi] + tapoff;                                                       \
+            aa[mi] = pt_cur + (uint32_t)pp * 64u + (uint32_t)((fh ^ ((pp >> 2) & 3)) << 4);        \
+        }                                                                                          \
+        const uint32_t bb = bs_base + (uint32_t)rp * (PP_B_FLOATS * 4) + b_k0;                     \
+        f32x4 a00 = PP_RD(0, aa[0]), a01 = PP_RD(0, aa[1]);                                        \
+        f32x4 a02 = PP_RD(0, aa[2]), a03 = PP_RD(0, aa[3]);                                        \
+        f32x4 b00 = PP_RD(0, bb), b01 = PP_RD(TSTR, bb);                                           \
+        f32x4 a10 = PP_RD(0, aa[0] ^ 32u), a11 = PP_RD(0, aa[1] ^ 32u);                            \
+        f32x4 a12 = PP_RD(0, aa[2] ^ 32u), a13 = PP_RD(0, aa[3] ^ 32u);                            \
+        f32x4 b10 = PP_RD(0, bb ^ 32u), b11 = PP_RD(TSTR, bb ^ 32u);                               \
+        /* the DMA goes out AFTER the fragment reads: the CU takes one 1 KB LDS-DMA instruction per ~32 cycles and a wave waits at \
+           its DMA instruction until the queue takes it -- in front of the reads that wait was on the interval's critical path */ \
+        if ((t) == 0) { PP_PATCH(0, pt_nxt, cc + 1) PP_PATCH(1, pt_nxt, cc + 1) }                  \
+        if ((t) == 1) { PP_PATCH(2, pt_nxt, cc + 1) PP_PATCH(3, pt_nxt, cc + 1) }                  \
+        if ((t) == 2) { PP_PATCH(4, pt_nxt, cc + 1) PP_PATCH(5, pt_nxt, cc + 1) }                  \
+        if ((t) == 3) { PP_PATCH(6, pt_nxt, cc + 1) }                                              \
+        PP_ISSUE_B(cc + ((t) + PP_D) / 9, ((t) + PP_D) % 9, ip)                                    \
+        rp = rp + 1 == PP_NST ? 0 : rp + 1;                                                        \
+        ip = ip + 1 == PP_NST ? 0 : ip + 1;                                                        \
+        if (SD_PP_ABL != 5) wait_vmcnt<NW>();                                                      \
+        __builtin_amdgcn_s_barrier();                                                              \
+        /* MFMA */                                                                                 \
+        SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01);                                             \
+        PP_T(t1_)                                                                                  \
+        if (SD_PP_ABL != 4) __builtin_amdgcn_s_setprio(1);                                         \
+        PP_MFMA(a00, b00, 0, 0) PP_MFMA(a01, b00, 1, 0) PP_MFMA(a02, b00, 2, 0) PP_MFMA(a03, b00, 3, 0) \
+        PP_MFMA(a00, b01, 0, 1) PP_MFMA(a01, b01, 1, 1) PP_MFMA(a02, b01, 2, 1) PP_MFMA(a03, b01, 3, 1) \
+        SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11);                                             \
+        PP_MFMA(a10, b10, 0, 0) PP_MFMA(a11, b10, 1, 0) PP_MFMA(a12, b10, 2, 0) PP_MFMA(a13, b10, 3, 0) \
+        PP_MFMA(a10, b11, 0, 1) PP_MFMA(a11, b11, 1, 1) PP_MFMA(a12, b11, 2, 1) PP_MFMA(a13, b11, 3, 1) \
+        __builtin_amdgcn_s_setprio(0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        PP_T(t2_)                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                              \
+        PP_T(t3_)                                                                                  \
+        PP_ACC(0, t0_, t1_) PP_ACC(1, t1_, t2_) PP_ACC(2, t2_, t3_)                                \
+    }
+#ifdef SD_PP_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tr_begin = __builtin_readcyclecounter();
+    const unsigned long long tr_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const uint32_t pt_cur = pt_base + (uint32_t)(cc & 1) * (PT_STAGE_FLOATS * 4);
+        float* const pt_nxt = Pt + ((cc + 1) & 1) * PT_STAGE_FLOATS;
+        PP_TAP(0, 6) PP_TAP(1, 8) PP_TAP(2, 10) PP_TAP(3, 11) PP_TAP(4, 9) PP_TAP(5, 7) PP_TAP(6, 5) PP_TAP(7, 4) PP_TAP(8, 4)
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+#ifdef SD_PP_TRACE
+    const unsigned long long tr_end = __builtin_readcyclecounter();
+    tr[3] = tr_end - tr_begin; tr[4] = tr_begin - tr_start; tr[7] = __builtin_amdgcn_s_memrealtime() - tr_rbegin;
+#endif
+#undef PP_TAP
+#undef PP_MFMA
+#undef PP_RD
+#undef PP_ISSUE_B
+#undef PP_PATCH
+    // 16-byte epilogue through the (now idle) LDS: 16 KB per wave; the barrier makes sure no past-the-end DMA is still landing.
+    // The 512-pixel tile is one statistics row: wave rows 0, 1 = group 0, rows 2, 3 = group 1.
+    __syncthreads();
+    float* T0 = pp_lds + wave * 4096;
+    tile_epilogue<BN, 4, 2, MT, NTW, true, true, true>(
+        p, acc, [&](int row) { return tile_m * PP_BM + row; },
+        [&](int, int m) {
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
+        },
+        tid, wave, fr, fh, (wave >> 1) * 128, wn0, n0, tile_m, T0, T0 + 2048);
+#ifdef SD_PP_TRACE
+    tr[5] = __builtin_readcyclecounter() - tr_end;
+    tr[6] = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_pp_trace[wave][k] = tr[k]; }
+#endif
 }
 
 #undef SD_BNRED_TERM
@@ -2172,6 +2421,18 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
     return a.pt_pieces * 256 <= (a.pt_rolling ? PT_FLOATS : PT_STAGE_FLOATS);
 }
 
+// k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered (not rolling) patch geometry, whole 512-pixel
+// tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
+static int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
+static bool conv_pp_geometry(ConvArgs& a, int mode) {
+    if (a.Nn % 128 || a.M % PP_BM) return false;
+    const int keep = g_patch_min_tiles;
+    g_patch_min_tiles = 1;
+    const bool ok = conv_patch_geometry(a, 128, mode, true);
+    g_patch_min_tiles = keep;
+    return ok && !a.pt_rolling && (a.M / PP_BM) * (a.Nn / 128) >= g_pp_min_tiles;
+}
+
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
@@ -2200,6 +2461,20 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     const int tiles = cdiv(a.M, BM) * (a.Nn / BN);
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
+    if (!stem && bf16) {
+        ConvArgs pa = a;
+        if (conv_pp_geometry(pa, mode)) {
+            static thread_local bool raised = false;      // per host thread: cheap, idempotent
+            if (!raised) {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_bf16_pp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           PP_LDS_FLOATS * (int)sizeof(float)));
+                raised = true;
+            }
+            hipLaunchKernelGGL(k_conv3x3_bf16_pp, dim3((pa.M / PP_BM) * (pa.Nn / 128)), dim3(512), PP_LDS_FLOATS * sizeof(float), st, pa);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (!stem) {
         ConvArgs pa = a;
         if (conv_patch_geometry(pa, BN, mode, bf16)) {
@@ -2246,7 +2521,9 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
 }
 
 // Split-K factor of the forward conv: only when the tile grid cannot fill the chip (small batch).
+static int g_fwd_split_k = 1;           // sd_set_option("conv_fwd_split_k", 0): small grids keep the single-pass kernels (tests of those kernels)
 static int fwd_splits(const sd_conv_desc* d, int ke = BK) {
+    if (!g_fwd_split_k) return 1;
     const int M = d->B * d->Ho * d->Wo;
     const int BN = (d->Cout % 128 == 0) ? 128 : 64;
     const int tiles = cdiv(M, BM) * (d->Cout / BN);
@@ -2322,6 +2599,8 @@ static int fwd_stat_rows(const sd_conv_desc* d, bool bf16 = false) {
     if (a.splits > 1) return 0;
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     ConvArgs t = a;
+    if (bf16 && conv_pp_geometry(t, 0)) return a.M / PP_BM;
+    t = a;
     return (conv_patch_geometry(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
@@ -2792,9 +3071,15 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
                               (float*)workspace + (size_t)rows * 2 * d->Cin, stream);
 }
 
+#ifdef SD_PP_TRACE
+int sd_debug_pp_trace(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(sd::g_pp_trace), sizeof(unsigned long long) * 64); }
+#endif
+
 int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_min_tiles")) { g_patch_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
+    if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
+    if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
@@ -2808,10 +3093,22 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         return name;
     }
     ConvArgs a{};
+    const bool bf16 = (pass & 16) != 0;
+    pass &= 15;
     if (pass == 0) fill_fwd(a, d); else fill_dgrad(a, d);
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
     ConvArgs t = a;
+    if (bf16) {          // the bf16 dispatch of launch_igemm (chunks of 64 channels; forward: split-K for small grids)
+        a.kchunks = a.Ck / 64; a.nk = a.R * a.S * a.kchunks;
+        a.splits = pass == 0 ? fwd_splits(d, 64) : 1;
+        t = a;
+        if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
+        t = a;
+        if (conv_patch_geometry(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, true>", BN);
+        else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
+        return name;
+    }
     if (conv_patch_geometry(t, BN, mode)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", BN);
     else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);

@@ -173,7 +173,7 @@ class _Engine:
         if amp:
             y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
             flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
-            self._timed("bf16:" + self._kname(d, 0), flops, lambda: L.check(
+            self._timed("bf16:" + self._kname(d, 16), flops, lambda: L.check(
                 self.lib.sd_conv2d_fwd_bf16(x.data_ptr(), self._w16(conv).data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),
                                             _ptr(res), int(res_up2), int(relu), 0, 0, L.stream()), "sd_conv2d_fwd_bf16"))
             return y, d
@@ -197,7 +197,7 @@ class _Engine:
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
         if amp:
             ws = self._ws(self.lib.sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(C.byref(d)), x.device)
-            self._timed("bf16:" + self._kname(d, 0), flops, lambda: L.check(
+            self._timed("bf16:" + self._kname(d, 16), flops, lambda: L.check(
                 self.lib.sd_conv2d_fwd_bf16_bn_stats(x.data_ptr(), self._w16(conv).data_ptr(), y.data_ptr(), C.byref(d), BN_EPS, BN_MOMENTUM,
                                                      bn.running_mean.data_ptr() if update_running else 0,
                                                      bn.running_var.data_ptr() if update_running else 0,
@@ -440,7 +440,7 @@ class _Engine:
         if amp:
             assert bn_next is None, "fuse_bn_bwd is an fp32-path experiment"
             mode = 2 if res_half else (1 if res is not None else 0)
-            self._timed("bf16:" + self._kname(d, 1), flops, lambda: L.check(
+            self._timed("bf16:" + self._kname(d, 17), flops, lambda: L.check(
                 self.lib.sd_conv2d_dgrad_bf16(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), _ptr(res), mode, L.stream()),
                 "sd_conv2d_dgrad_bf16"), phase="dgrad")
             return dx

@@ -259,3 +259,49 @@ def test_amp_training_reduces_loss_and_cli(tmp_path, monkeypatch, capsys):
     train.main(["-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json"), "--synthetic", "16", "-b", "8", "-e", "2", "--amp"])
     out = capsys.readouterr().out
     assert "epoch 1: total" in out and "validation (" in out
+
+
+@pytest.mark.parametrize("case", [(4, 32, 32, 128, 128, 3, 1, 1), (2, 16, 16, 256, 256, 3, 1, 1), (2, 64, 64, 128, 256, 3, 1, 1), (6, 16, 16, 128, 128, 3, 1, 1)])
+def test_conv_bf16_two_group_kernel(case):
+    """k_conv3x3_bf16_pp (512-pixel x 128-channel tiles, two wave groups half a tap apart, 7-stage weight ring): forced onto small
+    grids with sd_set_option, then the same checks as the other bf16 conv kernels (forward + fused statistics, data-gradient with
+    the three residual modes) plus the forward epilogue (folded BatchNorm, ReLU, residual, half-size residual upsampled)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W, cin, cout, k, stride, pad = case
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    L.check(lib.sd_set_option(b"conv_pp_min_tiles", 1))
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == "k_conv3x3_bf16_pp"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode() == "k_conv3x3_bf16_pp"
+        test_conv_bf16_forward_statistics_and_data_gradient(case)
+        g = torch.Generator().manual_seed(sum(case) + 1)
+        x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16().float()
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g).bfloat16().float()
+        half = torch.randn(B, cout, H // 2, W // 2, generator=g).bfloat16().float()
+        xd, wd = nhwc16(x), nhwc16(w)
+        scale_d, shift_d = scale.to(DEV), shift.to(DEV)                       # (named: a temporary would be freed before the launch)
+        y = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+        conv = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        for r16, up2, relu, ref in ((nhwc16(res), 0, 1, torch.relu(conv + res)),
+                                    (nhwc16(half), 1, 0, conv + F.interpolate(half, scale_factor=2, mode="nearest")),
+                                    (None, 0, 0, conv)):
+            L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
+                                           r16.data_ptr() if r16 is not None else 0, up2, relu, 0, 0, L.stream()))
+            close(back(y), ref, 8e-3)
+        # against the one-group kernel on the same operands: same accumulation order -> identical bits
+        L.check(lib.sd_set_option(b"conv_pp_min_tiles", 1 << 30))
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
+        y1 = torch.empty_like(y)
+        L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y1.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
+                                       0, 0, 0, 0, 0, L.stream()))
+        if lib.sd_conv2d_kernel_name(C.byref(d), 16).decode().startswith("k_conv3x3_patch"):
+            assert torch.equal(y, y1)
+    finally:
+        L.check(lib.sd_set_option(b"conv_pp_min_tiles", 200))
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
