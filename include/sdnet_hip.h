@@ -283,6 +283,12 @@ int sd_conv2d_fwd_bf16(const void* x_nhwc_bf16, const void* w_krsc_bf16, void* y
                        const float* scale, const float* shift, const void* residual_bf16, int res_up2, int relu,
                        void* workspace, size_t workspace_bytes, sd_stream_t stream);
 int sd_maxpool3x3s2_fwd_bf16(const void* x_bf16, void* y_bf16, int B, int Hi, int Wi, int C, sd_stream_t stream);
+/* network.py:59-63 `adpater` (conv1 7x7/s2 -> bn1 -> relu -> maxpool 3x3/s2) in ONE launch for the bf16 backbone: fp32 NCHW image, fp32
+ * weights [64][7][7][3], folded BatchNorm scale / shift, pooled NHWC bf16 output [B][Ho/2][Wo/2][64] (d describes the conv: Ho, Wo even).
+ * The full-resolution activation is never written.  Same values as sd_conv2d_stem_fwd(out_bf16 = 1) + sd_maxpool3x3s2_fwd_bf16 up to
+ * the fp32 summation order of the conv (<= 1 bf16 ulp). */
+int sd_stem_bn_relu_maxpool_fwd_bf16(const float* x_nchw, const float* w, const float* scale, const float* shift, void* y_bf16,
+                                     const sd_conv_desc* d, sd_stream_t stream);
 
 /* ---- mixed-precision training: the step the reference runs under `--amp` (src/sdnet/model/trainer.py:115-121: the forward and
  * the loss inside torch.autocast, backward in the dtypes the forward used, fp32 master weights updated by Adam).  Activations and

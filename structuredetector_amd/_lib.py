@@ -96,6 +96,7 @@ _SIGNATURES = {
     "sd_col_sum_bf16": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_size, c_vp]),
     "sd_upsample2x_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "sd_maxpool3x3s2_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "sd_stem_bn_relu_maxpool_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "sd_head_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_dgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp]),
     "sd_conv2d_transpose_weights": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),

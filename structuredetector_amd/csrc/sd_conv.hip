@@ -2210,6 +2210,185 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem conv + folded BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max-pool in ONE kernel (inference with the bf16 backbone;
+// network.py:59-63 `adpater` = conv1, bn1, relu, maxpool): the full-resolution activation (B x H/2 x W/2 x 64: 537 MB in bf16 at
+// bs=64 512x512, written by the conv and read back by the pool) never exists.  The pooling itself is exact with respect to the
+// two-kernel form (sd_conv2d_stem_fwd with bf16 output, then sd_maxpool3x3s2_fwd_bf16): rounding to bf16 is monotonic, so the max
+// of rounded values is the rounded max, and after the ReLU zero padding equals the pool's -inf padding; the conv sums its 147
+// products in another order (k' below), i.e. differs from k_stem_fwd<true> by fp32 summation rounding (<= 1 bf16 ulp after rounding).
+//   work unit : `rows` consecutive pooled rows q of one image; a persistent block walks its units.  Pooled row q needs conv rows
+//               2q-1, 2q, 2q+1: the block keeps the horizontally pooled row 2q+1 as the "carry" of row q+1 (a unit's first row
+//               recomputes conv row 2q-1 once).
+//   conv row  : tiles of 128 pixels, left to right; patch rows are (ci, r) x 261 columns as bf16 (converted ONCE at staging),
+//               reduction index k' = (ci*7 + r)*8 + 1 + s (slot 0 and row 21 meet zero weights; patch column 0 = image column
+//               2 ox0 - 4, so that four-column groups are 16-byte aligned in the image): a lane's eight k' of a 32x32x16 MFMA
+//               step are eight consecutive patch columns = 4 ds_read_b32, no conversion in the loop (k_stem_fwd<true>: 8 + 8 cvt)
+//   pooling   : the wave tile goes to `rowbuf` (129 pixels x 64 channels bf16; pixel 0 = the previous tile's last pixel) after
+//               scale / shift / ReLU / rounding; 16-byte items max over 3 pixels (v_pk_max_u16: non-negative bf16 order as
+//               integers), then against the carry row; odd conv rows store the pooled row (16-byte coalesced stores).
+// ---------------------------------------------------------------------------------------------
+constexpr int SF_ROWS = 22, SF_PITCH = 320;        // bf16 patch rows of 640 bytes: the two lane halves (rows 2 step, 2 step + 1) hit disjoint banks
+constexpr int SF_K = 176, SF_WROW = 184;           // weight image [64][184] bf16 (368-byte rows: conflict-free 16-byte reads)
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+static size_t stem_pool_lds_bytes(int Wp) { return (size_t)SF_ROWS * SF_PITCH * 2 + (size_t)64 * SF_WROW * 2 + 129 * 128 + (size_t)Wp * 128; }
+
+struct StemPoolArgs {
+    const float* x;        // NCHW image
+    const float* w;        // [64][147] stem weights as stored, k = (r*7 + s)*3 + ci
+    const float* scale;    // folded BatchNorm
+    const float* shift;
+    uint16_t* y;           // [B][Hp][Wp][64] bf16
+    int B, H, W, Ho, Wo, Hp, Wp, tiles_x, rows, units_per_img, nunits;
+};
+
+__global__ __launch_bounds__(256, 2) void k_stem_pool_bf16(StemPoolArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint16_t* patch = reinterpret_cast<uint16_t*>(lds);                 // [22][320]
+    uint16_t* wl = patch + SF_ROWS * SF_PITCH;                          // [64][184]
+    uint16_t* rowbuf = wl + 64 * SF_WROW;                               // [129][64]
+    uint16_t* carry = rowbuf + 129 * 64;                                // [Wp][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < SF_ROWS * SF_PITCH / 2; i += 256) reinterpret_cast<uint32_t*>(patch)[i] = 0;   // pad columns / row 21 stay zero
+    for (int i = tid; i < 64 * SF_WROW; i += 256) {
+        const int n = i / SF_WROW, kk = i - n * SF_WROW, row = kk >> 3, sx = kk & 7, ci = row / 7, r = row - ci * 7;
+        wl[i] = (kk < 168 && sx > 0) ? f2bf(p.w[n * STEM_K + (r * 7 + sx - 1) * 3 + ci]) : (uint16_t)0;     // slot 0 = the column left of the window
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    const int px = wave * 32 + fr;
+    const float sc0 = p.scale[fr], sc1 = p.scale[32 + fr], sh0 = p.shift[fr], sh1 = p.shift[32 + fr];
+    const uint16_t* wb = wl + fr * SF_WROW + 8 * fh;
+
+    // The tiles of a block form one sequence (unit -> conv row -> 128-pixel tile); the image patch of tile t+1 is fetched into
+    // registers while tile t is multiplied and pooled, so that a tile never waits for a global round trip.
+    struct Tile { int unit, t, nt, b, q0, oy0; bool valid; };
+    auto open_unit = [&](int unit) {
+        Tile it; it.unit = unit; it.t = 0; it.valid = unit < p.nunits;
+        it.b = unit / p.units_per_img; it.q0 = (unit - it.b * p.units_per_img) * p.rows;
+        const int q1 = min(it.q0 + p.rows, p.Hp);
+        it.oy0 = max(2 * it.q0 - 1, 0);                    // (row -1 is padding: the carry starts as zeros instead)
+        it.nt = (2 * q1 - it.oy0) * p.tiles_x;
+        return it;
+    };
+    auto next_tile = [&](const Tile& c) { Tile n = c; if (++n.t >= n.nt) n = open_unit(c.unit + gridDim.x); return n; };
+    // 21 rows x 66 groups of four columns; aligned 16-byte loads, 8-byte LDS stores
+    constexpr int TOTAL4 = 21 * 66, NLD = (TOTAL4 + 255) / 256;
+    float4 v[NLD];
+    int g_r[NLD], g_c4[NLD], g_off[NLD], g_lds[NLD];       // per-thread constants: filter row, first column, image / patch offsets
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + 256 * j;
+        const int row = i / 66, c4 = (i - row * 66) * 4, ci = row / 7;
+        g_r[j] = i < TOTAL4 ? row - ci * 7 : -(1 << 20);    // (past the patch: the row test below fails)
+        g_c4[j] = c4; g_off[j] = (ci * p.H + g_r[j]) * p.W + c4; g_lds[j] = row * SF_PITCH + c4;
+    }
+    auto fetch = [&](const Tile& it) {
+        const int oy = it.oy0 + it.t / p.tiles_x, ox0 = (it.t % p.tiles_x) * 128;
+        const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 4;
+        const float* img = p.x + (int64_t)it.b * 3 * p.H * p.W + (int64_t)iy0 * p.W + ix0;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int iy = iy0 + g_r[j], ix = ix0 + g_c4[j];
+            // no branch around a load (hipcc would wait for every conditional load: one global round trip each): a group of four
+            // columns is 16-byte aligned in the image (patch column 0 = image column 2 ox0 - 4), so it lies inside the row or outside
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            v[j] = *reinterpret_cast<const float4*>(ok ? img + g_off[j] : g_zero_line);
+        }
+    };
+    Tile it = open_unit(blockIdx.x);
+    if (it.valid) fetch(it);
+#ifdef SD_PP_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    while (it.valid) {
+        PP_T(s0_)
+        const int row_i = it.t / p.tiles_x, tx = it.t - row_i * p.tiles_x, oy = it.oy0 + row_i, b = it.b;
+        // conv row 2 q0 - 1: mode 0 (carry only); even rows: mode 1 (max into the carry); odd rows: mode 2 (store + new carry)
+        const int mode = oy < 2 * it.q0 ? 0 : ((oy & 1) ? 2 : 1);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {                     // the patch of this tile: rounded to bf16 once
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[j].x) | ((uint32_t)f2bf(v[j].y) << 16);
+            pk.y = (uint32_t)f2bf(v[j].z) | ((uint32_t)f2bf(v[j].w) << 16);
+            if (tid + 256 * j < TOTAL4) *reinterpret_cast<uint2*>(patch + g_lds[j]) = pk;
+        }
+        if (tx == 0 && tid < 8) reinterpret_cast<uint4*>(rowbuf)[tid] = make_uint4(0, 0, 0, 0);                 // left padding pixel
+        if (it.t == 0 && it.q0 == 0) {                      // above the image: the carry is the padding row
+            for (int i = tid; i < p.Wp * 8; i += 256) reinterpret_cast<uint4*>(carry)[i] = make_uint4(0, 0, 0, 0);
+        }
+        PP_T(s1_)
+        const Tile nxt = next_tile(it);
+        if (nxt.valid) fetch(nxt);
+        PP_T(s2_)
+        __syncthreads();                             // (1) patch staged (the first time: weights too)
+        PP_T(s3_)
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        {   // operands of steps s+1 and s+2 are in flight while the MFMAs of step s run (an LDS round trip is ~2 steps long)
+            constexpr int NS = SF_K / 16;
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(patch + fh * SF_PITCH + 2 * px);
+            uint4 fa[NS]; bf16x8 fb0[NS], fb1[NS];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const uint32_t* qn = q + st * SF_PITCH;
+                fa[st] = make_uint4(qn[0], qn[1], qn[2], qn[3]);
+                fb0[st] = *reinterpret_cast<const bf16x8*>(wb + 16 * st);
+                fb1[st] = *reinterpret_cast<const bf16x8*>(wb + 32 * SF_WROW + 16 * st);
+            }
+#pragma unroll
+            for (int step = 0; step < NS; ++step) {
+                if (step + 2 < NS) {
+                    const uint32_t* qn = q + (step + 2) * SF_PITCH;          // (uint32 units: two patch rows per step)
+                    fa[step + 2] = make_uint4(qn[0], qn[1], qn[2], qn[3]);
+                    fb0[step + 2] = *reinterpret_cast<const bf16x8*>(wb + 16 * (step + 2));
+                    fb1[step + 2] = *reinterpret_cast<const bf16x8*>(wb + 32 * SF_WROW + 16 * (step + 2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step]), fb0[step], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[step]), fb1[step], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int pl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            rowbuf[(1 + pl) * 64 + fr] = f2bf(fmaxf(acc0[e] * sc0 + sh0, 0.f));
+            rowbuf[(1 + pl) * 64 + 32 + fr] = f2bf(fmaxf(acc1[e] * sc1 + sh1, 0.f));
+        }
+        PP_T(s4_)
+        __syncthreads();                             // (2) the activated row tile is in rowbuf
+        PP_T(s5_)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k, jl = item >> 3, cg = item & 7, j = 64 * tx + jl;
+            if (j < p.Wp) {
+                const u16x8* rb = reinterpret_cast<const u16x8*>(rowbuf) + (2 * jl) * 8 + cg;
+                u16x8 hp = __builtin_elementwise_max(__builtin_elementwise_max(rb[0], rb[8]), rb[16]);
+                u16x8* cp = reinterpret_cast<u16x8*>(carry) + j * 8 + cg;
+                if (mode == 1) hp = __builtin_elementwise_max(hp, *cp);
+                if (mode == 2) {
+                    const u16x8 o = __builtin_elementwise_max(hp, *cp);
+                    *reinterpret_cast<u16x8*>(p.y + ((((int64_t)b * p.Hp + (oy >> 1)) * p.Wp + j) * 64 + cg * 8)) = o;
+                }
+                *cp = hp;
+            }
+        }
+        PP_T(s6_)
+        __syncthreads();                             // (3) rowbuf read: keep its last pixel as the next tile's left neighbour
+        if (tid < 8) reinterpret_cast<uint4*>(rowbuf)[tid] = reinterpret_cast<const uint4*>(rowbuf)[128 * 8 + tid];
+        it = nxt;
+        PP_T(s7_)
+        PP_ACC(0, s0_, s1_) PP_ACC(1, s1_, s2_) PP_ACC(2, s2_, s3_) PP_ACC(3, s3_, s4_) PP_ACC(4, s4_, s5_) PP_ACC(5, s5_, s6_) PP_ACC(6, s6_, s7_)
+#ifdef SD_PP_TRACE
+        tr[7] += 1;
+#endif
+    }
+#ifdef SD_PP_TRACE
+    if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_pp_trace[wave][k] = tr[k]; }
+#endif
+}
+
 // Weight gradient of the stem: persistent blocks walk the 128-pixel tiles, accumulating the whole 64 x 160 dW tile in
 // registers (each wave takes 32 of the 128 pixels: 10 accumulators = 160 VGPRs), then the four waves are summed
 // through LDS and the block writes ONE partial dW.
@@ -2995,6 +3174,34 @@ int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv
     else hipLaunchKernelGGL(k_wgrad3x3_bf16<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_stem_bn_relu_maxpool_fwd_bf16(const float* x_nchw, const float* w, const float* scale, const float* shift, void* y, const sd_conv_desc* d,
+                                     sd_stream_t stream) {
+    if (int e = check_conv("sd_stem_bn_relu_maxpool_fwd_bf16", d)) return e;
+    SD_REQUIRE(x_nchw && w && scale && shift && y, SD_ERR_INVALID, "sd_stem_bn_relu_maxpool_fwd_bf16: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_stem_bn_relu_maxpool_fwd_bf16: the stem is 7x7 / stride 2 / pad 3, 3 -> 64 (network.py:43)");
+    SD_REQUIRE(d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->Wo <= 4096, SD_ERR_INVALID, "sd_stem_bn_relu_maxpool_fwd_bf16: needs even Ho, Wo and Wo <= 4096");
+    SD_REQUIRE(d->Wi % 4 == 0, SD_ERR_INVALID, "sd_stem_bn_relu_maxpool_fwd_bf16: the image width must be a multiple of 4 (16-byte row groups)");
+    SD_REQUIRE(aligned16(y) && aligned16(x_nchw), SD_ERR_ALIGN, "sd_stem_bn_relu_maxpool_fwd_bf16: x and y must be 16-byte aligned");
+    StemPoolArgs a{};
+    a.x = x_nchw; a.w = w; a.scale = scale; a.shift = shift; a.y = (uint16_t*)y;
+    a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.Hp = d->Ho / 2; a.Wp = d->Wo / 2;
+    a.tiles_x = cdiv(d->Wo, 128);
+    const size_t lds = stem_pool_lds_bytes(a.Wp);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1, grid_max = 256 * per_cu;
+    // pooled rows per work unit: enough units to fill the persistent grid, at most 16 rows (a unit recomputes one conv row)
+    a.rows = std::max(1, std::min(16, (int)((int64_t)a.B * a.Hp / grid_max)));
+    a.units_per_img = cdiv(a.Hp, a.rows);
+    a.nunits = a.B * a.units_per_img;
+    static thread_local size_t raised = 0;
+    if (lds > raised) {
+        SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_pool_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = lds;
+    }
+    hipLaunchKernelGGL(k_stem_pool_bf16, dim3(std::min(a.nunits, grid_max)), dim3(256), lds, (hipStream_t)stream, a);
     SD_LAUNCH_CHECK();
     return 0;
 }

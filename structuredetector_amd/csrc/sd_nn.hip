@@ -878,6 +878,98 @@ __global__ __launch_bounds__(256) void k_head_fwd_bf16(const uint16_t* __restric
     }
 }
 
+// Head on a bf16 NHWC input of 128 channels (the default FPN depth), wave-private pipeline: every wave walks tiles of 64 pixels; the
+// tile (16 KB) comes in by LDS-DMA (16 wave-instructions of 1 KB, no staging registers, no block barrier) and is multiplied on the
+// bf16 MFMA with the fp32 weights split into two bf16 terms, w = hi + lo (|w - hi - lo| <= 2^-17 |w|: the activations are bf16
+// already, so x * hi + x * lo summed in fp32 equals the fp32 product to fp32 rounding).  Co <= 16: hi sits in columns 0 .. 15 and lo
+// in columns 16 .. 31 of ONE 32-column B operand (the two halves are added across lanes at the end); Co <= 32: two MFMAs per step.
+// The Co planes of the NCHW output are written 16 bytes (4 pixels) per lane.  k_head_fwd_bf16 staged 64 pixels per BLOCK, widened to
+// fp32, and re-read every row once per output-channel group (24x the input bytes in LDS traffic): 186 us for 268 MB at bs=64.
+//   LDS image of a tile: row r (pixel) x 16 slots of 16 bytes, slot c of row r at physical slot c ^ (r & 15): the DMA lane that lands in
+//   physical slot s of row r fetches chunk s ^ (r & 15) (swizzle on the SOURCE), and the 16 lanes of a ds_read_b128 group (rows r ..
+//   r+15, same chunk) hit 16 different slots.
+typedef float head_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 head_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_head_fwd_bf16_c128(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int64_t M, int HW, int Co, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4096];              // 16 KB per wave
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* T = lds + wave * 4096;
+    const int nwaves = gridDim.x * 4;
+    const int rsub = lane >> 4, slot = lane & 15;                              // DMA: lane -> (row within a 4-row piece, physical slot)
+    const int fr = lane & 31, fh = lane >> 5;
+    // B operands: lane (n = fr, k-half fh) holds w[n][16 s + 8 fh .. + 7] of step s as bf16
+    head_bf16x8 bh[8], bl[8];
+    {
+        const int n = SPLIT ? fr : (fr & 15);
+        const bool lo_col = !SPLIT && fr >= 16;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            uint16_t h[8], l[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wv = n < Co ? w[n * 128 + 16 * st + 8 * fh + k] : 0.f;
+                const uint16_t hi = f32_to_bf16(wv);
+                const uint16_t lo = f32_to_bf16(wv - bf16_to_f32(hi));
+                h[k] = lo_col ? lo : hi; l[k] = lo;
+            }
+            bh[st] = __builtin_bit_cast(head_bf16x8, h);
+            bl[st] = __builtin_bit_cast(head_bf16x8, l);
+        }
+    }
+    const float bv = (fr < Co && (SPLIT || fr < 16)) ? bias[fr] : 0.f;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+        const int64_t m0 = (int64_t)tile * 64;
+#pragma unroll
+        for (int pc = 0; pc < 16; ++pc) {
+            const int r = pc * 4 + rsub;
+            const int64_t m = min(m0 + r, M - 1);                              // (rows past the end re-read the last pixel; never stored)
+            const uint16_t* src = x + m * 128 + ((slot ^ (r & 15)) << 3);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(T + pc * 256), 16, 0, 0);
+#endif
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        head_f32x16 acc[2], accl[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[mi][e] = 0.f; accl[mi][e] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int r = mi * 32 + fr;
+                const head_bf16x8 a = *reinterpret_cast<const head_bf16x8*>(reinterpret_cast<const char*>(T) + r * 256 + (((2 * st + fh) ^ (r & 15)) << 4));
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bh[st], acc[mi], 0, 0, 0);
+                if (SPLIT) accl[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl[st], accl[mi], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // every LDS read of this tile is done before the next tile's DMA lands
+        // C/D map of the 32x32 MFMA: column (output channel) = lane & 31, rows (pixels) (e & 3) + 8 (e >> 2) + 4 fh: four consecutive pixels per e >> 2
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o;
+                float* op = &o.x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float hi = acc[mi][4 * g + k];
+                    const float lo = SPLIT ? accl[mi][4 * g + k] : __shfl_down(hi, 16);      // column n + 16 holds x * lo
+                    op[k] = hi + lo + bv;
+                }
+                const int64_t m = m0 + mi * 32 + 8 * g + 4 * fh;
+                if (fr < Co && (SPLIT || fr < 16) && m < M) {
+                    const int64_t b = m / HW, pix = m - b * HW;                // (HW % 4 == 0: the four pixels stay in one image)
+                    *reinterpret_cast<float4*>(y + (b * Co + fr) * HW + pix) = o;
+                }
+            }
+        }
+    }
+}
+
 // ---- bf16 activations, 16 bytes per lane (8 elements): the mixed-precision training path's BatchNorm passes.  Same arithmetic
 // as the templated 4-element kernels above (fp32, one rounding at the store; results are bit-identical to them) -- only the
 // access width differs: 8-byte accesses left these HBM-bound passes at ~60 % of the rate of their fp32 (16-byte) versions.
@@ -1392,6 +1484,13 @@ int sd_head_fwd_bf16(const void* x, const float* w, const float* bias, float* y,
     SD_REQUIRE(x && w && bias && y && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_fwd_bf16: bad arguments");
     SD_REQUIRE(C % 8 == 0 && C <= 512 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_fwd_bf16: needs C %% 8 == 0, C <= 512, Co <= %d", HEAD_MAX_CO);
     const int64_t M = (int64_t)B * HW;
+    if (C == 128 && HW % 4 == 0 && aligned16(x) && aligned16(y)) {       // wave-private LDS-DMA + bf16 MFMA pipeline (the default FPN depth)
+        const int ntiles = (int)cdiv(M, 64), blocks = std::max(1, std::min(cdiv(ntiles, 4), 1024));
+        if (Co <= 16) hipLaunchKernelGGL(k_head_fwd_bf16_c128<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, w, bias, y, M, HW, Co, ntiles);
+        else hipLaunchKernelGGL(k_head_fwd_bf16_c128<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, w, bias, y, M, HW, Co, ntiles);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = ((size_t)64 * (C + 4) + (size_t)Co * C) * sizeof(float);
     hipLaunchKernelGGL(k_head_fwd_bf16, dim3(cdiv(M, 64)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)x, w, bias, y, M, HW, C, Co);
     SD_LAUNCH_CHECK();

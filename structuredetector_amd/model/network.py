@@ -387,14 +387,19 @@ class _Engine:
             raise L.SdError("Network expects (B, 3, H, W) input with H, W multiples of 32")
         stem, bn0 = net.adpater[0], net.adpater[1]
         d0 = _desc(B, H, W, stem)
-        a0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.bfloat16, device=x.device)
         sc, sh = self.bn_fold(bn0)
-        wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
-        L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), a0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 1,
-                                       wss.data_ptr(), wss.numel(), L.stream()), "stem")
         Hc, Wc = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
         cur = torch.empty((B, Hc, Wc, 64), dtype=torch.bfloat16, device=x.device)
-        L.check(lib.sd_maxpool3x3s2_fwd_bf16(a0.data_ptr(), cur.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
+        if stem.k == 7 and stem.stride == 2 and stem.pad == 3 and d0.Wo <= 4096:
+            # conv1 -> bn1 -> relu -> maxpool in one launch: the (B, H/2, W/2, 64) activation is never written
+            L.check(lib.sd_stem_bn_relu_maxpool_fwd_bf16(x.data_ptr(), stem.weight.data_ptr(), sc.data_ptr(), sh.data_ptr(), cur.data_ptr(),
+                                                         C.byref(d0), L.stream()), "stem+maxpool")
+        else:
+            a0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.bfloat16, device=x.device)
+            wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
+            L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), a0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 1,
+                                           wss.data_ptr(), wss.numel(), L.stream()), "stem")
+            L.check(lib.sd_maxpool3x3s2_fwd_bf16(a0.data_ptr(), cur.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
         feats = []
         for layer in (net.down1, net.down2, net.down3, net.down4):
             for blk in layer:

@@ -607,3 +607,38 @@ def test_stem_conv_with_fused_bn_statistics():
         close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
         close(rm.cpu(), bn.running_mean, 1e-5)
         close(rv.cpu(), bn.running_var, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 1024, 1024)])
+def test_stem_bn_relu_maxpool_fused_bf16(shape):
+    """sd_stem_bn_relu_maxpool_fwd_bf16 (network.py:59-63 `adpater` in one launch) against the two-kernel form of the bf16 backbone
+    (sd_conv2d_stem_fwd with bf16 output, then sd_maxpool3x3s2_fwd_bf16: same values up to the summation order of the 147 products,
+    i.e. at most one bf16 ulp on a few elements) and against the PyTorch ops on bf16-rounded operands.  Shapes: partial last
+    128-pixel tile (96/2 = 48, 288/2 = 144), several tiles per row (1024), units of 1 / 16 pooled rows, a map smaller than a tile."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.5
+    d0 = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+    img_d, w_d, sc_d, sh_d = img.to(DEV), krsc(w), scale.to(DEV), shift.to(DEV)
+    Hp, Wp = d0.Ho // 2, d0.Wo // 2
+    fused = torch.empty(B, Hp, Wp, 64, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sd_stem_bn_relu_maxpool_fwd_bf16(img_d.data_ptr(), w_d.data_ptr(), sc_d.data_ptr(), sh_d.data_ptr(), fused.data_ptr(), C.byref(d0), L.stream()))
+    a0 = torch.empty(B, d0.Ho, d0.Wo, 64, dtype=torch.bfloat16, device=DEV)
+    wsf = torch.empty(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_conv2d_stem_fwd(img_d.data_ptr(), w_d.data_ptr(), a0.data_ptr(), C.byref(d0), sc_d.data_ptr(), sh_d.data_ptr(), 1, 1, wsf.data_ptr(),
+                                   wsf.numel(), L.stream()))
+    two = torch.empty_like(fused)
+    L.check(lib.sd_maxpool3x3s2_fwd_bf16(a0.data_ptr(), two.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()))
+    f32, t32 = fused.float().cpu(), two.float().cpu()
+    diff = (f32 - t32).abs()
+    # one bf16 ulp is <= 2^-7 relative; where scale * sum + shift cancels to ~0 the fp32 rounding of the sum (~1e-6 absolute) is many ulps
+    ulp = torch.maximum(f32.abs(), t32.abs()) * 2.0 ** -7 + 4e-6
+    assert bool((diff <= ulp).all()), f"max diff {diff.max():.3e}"
+    assert float((diff > 0).float().mean()) < 0.02                           # the two forms agree bit for bit almost everywhere
+    ref = F.max_pool2d(torch.relu(F.conv2d(img.bfloat16().float(), w.bfloat16().float(), None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    close(f32.permute(0, 3, 1, 2), ref, 6e-3)
