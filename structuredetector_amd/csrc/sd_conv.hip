@@ -1015,6 +1015,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 //   B     : three stages of BN rows x 16 floats, one per tap, ring position = tap % 3 (9 taps = 3 turns)
 //   sync  : per tap one counted `s_waitcnt vmcnt(n)` (n = what this wave issued during the tap) + bare s_barrier
 // ---------------------------------------------------------------------------------------------
+#ifndef SD_PATCH_READS_FIRST_F32
+#define SD_PATCH_READS_FIRST_F32 0      // fp32 patch kernel: 1 = fragment reads before the tap's LDS-DMA issue, as the bf16 instantiation does (A/B switch)
+#endif
 constexpr int PT_STAGE_FLOATS = 25 * 256;          // one double-buffer stage: 25 pieces of 1 KB (Wo = 64: 6 x 66 = 396 patch rows)
 constexpr int PT_FLOATS = 2 * PT_STAGE_FLOATS;     // 51.2 KB; the rolling mode (36 pieces) uses it as one buffer
 constexpr int PT_MAXP = 12;                        // patch pieces a wave can own (rolling: 4 rows x 3 slots)
@@ -1149,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #define PT_TAP(t)                                                                                  \
     {                                                                                              \
         int n_iss = PBW;                                                                           \
-        if (!BF16) {                                                                               \
+        if (!(BF16 || SD_PATCH_READS_FIRST_F32)) {                                                 \
             PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
         if (rolling) {                                                                             \
             /* taps 0..3: rows 2, 3 of this chunk; taps 4..7: rows 0, 1 of the next one; even tap: slot 0, odd: slots 1 (+2) */ \
@@ -1185,7 +1188,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         f32x4 b10 = lds_read128_async<0>(bb ^ 32u), b11 = lds_read128_async<TSTR>(bb ^ 32u);       \
         /* bf16: a wave gets one LDS-DMA instruction out per ~66 cycles and waits at it in order, and a bf16 tap is only 512 MFMA \
            cycles long -- the fragment reads go first (fp32 taps are 8x longer: the order does not matter there) */ \
-        if (BF16) {                                                                                \
+        if (BF16 || SD_PATCH_READS_FIRST_F32) {                                                    \
             PT_ISSUE_B(cc + ((t) + 2) / 9, ((t) + 2) % 9, ((t) + 2) % 3)                               \
         if (rolling) {                                                                             \
             /* taps 0..3: rows 2, 3 of this chunk; taps 4..7: rows 0, 1 of the next one; even tap: slot 0, odd: slots 1 (+2) */ \
