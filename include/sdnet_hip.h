@@ -339,6 +339,11 @@ int sd_conv2d_dgrad(const float* dy_nhwc, const float* w_t, float* dx_nhwc, cons
 int sd_conv2d_dgrad_half_res(const float* dy, const float* w_t, float* dx, const sd_conv_desc* d, const float* residual_half,
                              sd_stream_t stream);
 int sd_conv2d_transpose_weights(const float* w, float* w_t, int Cout, int taps, int Cin, sd_stream_t stream);
+/* The same transpose for MANY convs in one launch (a training step re-lays every conv's weights once per backward).  table (device,
+ * 8 ints per conv): {offset of w in w_base, offset of w_t in w_t_base (elements), Cout, taps, Cin, first block, ceil(Cin/32),
+ * ceil(Cout/32)}; a conv owns ceil(Cin/32) * ceil(Cout/32) * taps consecutive blocks; out_bf16: w_t_base is bf16 (mixed precision). */
+int sd_conv2d_transpose_weights_batched(const float* w_base, void* w_t_base, const int* table, int nconv, int total_blocks, int out_bf16,
+                                        sd_stream_t stream);
 /* dW[co][r][s][ci] (+)= sum_pixels dY * X, split over pixel ranges + deterministic reduce. */
 size_t sd_conv2d_wgrad_workspace_bytes(const sd_conv_desc* d);
 int sd_conv2d_wgrad(const float* dy_nhwc, const float* x_nhwc, float* dw_krsc, const sd_conv_desc* d,

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "sd_head_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_dgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp]),
     "sd_conv2d_transpose_weights": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "sd_conv2d_transpose_weights_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "sd_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_wgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),

@@ -2531,6 +2531,36 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* __restrict__ w
     }
 }
 
+// every conv's weights in ONE launch (the training step transposes all 41 data-gradient weights once per backward: 42 launches of ~5 us
+// were launch-bound).  table: 8 ints per conv {source offset, destination offset (elements), N, T, C, first block, blocks along C, blocks along N}
+template <typename WT>
+__global__ __launch_bounds__(256) void k_transpose_w_batched(const float* __restrict__ w, WT* __restrict__ wt, const int* __restrict__ table, int nconv) {
+    __shared__ float tile[32][33];
+    int ci = 0;
+    while (ci + 1 < nconv && (int)blockIdx.x >= table[(ci + 1) * 8 + 5]) ++ci;          // (block-uniform: scalar loads)
+    const int* t = table + ci * 8;
+    const int N = t[2], T = t[3], C = t[4], nbx = t[6], nby = t[7];
+    const float* src = w + t[0];
+    WT* dst = wt + t[1];
+    int b = blockIdx.x - t[5];
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby, tap = b / nby;
+    const int c0 = bx * 32, n0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j, c = c0 + tx;
+        tile[j][tx] = (n < N && c < C) ? src[((int64_t)n * T + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, n = n0 + tx;
+        if (n < N && c < C) {
+            if constexpr (sizeof(WT) == 2) dst[((int64_t)c * T + tap) * N + n] = f2bf(tile[tx][j]);
+            else dst[((int64_t)c * T + tap) * N + n] = tile[tx][j];
+        }
+    }
+}
+
 // split-K second pass: y = epilogue( sum over K slices of the partial tiles )
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
@@ -3031,6 +3061,15 @@ int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, i
     SD_REQUIRE(w && w_t_bf16 && Cout > 0 && taps > 0 && Cin > 0, SD_ERR_INVALID, "sd_conv2d_transpose_weights_bf16: bad arguments");
     hipLaunchKernelGGL(k_transpose_w<uint16_t>, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w_t_bf16,
                        Cout, taps, Cin);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_conv2d_transpose_weights_batched(const float* w_base, void* w_t_base, const int* table, int nconv, int total_blocks, int out_bf16,
+                                        sd_stream_t stream) {
+    SD_REQUIRE(w_base && w_t_base && table && nconv > 0 && total_blocks > 0, SD_ERR_INVALID, "sd_conv2d_transpose_weights_batched: bad arguments");
+    if (out_bf16) hipLaunchKernelGGL(k_transpose_w_batched<uint16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, w_base, (uint16_t*)w_t_base, table, nconv);
+    else hipLaunchKernelGGL(k_transpose_w_batched<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, w_base, (float*)w_t_base, table, nconv);
     SD_LAUNCH_CHECK();
     return 0;
 }

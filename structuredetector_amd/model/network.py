@@ -127,6 +127,7 @@ class _Engine:
         # (float4 reads of the BatchNorm input, mask bytes) it is exactly neutral (815.7 vs 815.4 img/s): the reduce passes it
         # removes run at HBM speed anyway.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
         self.fuse_bn_bwd = False
+        self._wt_plan, self._wt_flat, self._wt_valid = None, {}, None      # transposed data-gradient weights (see _transpose_all)
 
     def _kname(self, d, which):
         """device kernel the C ABI will launch for this conv (profiling label; same names as the rocprofv3 kernel trace)"""
@@ -427,8 +428,34 @@ class _Engine:
         return out
 
     # ---- backward ------------------------------------------------------------------------
+    def _transpose_all(self, amp):
+        """Every data-gradient conv's weights [Cout][taps][Cin] -> [Cin][taps][Cout] in ONE launch at the start of a backward pass
+        (42 launches of ~5 us each were launch-bound: 0.24 ms per step); _wt() then hands out views until the pass ends."""
+        net = self.net
+        if self._wt_plan is None:
+            convs = [m for m in net.modules() if isinstance(m, ConvParams) and m.cin % 64 == 0 and m.cout % 64 == 0]
+            rows, views, dst, blk = [], {}, 0, 0
+            for m in convs:
+                taps, n = m.k * m.k, m.weight.numel()
+                nbx, nby = (m.cin + 31) // 32, (m.cout + 31) // 32
+                rows.append([net._flat_off[id(m.weight)][0], dst, m.cout, taps, m.cin, blk, nbx, nby])
+                views[id(m)] = (dst, n)
+                dst += n; blk += nbx * nby * taps
+            table = torch.tensor(rows, dtype=torch.int32, device=net.flat_params.device).contiguous()
+            self._wt_plan = (table, len(convs), blk, views, dst)
+        table, nconv, blocks, _, total = self._wt_plan
+        key = "bf16" if amp else "f32"
+        if key not in self._wt_flat:
+            self._wt_flat[key] = torch.empty(total, dtype=torch.bfloat16 if amp else torch.float32, device=net.flat_params.device)
+        L.check(self.lib.sd_conv2d_transpose_weights_batched(net.flat_params.data_ptr(), self._wt_flat[key].data_ptr(), table.data_ptr(), nconv, blocks,
+                                                             int(amp), L.stream()), "sd_conv2d_transpose_weights_batched")
+        self._wt_valid = key
+
     def _wt(self, conv, amp=False):
         """[Cout][taps][Cin] -> [Cin][taps][Cout] for the data-gradient (amp: written as bf16 by the same pass)."""
+        if self._wt_valid == ("bf16" if amp else "f32") and id(conv) in self._wt_plan[3]:
+            off, n = self._wt_plan[3][id(conv)]
+            return self._wt_flat[self._wt_valid][off:off + n]
         wt = torch.empty(conv.cin * conv.k * conv.k * conv.cout, dtype=torch.bfloat16 if amp else torch.float32, device=conv.weight.device)
         transpose = self.lib.sd_conv2d_transpose_weights_bf16 if amp else self.lib.sd_conv2d_transpose_weights
         L.check(transpose(conv.weight.data_ptr(), wt.data_ptr(), conv.cout, conv.k * conv.k, conv.cin, L.stream()), "transpose_weights")
@@ -544,6 +571,7 @@ class _Engine:
         amp = bool(tape.get("amp"))
         if amp and self.fuse_bn_bwd:
             raise L.SdError("fuse_bn_bwd is an fp32-path experiment; switch it off for mixed-precision training")
+        self._transpose_all(amp)
         f1 = self._to_f32(tape["f1"]) if amp else tape["f1"]      # the 7-channel head runs in fp32 on both paths (HBM-bound, 0.4 % of a step)
         df = torch.empty_like(f1)
         ws = self._ws(lib.sd_head_bwd_workspace_bytes(B, H2 * W2, hc.cin, hc.cout), dhead.device)
@@ -647,6 +675,7 @@ class _Engine:
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
                                          ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
         self._join_side()
+        self._wt_valid = None                               # the optimizer step that follows changes the weights
         if on_stage:
             on_stage("down1_stem")
 
