@@ -399,6 +399,10 @@ int sd_head_fwd(const float* x_nhwc, const float* w, const float* bias, float* y
 size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co);
 int sd_head_bwd(const float* dy_nchw, const float* x_nhwc, const float* w, float* dx_nhwc, float* dw, float* dbias,
                 int B, int HW, int C, int Co, int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* The same with the head's input and its gradient in bf16 (mixed-precision training: no fp32 copies of the FPN output); dy, w, dw, dbias
+ * stay fp32.  C in {64, 128}, Co <= 8; same workspace size. */
+int sd_head_bwd_bf16(const float* dy, const void* x_bf16, const float* w, void* dx_bf16, float* dw, float* dbias, int B, int HW, int C, int Co,
+                     int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
 
 /* torch.optim.Adam step (defaults: no weight decay / amsgrad) over a flat fp32 buffer;
  * grad is multiplied by grad_scale first (1/world_size after a sum all-reduce). */

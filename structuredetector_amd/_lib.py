@@ -117,6 +117,7 @@ _SIGNATURES = {
     "sd_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "sd_head_bwd_workspace_bytes": (c_size, [c_int] * 4),
     "sd_head_bwd": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, c_size, c_vp]),
+    "sd_head_bwd_bf16": (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp, c_size, c_vp]),
     "sd_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_float, c_float, c_float, c_float, c_vp]),
     "sd_conv2d_kernel_name": (C.c_char_p, [c_vp, c_int]),
     "sd_set_option": (c_int, [C.c_char_p, c_int]),

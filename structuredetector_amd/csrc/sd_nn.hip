@@ -643,7 +643,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
 }
 
 // head data-gradient: dx[m][c] = sum_co dy[b][co][pix] * w[co][c]   (NCHW grad in, NHWC out)
-__global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+constexpr int HEAD_WG_PIX = 1024;   // pixels per block of the head weight-gradient kernels
+template <typename T>      // T = float, or uint16_t: dx is stored as bf16 (mixed-precision training)
+__global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
                                                      int64_t M, int HW, int C, int Co) {
     __shared__ float gs[HEAD_MAX_CO][64];
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -669,13 +671,99 @@ __global__ __launch_bounds__(256) void k_head_dgrad(const float* __restrict__ dy
             const float4 ww = *reinterpret_cast<const float4*>(ws + co * C + col * 4);
             o.x += g * ww.x; o.y += g * ww.y; o.z += g * ww.z; o.w += g * ww.w;
         }
-        reinterpret_cast<float4*>(dx + m * C)[col] = o;
+        if constexpr (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+            reinterpret_cast<uint2*>(dx + m * C)[col] = pk;
+        } else {
+            reinterpret_cast<float4*>(dx + m * C)[col] = o;
+        }
     }
+}
+
+// head weight / bias gradient partials from a bf16 NHWC activation (mixed precision): a thread owns 8 consecutive channels (one 16-byte
+// load per pixel: a wave-instruction reads 1 KB contiguous) and every 256 / (C / 8)-th pixel of a 64-pixel chunk, CO x 8 fp32 sums in
+// registers; the pixel lanes are combined by wave shuffles and through LDS in a fixed order.  Same partial layout as k_head_wgrad.
+template <int CO>
+__global__ __launch_bounds__(256) void k_head_wgrad_bf16(const float* __restrict__ dy, const uint16_t* __restrict__ x, float* __restrict__ partial,
+                                                          int64_t M, int HW, int C, int Co) {
+    __shared__ float gs[CO][64];
+    __shared__ float comb[4][CO * 128];               // per wave: [co][c] (C <= 128 here)
+    const int64_t mb = (int64_t)blockIdx.x * HEAD_WG_PIX;
+    const int CG = C >> 3, PL = 256 / CG;             // channel groups, pixel lanes (C = 128: 16 x 16; C = 64: 8 x 32)
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    float acc[CO][8];
+#pragma unroll
+    for (int j = 0; j < CO; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[j][k] = 0.f;
+    float bsum = 0.f;
+    for (int64_t m0 = mb; m0 < min(mb + HEAD_WG_PIX, M); m0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Co * 64; i += 256) {
+            const int co = i >> 6, px = i & 63;
+            const int64_t m = m0 + px;
+            float v = 0.f;
+            if (m < M) { const int64_t b = m / HW, pix = m - b * HW; v = dy[(b * Co + co) * HW + pix]; }
+            gs[co][px] = v;
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < 64; p0 += 4 * PL) {      // four 16-byte loads in flight per thread
+            uint4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = p0 + u * PL + pl;
+                const int64_t m = m0 + px;
+                xv[u] = reinterpret_cast<const uint4*>(x + (px < 64 && m < M ? m : mb) * C)[cg];      // masked rows meet gs == 0 (or are skipped below)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = p0 + u * PL + pl;
+                if (px >= 64) continue;
+                const float f[8] = {__uint_as_float(xv[u].x << 16), __uint_as_float(xv[u].x & 0xffff0000u), __uint_as_float(xv[u].y << 16),
+                                    __uint_as_float(xv[u].y & 0xffff0000u), __uint_as_float(xv[u].z << 16), __uint_as_float(xv[u].z & 0xffff0000u),
+                                    __uint_as_float(xv[u].w << 16), __uint_as_float(xv[u].w & 0xffff0000u)};
+#pragma unroll
+                for (int j = 0; j < CO; ++j) {
+                    if (j < Co) {
+                        const float g = gs[j][px];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[j][k] += g * f[k];
+                    }
+                }
+            }
+        }
+        if (threadIdx.x < Co) {
+            for (int px = 0; px < 64; ++px) bsum += gs[threadIdx.x][px];
+        }
+    }
+    // pixel lanes of one wave (lanes with the same cg: stride CG), then the four waves in order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < CO; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = acc[j][k];
+            for (int o = CG; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            acc[j][k] = v;
+        }
+    if (lane < CG) {
+#pragma unroll
+        for (int j = 0; j < CO; ++j)
+            if (j < Co) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) comb[wave][j * C + lane * 8 + k] = acc[j][k];
+            }
+    }
+    __syncthreads();
+    float* dst = partial + (int64_t)blockIdx.x * (Co * C + Co);
+    for (int i = threadIdx.x; i < Co * C; i += 256) dst[i] = (comb[0][i] + comb[1][i]) + (comb[2][i] + comb[3][i]);
+    if (threadIdx.x < Co) dst[Co * C + threadIdx.x] = bsum;
 }
 
 // head weight/bias gradient partials: block handles HEAD_WG_PIX pixels in 64-pixel chunks; thread (c, half)
 // accumulates Co sums over its half of every chunk (all 256 threads busy when C == 128), 8 loads in flight.
-constexpr int HEAD_WG_PIX = 1024;
 __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
                                                      int64_t M, int HW, int C, int Co) {
     __shared__ float gs[HEAD_MAX_CO][64];
@@ -1519,10 +1607,29 @@ int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, floa
     SD_REQUIRE(workspace_bytes >= sd_head_bwd_workspace_bytes(B, HW, C, Co), SD_ERR_WORKSPACE, "sd_head_bwd: workspace too small");
     const int64_t M = (int64_t)B * HW;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_dgrad, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, dx, M, HW, C, Co);
+    hipLaunchKernelGGL(k_head_dgrad<float>, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, dx, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     const int nb = cdiv(M, HEAD_WG_PIX);
     hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dy, x, (float*)workspace, M, HW, C, Co);
+    SD_LAUNCH_CHECK();
+    const int n = Co * C + Co;
+    hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_head_bwd_bf16(const float* dy, const void* x_bf16, const float* w, void* dx_bf16, float* dw, float* dbias, int B, int HW, int C, int Co,
+                     int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    SD_REQUIRE(dy && x_bf16 && w && dx_bf16 && dw && dbias && workspace && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_bwd_bf16: bad arguments");
+    SD_REQUIRE((C == 64 || C == 128) && Co > 0 && Co <= 8, SD_ERR_INVALID, "sd_head_bwd_bf16: needs C in {64, 128} and Co <= 8 (got %d, %d)", C, Co);
+    SD_REQUIRE(aligned16(x_bf16) && aligned16(dx_bf16), SD_ERR_ALIGN, "sd_head_bwd_bf16: x and dx must be 16-byte aligned");
+    SD_REQUIRE(workspace_bytes >= sd_head_bwd_workspace_bytes(B, HW, C, Co), SD_ERR_WORKSPACE, "sd_head_bwd_bf16: workspace too small");
+    const int64_t M = (int64_t)B * HW;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_head_dgrad<uint16_t>, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, (uint16_t*)dx_bf16, M, HW, C, Co);
+    SD_LAUNCH_CHECK();
+    const int nb = cdiv(M, HEAD_WG_PIX);
+    hipLaunchKernelGGL(k_head_wgrad_bf16<8>, dim3(nb), dim3(256), 0, st, dy, (const uint16_t*)x_bf16, (float*)workspace, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     const int n = Co * C + Co;
     hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);

@@ -572,14 +572,22 @@ class _Engine:
         if amp and self.fuse_bn_bwd:
             raise L.SdError("fuse_bn_bwd is an fp32-path experiment; switch it off for mixed-precision training")
         self._transpose_all(amp)
-        f1 = self._to_f32(tape["f1"]) if amp else tape["f1"]      # the 7-channel head runs in fp32 on both paths (HBM-bound, 0.4 % of a step)
-        df = torch.empty_like(f1)
         ws = self._ws(lib.sd_head_bwd_workspace_bytes(B, H2 * W2, hc.cin, hc.cout), dhead.device)
-        L.check(lib.sd_head_bwd(dhead.data_ptr(), f1.data_ptr(), hc.weight.data_ptr(), df.data_ptr(), net.grad_of(hc.weight).data_ptr(),
-                                net.grad_of(hc.bias).data_ptr(), B, H2 * W2, hc.cin, hc.cout, 0, ws.data_ptr(), ws.numel(), L.stream()),
-                "sd_head_bwd")
-        if amp:
-            df = self._to_bf16(df)
+        if amp and hc.cin in (64, 128) and hc.cout <= 8:
+            # bf16 FPN output in, bf16 gradient out (fp32 arithmetic, fp32 weight / bias gradients): no fp32 copies of the two maps
+            f1 = tape["f1"]
+            df = torch.empty_like(f1)
+            L.check(lib.sd_head_bwd_bf16(dhead.data_ptr(), f1.data_ptr(), hc.weight.data_ptr(), df.data_ptr(), net.grad_of(hc.weight).data_ptr(),
+                                         net.grad_of(hc.bias).data_ptr(), B, H2 * W2, hc.cin, hc.cout, 0, ws.data_ptr(), ws.numel(), L.stream()),
+                    "sd_head_bwd_bf16")
+        else:
+            f1 = self._to_f32(tape["f1"]) if amp else tape["f1"]      # wide heads: fp32 kernels on widened copies
+            df = torch.empty_like(f1)
+            L.check(lib.sd_head_bwd(dhead.data_ptr(), f1.data_ptr(), hc.weight.data_ptr(), df.data_ptr(), net.grad_of(hc.weight).data_ptr(),
+                                    net.grad_of(hc.bias).data_ptr(), B, H2 * W2, hc.cin, hc.cout, 0, ws.data_ptr(), ws.numel(), L.stream()),
+                    "sd_head_bwd")
+            if amp:
+                df = self._to_bf16(df)
 
         # FPN, finest level first.  The lateral 1x1 data-gradients are deferred until the trunk's own
         # gradient for that tensor exists, so the sum of the two is the dgrad kernel's residual epilogue.

@@ -305,3 +305,32 @@ def test_conv_bf16_two_group_kernel(case):
         L.check(lib.sd_set_option(b"conv_pp_min_tiles", 200))
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+
+
+@pytest.mark.parametrize("case", [(2, 6, 10, 128, 7), (3, 32, 40, 128, 8), (2, 16, 16, 64, 5), (1, 128, 128, 128, 7)])
+def test_head_backward_on_bf16_activations(case):
+    """sd_head_bwd_bf16 (bf16 FPN output in, bf16 input gradient out, fp32 weight / bias gradients) against PyTorch on the same bf16-rounded
+    activation: dx within one bf16 rounding, dw / dbias to fp32 accuracy.  Pixel counts that are not multiples of 64 / 1024 included."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W, Cc, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cc, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(Co, Cc, 1, 1, generator=g) / 11).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    F.conv2d(x, w, b).backward(dy)
+    x16 = nhwc16(x.detach())
+    dy_d, w_d = dy.to(DEV), w.detach().reshape(Co, Cc).to(DEV)
+    dx = torch.empty(B, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+    dw = torch.empty(Co, Cc, device=DEV); db = torch.empty(Co, device=DEV)
+    ws = torch.empty(max(lib.sd_head_bwd_workspace_bytes(B, H * W, Cc, Co), 256), dtype=torch.uint8, device=DEV)
+    L.check(lib.sd_head_bwd_bf16(dy_d.data_ptr(), x16.data_ptr(), w_d.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H * W, Cc, Co, 0,
+                                 ws.data_ptr(), ws.numel(), L.stream()))
+    close(back(dx), x.grad, 5e-3)
+    close(dw.cpu(), w.grad.reshape(Co, Cc), 2e-5)
+    close(db.cpu(), b.grad, 2e-5)
+    # accumulate = 1 adds onto the existing gradients
+    L.check(lib.sd_head_bwd_bf16(dy_d.data_ptr(), x16.data_ptr(), w_d.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H * W, Cc, Co, 1,
+                                 ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw.cpu(), 2 * w.grad.reshape(Co, Cc), 2e-5)
