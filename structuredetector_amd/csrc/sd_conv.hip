@@ -1464,6 +1464,208 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 3x3 / stride 1 / pad 1 convolution of the 64 -> 64 channel layers (layer1; forward and flipped-tap data-gradient) as a ROW
+// STREAM with the weights in registers.  K is only 576 here: a 256-pixel tile is 18 taps long, so a tile kernel spends as long in its
+// prologue / epilogue as in its loop (k_conv3x3_patch<64, true>: 130-170 us per launch = 450-590 TFLOP/s).  Here a persistent block
+// (4 waves, one per SIMD) walks down a 128-pixel-wide strip of one image, one output row per step:
+//   weights : every wave holds ALL 72 B fragments (9 taps x 4 k-steps x 2 column tiles = 288 registers, loaded once per block); no
+//             weight traffic and no weight LDS reads in the loop
+//   input   : ring of 5 input rows (136 pixels x 128 bytes, slot c of pixel x at c ^ ((x >> 1) & 7): conflict-free ds_read_b128) filled
+//             by LDS-DMA three rows ahead; a wave multiplies 32 pixels x 64 channels per row: 36 A reads + 72 MFMAs (LDS traffic 25 %
+//             of the array's rate -- with the weights in LDS a 32 x 64 wave tile would need 75 %)
+//   output  : accumulators -> (scale, shift) -> wave-private LDS scratch; stored ONE ROW LATER as rows (16-byte stores) with the residual
+//             (prefetched a row earlier), ReLU and the BatchNorm column sums of the rounded values, so that neither the stores nor the
+//             residual loads are waited for; one s_barrier + vmcnt(0) per row (2304 MFMA cycles)
+//   unit    : (image, strip, `rows` consecutive output rows); statistics: one partial row per unit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_PX = 136, RS_ROW_BYTES = RS_PX * 128, RS_NR = 5, RS_SCR = 72;     // ring row: 17 DMA pieces of 8 pixels; scratch row stride (floats)
+constexpr int RS_LDS_BYTES = RS_NR * RS_ROW_BYTES + 4 * 32 * RS_SCR * 4 + 4 * 128 * 4;
+
+struct RowsArgs {
+    const uint16_t* x;     // [B][H][W][64] bf16
+    const uint16_t* w;     // [64 n][9][64 c] bf16 (data-gradient: the transposed weights, flip = 1)
+    uint16_t* y;           // [B][H][W][64] bf16
+    const float* scale;    // nullable
+    const float* shift;    // nullable
+    const uint16_t* res;   // nullable, same shape as y
+    float* stat;           // nullable: [nunits][2][64] column sums / sums of squares of the rounded output
+    int B, H, W, relu, flip, rows, units_per_col, segs, nunits;
+};
+
+__global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    char* const ring = reinterpret_cast<char*>(rs_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const scr = reinterpret_cast<float*>(ring + RS_NR * RS_ROW_BYTES) + wave * 32 * RS_SCR;
+    float* const sred = reinterpret_cast<float*>(ring + RS_NR * RS_ROW_BYTES) + 4 * 32 * RS_SCR;      // [4][128]
+    const int fr = lane & 31, fh = lane >> 5;
+    const uint16_t* const zero_ = reinterpret_cast<const uint16_t*>(g_zero_line);
+
+    // ---- every B fragment of the layer: lane (n = 32 ni + fr, k-half fh) holds w[n][tap][16 kc + 8 fh .. + 7]
+    bf16x8 Bw[72];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                Bw[(t * 4 + kc) * 2 + ni] = *reinterpret_cast<const bf16x8*>(p.w + ((ni * 32 + fr) * 9 + (p.flip ? 8 - t : t)) * 64 + kc * 16 + fh * 8);
+    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        if (p.scale) sc[ni] = p.scale[ni * 32 + fr];
+        if (p.shift) sh[ni] = p.shift[ni * 32 + fr];
+    }
+    // A fragment offsets inside a ring row: output pixel 32 wave + fr, tap column s -> ring pixel 32 wave + fr + s (ring pixel 0 = image column x0 - 1)
+    uint32_t aoff[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int pxr = wave * 32 + fr + s;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) aoff[s][kc] = (uint32_t)pxr * 128u + (uint32_t)(((2 * kc + fh) ^ ((pxr >> 1) & 7)) << 4);
+    }
+    const uint32_t ring_base = lds_addr(ring);
+    const int dpx = lane >> 3, dslot = lane & 7;          // LDS-DMA: lane -> (pixel within an 8-pixel piece, physical 16-byte slot)
+    const int spx = lane >> 3, sc8 = lane & 7;            // row form of the output: lane -> (pixel within 8, 8-channel group)
+
+    for (int unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
+        const int col = unit / p.units_per_col, yu = unit - col * p.units_per_col;
+        const int b = col / p.segs, x0 = (col - b * p.segs) * 128;
+        const int y0 = yu * p.rows, y1 = min(y0 + p.rows, p.H);
+        const uint16_t* const img = p.x + (int64_t)b * p.H * p.W * 64;
+        // input row iy -> ring slot (iy - y0 + 1) % 5; wave w loads pieces w, w + 4, ...
+        auto issue_row = [&](int iy) {
+            const int slot = (iy - y0 + 1) % RS_NR;
+            float* const dst = reinterpret_cast<float*>(ring + slot * RS_ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pc = wave + 4 * j;
+                if (pc < 17) {
+                    const int pxr = pc * 8 + dpx, ix = x0 - 1 + pxr;
+                    const bool ok = pxr < 130 && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+                    const uint16_t* src = ok ? img + ((int64_t)iy * p.W + ix) * 64 + ((dslot ^ ((pxr >> 1) & 7)) << 3) : zero_ + (dslot << 3);
+                    lds_dma16(src, dst + pc * 256);
+                }
+            }
+        };
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+        uint4 resv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        // the row form of output row yy: scratch (+ residual) -> ReLU -> bf16 -> statistics -> 16-byte stores
+        auto store_row = [&](int yy) {
+            const int64_t rowbase = (((int64_t)b * p.H + yy) * p.W + x0 + wave * 32) * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pxl = spx + 8 * it;
+                const float4 v0 = *reinterpret_cast<const float4*>(scr + pxl * RS_SCR + sc8 * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(scr + pxl * RS_SCR + sc8 * 8 + 4);
+                float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (p.res) {
+                    const uint4 r = resv[it];
+                    f[0] += bf2f((uint16_t)(r.x & 0xffff)); f[1] += bf2f((uint16_t)(r.x >> 16)); f[2] += bf2f((uint16_t)(r.y & 0xffff)); f[3] += bf2f((uint16_t)(r.y >> 16));
+                    f[4] += bf2f((uint16_t)(r.z & 0xffff)); f[5] += bf2f((uint16_t)(r.z >> 16)); f[6] += bf2f((uint16_t)(r.w & 0xffff)); f[7] += bf2f((uint16_t)(r.w >> 16));
+                }
+                uint16_t h[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (p.relu) f[k] = fmaxf(f[k], 0.f);
+                    h[k] = f2bf(f[k]);
+                    const float a = bf2f(h[k]);
+                    ssum[k] += a; ssq[k] += a * a;
+                }
+                uint4 o;
+                o.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); o.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                o.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16); o.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+                *reinterpret_cast<uint4*>(p.y + rowbase + pxl * 64 + sc8 * 8) = o;
+            }
+        };
+        auto fetch_res = [&](int yy) {
+            const int64_t rowbase = (((int64_t)b * p.H + yy) * p.W + x0 + wave * 32) * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) resv[it] = *reinterpret_cast<const uint4*>(p.res + rowbase + (spx + 8 * it) * 64 + sc8 * 8);
+        };
+
+        for (int iy = y0 - 1; iy <= min(y0 + 2, y1); ++iy) issue_row(iy);
+        wait_vmcnt<0>();
+        __syncthreads();
+#ifdef SD_PP_TRACE
+        unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        for (int y = y0; y < y1; ++y) {
+            PP_T(r0_)
+            if (y + 3 <= y1) issue_row(y + 3);
+            PP_T(r1_)
+            if (y > y0) store_row(y - 1);
+            if (p.res) fetch_res(y);
+            PP_T(r2_)
+            // ---- 36 steps (input row r, tap column s, k-step kc): A from the ring, B from registers; reads run one group of six ahead
+            f32x16 acc[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+            uint32_t sb[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) sb[r] = ring_base + (uint32_t)((y - 1 + r - y0 + 1) % RS_NR) * RS_ROW_BYTES;
+            f32x4 A[2][6];
+#define RS_ADDR(i) (sb[(i) / 12] + aoff[((i) % 12) / 4][(i) % 4])
+#pragma unroll
+            for (int u = 0; u < 6; ++u) A[0][u] = lds_read128_async<0>(RS_ADDR(u));
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g + 1 < 6) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) A[(g + 1) & 1][u] = lds_read128_async<0>(RS_ADDR(6 * (g + 1) + u));
+                    SD_LDS_WAIT6(6, A[g & 1][0], A[g & 1][1], A[g & 1][2], A[g & 1][3], A[g & 1][4], A[g & 1][5]);
+                } else {
+                    SD_LDS_WAIT6(0, A[g & 1][0], A[g & 1][1], A[g & 1][2], A[g & 1][3], A[g & 1][4], A[g & 1][5]);
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int i = 6 * g + u, t = (i / 12) * 3 + (i % 12) / 4, kc = i % 4;
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, A[g & 1][u]);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bw[(t * 4 + kc) * 2 + 0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bw[(t * 4 + kc) * 2 + 1], acc[1], 0, 0, 0);
+                }
+            }
+#undef RS_ADDR
+            PP_T(r3_)
+            // everything this wave issued at the top of the row (DMA pieces of row y + 3, the stores of row y - 1, the residual of row y) is
+            // 72 MFMAs old by now; the scratch is free (row y - 1 went out above)
+            wait_vmcnt<0>();
+            PP_T(r4_)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    scr[((e & 3) + 8 * (e >> 2) + 4 * fh) * RS_SCR + ni * 32 + fr] = acc[ni][e] * sc[ni] + sh[ni];
+            PP_T(r5_)
+            __syncthreads();                 // every wave is done with input row y - 1 and has published its pieces of row y + 3
+            PP_T(r6_)
+            PP_ACC(0, r0_, r1_) PP_ACC(1, r1_, r2_) PP_ACC(2, r2_, r3_) PP_ACC(3, r3_, r4_) PP_ACC(4, r4_, r5_) PP_ACC(5, r5_, r6_)
+#ifdef SD_PP_TRACE
+            tr[7] += 1;
+#endif
+        }
+#ifdef SD_PP_TRACE
+        if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_pp_trace[wave][k] = tr[k]; }
+#endif
+        store_row(y1 - 1);
+        if (p.stat) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = ssum[k], q = ssq[k];
+                for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                if (lane < 8) { sred[wave * 128 + lane * 8 + k] = a; sred[wave * 128 + 64 + lane * 8 + k] = q; }
+            }
+            __syncthreads();
+            if (tid < 128) p.stat[(int64_t)unit * 128 + tid] = (sred[tid] + sred[128 + tid]) + (sred[256 + tid] + sred[384 + tid]);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();                     // the ring, the scratch and sred are reused by the next unit
+    }
+}
+
 #undef SD_BNRED_TERM
 
 // ---------------------------------------------------------------------------------------------
@@ -2633,6 +2835,25 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
     return a.pt_pieces * 256 <= (a.pt_rolling ? PT_FLOATS : PT_STAGE_FLOATS);
 }
 
+// k_conv3x3_c64_rows_bf16 applies: bf16, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
+// multiple of 128, plain or same-size residual, no split-K, and enough (image, strip, row range) units to fill the chip.
+static int g_rows64_min_units = 128;    // sd_set_option("conv_rows64_min_units", n) (tests: 1; off: 1 << 30)
+static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
+    if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+    if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
+    if (a.Ho != a.Hi || a.Wo != a.Wi || a.Wo % 128 || a.res_up2 || a.bn_x) return false;
+    r = RowsArgs{};
+    r.B = a.B; r.H = a.Ho; r.W = a.Wo; r.segs = a.Wo / 128;
+    const int cols = r.B * r.segs;
+    r.rows = std::min(r.H, std::max(8, cdiv(r.H * cols, 256)));        // ~256 units (one persistent block per CU), at least 8 rows each
+    r.units_per_col = cdiv(r.H, r.rows);
+    r.nunits = cols * r.units_per_col;
+    if (r.nunits < g_rows64_min_units) return false;
+    r.x = (const uint16_t*)a.x; r.w = (const uint16_t*)a.w; r.y = (uint16_t*)a.y; r.scale = a.scale; r.shift = a.shift;
+    r.res = (const uint16_t*)a.res; r.stat = a.stat; r.relu = a.relu; r.flip = a.rsign < 0;
+    return true;
+}
+
 // k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered (not rolling) patch geometry, whole 512-pixel
 // tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
 static int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
@@ -2674,6 +2895,17 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
     if (!stem && bf16) {
+        RowsArgs ra;
+        if (conv_rows64_geometry(a, mode, ra)) {
+            static thread_local bool raised64 = false;
+            if (!raised64) {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_rows_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES));
+                raised64 = true;
+            }
+            hipLaunchKernelGGL(k_conv3x3_c64_rows_bf16, dim3(std::min(ra.nunits, 256)), dim3(256), RS_LDS_BYTES, st, ra);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
         ConvArgs pa = a;
         if (conv_pp_geometry(pa, mode)) {
             static thread_local bool raised = false;      // per host thread: cheap, idempotent
@@ -2811,6 +3043,8 @@ static int fwd_stat_rows(const sd_conv_desc* d, bool bf16 = false) {
     if (a.splits > 1) return 0;
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     ConvArgs t = a;
+    RowsArgs ra;
+    if (bf16 && conv_rows64_geometry(a, 0, ra)) return ra.nunits;
     if (bf16 && conv_pp_geometry(t, 0)) return a.M / PP_BM;
     t = a;
     return (conv_patch_geometry(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
@@ -3329,6 +3563,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
+    if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
@@ -3352,6 +3587,8 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         a.kchunks = a.Ck / 64; a.nk = a.R * a.S * a.kchunks;
         a.splits = pass == 0 ? fwd_splits(d, 64) : 1;
         t = a;
+        RowsArgs ra;
+        if (conv_rows64_geometry(a, mode, ra)) return "k_conv3x3_c64_rows_bf16";
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
         t = a;
         if (conv_patch_geometry(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, true>", BN);

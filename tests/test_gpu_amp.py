@@ -334,3 +334,38 @@ def test_head_backward_on_bf16_activations(case):
     L.check(lib.sd_head_bwd_bf16(dy_d.data_ptr(), x16.data_ptr(), w_d.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, H * W, Cc, Co, 1,
                                  ws.data_ptr(), ws.numel(), L.stream()))
     close(dw.cpu(), 2 * w.grad.reshape(Co, Cc), 2e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 128, 64, 64, 3, 1, 1), (1, 24, 256, 64, 64, 3, 1, 1), (3, 9, 128, 64, 64, 3, 1, 1), (8, 40, 128, 64, 64, 3, 1, 1)])
+def test_conv_bf16_row_stream_kernel_64_channels(case):
+    """k_conv3x3_c64_rows_bf16 (layer1's 64 -> 64 convs: persistent blocks stream the rows of a 128-pixel strip, weights in registers,
+    output stored one row late with the residual / ReLU / BatchNorm column sums): forced onto small problems with sd_set_option, then
+    the checks of the other bf16 conv kernels (forward + fused statistics, data-gradient plain / + residual) plus the forward epilogue.
+    Shapes: two strips per row (W = 256), row counts that are not a multiple of the unit, several units per strip."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W, cin, cout, k, stride, pad = case
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    L.check(lib.sd_set_option(b"conv_rows64_min_units", 1))
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == "k_conv3x3_c64_rows_bf16"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode() == "k_conv3x3_c64_rows_bf16"
+        test_conv_bf16_forward_statistics_and_data_gradient(case)
+        g = torch.Generator().manual_seed(sum(case) + 2)
+        x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16().float()
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g).bfloat16().float()
+        xd, wd, res_d = nhwc16(x), nhwc16(w), nhwc16(res)
+        scale_d, shift_d = scale.to(DEV), shift.to(DEV)
+        y = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+        conv = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        for r16, relu, ref in ((res_d, 1, torch.relu(conv + res)), (None, 1, torch.relu(conv)), (None, 0, conv)):
+            L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
+                                           r16.data_ptr() if r16 is not None else 0, 0, relu, 0, 0, L.stream()))
+            close(back(y), ref, 8e-3)
+    finally:
+        L.check(lib.sd_set_option(b"conv_rows64_min_units", 128))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
