@@ -43,7 +43,7 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #ifndef SD_ABLATE_PATCH
 #define SD_ABLATE_PATCH 0     // timing-only experiment: stage the A tile for ~1.6 of the 9 taps only (what patch staging would need) -- WRONG RESULTS
 #endif
-#if SD_ABLATE_HOT || SD_ABLATE_STORE || SD_ABLATE_PATCH || defined(SD_PP_ABL)
+#if SD_ABLATE_HOT || SD_ABLATE_STORE || SD_ABLATE_PATCH || defined(SD_PP_ABL) || defined(SD_RS_ABL)
 #warning "timing-only ablation build: this libsdnet_hip.so computes WRONG RESULTS; the Python loader refuses it unless SDNET_ALLOW_ABLATION=1"
 #endif
 // Reported through the C ABI (sd_build_flags): the loader, build() and the CPU tests assert 0, so an experiment build can never
@@ -1493,6 +1493,36 @@ struct RowsArgs {
     int B, H, W, relu, flip, rows, units_per_col, segs, nunits;
 };
 
+// The MFMA of the row-stream kernel with explicit register classes: accumulators and the first RS_B_AGPR weight fragments live in AGPRs and
+// are read from there (hipcc otherwise parks most of the 288 weight registers in AGPRs and copies four of them to VGPRs in front of EVERY
+// MFMA: 288 v_accvgpr_read per row = half of the vector issue slots the MFMAs leave free).  256 AGPRs = 32 accumulator + 56 x 4 weights.
+constexpr int RS_B_AGPR = 56;
+typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+typedef short rs_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rs_pack2(float lo, float hi) {            // two fp32 -> one dword of two bf16 (round-to-nearest-even)
+    const rs_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rs_bf16x2));
+}
+__device__ __forceinline__ uint32_t rs_relu2(uint32_t two_bf16) {             // negative bf16 are negative int16: max(x, 0) per half
+    const rs_i16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(rs_i16x2, two_bf16), z));
+}
+template <bool B_IN_AGPR, bool ZERO>
+__device__ __forceinline__ void rs_mfma(f32x16& acc, const f32x4& a, const bf16x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ZERO) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+#else
+    (void)acc; (void)a; (void)b;
+#endif
+}
+
 __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
     extern __shared__ __attribute__((aligned(16))) float rs_lds[];
     char* const ring = reinterpret_cast<char*>(rs_lds);
@@ -1593,45 +1623,120 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
 #ifdef SD_PP_TRACE
         unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+        // One wave per SIMD: nothing else hides the row form of the previous output row (4 items of ~60 vector instructions + a store)
+        // or the LDS-DMA issue (one instruction per 66 cycles and wave), so both are spread between the MFMAs of this row (an MFMA
+        // holds the vector issue 8 of its 32 cycles).  LDS ordering: the scratch reads S(it) of item `it` are issued one group before
+        // the item, behind that group's counted wait; the next group's wait `lgkmcnt(6)` leaves only its own six A reads outstanding,
+        // so S(it) has landed with it (LDS operations return in order).  The first row of a unit has no previous row: the item work is
+        // skipped (wave-uniform branches).
+        const uint32_t scr_base = lds_addr(scr);
         for (int y = y0; y < y1; ++y) {
             PP_T(r0_)
-            if (y + 3 <= y1) issue_row(y + 3);
-            PP_T(r1_)
-            if (y > y0) store_row(y - 1);
-            if (p.res) fetch_res(y);
-            PP_T(r2_)
-            // ---- 36 steps (input row r, tap column s, k-step kc): A from the ring, B from registers; reads run one group of six ahead
-            f32x16 acc[2];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+#ifdef SD_RS_ABL
+            const bool prev = false;                                          // timing experiment (WRONG RESULTS): no row form of the previous row
+#else
+            const bool prev = y > y0;
+#endif
+            const int64_t srow = (((int64_t)b * p.H + y - 1) * p.W + x0 + wave * 32) * 64;      // the previous row (items are skipped on a unit's first row)
+#if defined(SD_RS_ABL) && SD_RS_ABL >= 2
+            const bool more = false;                                          // timing experiment (WRONG RESULTS): no LDS-DMA in the loop
+#else
+            const bool more = y + 3 <= y1;
+#endif
+            const int dslot_row = (y + 3 - y0 + 1) % RS_NR;
+            float* const ddst = reinterpret_cast<float*>(ring + dslot_row * RS_ROW_BYTES);
+            f32x16 acc[2];                                                    // (the first MFMA of the row starts them from 0)
             uint32_t sb[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) sb[r] = ring_base + (uint32_t)((y - 1 + r - y0 + 1) % RS_NR) * RS_ROW_BYTES;
-            f32x4 A[2][6];
+            f32x4 A[2][6], S[2][2];
 #define RS_ADDR(i) (sb[(i) / 12] + aoff[((i) % 12) / 4][(i) % 4])
+#define RS_SCR_RD(it) { const uint32_t sa_ = scr_base + (uint32_t)(((spx + 8 * (it)) * RS_SCR + sc8 * 8) * 4); \
+                        S[(it) & 1][0] = lds_read128_async<0>(sa_); S[(it) & 1][1] = lds_read128_async<16>(sa_); }
+            RS_SCR_RD(0)
 #pragma unroll
             for (int u = 0; u < 6; ++u) A[0][u] = lds_read128_async<0>(RS_ADDR(u));
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                if (g + 1 < 6) {
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) A[(g + 1) & 1][u] = lds_read128_async<0>(RS_ADDR(6 * (g + 1) + u));
-                    SD_LDS_WAIT6(6, A[g & 1][0], A[g & 1][1], A[g & 1][2], A[g & 1][3], A[g & 1][4], A[g & 1][5]);
-                } else {
-                    SD_LDS_WAIT6(0, A[g & 1][0], A[g & 1][1], A[g & 1][2], A[g & 1][3], A[g & 1][4], A[g & 1][5]);
-                }
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int i = 6 * g + u, t = (i / 12) * 3 + (i % 12) / 4, kc = i % 4;
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, A[g & 1][u]);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bw[(t * 4 + kc) * 2 + 0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bw[(t * 4 + kc) * 2 + 1], acc[1], 0, 0, 0);
-                }
+            uint4 resn[4];                                                    // residual of THIS row (used one row later)
+            float f[8]; uint4 o;
+#define RS_MFMA2(G, u)                                                                                                                \
+            {                                                                                                                         \
+                constexpr int i_ = 6 * (G) + (u), t_ = (i_ / 12) * 3 + (i_ % 12) / 4, kc_ = i_ % 4, b0_ = (t_ * 4 + kc_) * 2;           \
+                rs_mfma<(b0_ < RS_B_AGPR), i_ == 0>(acc[0], A[(G) & 1][u], Bw[b0_]);                                                   \
+                rs_mfma<(b0_ + 1 < RS_B_AGPR), i_ == 0>(acc[1], A[(G) & 1][u], Bw[b0_ + 1]);                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
             }
+#define RS_DMA_PIECE(pc_expr, chk)                                                                                                    \
+            {                                                                                                                         \
+                const int pc = (pc_expr), pxr = pc * 8 + dpx, ix = x0 - 1 + pxr;                                                       \
+                const bool ok = (!(chk) || pxr < 130) && (unsigned)ix < (unsigned)p.W && (unsigned)(y + 3) < (unsigned)p.H;            \
+                lds_dma16(ok ? img + ((int64_t)(y + 3) * p.W + ix) * 64 + ((dslot ^ ((pxr >> 1) & 7)) << 3) : zero_ + (dslot << 3), ddst + pc * 256); \
+            }
+            // group G: item G of the previous row (G < 4) and, in group 0, the LDS-DMA of row y + 3, cut into pieces between the MFMAs
+#define RS_GROUP(G)                                                                                                                   \
+            {                                                                                                                         \
+                if ((G) + 1 < 6) {                                                                                                    \
+                    _Pragma("unroll") for (int u = 0; u < 6; ++u) A[((G) + 1) & 1][u] = lds_read128_async<0>(RS_ADDR(6 * ((G) + 1) + u)); \
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[(G) & 1][0]), "+v"(A[(G) & 1][1]), "+v"(A[(G) & 1][2]), "+v"(A[(G) & 1][3]), \
+                                 "+v"(A[(G) & 1][4]), "+v"(A[(G) & 1][5]), "+v"(S[(G) & 1][0]), "+v"(S[(G) & 1][1]) :: "memory");       \
+                } else {                                                                                                              \
+                    SD_LDS_WAIT6(0, A[(G) & 1][0], A[(G) & 1][1], A[(G) & 1][2], A[(G) & 1][3], A[(G) & 1][4], A[(G) & 1][5]);         \
+                }                                                                                                                     \
+                if ((G) < 3) RS_SCR_RD((G) + 1)                                                                                       \
+                RS_MFMA2(G, 0)                                                                                                        \
+                if ((G) < 4 && prev) {                                                                                                \
+                    const f32x4 v0 = S[(G) & 1][0], v1 = S[(G) & 1][1];                                                               \
+                    f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3]; f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];    \
+                    if (p.res) {                                                                                                      \
+                        const uint4 r = resv[(G) & 3];                                                                                \
+                        f[0] += __uint_as_float(r.x << 16); f[1] += __uint_as_float(r.x & 0xffff0000u); f[2] += __uint_as_float(r.y << 16); f[3] += __uint_as_float(r.y & 0xffff0000u); \
+                        f[4] += __uint_as_float(r.z << 16); f[5] += __uint_as_float(r.z & 0xffff0000u); f[6] += __uint_as_float(r.w << 16); f[7] += __uint_as_float(r.w & 0xffff0000u); \
+                    }                                                                                                                 \
+                }                                                                                                                     \
+                if ((G) == 0 && more) { RS_DMA_PIECE(wave, 0) RS_DMA_PIECE(wave + 4, 0) }                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
+                RS_MFMA2(G, 1)                                                                                                        \
+                if ((G) < 4 && prev) {   /* one v_cvt_pk_bf16_f32 per pair; ReLU on the packed pairs: max as signed 16-bit integers */ \
+                    o.x = rs_pack2(f[0], f[1]); o.y = rs_pack2(f[2], f[3]); o.z = rs_pack2(f[4], f[5]); o.w = rs_pack2(f[6], f[7]);    \
+                    if (p.relu) { o.x = rs_relu2(o.x); o.y = rs_relu2(o.y); o.z = rs_relu2(o.z); o.w = rs_relu2(o.w); }                \
+                }                                                                                                                     \
+                if ((G) == 0 && more) RS_DMA_PIECE(wave + 8, 0)                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
+                RS_MFMA2(G, 2)                                                                                                        \
+                if ((G) < 4 && prev && p.stat) {                                                                                      \
+                    const uint32_t od[4] = {o.x, o.y, o.z, o.w};                                                                      \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                   \
+                        const float a0 = __uint_as_float(od[k] << 16), a1 = __uint_as_float(od[k] & 0xffff0000u);                      \
+                        ssum[2 * k] += a0; ssq[2 * k] += a0 * a0; ssum[2 * k + 1] += a1; ssq[2 * k + 1] += a1 * a1;                    \
+                    }                                                                                                                 \
+                }                                                                                                                     \
+                if ((G) == 0 && more) RS_DMA_PIECE(wave + 12, 0)                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
+                RS_MFMA2(G, 3)                                                                                                        \
+                if ((G) < 4 && prev) *reinterpret_cast<uint4*>(p.y + srow + (spx + 8 * ((G) & 3)) * 64 + sc8 * 8) = o;                 \
+                if ((G) == 0 && more && wave == 0) RS_DMA_PIECE(16, 1)                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
+                RS_MFMA2(G, 4)                                                                                                        \
+                if ((G) < 4 && p.res) {   /* residual of this row, item G: consumed one row later */                                  \
+                    resn[(G) & 3] = *reinterpret_cast<const uint4*>(p.res + (((int64_t)b * p.H + y) * p.W + x0 + wave * 32) * 64 + (spx + 8 * ((G) & 3)) * 64 + sc8 * 8); \
+                }                                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                                    \
+                RS_MFMA2(G, 5)                                                                                                        \
+            }
+            RS_GROUP(0) RS_GROUP(1) RS_GROUP(2) RS_GROUP(3) RS_GROUP(4) RS_GROUP(5)
+#undef RS_GROUP
+#undef RS_DMA_PIECE
+#undef RS_MFMA2
+            // the asm MFMAs are invisible to the hazard recogniser: their results must not be read (v_accvgpr_read) for 18 wait states
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #undef RS_ADDR
+#undef RS_SCR_RD
+            if (p.res) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) resv[it] = resn[it];
+            }
             PP_T(r3_)
-            // everything this wave issued at the top of the row (DMA pieces of row y + 3, the stores of row y - 1, the residual of row y) is
-            // 72 MFMAs old by now; the scratch is free (row y - 1 went out above)
+            // the DMA pieces of row y + 3 went out in group 0 (~2000 cycles ago); what the next row needs (row y + 2) was issued a row ago.
+            // vmcnt(0) also covers this row's four stores and residual loads (issued in groups 0 .. 3)
             wait_vmcnt<0>();
             PP_T(r4_)
 #pragma unroll
@@ -1642,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
             PP_T(r5_)
             __syncthreads();                 // every wave is done with input row y - 1 and has published its pieces of row y + 3
             PP_T(r6_)
-            PP_ACC(0, r0_, r1_) PP_ACC(1, r1_, r2_) PP_ACC(2, r2_, r3_) PP_ACC(3, r3_, r4_) PP_ACC(4, r4_, r5_) PP_ACC(5, r5_, r6_)
+            PP_ACC(2, r0_, r3_) PP_ACC(3, r3_, r4_) PP_ACC(4, r4_, r5_) PP_ACC(5, r5_, r6_)
 #ifdef SD_PP_TRACE
             tr[7] += 1;
 #endif
