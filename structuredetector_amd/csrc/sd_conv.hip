@@ -1496,6 +1496,11 @@ struct RowsArgs {
 // The MFMA of the row-stream kernel with explicit register classes: accumulators and the first RS_B_AGPR weight fragments live in AGPRs and
 // are read from there (hipcc otherwise parks most of the 288 weight registers in AGPRs and copies four of them to VGPRs in front of EVERY
 // MFMA: 288 v_accvgpr_read per row = half of the vector issue slots the MFMAs leave free).  256 AGPRs = 32 accumulator + 56 x 4 weights.
+#if defined(SD_RS_ABL) && SD_RS_ABL == 3
+#define SD_RS_NOWAIT 1          // timing experiment (WRONG RESULTS): the A fragments are not waited for
+#else
+#define SD_RS_NOWAIT 0
+#endif
 constexpr int RS_B_AGPR = 56;
 typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
@@ -1625,14 +1630,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
 #endif
         // One wave per SIMD: nothing else hides the row form of the previous output row (4 items of ~60 vector instructions + a store)
         // or the LDS-DMA issue (one instruction per 66 cycles and wave), so both are spread between the MFMAs of this row (an MFMA
-        // holds the vector issue 8 of its 32 cycles).  LDS ordering: the scratch reads S(it) of item `it` are issued one group before
-        // the item, behind that group's counted wait; the next group's wait `lgkmcnt(6)` leaves only its own six A reads outstanding,
-        // so S(it) has landed with it (LDS operations return in order).  The first row of a unit has no previous row: the item work is
+        // holds the vector issue 8 of its 32 cycles).  LDS ordering: A fragment i + 6 is read at step i (rolling window of six), the
+        // scratch reads S(it) of item `it` go out six steps before the item; every step waits `lgkmcnt(6)` = everything but the six
+        // youngest operations is back (LDS operations return in order), so S(it) has long landed when item `it` starts.  The first row of a unit has no previous row: the item work is
         // skipped (wave-uniform branches).
         const uint32_t scr_base = lds_addr(scr);
         for (int y = y0; y < y1; ++y) {
             PP_T(r0_)
-#ifdef SD_RS_ABL
+#if defined(SD_RS_ABL) && SD_RS_ABL != 3
             const bool prev = false;                                          // timing experiment (WRONG RESULTS): no row form of the previous row
 #else
             const bool prev = y > y0;
@@ -1649,20 +1654,34 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
             uint32_t sb[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) sb[r] = ring_base + (uint32_t)((y - 1 + r - y0 + 1) % RS_NR) * RS_ROW_BYTES;
-            f32x4 A[2][6], S[2][2];
+            f32x4 A[8], S[2][2];                                              // A: rolling window, read i + 6 is issued at step i
 #define RS_ADDR(i) (sb[(i) / 12] + aoff[((i) % 12) / 4][(i) % 4])
 #define RS_SCR_RD(it) { const uint32_t sa_ = scr_base + (uint32_t)(((spx + 8 * (it)) * RS_SCR + sc8 * 8) * 4); \
                         S[(it) & 1][0] = lds_read128_async<0>(sa_); S[(it) & 1][1] = lds_read128_async<16>(sa_); }
             RS_SCR_RD(0)
 #pragma unroll
-            for (int u = 0; u < 6; ++u) A[0][u] = lds_read128_async<0>(RS_ADDR(u));
+            for (int u = 0; u < 6; ++u) A[u] = lds_read128_async<0>(RS_ADDR(u));
             uint4 resn[4];                                                    // residual of THIS row (used one row later)
             float f[8]; uint4 o;
 #define RS_MFMA2(G, u)                                                                                                                \
             {                                                                                                                         \
                 constexpr int i_ = 6 * (G) + (u), t_ = (i_ / 12) * 3 + (i_ % 12) / 4, kc_ = i_ % 4, b0_ = (t_ * 4 + kc_) * 2;           \
-                rs_mfma<(b0_ < RS_B_AGPR), i_ == 0>(acc[0], A[(G) & 1][u], Bw[b0_]);                                                   \
-                rs_mfma<(b0_ + 1 < RS_B_AGPR), i_ == 0>(acc[1], A[(G) & 1][u], Bw[b0_ + 1]);                                           \
+                /* read i + 6 goes out, then all but the six youngest LDS operations must be back: read i is (the scratch reads that sit \
+                   between the A reads only make the wait stricter; LDS operations return in order) */                                   \
+                if (i_ + 6 < 36) A[(i_ + 6) & 7] = lds_read128_async<0>(RS_ADDR(i_ + 6 < 36 ? i_ + 6 : 0));                            \
+                /* the fragment the MFMAs just issued are still reading stays allocated: hipcc otherwise computes the next read address \
+                   (a VALU write) and lands the read in those very registers, and the write waits for the MFMA's operand reads */       \
+                if (i_ > 0) asm volatile("" :: "v"(A[(i_ - 1) & 7]));                                                                  \
+                if (SD_RS_NOWAIT && i_ + 6 < 36) asm volatile("" : "+v"(A[i_ & 7]) :: "memory");                                        \
+                else if (i_ + 6 < 36) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[i_ & 7]) :: "memory");                               \
+                else if (i_ == 30) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(A[i_ & 7]) :: "memory");                                  \
+                else if (i_ == 31) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[i_ & 7]) :: "memory");                                  \
+                else if (i_ == 32) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[i_ & 7]) :: "memory");                                  \
+                else if (i_ == 33) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[i_ & 7]) :: "memory");                                  \
+                else if (i_ == 34) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(A[i_ & 7]) :: "memory");                                  \
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[i_ & 7]) :: "memory");                                                \
+                rs_mfma<(b0_ < RS_B_AGPR), i_ == 0>(acc[0], A[i_ & 7], Bw[b0_]);                                                       \
+                rs_mfma<(b0_ + 1 < RS_B_AGPR), i_ == 0>(acc[1], A[i_ & 7], Bw[b0_ + 1]);                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                                                    \
             }
 #define RS_DMA_PIECE(pc_expr, chk)                                                                                                    \
@@ -1674,15 +1693,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
             // group G: item G of the previous row (G < 4) and, in group 0, the LDS-DMA of row y + 3, cut into pieces between the MFMAs
 #define RS_GROUP(G)                                                                                                                   \
             {                                                                                                                         \
-                if ((G) + 1 < 6) {                                                                                                    \
-                    _Pragma("unroll") for (int u = 0; u < 6; ++u) A[((G) + 1) & 1][u] = lds_read128_async<0>(RS_ADDR(6 * ((G) + 1) + u)); \
-                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[(G) & 1][0]), "+v"(A[(G) & 1][1]), "+v"(A[(G) & 1][2]), "+v"(A[(G) & 1][3]), \
-                                 "+v"(A[(G) & 1][4]), "+v"(A[(G) & 1][5]), "+v"(S[(G) & 1][0]), "+v"(S[(G) & 1][1]) :: "memory");       \
-                } else {                                                                                                              \
-                    SD_LDS_WAIT6(0, A[(G) & 1][0], A[(G) & 1][1], A[(G) & 1][2], A[(G) & 1][3], A[(G) & 1][4], A[(G) & 1][5]);         \
-                }                                                                                                                     \
-                if ((G) < 3) RS_SCR_RD((G) + 1)                                                                                       \
                 RS_MFMA2(G, 0)                                                                                                        \
+                /* S(G) was issued six steps ago, in front of A reads that have been waited for since */                              \
+                if ((G) < 4) asm volatile("" : "+v"(S[(G) & 1][0]), "+v"(S[(G) & 1][1]));                                              \
+                if ((G) < 3) RS_SCR_RD((G) + 1)                                                                                       \
                 if ((G) < 4 && prev) {                                                                                                \
                     const f32x4 v0 = S[(G) & 1][0], v1 = S[(G) & 1][1];                                                               \
                     f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3]; f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];    \
