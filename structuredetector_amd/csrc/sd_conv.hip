@@ -57,7 +57,12 @@ __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(ui
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG; }
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL)
+#define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
+#else
+#define SD_EXPERIMENT_FLAG 0
+#endif
+extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG | SD_EXPERIMENT_FLAG; }
 
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
