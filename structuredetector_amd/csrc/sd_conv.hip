@@ -2961,7 +2961,7 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
 
 // k_conv3x3_c64_rows_bf16 applies: bf16, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
 // multiple of 128, plain or same-size residual, no split-K, and enough (image, strip, row range) units to fill the chip.
-static int g_rows64_min_units = 128;    // sd_set_option("conv_rows64_min_units", n) (tests: 1; off: 1 << 30)
+static int g_rows64_min_units = 192;    // sd_set_option("conv_rows64_min_units", n) (tests: 1; off: 1 << 30)
 static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
@@ -2972,7 +2972,9 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     r.rows = std::min(r.H, std::max(8, cdiv(r.H * cols, 256)));        // ~256 units (one persistent block per CU), at least 8 rows each
     r.units_per_col = cdiv(r.H, r.rows);
     r.nunits = cols * r.units_per_col;
-    if (r.nunits < g_rows64_min_units) return false;
+    // a unit pays for 288 weight registers and four input rows before its first MFMA: below 16 rows per unit (batches under ~32 at
+    // 128 x 128) the tile kernels keep the layer (g_rows64_min_units = 1 lifts both limits: tests)
+    if (r.nunits < g_rows64_min_units || (g_rows64_min_units > 1 && r.rows < 16)) return false;
     r.x = (const uint16_t*)a.x; r.w = (const uint16_t*)a.w; r.y = (uint16_t*)a.y; r.scale = a.scale; r.shift = a.shift;
     r.res = (const uint16_t*)a.res; r.stat = a.stat; r.relu = a.relu; r.flip = a.rsign < 0;
     return true;

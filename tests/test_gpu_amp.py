@@ -367,5 +367,5 @@ def test_conv_bf16_row_stream_kernel_64_channels(case):
                                            r16.data_ptr() if r16 is not None else 0, 0, relu, 0, 0, L.stream()))
             close(back(y), ref, 8e-3)
     finally:
-        L.check(lib.sd_set_option(b"conv_rows64_min_units", 128))
+        L.check(lib.sd_set_option(b"conv_rows64_min_units", 192))
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
