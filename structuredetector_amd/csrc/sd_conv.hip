@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 //   the weight ring has 7 stages of one tap (8 KB), tap t + 5 is issued during tap t (all 8 waves, one 1 KB piece each):
 //     staged weight bytes per MFMA are half of the 256-pixel tile's and a piece has > 5 tap times to land;
 //   the groups run half a tap apart (group 1 does one extra s_barrier first, group 0 one last): every tap is
-//     LOAD [issue DMA, 12 ds_read_b128, counted vmcnt] - s_barrier - MFMA [16 x 32x32x16, raised priority] - s_barrier
+//     LOAD [12 ds_read_b128, then the tap's LDS-DMA, counted vmcnt] - s_barrier - MFMA [16 x 32x32x16, raised priority] - s_barrier
 //     so that one group's LOAD always runs under the other group's MFMAs on the same SIMDs (2 waves per SIMD).
 //   Hazards (t = tap, interval = time between two barriers; group 0 LOADs tap t in interval 2t, group 1 in 2t + 1):
 //     RAW  a piece of tap t+1 is covered by its issuer's vmcnt wait in LOAD(t), which ends with a barrier every reader passes
