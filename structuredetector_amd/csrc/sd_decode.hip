@@ -33,7 +33,10 @@ __device__ __forceinline__ uint64_t make_key(float v, uint32_t flat) {
 //   MODE 0: dense output  out = keep ? v : 0            (nms(), utils.py:441-443)
 //   MODE 1: compaction    survivors appended as keys to the per-(image, group) candidate list
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 16, HALO = 2;
+#ifndef SD_DECODE_TH
+#define SD_DECODE_TH 16      // NMS tile height (A/B switch: 32 halves the number of tile blocks)
+#endif
+constexpr int TW = 64, TH = SD_DECODE_TH, HALO = 2;
 constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
 
 struct Group {
