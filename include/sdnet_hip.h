@@ -305,6 +305,16 @@ int sd_conv2d_fwd_bf16_bn_stats(const void* x_nhwc_bf16, const void* w_krsc_bf16
 int sd_conv2d_stem_fwd_bn_stats_bf16mm(const float* x_nchw, const float* w, float* y, const sd_conv_desc* d, float eps, float momentum,
                                        float* running_mean, float* running_var, float* mean, float* invstd,
                                        void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* ... and with a bf16 NHWC output (statistics of the rounded values): the mixed-precision step's stem; its tail reads that tensor through
+ * sd_bn_relu_maxpool_fwd_bf16 / sd_maxpool_bn_relu_bwd_bf16 (fp32 arithmetic, bf16 conv output / pooled map / pooled gradient, fp32 dx). */
+int sd_conv2d_stem_fwd_bn_stats_bf16(const float* x_nchw, const float* w, void* y_bf16, const sd_conv_desc* d, float eps, float momentum,
+                                     float* running_mean, float* running_var, float* mean, float* invstd, void* workspace,
+                                     size_t workspace_bytes, sd_stream_t stream);
+int sd_bn_relu_maxpool_fwd_bf16(const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, void* y_pool_bf16, uint8_t* idx, sd_stream_t stream);
+int sd_maxpool_bn_relu_bwd_bf16(const void* dpool_bf16, const uint8_t* idx, const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* [Cout][taps][Cin] fp32 -> [Cin][taps][Cout] bf16 in one pass (the data-gradient's weights under --amp). */
 int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, int taps, int Cin, sd_stream_t stream);
 /* dx = dgrad(dy) [+ residual]: bf16 dy / transposed weights [Cin][R][S][Cout] / dx; res_mode 0 none, 1 bf16 tensor of dx's shape,

@@ -124,9 +124,12 @@ _SIGNATURES = {
     "sd_conv2d_stem_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_stem_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_fwd_bn_stats_bf16mm": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
+    "sd_conv2d_stem_fwd_bn_stats_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_dgrad_half_res": (c_int, [c_vp] * 6),
     "sd_bn_relu_maxpool_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7),
+    "sd_bn_relu_maxpool_fwd_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7),
     "sd_maxpool_bn_relu_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_vp, c_size, c_vp]),
+    "sd_maxpool_bn_relu_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_vp, c_size, c_vp]),
     "sd_conv2d_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_dgrad_bn_reduce_workspace_bytes": (c_size, [c_vp]),

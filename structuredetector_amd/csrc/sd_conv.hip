@@ -2521,7 +2521,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+                if (ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh < p.Wo) {
+                    // (bf16 output: the statistics of the ROUNDED values, i.e. of the tensor the BatchNorm normalises.  Compile-time for the
+                    // fp32 instantiation: its instruction stream -- and with it the last bit of the statistics -- stays what it was)
+                    const float a0 = (BF16MM && p.out_bf16) ? bf2f(f2bf(acc0[e])) : acc0[e], a1 = (BF16MM && p.out_bf16) ? bf2f(f2bf(acc1[e])) : acc1[e];
+                    s0 += a0; q0 += a0 * a0; s1 += a1; q1 += a1 * a1;
+                }
             }
             s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
             if (fh == 0) {
@@ -3375,6 +3380,28 @@ int sd_conv2d_stem_fwd_bn_stats_bf16mm(const float* x_nchw, const float* w, floa
     float* partial = (float*)((char*)workspace + align_up((size_t)STEM_K * 64 * sizeof(float), 256));
     StemArgs a{};
     a.x = x_nchw; a.w = w; a.y = y; a.stat = partial;
+    stem_args(a, d);
+    const size_t lds = STEM_FWD_LDS_BYTES;
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr_once;
+    hipLaunchKernelGGL(k_stem_fwd<true>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
+    SD_LAUNCH_CHECK();
+    return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+                                partial + (size_t)a.ntiles * 128, stream);
+}
+
+// the same with a bf16 NHWC output (mixed-precision training: the conv output is read twice more by the stem tail, 1 GB in fp32 at bs=64)
+int sd_conv2d_stem_fwd_bn_stats_bf16(const float* x_nchw, const float* w, void* y_bf16, const sd_conv_desc* d, float eps, float momentum,
+                                     float* running_mean, float* running_var, float* mean, float* invstd, void* workspace,
+                                     size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_fwd_bn_stats_bf16", d)) return e;
+    SD_REQUIRE(x_nchw && w && y_bf16 && mean && invstd && workspace, SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats_bf16: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_fwd_bn_stats_bf16: the stem is a 7x7 / stride 2 / pad 3 conv, 3 -> 64 channels");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_fwd_bn_stats_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_fwd_bn_stats_bf16: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)((char*)workspace + align_up((size_t)STEM_K * 64 * sizeof(float), 256));
+    StemArgs a{};
+    a.x = x_nchw; a.w = w; a.y = (float*)y_bf16; a.stat = partial; a.out_bf16 = 1;
     stem_args(a, d);
     const size_t lds = STEM_FWD_LDS_BYTES;
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

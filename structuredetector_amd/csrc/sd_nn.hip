@@ -5,6 +5,7 @@
 // src/sdnet/model/network.py:6-57 and torchvision's resnet34 (BasicBlock), and
 // torch.optim.Adam in src/sdnet/model/trainer.py:53,124.
 #include "sd_common.h"
+#include <type_traits>
 
 namespace sd {
 
@@ -309,9 +310,12 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
 // ---- stem tail fused: BatchNorm(train) + ReLU + MaxPool2d(3, 2, 1) without materialising the full-resolution activation.
 // forward: the pooled map and the winning taps straight from the conv output x (same affine expression as k_bn_apply, same
 // first-maximum rule as k_maxpool_fwd).
-__global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const float* __restrict__ x, const float* __restrict__ mean,
+// XT / PT: element type of the conv output x and of the pooled map (float, or uint16_t = bf16 in the mixed-precision step: fp32 arithmetic,
+// one rounding at the store; the winning tap is decided on the fp32 values)
+template <typename XT, typename PT>
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const XT* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              const float* __restrict__ beta, PT* __restrict__ y,
                                                               uint8_t* __restrict__ idx, int B, int Hi, int Wi, int Ho, int Wo, int C) {
     const int cols = C >> 2;
     const int64_t n4 = (int64_t)B * Ho * Wo * cols;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const float* __rest
         for (int s = 0; s < 3; ++s) {
             const int iy = oy * 2 - 1 + r, ix = ox * 2 - 1 + s;
             if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-            const float4 xv = reinterpret_cast<const float4*>(x + (((int64_t)b * Hi + iy) * Wi + ix) * C)[col];
+            const float4 xv = ld4(x, (((int64_t)b * Hi + iy) * Wi + ix) * cols + col);
             float4 v;
             v.x = fmaxf((xv.x - mu.x) * is.x * ga.x + be.x, 0.f); v.y = fmaxf((xv.y - mu.y) * is.y * ga.y + be.y, 0.f);
             v.z = fmaxf((xv.z - mu.z) * is.z * ga.z + be.z, 0.f); v.w = fmaxf((xv.w - mu.w) * is.w * ga.w + be.w, 0.f);
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const float* __rest
             if (v.w > m.w) { m.w = v.w; w.w = tap; }
         }
     }
-    reinterpret_cast<float4*>(y)[i] = m;
+    st4(y, i, m);
     reinterpret_cast<uchar4*>(idx)[i] = w;
 }
 
@@ -379,7 +383,8 @@ __device__ __forceinline__ float4 pool_relu_grad(const float* __restrict__ dpool
 // The same gradient for the four pixels (2k + dy, 2j + dx) of an even-aligned 2x2 quad at once (Hi, Wi even): they only see the
 // windows (k, j), (k, j+1), (k+1, j), (k+1, j+1), so four window loads serve four pixels (the per-pixel gather needs nine) and
 // the window set is fixed -- no data-dependent loops.  g[2 * dy + dx].
-__device__ __forceinline__ void pool_relu_grad_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int k, int j,
+template <typename PT>
+__device__ __forceinline__ void pool_relu_grad_quad(const PT* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int k, int j,
                                                     int col, int cols, int Ho, int Wo, const float4* xv, const float4 mu, const float4 is,
                                                     const float4 ga, const float4 be, float4* g) {
     const bool hy = k + 1 < Ho, hx = j + 1 < Wo;
@@ -387,9 +392,9 @@ __device__ __forceinline__ void pool_relu_grad_quad(const float* __restrict__ dp
     const int64_t o01 = hx ? o00 + cols : o00, o10 = hy ? o00 + (int64_t)Wo * cols : o00, o11 = (hx && hy) ? o00 + (int64_t)(Wo + 1) * cols : o00;
     const uchar4 w00 = reinterpret_cast<const uchar4*>(idx)[o00], w01 = reinterpret_cast<const uchar4*>(idx)[o01];
     const uchar4 w10 = reinterpret_cast<const uchar4*>(idx)[o10], w11 = reinterpret_cast<const uchar4*>(idx)[o11];
-    const float4 d00 = reinterpret_cast<const float4*>(dpool)[o00];
-    float4 d01 = reinterpret_cast<const float4*>(dpool)[o01], d10 = reinterpret_cast<const float4*>(dpool)[o10];
-    float4 d11 = reinterpret_cast<const float4*>(dpool)[o11];
+    const float4 d00 = ld4(dpool, o00);
+    float4 d01 = ld4(dpool, o01), d10 = ld4(dpool, o10);
+    float4 d11 = ld4(dpool, o11);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!hx) d01 = z;
     if (!hy) d10 = z;
@@ -416,8 +421,9 @@ __device__ __forceinline__ void pool_relu_grad_quad(const float* __restrict__ dp
 }
 
 // quad form of the reduction pass: a block takes RED_ROWS_PER_BLOCK / 4 quads (same partial-row count as the pixel form)
-__global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                                  const float* __restrict__ x, const float* __restrict__ mean,
+template <typename XT, typename PT>
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const PT* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                  const XT* __restrict__ x, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, int Hi, int Wi, int Ho, int Wo, int64_t MQ,
                                                                   int C, float* __restrict__ partial) {
@@ -437,8 +443,8 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const float* __
             const int k = (int)(t % Hq), b = (int)(t / Hq);
             const int64_t p00 = (((int64_t)b * Hi + 2 * k) * Wi + 2 * j) * cols + col;
             float4 xv[4], g[4];
-            xv[0] = reinterpret_cast<const float4*>(x)[p00]; xv[1] = reinterpret_cast<const float4*>(x)[p00 + cols];
-            xv[2] = reinterpret_cast<const float4*>(x)[p00 + (int64_t)Wi * cols]; xv[3] = reinterpret_cast<const float4*>(x)[p00 + (int64_t)(Wi + 1) * cols];
+            xv[0] = ld4(x, p00); xv[1] = ld4(x, p00 + cols);
+            xv[2] = ld4(x, p00 + (int64_t)Wi * cols); xv[3] = ld4(x, p00 + (int64_t)(Wi + 1) * cols);
             pool_relu_grad_quad(dpool, idx, b, k, j, col, cols, Ho, Wo, xv, mu, is, ga, be, g);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -463,8 +469,9 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const float* __
     }
 }
 
-__global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+template <typename XT, typename PT>
+__global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const PT* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                 const XT* __restrict__ x, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ mg,
                                                                  const float* __restrict__ mgx, int Hi, int Wi, int Ho, int Wo, int64_t nq4,
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const float* __r
     const int64_t off[4] = {p00, p00 + cols, p00 + (int64_t)Wi * cols, p00 + (int64_t)(Wi + 1) * cols};
     float4 xv[4], g[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = reinterpret_cast<const float4*>(x)[off[u]];
+    for (int u = 0; u < 4; ++u) xv[u] = ld4(x, off[u]);
     pool_relu_grad_quad(dpool, idx, b, k, j, col, cols, Ho, Wo, xv, mu, is, ga, be, g);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1421,20 +1428,33 @@ int sd_bn_relu_maxpool_fwd(const float* x, int B, int Hi, int Wi, int C, const f
                "sd_bn_relu_maxpool_fwd: bad arguments");
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
-    hipLaunchKernelGGL(k_bn_relu_maxpool_fwd, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y_pool, idx,
+    hipLaunchKernelGGL((k_bn_relu_maxpool_fwd<float, float>), dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y_pool, idx,
                        B, Hi, Wi, Ho, Wo, C);
     SD_LAUNCH_CHECK();
     return 0;
 }
 
-int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* x, int B, int Hi, int Wi, int C, const float* mean,
-                           const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
-                           void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+int sd_bn_relu_maxpool_fwd_bf16(const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, void* y_pool_bf16, uint8_t* idx, sd_stream_t stream) {
+    SD_REQUIRE(x_bf16 && mean && invstd && gamma && beta && y_pool_bf16 && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0, SD_ERR_INVALID,
+               "sd_bn_relu_maxpool_fwd_bf16: bad arguments");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    hipLaunchKernelGGL((k_bn_relu_maxpool_fwd<uint16_t, uint16_t>), dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, mean,
+                       invstd, gamma, beta, (uint16_t*)y_pool_bf16, idx, B, Hi, Wi, Ho, Wo, C);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C++" {
+template <typename XT, typename PT>
+static int maxpool_bn_relu_bwd_any(const char* what, const PT* dpool, const uint8_t* idx, const XT* x, int B, int Hi, int Wi, int C, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                   void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     const int64_t M = (int64_t)B * Hi * Wi;
-    if (int e = check_mc("sd_maxpool_bn_relu_bwd", M, C)) return e;
-    SD_REQUIRE(dpool && idx && x && mean && invstd && gamma && beta && dx && dgamma && dbeta && workspace, SD_ERR_INVALID,
-               "sd_maxpool_bn_relu_bwd: null pointer");
-    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "sd_maxpool_bn_relu_bwd: workspace too small");
+    if (int e = check_mc(what, M, C)) return e;
+    SD_REQUIRE(dpool && idx && x && mean && invstd && gamma && beta && dx && dgamma && dbeta && workspace, SD_ERR_INVALID, "%s: null pointer", what);
+    SD_REQUIRE(workspace_bytes >= sd_col_reduce_workspace_bytes(M, C), SD_ERR_WORKSPACE, "%s: workspace too small", what);
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const int nb = cdiv(M, RED_ROWS_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
@@ -1442,8 +1462,10 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
     const bool quad = Hi % 2 == 0 && Wi % 2 == 0;        // even maps: 2x2 quads share their four windows
-    if (quad) hipLaunchKernelGGL(k_pool_bn_bwd_reduce_quad, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M / 4, C, partial);
-    else hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
+    constexpr bool F32 = std::is_same<XT, float>::value && std::is_same<PT, float>::value;
+    SD_REQUIRE(quad || F32, SD_ERR_INVALID, "%s: the bf16 form needs even Hi, Wi", what);
+    if (quad) hipLaunchKernelGGL((k_pool_bn_bwd_reduce_quad<XT, PT>), dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M / 4, C, partial);
+    else if constexpr (F32) hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
     SD_LAUNCH_CHECK();
     int rows = nb;
     const float* fin = fold_partials(partial, rows, C, mgx + C, st);
@@ -1451,12 +1473,27 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    if (quad) hipLaunchKernelGGL(k_pool_bn_bwd_apply_quad, dim3(cdiv(n4 / 4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta,
+    if (quad) hipLaunchKernelGGL((k_pool_bn_bwd_apply_quad<XT, PT>), dim3(cdiv(n4 / 4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta,
                                  (const float*)mg, (const float*)mgx, Hi, Wi, Ho, Wo, n4 / 4, C, dx);
-    else hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
-                            (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
+    else if constexpr (F32) hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
+                                               (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
     SD_LAUNCH_CHECK();
     return 0;
+}
+}  // extern "C++"
+
+int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* x, int B, int Hi, int Wi, int C, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                           void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    return maxpool_bn_relu_bwd_any<float, float>("sd_maxpool_bn_relu_bwd", dpool, idx, x, B, Hi, Wi, C, mean, invstd, gamma, beta, dx, dgamma, dbeta,
+                                                 accumulate, workspace, workspace_bytes, stream);
+}
+
+int sd_maxpool_bn_relu_bwd_bf16(const void* dpool_bf16, const uint8_t* idx, const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    return maxpool_bn_relu_bwd_any<uint16_t, uint16_t>("sd_maxpool_bn_relu_bwd_bf16", (const uint16_t*)dpool_bf16, idx, (const uint16_t*)x_bf16, B, Hi, Wi, C,
+                                                       mean, invstd, gamma, beta, dx, dgamma, dbeta, accumulate, workspace, workspace_bytes, stream);
 }
 
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream) {

@@ -266,10 +266,13 @@ class _Engine:
         # stem: conv7x7/2 + BN + ReLU + maxpool3x3/2 (network.py:43-45)
         stem, bn0 = net.adpater[0], net.adpater[1]
         d0 = _desc(B, H, W, stem)
-        s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.float32, device=x.device)
+        # mixed precision: the stem's conv output and pooled map are bf16 too (even maps: the quad form of the tail's backward); BatchNorm
+        # statistics / arithmetic stay fp32
+        amp_stem = bool(amp and training and d0.Ho % 2 == 0 and d0.Wo % 2 == 0)
+        s0 = torch.empty((B, d0.Ho, d0.Wo, 64), dtype=torch.bfloat16 if amp_stem else torch.float32, device=x.device)
         wss = self._ws(lib.sd_conv2d_stem_fwd_workspace_bytes(C.byref(d0)), x.device)
         Hp, Wp = (d0.Ho + 2 - 3) // 2 + 1, (d0.Wo + 2 - 3) // 2 + 1
-        p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.float32, device=x.device)
+        p1 = torch.empty((B, Hp, Wp, 64), dtype=torch.bfloat16 if amp_stem else torch.float32, device=x.device)
         pidx = torch.empty((B, Hp, Wp, 64), dtype=torch.uint8, device=x.device)
         if training:
             # BatchNorm + ReLU + max-pool in one pass over the conv output: the full-resolution activation (1 GB at bs=64,
@@ -277,13 +280,15 @@ class _Engine:
             m0 = torch.empty(64, dtype=torch.float32, device=x.device)
             i0 = torch.empty_like(m0)
             ws = self._ws(lib.sd_conv2d_stem_fwd_bn_stats_workspace_bytes(C.byref(d0)), x.device)
-            stem_fwd = lib.sd_conv2d_stem_fwd_bn_stats_bf16mm if amp else lib.sd_conv2d_stem_fwd_bn_stats      # amp: product on the bf16 MFMA
+            stem_fwd = (lib.sd_conv2d_stem_fwd_bn_stats_bf16 if amp_stem else lib.sd_conv2d_stem_fwd_bn_stats_bf16mm) if amp \
+                else lib.sd_conv2d_stem_fwd_bn_stats                                                           # amp: product on the bf16 MFMA
             L.check(stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), BN_EPS, BN_MOMENTUM,
                              bn0.running_mean.data_ptr(), bn0.running_var.data_ptr(), m0.data_ptr(), i0.data_ptr(),
                              ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_fwd_bn_stats")
             self._nbt.append(bn0.num_batches_tracked)
-            L.check(lib.sd_bn_relu_maxpool_fwd(s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(), bn0.weight.data_ptr(),
-                                               bn0.bias.data_ptr(), p1.data_ptr(), pidx.data_ptr(), L.stream()), "sd_bn_relu_maxpool_fwd")
+            pool_fwd = lib.sd_bn_relu_maxpool_fwd_bf16 if amp_stem else lib.sd_bn_relu_maxpool_fwd
+            L.check(pool_fwd(s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(), bn0.weight.data_ptr(),
+                             bn0.bias.data_ptr(), p1.data_ptr(), pidx.data_ptr(), L.stream()), "sd_bn_relu_maxpool_fwd")
         else:
             sc, sh = self.bn_fold(bn0)
             L.check(lib.sd_conv2d_stem_fwd(x.data_ptr(), stem.weight.data_ptr(), s0.data_ptr(), C.byref(d0), sc.data_ptr(), sh.data_ptr(), 1, 0,
@@ -292,8 +297,8 @@ class _Engine:
             L.check(lib.sd_maxpool3x3s2_fwd(s0.data_ptr(), p1.data_ptr(), pidx.data_ptr(), B, d0.Ho, d0.Wo, 64, L.stream()), "maxpool")
         if rec:
             tape["x"], tape["stem"], tape["amp"] = x, (d0, s0, m0, i0, pidx), bool(amp)
-        if amp:
-            p1 = self._to_bf16(p1)          # the stem's output, statistics and tail stay fp32; everything behind the max-pool is bf16
+        if amp and not amp_stem:
+            p1 = self._to_bf16(p1)          # (odd maps: fp32 stem tail) everything behind the max-pool is bf16
 
         # trunk (network.py:47-50)
         feats, cur, Hc, Wc = [], p1, Hp, Wp
@@ -671,13 +676,15 @@ class _Engine:
         # stem
         d0, s0, m0, i0, pidx = tape["stem"]
         bn0 = net.adpater[1]
-        if amp:
-            dcur = self._to_f32(dcur)           # the stem tail (max-pool / ReLU / BatchNorm backward, 7x7 weight gradient) is the fp32 one
-        ds0 = torch.empty_like(s0)
+        amp_stem = s0.dtype == torch.bfloat16       # bf16 conv output / pooled gradient in, fp32 gradient out (the 7x7 weight gradient is the fp32 one)
+        if amp and not amp_stem:
+            dcur = self._to_f32(dcur)
+        ds0 = torch.empty(s0.shape, dtype=torch.float32, device=s0.device)
         ws = self._ws(lib.sd_col_reduce_workspace_bytes(B * d0.Ho * d0.Wo, 64), s0.device)
-        L.check(lib.sd_maxpool_bn_relu_bwd(dcur.data_ptr(), pidx.data_ptr(), s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(),
-                                           bn0.weight.data_ptr(), bn0.bias.data_ptr(), ds0.data_ptr(), net.grad_of(bn0.weight).data_ptr(),
-                                           net.grad_of(bn0.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_maxpool_bn_relu_bwd")
+        pool_bwd = lib.sd_maxpool_bn_relu_bwd_bf16 if amp_stem else lib.sd_maxpool_bn_relu_bwd
+        L.check(pool_bwd(dcur.data_ptr(), pidx.data_ptr(), s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(),
+                         bn0.weight.data_ptr(), bn0.bias.data_ptr(), ds0.data_ptr(), net.grad_of(bn0.weight).data_ptr(),
+                         net.grad_of(bn0.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_maxpool_bn_relu_bwd")
         stem = net.adpater[0]
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
         L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,

@@ -369,3 +369,41 @@ def test_conv_bf16_row_stream_kernel_64_channels(case):
     finally:
         L.check(lib.sd_set_option(b"conv_rows64_min_units", 192))
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24), (3, 64, 32), (1, 256, 256)])
+def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
+    """sd_bn_relu_maxpool_fwd_bf16 / sd_maxpool_bn_relu_bwd_bf16 (mixed-precision stem tail: bf16 conv output, pooled map and pooled
+    gradient; fp32 arithmetic) against the fp32 kernels on the widened tensors: same winning taps, pooled map = the fp32 result rounded
+    once, input gradient / dgamma / dbeta bit-identical."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W = shape
+    Cc = 64
+    g = torch.Generator().manual_seed(B + H + W)
+    x16 = torch.randn(B, H, W, Cc, generator=g).bfloat16().to(DEV)
+    x32 = x16.float()
+    mean = torch.randn(Cc, generator=g).to(DEV) * 0.1
+    invstd = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(Cc, generator=g) * 0.2).to(DEV)
+    Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y32 = torch.empty(B, Hp, Wp, Cc, device=DEV); i32 = torch.empty(B, Hp, Wp, Cc, dtype=torch.uint8, device=DEV)
+    y16 = torch.empty(B, Hp, Wp, Cc, dtype=torch.bfloat16, device=DEV); i16 = torch.empty_like(i32)
+    L.check(lib.sd_bn_relu_maxpool_fwd(x32.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                       y32.data_ptr(), i32.data_ptr(), L.stream()))
+    L.check(lib.sd_bn_relu_maxpool_fwd_bf16(x16.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            y16.data_ptr(), i16.data_ptr(), L.stream()))
+    assert torch.equal(i16, i32)
+    assert torch.equal(y16, y32.bfloat16())
+    dp16 = torch.randn(B, Hp, Wp, Cc, generator=g).bfloat16().to(DEV)
+    dp32 = dp16.float()
+    ws = torch.empty(max(lib.sd_col_reduce_workspace_bytes(B * H * W, Cc), 256), dtype=torch.uint8, device=DEV)
+    out = {}
+    for tag, fn, dp, xx in (("f32", lib.sd_maxpool_bn_relu_bwd, dp32, x32), ("bf16", lib.sd_maxpool_bn_relu_bwd_bf16, dp16, x16)):
+        dx = torch.empty(B, H, W, Cc, device=DEV); dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+        L.check(fn(dp.data_ptr(), i32.data_ptr(), xx.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()))
+        out[tag] = (dx, dg, db)
+    for a, b in zip(out["f32"], out["bf16"]):
+        assert torch.equal(a, b)

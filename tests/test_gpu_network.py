@@ -348,7 +348,10 @@ def test_network_train_forward_backward():
         assert gg.shape == gr.shape, name
         err = (gg - gr).abs().max().item() / (gr.abs().max().item() + 1e-12)
         worst = max(worst, err)
-        assert err < 2e-3, f"{name}: rel err {err:.2e}"       # 44 fp32 layers deep, BN-coupled batch of 4
+        # 44 fp32 layers deep, BN-coupled batch of 4.  NOTE: with ~400k ReLU inputs some lie within 2e-6 of zero (seed search over 1500 inputs:
+        # never more than 7e-6 away), so this comparison also needs OUR forward to put each of them on the reference's side -- an ulp of
+        # difference in, e.g., the stem's BatchNorm statistics flipped one mask at down2.2 and moved every upstream gradient by 1e-2
+        assert err < 2e-3, f"{name}: rel err {err:.2e}"
     # running statistics follow torch's momentum / unbiased-variance rule
     for name, b in net.named_buffers():
         rb = dict(ref.named_buffers())[name]
