@@ -415,9 +415,9 @@ def main():
                 step.amp = False
             return {"batch": B, "ms_per_step": round(t_amp * 1e3, 3), "images_per_sec": round(B / t_amp, 1),
                     "speedup_vs_fp32_step": round((dt / a.steps) / t_amp, 2),
-                    "note": "bf16 MFMA: stem conv, forward, data-gradient, weight-gradient (transposed LDS reads), head forward; bf16 activations "
-                            "everywhere between the stem conv and the head (stem tail and head backward included); fp32: the stem's weight gradient, all BatchNorm "
-                            "statistics / arithmetic, loss, Adam on fp32 master weights"}
+                    "note": "bf16 MFMA: stem conv and its weight gradient, forward, data-gradient, weight-gradient (transposed LDS reads), head forward; bf16 activations "
+                            "everywhere between the stem conv and the head (stem tail and head backward included); fp32: all BatchNorm statistics / arithmetic, "
+                            "accumulation, loss, Adam on fp32 master weights"}
 
         def fig_stress():
             # BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, K=128, P=512, dense scenes (64-96 objects), bf16 backbone + fp32 decode

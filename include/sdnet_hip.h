@@ -364,6 +364,10 @@ int sd_conv2d_wgrad(const float* dy_nhwc, const float* x_nhwc, float* dw_krsc, c
 size_t sd_conv2d_stem_wgrad_workspace_bytes(const sd_conv_desc* d);
 int sd_conv2d_stem_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw_krsc, const sd_conv_desc* d,
                          int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* ... with the product on the bf16 MFMA (mixed-precision training): dy and the image are rounded to bf16 on their way into the operands,
+ * the sums and dw stay fp32.  Same workspace. */
+int sd_conv2d_stem_wgrad_bf16mm(const float* dy, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream);
 
 /* BatchNorm2d over [M][C] (M = B*H*W): training statistics (biased var for normalisation,
  * running stats with momentum and the unbiased var, torch semantics), apply (+residual, +ReLU),

@@ -2807,6 +2807,141 @@ __global__ __launch_bounds__(256, 1) void k_stem_wgrad2(StemArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient on the bf16 MFMA (mixed-precision step; under autocast the reference's conv1 backward runs in bf16 too):
+// dW[n][k] = sum over pixels of dy[px][n] * patch[px][k] -- the reduction index of the MFMA is the PIXEL, so each operand must present
+// 8 consecutive pixels per lane:
+//   dy    : the tile's 128 x 64 block is transposed on its way into LDS, DT[n][px] (bf16)
+//   patch : element (px, k = (r, s, ci)) is image column 2 px + s of patch row (ci, r): for fixed k the pixels walk every second column.
+//           The patch is split into its even / odd column planes, plane_p[row][i] = patch[row][2 i + p]; then (px, s) is
+//           plane_{s & 1}[row][px + (s >> 1)] -- consecutive in px -- and FOUR copies of every plane, shifted by 0 .. 3 elements, make
+//           each such 8-pixel run a 16-byte aligned ds_read_b128: copy sh holds plane[i + sh] at position i.
+// 16-24 MFMAs (32x32x16) per wave and 128-pixel tile instead of 160 (32x32x2); persistent blocks keep the 64 x 160 dW tile in registers
+// (2-3 of its ten 32 x 32 tiles per wave) and write one partial dW per block.
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_RL = 136;                                    // row length (elements) of the plane copies and of DT: 272-byte rows
+constexpr int SW_ROWS = 22;                                   // 21 (ci, r) rows + one zero row (k >= 147)
+constexpr int SW_PLANES = 2 * 4 * SW_ROWS * SW_RL;            // elements
+constexpr size_t SW_LDS_BYTES = (size_t)(SW_PLANES + 64 * SW_RL) * 2 > (size_t)64 * 160 * 4 ? (size_t)(SW_PLANES + 64 * SW_RL) * 2 : (size_t)64 * 160 * 4;
+
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad_bf16(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint16_t* planes = reinterpret_cast<uint16_t*>(lds);      // [p][sh][row][SW_RL]
+    uint16_t* DT = planes + SW_PLANES;                        // [64][SW_RL]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int i = tid; i < (SW_PLANES + 64 * SW_RL) / 2; i += 256) reinterpret_cast<uint32_t*>(planes)[i] = 0;     // zero row, pads
+    // The ten 32 x 32 tiles of dW (2 along n, 5 along k) are dealt to the waves: wave w owns tiles w, w + 4, w + 8 (three for waves 0 / 1)
+    // over ALL pixels -- 48 accumulator registers, no cross-wave sum at the end (a pixel split needs 160 and spilled).
+    // B operand of k-tile kt: lane fr <-> k = 32 kt + fr = (r * 7 + s) * 3 + ci -> copy (s & 1, s >> 1), row ci * 7 + r
+    int boff[3], aoff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = wave + 4 * u, ni = (t < 10 ? t : 0) / 5, kt = (t < 10 ? t : 0) % 5;
+        const int k = kt * 32 + fr;
+        aoff[u] = (ni * 32 + fr) * SW_RL;
+        if (k < STEM_K) {
+            const int ci = k % 3, tap = k / 3, r = tap / 7, sx = tap - r * 7;
+            boff[u] = ((((sx & 1) * 4 + (sx >> 1)) * SW_ROWS) + ci * 7 + r) * SW_RL;
+        } else {
+            boff[u] = (SW_ROWS - 1) * SW_RL;                   // the zero row of copy (0, 0)
+        }
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+
+    // the operands of a tile: global -> registers -> LDS, the image patch first, then dy (two resident blocks per CU overlap each other's
+    // round trips; fetching tile t + 1 under tile t's MFMAs was measured: 22 spilled registers, 20 % slower)
+    constexpr int TOTAL = SP_ROWS * SP_PITCH, NLD = (TOTAL + 255) / 256;
+    const int pg = tid >> 4, c4 = (tid & 15) * 4;              // dy: pixel group (8 pixels), first of 4 channels
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
+        const int ox0 = tx * 128;
+        __syncthreads();                                       // the previous tile's operands have been read
+        {   // image patch: 21 rows x 261 columns, coalesced along the columns; every element goes to its plane's four shifted copies
+            const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 3;
+            const float* img = p.x + (int64_t)b * 3 * p.H * p.W;
+            float v[NLD];
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = tid + 256 * j;
+                const int row = i / SP_PITCH, col = i - row * SP_PITCH;
+                const int ci = row / 7, r = row - ci * 7;
+                const int iy = iy0 + r, ix = ix0 + col;
+                const bool ok = i < TOTAL && col < SP_USED && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                v[j] = *(ok ? img + ((int64_t)ci * p.H + iy) * p.W + ix : g_zero_line);
+            }
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = tid + 256 * j;
+                const int row = i / SP_PITCH, col = i - row * SP_PITCH;
+                if (i < TOTAL && col < SP_USED) {
+                    const uint16_t h = f2bf(v[j]);
+                    uint16_t* dst = planes + ((col & 1) * 4 * SW_ROWS + row) * SW_RL + (col >> 1);
+#pragma unroll
+                    for (int sh = 0; sh < 4; ++sh)
+                        if ((col >> 1) >= sh) dst[sh * SW_ROWS * SW_RL - sh] = h;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // dy tile, transposed: DT[n][px].  A thread takes 4 channels x 8 consecutive pixels (eight 16-byte loads, a wave-instruction reads
+            // four 256-byte pixel rows) and stores one 16-byte run of 8 pixels per channel
+            const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo + ox0;
+            float4 dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = pg * 8 + j;
+                const float* src = (ox0 + px < p.Wo) ? p.dy + (row0 + px) * 64 + c4 : g_zero_line;
+                dv[j] = *reinterpret_cast<const float4*>(src);
+            }
+            uint4 o[4];
+#define SW_PK(a, b) ((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16))
+            o[0] = make_uint4(SW_PK(dv[0].x, dv[1].x), SW_PK(dv[2].x, dv[3].x), SW_PK(dv[4].x, dv[5].x), SW_PK(dv[6].x, dv[7].x));
+            o[1] = make_uint4(SW_PK(dv[0].y, dv[1].y), SW_PK(dv[2].y, dv[3].y), SW_PK(dv[4].y, dv[5].y), SW_PK(dv[6].y, dv[7].y));
+            o[2] = make_uint4(SW_PK(dv[0].z, dv[1].z), SW_PK(dv[2].z, dv[3].z), SW_PK(dv[4].z, dv[5].z), SW_PK(dv[6].z, dv[7].z));
+            o[3] = make_uint4(SW_PK(dv[0].w, dv[1].w), SW_PK(dv[2].w, dv[3].w), SW_PK(dv[4].w, dv[5].w), SW_PK(dv[6].w, dv[7].w));
+#undef SW_PK
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(DT + (c4 + k) * SW_RL + pg * 8) = o[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int px0 = kk * 16 + fh * 8;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (u < 2 || wave < 2) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(DT + aoff[u] + px0);
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(planes + boff[u] + px0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // every wave writes its tiles: R[n][160]
+    __syncthreads();
+    float* R = lds;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int t = wave + 4 * u;
+        if (t < 10) {
+            const int ni = t / 5, kt = t % 5;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) R[(ni * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * 160 + kt * 32 + fr] = acc[u][e];
+        }
+    }
+    __syncthreads();
+    float* out = p.y + (int64_t)blockIdx.x * 64 * STEM_K;
+    for (int i = tid; i < 64 * STEM_K; i += 256) {
+        const int n = i / STEM_K, k = i - n * STEM_K;
+        out[i] = R[n * 160 + k];
+    }
+}
+
 // parallel split reduction: 8 float4 outputs x 32 lanes over the partial copies per block (deterministic order)
 __global__ __launch_bounds__(256) void k_wgrad_reduce_par(const float* __restrict__ part, float* __restrict__ dw, int64_t n4, int splits,
                                                            int accumulate) {
@@ -3660,6 +3795,28 @@ int sd_conv2d_stem_wgrad(const float* dy, const float* x_nchw, float* dw, const 
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr_once;
     hipLaunchKernelGGL(k_stem_wgrad2, dim3(blocks), dim3(256), lds, st, a);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = 64 * STEM_K / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same gradient with the product on the bf16 MFMA (dy and the image are rounded to bf16 on their way into the operands; fp32 sums)
+int sd_conv2d_stem_wgrad_bf16mm(const float* dy, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_wgrad_bf16mm", d)) return e;
+    SD_REQUIRE(dy && x_nchw && dw && workspace, SD_ERR_INVALID, "sd_conv2d_stem_wgrad_bf16mm: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_wgrad_bf16mm: the stem is 7x7 / stride 2 / pad 3, 3 -> 64");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_wgrad_bf16mm: workspace too small");
+    StemArgs a{};
+    a.x = x_nchw; a.dy = dy; a.y = (float*)workspace;
+    stem_args(a, d);
+    const int blocks = stem_blocks(d);
+    hipStream_t st = (hipStream_t)stream;
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_BYTES);
+    (void)attr_once;
+    hipLaunchKernelGGL(k_stem_wgrad_bf16, dim3(blocks), dim3(256), SW_LDS_BYTES, st, a);
     SD_LAUNCH_CHECK();
     const int64_t n4 = 64 * STEM_K / 4;
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);

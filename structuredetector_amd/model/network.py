@@ -687,8 +687,9 @@ class _Engine:
                          net.grad_of(bn0.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_maxpool_bn_relu_bwd")
         stem = net.adpater[0]
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
-        L.check(lib.sd_conv2d_stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
-                                         ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
+        stem_wgrad = lib.sd_conv2d_stem_wgrad_bf16mm if amp else lib.sd_conv2d_stem_wgrad      # amp: product on the bf16 MFMA (autocast: conv1 in bf16)
+        L.check(stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
+                           ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
         self._join_side()
         self._wt_valid = None                               # the optimizer step that follows changes the weights
         if on_stage:

@@ -407,3 +407,30 @@ def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
         out[tag] = (dx, dg, db)
     for a, b in zip(out["f32"], out["bf16"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32)])
+def test_stem_weight_gradient_on_the_bf16_mfma(shape):
+    """sd_conv2d_stem_wgrad_bf16mm (pixel-major operands transposed on their way into LDS, even / odd column planes of the image patch in
+    four shifted copies) against the fp32 kernel on bf16-rounded operands (products of two bf16 are exact in fp32: only the summation order
+    differs) and against autograd.  Shapes: partial last 128-pixel tile, two tiles per row, a map smaller than a tile."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 3 + W)
+    img = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    d0 = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+    dy = torch.randn(B, 64, d0.Ho, d0.Wo, generator=g).bfloat16().float()
+    img_d = img.to(DEV)
+    dy_d = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = torch.empty(max(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), 256), dtype=torch.uint8, device=DEV)
+    dw32 = torch.empty(64, 7, 7, 3, device=DEV); dw16 = torch.empty_like(dw32)
+    L.check(lib.sd_conv2d_stem_wgrad(dy_d.data_ptr(), img_d.data_ptr(), dw32.data_ptr(), C.byref(d0), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    L.check(lib.sd_conv2d_stem_wgrad_bf16mm(dy_d.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw16.cpu(), dw32.cpu(), 2e-5)
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(img, w, None, 2, 3).backward(dy)
+    close(dw16.permute(0, 3, 1, 2).cpu(), w.grad, 2e-5)
+    # accumulate = 1
+    L.check(lib.sd_conv2d_stem_wgrad_bf16mm(dy_d.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 1, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw16.permute(0, 3, 1, 2).cpu(), 2 * w.grad, 2e-5)
