@@ -122,6 +122,10 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
                     const float* embeddings, int64_t e_sb, int64_t e_sc,
                     int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk,
                     void* packed, void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* Tuning knob of sd_decode_fused (process-wide, not a result-changing setting): "tall_tiles_from" = number of 64x16-pixel tile
+ * blocks of a launch (B x (M+N) x tiles) from which the NMS runs on 64x32 tiles instead (default 2688: batches of 56 and more
+ * at 128x128 maps; 1 = always, 1 << 30 = never).  The sizes returned by sd_decode_state_bytes / _workspace_bytes cover both. */
+int sd_decode_set_option(const char* name, int value);
 
 /* Explicit host wait for everything queued on `stream` (hipStreamSynchronize): the ONE blocking call of the decoder's host side,
  * after which a `packed` buffer that lives in pinned, device-mapped host memory may be read (decoders.py:103-139 reads its

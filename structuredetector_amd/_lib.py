@@ -122,6 +122,7 @@ _SIGNATURES = {
     "sd_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_float, c_float, c_float, c_float, c_float, c_vp]),
     "sd_conv2d_kernel_name": (C.c_char_p, [c_vp, c_int]),
     "sd_set_option": (c_int, [C.c_char_p, c_int]),
+    "sd_decode_set_option": (c_int, [C.c_char_p, c_int]),
     "sd_conv2d_stem_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_stem_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_fwd_bn_stats_bf16mm": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),

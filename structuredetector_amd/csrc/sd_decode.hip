@@ -6,6 +6,8 @@
 // file.
 #pragma clang fp contract(off)
 #include "sd_common.h"
+#include <atomic>
+#include <cstring>
 
 namespace sd {
 
@@ -264,7 +266,7 @@ struct FlatSrc {
     }
 };
 
-constexpr int TILE_CAP = TW * TH;     // candidate slots of one tile: every pixel of a plateau survives the NMS
+// (a tile owns TW x tile-height candidate slots -- TILE_CAP in the comments: every pixel of a plateau survives the NMS)
 constexpr int SPEC = 6;               // keys of a tile that travel INSIDE its 64-byte hand-off record (count word + 6 keys): one round trip
 constexpr int SPEC_TILES = 256;       // ... captured in LDS for the first SPEC_TILES tiles of the image (the others re-read them from the slots)
 
@@ -276,10 +278,11 @@ struct TiledSrc {
     const uint64_t* spec;   // LDS: the first SPEC keys of the tiles that were loaded speculatively (image-wide tile index)
     int tile0;              // image-wide index of the list's first tile
     int ntiles, n;
+    int cap;                // candidate slots of one tile (TW x tile height of the launch)
     __device__ __forceinline__ uint64_t key_at(int t, int j) const {
         const int ti = tile0 + t;
         if (j < SPEC && ti < SPEC_TILES) return spec[ti * SPEC + j];
-        return ldkey<true>(base + (int64_t)t * TILE_CAP + j);
+        return ldkey<true>(base + (int64_t)t * cap + j);
     }
     // candidate g of the list (0 <= g < n) -> (tile, slot): binary search in the exclusive prefix `off`
     __device__ __forceinline__ uint64_t key_of(int gidx) const {
@@ -668,7 +671,7 @@ constexpr int POLL_LIMIT = 1 << 21;
 struct FusedLds {       // byte offsets into the dynamic LDS block of the selector
     int buf, spec, tcnt, toff, hist, flags, out, outk, as_, ps_, posx, posy, ai_, ac_, pi_, pc_, total;
 };
-__host__ __device__ inline FusedLds fused_lds(int K, int P, int ntiles_img, int sort_cap) {
+__host__ __device__ inline FusedLds fused_lds(int K, int P, int ntiles_img, int sort_cap, int th) {
     FusedLds L;
     int o = 0;
     auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
@@ -686,14 +689,16 @@ __host__ __device__ inline FusedLds fused_lds(int K, int P, int ntiles_img, int 
     }
     L.as_ = take(K * 4); L.posx = take(K * 4); L.posy = take(K * 4); L.ai_ = take(K * 4); L.ac_ = take(K * 4);
     L.ps_ = take(P * 4); L.pi_ = take(P * 4); L.pc_ = take(P * 4);
-    const int nms = (LH * LW + LH * TW) * 4;
+    const int nms = ((th + 2 * HALO) * LW + (th + 2 * HALO) * TW) * 4;
     L.total = o > nms ? o : nms;
     return L;
 }
 
+template <int TH_>
 __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group g1, int h, int w, int tiles_x, int tiles, float min_score,
                                                                  uint64_t* cand, unsigned* records, int K, int P, int sort_cap,
                                                                  float conf, float dist_px, RegMaps rm, void* packed, int B) {
+    constexpr int LH_ = TH_ + 2 * HALO, CAP_ = TW * TH_;      // tile height of this launch: fused_tile_height()
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int keep_n;
     __shared__ int misc[2][4];
@@ -705,9 +710,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
     const int64_t blk = blockIdx.x;
 
     if (blk < (int64_t)B * nti) {
-        // ================= tile block: clamped sigmoid + 5x5 NMS of one 64x16 tile ==========================================
+        // ================= tile block: clamped sigmoid + 5x5 NMS of one 64 x TH_ tile ==========================================
         float (*S)[LW] = reinterpret_cast<float(*)[LW]>(smem);
-        float (*Hm)[TW] = reinterpret_cast<float(*)[TW]>(smem + sizeof(float) * LH * LW);
+        float (*Hm)[TW] = reinterpret_cast<float(*)[TW]>(smem + sizeof(float) * LH_ * LW);
         const int b = (int)(blk / nti);
         const int rem = (int)(blk - (int64_t)b * nti);
         const int m = rem / tiles, tile = rem - m * tiles;     // map of the image: anchors 0..M-1, parts M..M+N-1
@@ -715,20 +720,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
         const Group g = grp ? g1 : g0;
         const int c = grp ? m - g0.C : m;
         const int tx0 = (tile % tiles_x) * TW;
-        const int ty0 = (tile / tiles_x) * TH;
+        const int ty0 = (tile / tiles_x) * TH_;
         const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
-        uint64_t* mine = cand + blk * TILE_CAP;
+        uint64_t* mine = cand + blk * CAP_;
         unsigned* rec = records + blk * REC_WORDS;
         SD_TRACE(blk < 1024 ? blk * 4 + 0 : -1);
         if (tid == 0) keep_n = 0;
-        constexpr int NLD = (LH * LW + FUSED_THREADS - 1) / FUSED_THREADS;
+        constexpr int NLD = (LH_ * LW + FUSED_THREADS - 1) / FUSED_THREADS;
         float ld[NLD];
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + j * FUSED_THREADS;
             const int r = i / LW, cc = i - r * LW;
             const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
-            const bool ok = i < LH * LW && y >= 0 && y < h && x >= 0 && x < w;
+            const bool ok = i < LH_ * LW && y >= 0 && y < h && x >= 0 && x < w;
             ld[j] = plane[ok ? (int64_t)y * w + x : 0];
         }
 #pragma unroll
@@ -737,18 +742,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
             const int r = i / LW, cc = i - r * LW;
             const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
             const bool ok = y >= 0 && y < h && x >= 0 && x < w;
-            if (i < LH * LW) S[r][cc] = ok ? clamped_sigmoid(ld[j]) : -INFINITY;
+            if (i < LH_ * LW) S[r][cc] = ok ? clamped_sigmoid(ld[j]) : -INFINITY;
         }
         __syncthreads();
         SD_TRACE(blk < 1024 ? blk * 4 + 1 : -1);
-        for (int i = tid; i < LH * TW; i += FUSED_THREADS) {
+        for (int i = tid; i < LH_ * TW; i += FUSED_THREADS) {
             const int r = i / TW, cc = i - r * TW;
             float mx = fmaxf(fmaxf(S[r][cc], S[r][cc + 1]), fmaxf(S[r][cc + 2], S[r][cc + 3]));
             Hm[r][cc] = fmaxf(mx, S[r][cc + 4]);
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < (TW * TH) / FUSED_THREADS; ++j) {
+        for (int j = 0; j < (TW * TH_) / FUSED_THREADS; ++j) {
             const int i = tid + j * FUSED_THREADS;
             const int r = i / TW, cc = i - r * TW;
             const int y = ty0 + r, x = tx0 + cc;
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
 
     // ================= selector block of image b: wait for the image's records, exact top-K / top-P, association ============
     const int b = (int)(blk - (int64_t)B * nti);
-    const FusedLds Lo = fused_lds(K, P, nti, sort_cap);
+    const FusedLds Lo = fused_lds(K, P, nti, sort_cap, TH_);
     uint64_t* buf = reinterpret_cast<uint64_t*>(smem + Lo.buf);
     uint64_t* spec = reinterpret_cast<uint64_t*>(smem + Lo.spec);
     int* tcnt = reinterpret_cast<int*>(smem + Lo.tcnt);
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
     int* pi_ = reinterpret_cast<int*>(smem + Lo.pi_);
     int* pc_ = reinterpret_cast<int*>(smem + Lo.pc_);
     unsigned* rec_img = records + (int64_t)b * nti * REC_WORDS;
-    const uint64_t* cand_img = cand + (int64_t)b * nti * TILE_CAP;
+    const uint64_t* cand_img = cand + (int64_t)b * nti * CAP_;
     const PackedLayout L = packed_layout(packed, B, K, P);
     SD_TRACE(4096 + b * 8 + 0);
     if (tid < 2) alive[tid] = 0;
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_decode_fused(Group g0, Group 
                      reinterpret_cast<uint64_t*>(smem + Lo.out) + team * Lo.outk, team, alive};
         const int n = team ? n1 : n0, k = team ? P : K;
         const int t0 = team ? split : 0;
-        const TiledSrc<FUSED_TEAM> src{cand_img + (int64_t)t0 * TILE_CAP, tcnt + t0, toff + t0, spec, t0, team ? nti - split : split, n};
+        const TiledSrc<FUSED_TEAM> src{cand_img + (int64_t)t0 * CAP_, tcnt + t0, toff + t0, spec, t0, team ? nti - split : split, n, CAP_};
         team_select_topk<FUSED_TEAM>(T, src, k, max(n0, n1), maxkp, sort_cap);
         SD_TRACE(4096 + b * 8 + 3);
         fill_zero_slots<FUSED_TEAM>(T, min(n, k), k);
@@ -1109,15 +1114,32 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
 
 constexpr int FUSED_LDS_LIMIT = 96 * 1024;    // dynamic LDS the launcher asks for at most (gfx950: 160 KB per CU)
 static int next_pow2_host(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-static size_t fused_tiles(int h, int w) { return (size_t)cdiv(w, TW) * cdiv(h, TH); }
+// Tile height of one fused launch.  64x16 tiles give a small batch the most workgroups (bs=1: 32 + 1); once the launch holds more
+// tile blocks than the chip keeps resident at once (about 1200 with the selector's LDS block), they run in rounds and 64x32 tiles --
+// half the blocks, half the records the selectors wait for, 36 halo rows per 32 instead of 20 per 16 -- finish sooner.  Measured
+// (tools/decode_tile_sweep.py, 3 maps of 128x128, us per launch 64x16 / 64x32): bs=1 12.8 / 14.0, bs=16 14.6 / 15.2, bs=32 16.6 / 16.7,
+// bs=48 18.7 / 18.9, bs=64 21.1 / 20.1, bs=96 25.3 / 23.6, bs=128 29.6 / 27.1: the switch sits at 2688 blocks (bs=56).  sd_decode_set_option("tall_tiles_from", n) moves the switch.
+static std::atomic<int> g_tall_tiles_from{2688};
+int sd_decode_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from.store(value); return 0; }
+    sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
+    return SD_ERR_INVALID;
+}
+static int fused_tile_height(int B, int M, int N, int h, int w) {
+    const int64_t blocks16 = (int64_t)std::max(B, 1) * (M + N) * cdiv(w, TW) * cdiv(h, 16);
+    return blocks16 >= g_tall_tiles_from.load(std::memory_order_relaxed) ? 32 : 16;
+}
+static size_t fused_tiles(int h, int w, int th) { return (size_t)cdiv(w, TW) * cdiv(h, th); }
 
+// both sizes cover EITHER tile height (the option may change between sizing and launch)
 size_t sd_decode_state_bytes(int B, int M, int N, int h, int w) {
-    return align_up((size_t)std::max(B, 1) * (M + N) * fused_tiles(h, w) * REC_WORDS * sizeof(unsigned), 256);
+    return align_up((size_t)std::max(B, 1) * (M + N) * fused_tiles(h, w, 16) * REC_WORDS * sizeof(unsigned), 256);
 }
 
 size_t sd_decode_fused_workspace_bytes(int B, int M, int N, int h, int w, int K, int P) {
     (void)K; (void)P;
-    return align_up((size_t)B * (M + N) * fused_tiles(h, w) * TILE_CAP * 8, 256);
+    const size_t t = std::max(fused_tiles(h, w, 16) * TW * 16, fused_tiles(h, w, 32) * TW * 32);
+    return align_up((size_t)B * (M + N) * t * 8, 256);
 }
 
 #ifdef SD_DECODE_TRACE
@@ -1135,9 +1157,10 @@ int sd_stream_synchronize(sd_stream_t stream) {
 
 int sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P) {
     if (B <= 0 || M <= 0 || N <= 0 || h <= 0 || w <= 0 || K <= 0 || P <= 0) return 0;
-    const int64_t nti = (int64_t)(M + N) * fused_tiles(h, w);
+    // judged on the 64x16 tiling (more tiles, more LDS for their counts): what fits there fits with 64x32 tiles
+    const int64_t nti = (int64_t)(M + N) * fused_tiles(h, w, 16);
     return K <= FUSED_MAX_TOPK && P <= FUSED_MAX_TOPK && B <= 256 && nti <= 32 * FUSED_THREADS && (int64_t)B * nti + B < (1ll << 31) &&
-           fused_lds(K, P, (int)nti, std::max(FUSED_CAP_EXACT, 2 * next_pow2_host(std::max(K, P)))).total <= FUSED_LDS_LIMIT;
+           fused_lds(K, P, (int)nti, std::max(FUSED_CAP_EXACT, 2 * next_pow2_host(std::max(K, P))), 32).total <= FUSED_LDS_LIMIT;
 }
 
 int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* part_hm, int64_t p_sb, int64_t p_sc,
@@ -1155,7 +1178,8 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const fl
     // at most B selector blocks wait inside the grid: keep them far below the resident block slots of the chip (256 CUs x >= 2)
     SD_REQUIRE(B <= 256, SD_ERR_INVALID, "sd_decode_fused: batch %d > 256 (selector blocks must stay resident); use sd_decode", B);
     SD_REQUIRE(packed && workspace && state, SD_ERR_INVALID, "sd_decode_fused: null pointer");
-    const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
+    const int th = fused_tile_height(B, M, N, h, w);
+    const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, th);
     const int tiles = tiles_x * tiles_y;
     const int64_t nti = (int64_t)(M + N) * tiles;
     SD_REQUIRE(nti <= 32 * FUSED_THREADS, SD_ERR_INVALID, "sd_decode_fused: %lld tiles per image > %d; use sd_decode", (long long)nti,
@@ -1168,19 +1192,20 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const fl
     // rank sort needs 2 * np2 <= cap with np2 >= max(K, P): never below 2 * next_pow2(max(K, P))
     int sort_cap = exact_topk ? FUSED_CAP_EXACT : FUSED_CAP_FAST;
     while (sort_cap < 2 * std::max(K, P)) sort_cap *= 2;
-    const FusedLds lds = fused_lds(K, P, (int)nti, sort_cap);
+    const FusedLds lds = fused_lds(K, P, (int)nti, sort_cap, th);
     SD_REQUIRE(lds.total <= FUSED_LDS_LIMIT, SD_ERR_INVALID, "sd_decode_fused: %d maps x %d tiles need %d bytes of LDS (> %d); use sd_decode",
                M + N, tiles, lds.total, FUSED_LDS_LIMIT);
+    auto kern = th == 32 ? k_decode_fused<32> : k_decode_fused<16>;
     if (lds.total > 48 * 1024) {
-        static thread_local bool raised = false;      // per host thread: cheap, idempotent
-        if (!raised) {
-            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fused), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_LIMIT));
-            raised = true;
+        static thread_local bool raised[2] = {false, false};      // per host thread: cheap, idempotent
+        if (!raised[th == 32]) {
+            SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_LIMIT));
+            raised[th == 32] = true;
         }
     }
     Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
     RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
-    hipLaunchKernelGGL(k_decode_fused, dim3((unsigned)(B * nti + B)), dim3(FUSED_THREADS), (size_t)lds.total, (hipStream_t)stream, g0, g1,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * nti + B)), dim3(FUSED_THREADS), (size_t)lds.total, (hipStream_t)stream, g0, g1,
                        h, w, tiles_x, tiles, exact_topk ? 0.f : conf, reinterpret_cast<uint64_t*>(workspace),
                        reinterpret_cast<unsigned*>(state), K, P, sort_cap, conf, dist_px, rm, packed, B);
     SD_LAUNCH_CHECK();

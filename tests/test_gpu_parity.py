@@ -459,11 +459,17 @@ def test_fused_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, k
                                              M, N, noise=0.3) for _ in range(B)])
     views = head_views(dev(head), M, N)
     dec = Decoder(make_args(M, N, K, P))
-    for exact in (True, False, True):
-        want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-        for _ in range(3):                                                                       # back-to-back: no memset in between
-            got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=True)
-            assert torch.equal(got, want), f"exact_topk={exact}"
+    from structuredetector_amd import _lib as L
+    try:
+        for tall_from in (1 << 30, 1, 2688):                                                     # 64x16 tiles, 64x32 tiles, the default switch
+            L.check(L.lib().sd_decode_set_option(b"tall_tiles_from", tall_from))
+            for exact in (True, False, True):
+                want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+                for _ in range(3):                                                               # back-to-back: no memset in between
+                    got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=True)
+                    assert torch.equal(got, want), f"exact_topk={exact} tall_tiles_from={tall_from}"
+    finally:
+        L.check(L.lib().sd_decode_set_option(b"tall_tiles_from", 2688))
     state = next(iter(dec._state.values()))
     assert int(state.view(torch.int32).abs().sum()) == 0                                        # counters left zero
     if kind == "scene":

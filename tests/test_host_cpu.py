@@ -187,6 +187,12 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_set_option(b"conv_patch_bn64", 0) == 0
     assert lib.sd_set_option(b"no_such_option", 1) == -1
     assert b"no_such_option" in lib.sd_last_error()
+    # the decoder's tuning knob: sizes handed out cover both tile heights, whatever the knob says at launch time
+    ws = lib.sd_decode_fused_workspace_bytes(64, 2, 1, 132, 128, 20, 40)
+    assert lib.sd_decode_set_option(b"tall_tiles_from", 1) == 0
+    assert lib.sd_decode_fused_workspace_bytes(64, 2, 1, 132, 128, 20, 40) == ws >= 64 * 3 * 2 * 5 * 2048 * 8
+    assert lib.sd_decode_set_option(b"tall_tiles_from", 2688) == 0
+    assert lib.sd_decode_set_option(b"nope", 1) == -1 and b"nope" in lib.sd_last_error()
     # kernel choice is host arithmetic on the descriptor: a 3x3 / 1 / 1 conv with a chip-filling grid takes the patch kernel,
     # a strided one the 256-row tile kernel, a small one the 128-row tiles
     d = L.ConvDesc()
