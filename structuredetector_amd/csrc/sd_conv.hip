@@ -514,35 +514,48 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         // (now idle) LDS stage buffers once -- each wave has a 64 x BN/2 float region of its own, no block barrier -- and comes
         // back as rows: 16 + 16 instructions of 16 bytes per lane.
         constexpr int TWC = BN / 2;                    // wave tile columns
+        constexpr int LPR = TWC / 4, RPI = 64 / LPR;   // lanes per row, rows per pass
+        const int c4 = (lane % LPR) * 4, n = n0 + wn0 + c4;
         float* T = reinterpret_cast<float*>(BN == 128 ? (wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? Bs0 : Bs1)
                                                       : (wave == 0 ? Bs0 : wave == 1 ? Bs1 : wave == 2 ? As0 : As1));
+        // bf16: the residual rows of the whole wave tile are requested BEFORE the trip through LDS (one memory round trip per
+        // tile instead of one per four rows: the residual convs were 25 % slower than the plain ones for nothing but this latency)
+        uint2 rr[64 / RPI] = {};
+        if constexpr (BF16) {
+            if (p.res) {
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int row = it * RPI + lane / LPR;
+                    const int m = orow[wm0 + row];
+                    const int64_t rm = m < 0 ? -1 : (p.res_up2 ? (int64_t)rrow[wm0 + row] : (int64_t)m);
+                    // (no row: any valid address -- the value is dropped below; a select, not a branch around the load)
+                    rr[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + (rm >= 0 ? rm * p.Nn : 0) + n);
+                }
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) T[(mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * TWC + ni * 32 + fr] = acc[mi][ni][e];
-        constexpr int LPR = TWC / 4, RPI = 64 / LPR;   // lanes per row, rows per pass
-        const int c4 = (lane % LPR) * 4, n = n0 + wn0 + c4;
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
         if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
         BnRed4 br;
         if (bwd_red) bnred4_init(br, p, n);
-#pragma unroll 4
-        for (int it = 0; it < 64 / RPI; ++it) {
+        auto out_row = [&](int it, uint2 r16) {
             const int row = it * RPI + lane / LPR;
             const int m = orow[wm0 + row];
-            if (m < 0) continue;
+            if (m < 0) return;
             float4 v = *reinterpret_cast<const float4*>(T + row * TWC + c4);
             v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
             if (p.res) {
                 const int64_t rm = p.res_up2 ? rrow[wm0 + row] : m;
                 if (rm >= 0) {
                     if (BF16) {
-                        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + rm * p.Nn + n);
-                        v.x += bf2f((uint16_t)(r.x & 0xffff)); v.y += bf2f((uint16_t)(r.x >> 16));
-                        v.z += bf2f((uint16_t)(r.y & 0xffff)); v.w += bf2f((uint16_t)(r.y >> 16));
+                        v.x += bf2f((uint16_t)(r16.x & 0xffff)); v.y += bf2f((uint16_t)(r16.x >> 16));
+                        v.z += bf2f((uint16_t)(r16.y & 0xffff)); v.w += bf2f((uint16_t)(r16.y >> 16));
                     } else {
                         const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -559,6 +572,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
                 if (bwd_red) bnred4_add(br, p, v, m, n);
             }
+        };
+        if constexpr (BF16) {
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) out_row(it, rr[it]);
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 64 / RPI; ++it) out_row(it, make_uint2(0u, 0u));
         }
         if (bwd_red) {      // BatchNorm-backward reduction: lanes -> wave (64 rows) -> the two wave rows -> one partial row per tile
             bnred4_wave_sum<LPR>(br);
@@ -628,6 +648,21 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         const bool two = T1 != nullptr;
         const int npass = two ? MT / 2 : MT, rpp = two ? 64 : 32;
         for (int h = 0; h < npass; ++h) {
+            // bf16: the residual rows of the pass are requested before its trip through LDS (see k_conv_igemm's epilogue)
+            uint2 rr[16] = {};
+            if constexpr (BF16) {
+                if (p.res) {
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        if (it * 4 < rpp) {
+                            const int trow = wm0 + h * rpp + it * 4 + (lane >> 4);
+                            const int m = row_to_m(trow);
+                            const int64_t rm = m < 0 ? -1 : (p.res_up2 ? (int64_t)row_to_res(trow, m) : (int64_t)m);
+                            rr[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + (rm >= 0 ? rm * p.Nn : 0) + n);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int ni = 0; ni < NTW; ++ni)
 #pragma unroll
@@ -643,22 +678,19 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                     T0[r * 64 + ni * 32 + fr] = v0;
                     if (two) T1[r * 64 + ni * 32 + fr] = v1;
                 }
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                if (it * 4 >= rpp) break;
+            auto out_row = [&](int it, uint2 r16) {
                 const int rl = it * 4 + (lane >> 4);                      // row inside this pass
                 const int trow = wm0 + h * rpp + rl;
                 const int m = row_to_m(trow);
-                if (m < 0) continue;
+                if (m < 0) return;
                 float4 v = *reinterpret_cast<const float4*>((rl < 32 ? T0 : T1) + (rl & 31) * 64 + c4);
                 v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
                 if (p.res) {
                     const int64_t rm = p.res_up2 ? (int64_t)row_to_res(trow, m) : (int64_t)m;
                     if (rm >= 0) {
                         if (BF16) {
-                            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + rm * p.Nn + n);
-                            v.x += bf2f((uint16_t)(r.x & 0xffff)); v.y += bf2f((uint16_t)(r.x >> 16));
-                            v.z += bf2f((uint16_t)(r.y & 0xffff)); v.w += bf2f((uint16_t)(r.y >> 16));
+                            v.x += bf2f((uint16_t)(r16.x & 0xffff)); v.y += bf2f((uint16_t)(r16.x >> 16));
+                            v.z += bf2f((uint16_t)(r16.y & 0xffff)); v.w += bf2f((uint16_t)(r16.y >> 16));
                         } else {
                             const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -674,6 +706,17 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
                     if (bwd_red) bnred4_add(br, p, v, m, n);
+                }
+            };
+            if constexpr (BF16) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it)
+                    if (it * 4 < rpp) out_row(it, rr[it]);
+            } else {
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    if (it * 4 >= rpp) break;
+                    out_row(it, make_uint2(0u, 0u));
                 }
             }
         }
