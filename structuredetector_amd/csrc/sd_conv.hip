@@ -96,6 +96,7 @@ struct ConvArgs {
                           // raw conv output (sum, sum of squares), finished by sd_bn_finalize / k_col_finalize<0> (nullable)
     // k_conv3x3_patch geometry (host-computed): tile = 256 consecutive output pixels = 256/Wo whole rows of a 2^pt_tw_log2-wide map
     int pt_tw_log2, pt_pw, pt_pieces, pt_rolling, pt_flip;
+    int pt_strip_log2;       // k_conv3x3_bf16_pp: log2 of the column strips a map row is cut into (0: a sub-tile's rows span the map)
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
                           // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
 };
@@ -1344,10 +1345,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = tile / n_tiles;
     const int n0 = (tile % n_tiles) * BN;
-    const int m0 = tile_m * PP_BM + grp * BMB;                  // this group's 256-pixel sub-tile
+    // this group's 256-pixel sub-tile: TH rows of TW pixels -- whole map rows, or (maps of 128 pixels and wider) a 64-pixel column
+    // strip of four rows, so that its patch still fits a double-buffered 25 KB stage; the two groups of a block take neighbours
     const int TWl = p.pt_tw_log2, TW = 1 << TWl, PW = p.pt_pw, TH = BMB >> TWl;
-    const int hw = p.Ho * p.Wo;
-    const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> TWl;
+    const int q = tile_m * 2 + grp, spi = (p.Ho / TH) << p.pt_strip_log2;      // sub-tile, sub-tiles per image
+    const int bimg = q / spi, rq = q - bimg * spi;
+    const int y0 = (rq >> p.pt_strip_log2) * TH, x0 = (rq & ((1 << p.pt_strip_log2) - 1)) << TWl;
+    const int mbase = (bimg * p.Ho + y0) * p.Wo + x0;           // output pixel of the sub-tile's first row / column
     const int nchunks = p.Ck / KC;
     float* const Pt = pp_lds + grp * (2 * PT_STAGE_FLOATS);
     float* const Bs = pp_lds + 4 * PT_STAGE_FLOATS;
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
         const int j = (wl + 4 * i < p.pt_pieces) ? wl + 4 * i : wl;
         const int pp = j * 16 + prow;
         const int py = pp / PW, pxx = pp - py * PW;
-        const int iy = y0 - 1 + py, ix = pxx - 1;
+        const int iy = y0 - 1 + py, ix = x0 + pxx - 1;
         const bool ok = py < TH + 2 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         const int qe = (pslot ^ ((pp >> 2) & 3)) * EPS;
         pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : zero_ + qe;
@@ -1499,7 +1503,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     __syncthreads();
     float* T0 = pp_lds + wave * 4096;
     tile_epilogue<BN, 4, 2, MT, NTW, true, true, true>(
-        p, acc, [&](int row) { return tile_m * PP_BM + row; },
+        p, acc, [&](int row) { const int ml = row & (BMB - 1); return mbase + (ml >> TWl) * p.Wo + (ml & (TW - 1)); },   // (rows of the wave's own group)
         [&](int, int m) {
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
@@ -1664,12 +1668,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
                 *reinterpret_cast<uint4*>(p.y + rowbase + pxl * 64 + sc8 * 8) = o;
             }
         };
-        auto fetch_res = [&](int yy) {
-            const int64_t rowbase = (((int64_t)b * p.H + yy) * p.W + x0 + wave * 32) * 64;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) resv[it] = *reinterpret_cast<const uint4*>(p.res + rowbase + (spx + 8 * it) * 64 + sc8 * 8);
-        };
-
         for (int iy = y0 - 1; iy <= min(y0 + 2, y1); ++iy) issue_row(iy);
         wait_vmcnt<0>();
         __syncthreads();
@@ -3163,16 +3161,29 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     return true;
 }
 
-// k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered (not rolling) patch geometry, whole 512-pixel
-// tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
+// k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered patch geometry (maps up to 64 pixels wide as whole
+// rows, wider ones as 64-pixel column strips), whole 512-pixel tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
 static int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
+static int g_pp_strips = 1;             // sd_set_option("conv_pp_strips", 0): maps of 128 pixels and wider stay on k_conv3x3_patch (A/B)
 static bool conv_pp_geometry(ConvArgs& a, int mode) {
-    if (a.Nn % 128 || a.M % PP_BM) return false;
+    if (a.Nn % 128 || a.M % PP_BM || (a.M / PP_BM) * (a.Nn / 128) < g_pp_min_tiles) return false;
+    a.pt_strip_log2 = 0;
+    int l2 = 0;
+    while ((1 << l2) < a.Wo) ++l2;
+    if (g_pp_strips && (1 << l2) == a.Wo && a.Wo >= 128 && a.Wo <= 4096 && a.Ho % 4 == 0) {
+        // maps of 128 pixels and wider: a sub-tile is a 64-pixel column strip of four rows (patch 6 x 66 pixels, the geometry of a
+        // 64-pixel-wide map) -- k_conv3x3_patch would take them with its single rolling buffer.  Same conditions as conv_patch_geometry.
+        if (!SD_CONV_PATCH || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+        if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
+        if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % 32) return false;
+        a.pt_tw_log2 = 6; a.pt_strip_log2 = l2 - 6; a.pt_rolling = 0; a.pt_pw = 66; a.pt_pieces = cdiv(6 * 66, 16); a.pt_flip = a.rsign < 0;
+        return true;
+    }
     const int keep = g_patch_min_tiles;
     g_patch_min_tiles = 1;
     const bool ok = conv_patch_geometry(a, 128, mode, true);
     g_patch_min_tiles = keep;
-    return ok && !a.pt_rolling && (a.M / PP_BM) * (a.Nn / 128) >= g_pp_min_tiles;
+    return ok && !a.pt_rolling;
 }
 
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
@@ -3915,6 +3926,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_min_tiles")) { g_patch_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
+    if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");

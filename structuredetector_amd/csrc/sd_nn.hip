@@ -1020,9 +1020,11 @@ __global__ __launch_bounds__(256) void k_head_fwd_bf16_c128(const uint16_t* __re
         for (int pc = 0; pc < 16; ++pc) {
             const int r = pc * 4 + rsub;
             const int64_t m = min(m0 + r, M - 1);                              // (rows past the end re-read the last pixel; never stored)
-            const uint16_t* src = x + m * 128 + ((slot ^ (r & 15)) << 3);
 #if defined(__HIP_DEVICE_COMPILE__)
+            const uint16_t* src = x + m * 128 + ((slot ^ (r & 15)) << 3);
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(T + pc * 256), 16, 0, 0);
+#else
+            (void)m; (void)slot;
 #endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

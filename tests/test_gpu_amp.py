@@ -261,7 +261,9 @@ def test_amp_training_reduces_loss_and_cli(tmp_path, monkeypatch, capsys):
     assert "epoch 1: total" in out and "validation (" in out
 
 
-@pytest.mark.parametrize("case", [(4, 32, 32, 128, 128, 3, 1, 1), (2, 16, 16, 256, 256, 3, 1, 1), (2, 64, 64, 128, 256, 3, 1, 1), (6, 16, 16, 128, 128, 3, 1, 1)])
+@pytest.mark.parametrize("case", [(4, 32, 32, 128, 128, 3, 1, 1), (2, 16, 16, 256, 256, 3, 1, 1), (2, 64, 64, 128, 256, 3, 1, 1), (6, 16, 16, 128, 128, 3, 1, 1),
+                                  # maps of 128 pixels and wider: 64-pixel column strips of four rows (2 and 4 strips; 3 row blocks)
+                                  (1, 8, 128, 128, 128, 3, 1, 1), (1, 4, 256, 128, 128, 3, 1, 1), (2, 12, 128, 128, 256, 3, 1, 1)])
 def test_conv_bf16_two_group_kernel(case):
     """k_conv3x3_bf16_pp (512-pixel x 128-channel tiles, two wave groups half a tap apart, 7-stage weight ring): forced onto small
     grids with sd_set_option, then the same checks as the other bf16 conv kernels (forward + fused statistics, data-gradient with

@@ -207,7 +207,7 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm<128, 0, false>"
     # the bf16 dispatch (passes 16 / 17 = sd_conv2d_fwd_bf16 / sd_conv2d_dgrad_bf16) at bs=64, 512x512: layer2 / layer3 3x3 convs take the
     # two-group kernel (>= 200 tiles of 512 pixels), layer1 the row stream (>= 16 rows per unit), layer4 (128 tiles) and strided convs the
-    # generic implicit GEMM, up4.conv (128-wide map) the one-group patch kernel; small batches fall back to the tile kernels / split-K
+    # generic implicit GEMM, up4.conv (128-wide map) the two-group kernel on column strips (the one-group patch kernel without them); small batches fall back to the tile kernels / split-K
     def name(B, H, cin, cout, k=3, stride=1, pad=1, which=16):
         e = L.ConvDesc()
         e.B, e.Hi, e.Wi, e.Cin, e.Cout, e.R, e.S, e.stride, e.pad = B, H, H, cin, cout, k, k, stride, pad
@@ -218,7 +218,10 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
         assert name(64, 32, 256, 256, which=which) == "k_conv3x3_bf16_pp"
         assert name(64, 128, 64, 64, which=which) == "k_conv3x3_c64_rows_bf16"
         assert name(64, 16, 512, 512, which=which) == "k_conv_igemm<128, 0, true>"
+        assert name(64, 128, 128, 128, which=which) == "k_conv3x3_bf16_pp"          # up4.conv: 64-pixel column strips
+        assert lib.sd_set_option(b"conv_pp_strips", 0) == 0
         assert name(64, 128, 128, 128, which=which) == "k_conv3x3_patch<128, true>"
+        assert lib.sd_set_option(b"conv_pp_strips", 1) == 0
     assert name(64, 64, 128, 256, stride=2) == "k_conv_igemm<128, 0, true>"
     assert name(64, 64, 128, 256, stride=2, which=17) == "k_conv_igemm<128, 2, true>"
     assert name(16, 64, 128, 128) == "k_conv_igemm<128, 0, true>"         # 128 two-group tiles < 200 and 256 one-group tiles < 512
