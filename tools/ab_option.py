@@ -36,7 +36,7 @@ def ab(label, fn):
     print(f"{label}: {name.decode()}={va}: {min(res[va]):.3f} ms   ={vb}: {min(res[vb]):.3f} ms   ({min(res[vb]) / min(res[va]) - 1:+.1%})", flush=True)
 
 
-for (B, img, M, N, K, P) in ((64, 512, 2, 1, 20, 40), (16, 1024, 8, 8, 128, 512)):
+for (B, img, M, N, K, P) in (() if "--train-only" in sys.argv else ((64, 512, 2, 1, 20, 40), (16, 1024, 8, 8, 128, 512))):
     args = make_args(dev, M, N, K, P)
     net = Network(args, pretrained=False).to(dev).eval()
     net.bf16_inference = True
@@ -57,3 +57,5 @@ step = TrainStep(net, args)
 images = torch.randn(64, 3, 512, 512, device=dev)
 plan = enc.upload(enc.plan(512, 512, *synthetic_batch(np.random.default_rng(0), 64, 512, 512, 2, 1)))
 ab("mixed-precision train step B=64", lambda: step(images, enc.render_device(plan)))
+step.amp = False
+ab("fp32 train step B=64", lambda: step(images, enc.render_device(plan)))
