@@ -22,6 +22,7 @@ python3 bench.py > $OUT/${TAG}_bench_default_run.json 2> gpurun_out/mp_bench.err
 stats train_fp32 tools/prof_train.py 4
 stats train_amp tools/prof_train.py 4 amp
 stats fwd_bf16 tools/prof_bf16_fwd.py 6
+stats fwd_bf16_stress tools/prof_bf16_fwd.py 6 stress
 # 4. decoder variants (per-kernel durations + device span per call)
 bash tools/decode_prof.sh $TAG > /dev/null 2>&1 && cp gpurun_out/decode_prof_$TAG.txt $OUT/${TAG}_decode_variants.txt
 # 5. HBM traffic of the conv kernels (PMC, separate passes)
