@@ -3122,9 +3122,9 @@ static int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_op
 
 // k_conv3x3_patch applies: unit-stride 3x3 with pad 1 (fwd: rsign +1, off -1; dgrad: rsign -1, off +1), map width 16..128 (power
 // of two), images that are whole 256-pixel tiles, no split-K, and a grid that fills the chip.  Fills the geometry fields.
-static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false) {
+static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false, bool allow64 = false) {
     // (64-channel tiles: on for bf16, where they gain 2 %; opt-in for fp32)
-    if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64 && !bf16) || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+    if (!SD_CONV_PATCH || (BN == 64 && !g_patch_bn64 && !bf16 && !allow64) || mode != 0 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
     if (a.Ho != a.Hi || a.Wo != a.Wi || a.Ck % (bf16 ? 32 : BKB)) return false;
     int l2 = 0;
@@ -3138,6 +3138,20 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
     a.pt_pieces = a.pt_rolling ? 36 : cdiv((th + 2) * a.pt_pw, 16);
     a.pt_flip = a.rsign < 0;
     return a.pt_pieces * 256 <= (a.pt_rolling ? PT_FLOATS : PT_STAGE_FLOATS);
+}
+
+// Output-channel width of the patch-staging tile that takes this conv (0: none; fills the geometry fields).  128-channel tiles when
+// they fill the chip; an fp32 layer whose 128-channel tiles do not (layer4 at bs=64: 256 tiles) takes 64-channel tiles if those do
+// (sd_set_option("conv_patch_narrow", 0) switches that off).
+static int g_patch_narrow = 1;            // same-box A/B (tools/ab_option.py): fp32 step -0.5 % (layer4: k_conv_igemm<128> -> k_conv3x3_patch<64>)
+static int patch_tile_bn(ConvArgs& a, int BN, int mode, bool bf16) {
+    ConvArgs t = a;
+    if (conv_patch_geometry(t, BN, mode, bf16)) { a = t; return BN; }
+    if (!bf16 && BN == 128 && g_patch_narrow) {
+        t = a;
+        if (conv_patch_geometry(t, 64, mode, false, true)) { a = t; return 64; }
+    }
+    return 0;
 }
 
 // k_conv3x3_c64_rows_bf16 applies: bf16, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
@@ -3241,13 +3255,13 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     }
     if (!stem) {
         ConvArgs pa = a;
-        if (conv_patch_geometry(pa, BN, mode, bf16)) {
-            const int pt_tiles = (pa.M / BMB) * (pa.Nn / BN);
+        if (const int PBN = patch_tile_bn(pa, BN, mode, bf16)) {
+            const int pt_tiles = (pa.M / BMB) * (pa.Nn / PBN);
             if (bf16) {
-                if (BN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
                 else hipLaunchKernelGGL((k_conv3x3_patch<64, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
             } else {
-                if (BN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
                 else hipLaunchKernelGGL((k_conv3x3_patch<64, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
             }
             SD_LAUNCH_CHECK();
@@ -3367,7 +3381,7 @@ static int fwd_stat_rows(const sd_conv_desc* d, bool bf16 = false) {
     if (bf16 && conv_rows64_geometry(a, 0, ra)) return ra.nunits;
     if (bf16 && conv_pp_geometry(t, 0)) return a.M / PP_BM;
     t = a;
-    return (conv_patch_geometry(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+    return (patch_tile_bn(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
 size_t sd_conv2d_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d) {
@@ -3885,7 +3899,7 @@ static int dgrad_stat_rows(const sd_conv_desc* d) {
     const int BN = (a.Nn % 128 == 0) ? 128 : 64;
     const int mode = a.par ? 2 : (a.div > 1 ? 3 : 0);
     ConvArgs t = a;
-    return (conv_patch_geometry(t, BN, mode) || igemm_big_tiles(a, BN, mode)) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
+    return (patch_tile_bn(t, BN, mode, false) || igemm_big_tiles(a, BN, mode)) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
 }
 
 size_t sd_conv2d_dgrad_bn_reduce_workspace_bytes(const sd_conv_desc* d) {
@@ -3927,6 +3941,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
+    if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
@@ -3960,7 +3975,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
         return name;
     }
-    if (conv_patch_geometry(t, BN, mode)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", BN);
+    if (const int PBN = patch_tile_bn(t, BN, mode, false)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", PBN);
     else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
     return name;

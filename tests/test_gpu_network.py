@@ -455,6 +455,7 @@ def test_bn_backward_reduction_fused_into_dgrad_matches_separate_pass():
     assert (grads[0] - grads[1]).abs().max().item() <= 2e-4 * scale
 
 
+NARROW_DEFAULT = 1      # sd_set_option("conv_patch_narrow") default of the library
 PATCH_CASES = [  # B, H, W, cin, cout: 3x3 / 1 / 1 convs whose geometry fits k_conv3x3_patch (rows of 16..128 pixels, 256-pixel tiles)
     (3, 16, 16, 64, 64), (2, 32, 32, 128, 128), (1, 64, 64, 64, 128), (1, 8, 128, 64, 64), (1, 4, 128, 128, 256), (5, 16, 16, 256, 128),
     (2, 6, 128, 128, 128),
@@ -524,6 +525,51 @@ def test_conv3x3_patch_kernel_with_fused_bn_statistics():
         close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
     finally:
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+
+
+def test_conv3x3_patch_kernel_narrow_tiles_for_wide_layers():
+    """A layer whose 128-channel patch tiles do not fill the chip (layer4 at bs=64: 256 tiles) takes 64-channel tiles when those do
+    (`conv_patch_narrow`): forward with the fused BatchNorm statistics (one partial row per 256-pixel tile row, eight channel tiles)
+    and the data-gradient with a residual, against torch."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout = 4, 16, 16, 256, 256
+    lib = L.lib()
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
+    L.check(lib.sd_set_option(b"conv_patch_min_tiles", 12))          # 4 x 2 tiles of 128 channels < 12 <= 4 x 4 tiles of 64
+    L.check(lib.sd_set_option(b"conv_patch_narrow", 1))
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_patch<64, false>"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 1).decode() == "k_conv3x3_patch<64, false>"
+        L.check(lib.sd_set_option(b"conv_patch_narrow", 0))
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv_igemm<128, 0, false>"
+        L.check(lib.sd_set_option(b"conv_patch_narrow", 1))
+        y = torch.empty(B, H, W, cout, device=DEV)
+        mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        ws = torch.empty(max(lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+        xd, wd = nhwc(x), krsc(w)
+        L.check(lib.sd_conv2d_fwd_bn_stats(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, 0, 0, mean.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+        ref = F.conv2d(x, w, None, 1, 1)
+        close(from_nhwc(y), ref, 2e-6 * (cin * 9) ** 0.5)
+        close(mean.cpu(), ref.double().mean((0, 2, 3)).float(), 1e-5)
+        close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
+        dy = torch.randn(B, cout, H, W, generator=g)
+        skip = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.empty(cin * 9 * cout, device=DEV)
+        L.check(lib.sd_conv2d_transpose_weights(wd.data_ptr(), wt.data_ptr(), cout, 9, cin, L.stream()))
+        dx = torch.empty(B, H, W, cin, device=DEV)
+        L.check(lib.sd_conv2d_dgrad(nhwc(dy).data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc(skip).data_ptr(), L.stream()))
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, 1, 1).backward(dy)
+        close(from_nhwc(dx), xr.grad + skip, 1e-5)
+    finally:
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+        L.check(lib.sd_set_option(b"conv_patch_narrow", NARROW_DEFAULT))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
 
 
 def test_fused_bn_relu_maxpool_forward_backward():

@@ -201,6 +201,14 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<128, false>"
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<128, false>"
     assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
+    # layer4 at bs=64 (16x16 maps, 512 channels): 256 patch tiles of 128 channels do not fill the chip, 512 tiles of 64 channels do
+    d.Hi = d.Wi = d.Ho = d.Wo = 16; d.Cin = d.Cout = 512
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<64, false>"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<64, false>"
+    assert lib.sd_set_option(b"conv_patch_narrow", 0) == 0
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv_igemm<128, 0, false>"
+    assert lib.sd_set_option(b"conv_patch_narrow", 1) == 0
+    d.Hi = d.Wi = d.Ho = d.Wo = 64; d.Cin = d.Cout = 128
     d.stride, d.Ho, d.Wo = 2, 32, 32
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2>"
     d.B, d.stride, d.Ho, d.Wo = 1, 1, 64, 64
