@@ -269,8 +269,8 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * patch-staging kernel (default 512 = two resident blocks per CU; 1 = always, for tests; 1 << 30 = never);
  * "conv_patch_bn64": 1 = also for layers with 64 output channels (default 0: slower inside the training step);
  * "conv_pp_min_tiles": smallest grid of 512-pixel x 128-channel tiles for which the bf16 3x3 stride-1 convs take the two-group
- * kernel k_conv3x3_bf16_pp (default 200; 1 = always, for tests; 1 << 30 = never); "conv_patch_narrow": 0 = fp32 layers whose 128-channel patch
- * tiles do not fill the chip do not fall back to 64-channel patch tiles (default 1); "conv_pp_strips": 0 = maps of 128 pixels and wider are
+ * kernel k_conv3x3_bf16_pp (default 200; 1 = always, for tests; 1 << 30 = never); "conv_patch_narrow": layers whose 128-channel patch
+ * tiles do not fill the chip fall back to 64-channel patch tiles (0 never, 1 fp32 only, 2 = default: fp32 and bf16); "conv_pp_strips": 0 = maps of 128 pixels and wider are
  * not cut into 64-pixel column strips for that kernel (default 1; A/B measurements); "conv_fwd_split_k": 0 = the forward convs never
  * split K over blocks (default 1: small grids do), so that tests can put small problems on the single-pass kernels;
  * "conv_rows64_min_units": smallest number of (image, 128-pixel strip, row range) units for which the bf16 64 -> 64 channel 3x3 convs take

@@ -3141,15 +3141,15 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
 }
 
 // Output-channel width of the patch-staging tile that takes this conv (0: none; fills the geometry fields).  128-channel tiles when
-// they fill the chip; an fp32 layer whose 128-channel tiles do not (layer4 at bs=64: 256 tiles) takes 64-channel tiles if those do
-// (sd_set_option("conv_patch_narrow", 0) switches that off).
-static int g_patch_narrow = 1;            // same-box A/B (tools/ab_option.py): fp32 step -0.5 % (layer4: k_conv_igemm<128> -> k_conv3x3_patch<64>)
+// they fill the chip; a layer whose 128-channel tiles do not (layer4 at bs=64: 256 tiles) takes 64-channel tiles if those do
+// (sd_set_option("conv_patch_narrow", n): 0 off, 1 fp32 only, 2 fp32 and bf16).
+static int g_patch_narrow = 2;            // 1: fp32 only, 2: bf16 too.  Same-box A/B (tools/ab_option.py): fp32 step -0.4 % (layer4: k_conv_igemm<128> -> k_conv3x3_patch<64>), bf16 eval forward -1.6 %, mixed-precision step -0.7 %
 static int patch_tile_bn(ConvArgs& a, int BN, int mode, bool bf16) {
     ConvArgs t = a;
     if (conv_patch_geometry(t, BN, mode, bf16)) { a = t; return BN; }
-    if (!bf16 && BN == 128 && g_patch_narrow) {
+    if (BN == 128 && (bf16 ? g_patch_narrow >= 2 : g_patch_narrow >= 1)) {
         t = a;
-        if (conv_patch_geometry(t, 64, mode, false, true)) { a = t; return 64; }
+        if (conv_patch_geometry(t, 64, mode, bf16, true)) { a = t; return 64; }
     }
     return 0;
 }
@@ -3971,7 +3971,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         if (conv_rows64_geometry(a, mode, ra)) return "k_conv3x3_c64_rows_bf16";
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
         t = a;
-        if (conv_patch_geometry(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, true>", BN);
+        if (const int PBN = patch_tile_bn(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, true>", PBN);
         else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
         return name;
     }

@@ -309,6 +309,28 @@ def test_conv_bf16_two_group_kernel(case):
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
 
 
+def test_conv_bf16_narrow_patch_tiles_for_wide_layers():
+    """bf16 layers whose 128-channel patch tiles do not fill the chip (layer4 at bs=64) take 64-channel patch tiles (`conv_patch_narrow` = 2):
+    the checks of the other bf16 conv kernels on a 256 -> 256 channel layer cut into four channel tiles."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    case = (4, 16, 16, 256, 256, 3, 1, 1)
+    d = make_desc(L, *case)
+    L.check(lib.sd_set_option(b"conv_patch_min_tiles", 12))          # 4 x 2 tiles of 128 channels < 12 <= 4 x 4 tiles of 64
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == "k_conv3x3_patch<64, true>"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode() == "k_conv3x3_patch<64, true>"
+        L.check(lib.sd_set_option(b"conv_patch_narrow", 1))
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == "k_conv_igemm<128, 0, true>"
+        L.check(lib.sd_set_option(b"conv_patch_narrow", 2))
+        test_conv_bf16_forward_statistics_and_data_gradient(case)
+    finally:
+        L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
+        L.check(lib.sd_set_option(b"conv_patch_narrow", 2))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+
+
 @pytest.mark.parametrize("case", [(2, 6, 10, 128, 7), (3, 32, 40, 128, 8), (2, 16, 16, 64, 5), (1, 128, 128, 128, 7)])
 def test_head_backward_on_bf16_activations(case):
     """sd_head_bwd_bf16 (bf16 FPN output in, bf16 input gradient out, fp32 weight / bias gradients) against PyTorch on the same bf16-rounded

@@ -455,7 +455,7 @@ def test_bn_backward_reduction_fused_into_dgrad_matches_separate_pass():
     assert (grads[0] - grads[1]).abs().max().item() <= 2e-4 * scale
 
 
-NARROW_DEFAULT = 1      # sd_set_option("conv_patch_narrow") default of the library
+NARROW_DEFAULT = 2      # sd_set_option("conv_patch_narrow") default of the library
 PATCH_CASES = [  # B, H, W, cin, cout: 3x3 / 1 / 1 convs whose geometry fits k_conv3x3_patch (rows of 16..128 pixels, 256-pixel tiles)
     (3, 16, 16, 64, 64), (2, 32, 32, 128, 128), (1, 64, 64, 64, 128), (1, 8, 128, 64, 64), (1, 4, 128, 128, 256), (5, 16, 16, 256, 128),
     (2, 6, 128, 128, 128),

@@ -207,14 +207,14 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<64, false>"
     assert lib.sd_set_option(b"conv_patch_narrow", 0) == 0
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv_igemm<128, 0, false>"
-    assert lib.sd_set_option(b"conv_patch_narrow", 1) == 0
+    assert lib.sd_set_option(b"conv_patch_narrow", 2) == 0
     d.Hi = d.Wi = d.Ho = d.Wo = 64; d.Cin = d.Cout = 128
     d.stride, d.Ho, d.Wo = 2, 32, 32
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2>"
     d.B, d.stride, d.Ho, d.Wo = 1, 1, 64, 64
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm<128, 0, false>"
     # the bf16 dispatch (passes 16 / 17 = sd_conv2d_fwd_bf16 / sd_conv2d_dgrad_bf16) at bs=64, 512x512: layer2 / layer3 3x3 convs take the
-    # two-group kernel (>= 200 tiles of 512 pixels), layer1 the row stream (>= 16 rows per unit), layer4 (128 tiles) and strided convs the
+    # two-group kernel (>= 200 tiles of 512 pixels), layer1 the row stream (>= 16 rows per unit), layer4 (128 tiles) 64-channel patch tiles, strided convs the
     # generic implicit GEMM, up4.conv (128-wide map) the two-group kernel on column strips (the one-group patch kernel without them); small batches fall back to the tile kernels / split-K
     def name(B, H, cin, cout, k=3, stride=1, pad=1, which=16):
         e = L.ConvDesc()
@@ -225,14 +225,15 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
         assert name(64, 64, 128, 128, which=which) == "k_conv3x3_bf16_pp"
         assert name(64, 32, 256, 256, which=which) == "k_conv3x3_bf16_pp"
         assert name(64, 128, 64, 64, which=which) == "k_conv3x3_c64_rows_bf16"
-        assert name(64, 16, 512, 512, which=which) == "k_conv_igemm<128, 0, true>"
+        assert name(64, 16, 512, 512, which=which) == "k_conv3x3_patch<64, true>"      # layer4: 128 two-group tiles, 256 patch tiles of 128 channels, 512 of 64
         assert name(64, 128, 128, 128, which=which) == "k_conv3x3_bf16_pp"          # up4.conv: 64-pixel column strips
         assert lib.sd_set_option(b"conv_pp_strips", 0) == 0
         assert name(64, 128, 128, 128, which=which) == "k_conv3x3_patch<128, true>"
         assert lib.sd_set_option(b"conv_pp_strips", 1) == 0
     assert name(64, 64, 128, 256, stride=2) == "k_conv_igemm<128, 0, true>"
     assert name(64, 64, 128, 256, stride=2, which=17) == "k_conv_igemm<128, 2, true>"
-    assert name(16, 64, 128, 128) == "k_conv_igemm<128, 0, true>"         # 128 two-group tiles < 200 and 256 one-group tiles < 512
+    assert name(16, 64, 128, 128) == "k_conv3x3_patch<64, true>"          # 128 two-group tiles < 200, 256 one-group tiles < 512 <= 512 of 64 channels
+    assert name(8, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # ... and 256 of 64 channels < 512
     assert name(32, 64, 128, 128) == "k_conv3x3_bf16_pp"                  # 256 two-group tiles
     assert name(16, 128, 64, 64) == "k_conv3x3_patch<64, true>"           # 8 rows per unit < 16
     assert name(16, 256, 64, 64) == "k_conv3x3_c64_rows_bf16"             # stress config (1024 x 1024 inputs): two strips per row
