@@ -274,7 +274,8 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * not cut into 64-pixel column strips for that kernel (default 1; A/B measurements); "conv_fwd_split_k": 0 = the forward convs never
  * split K over blocks (default 1: small grids do), so that tests can put small problems on the single-pass kernels;
  * "conv_rows64_min_units": smallest number of (image, 128-pixel strip, row range) units for which the bf16 64 -> 64 channel 3x3 convs take
- * the row-stream kernel k_conv3x3_c64_rows_bf16 (default 192, and at least 16 rows per unit; 1 = always, for tests; 1 << 30 = never). */
+ * the row-stream kernel k_conv3x3_c64_rows_bf16 (default 192, and at least 16 rows per unit; 1 = always, for tests; 1 << 30 = never);
+ * "conv_rows_f32_min_units": the same for the fp32 row-stream kernel k_conv3x3_c64_rows_f32 (units = image x 64-pixel strip x row range). */
 int sd_set_option(const char* name, int value);
 
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,

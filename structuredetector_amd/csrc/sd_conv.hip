@@ -1831,6 +1831,207 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 3x3 / stride 1 / pad 1 convolution of the 64 -> 64 channel layers (layer1; forward and flipped-tap data-gradient) as a ROW
+// STREAM with the weights in registers -- the fp32 twin of k_conv3x3_c64_rows_bf16.  K is only 576: a tile kernel re-stages the
+// 147 KB of weights for every 128-pixel tile and spends 10 % of a tile in prologue + epilogue (k_conv_igemm<64, 0>: 115 TFLOP/s).
+// Here a persistent block (4 waves, one per SIMD) walks down a 64-pixel-wide strip of one image, one output row per step:
+//   weights : wave (pixel half ph, channel half ch) holds the B operands of its 32 output channels for all 9 taps x 64 input
+//             channels = 288 registers (240 AGPRs + 48 VGPRs), loaded once per block;
+//   input   : ring of 5 input rows (72 pixels x 256 bytes; 16-byte slot c of pixel x at c ^ (x & 7): two-way ds_read_b128 conflicts, far from binding)
+//             filled by LDS-DMA three rows ahead; the reduction index inside a tap is permuted so that a lane's four k of four
+//             consecutive 32x32x2 MFMAs are ONE 16-byte read: k-step (q, e) <-> input channel 8 q + 4 (lane / 32) + e;
+//   a row   : 72 reads + 288 MFMAs (18432 MFMA cycles) per wave.  With ONE wave per SIMD every VALU instruction between two MFMAs costs
+//             16 cycles of the matrix pipe (tools/micro/mfma_f32_mix.hip: 64.0 -> 68.0 cycles per MFMA for one v_add per four;
+//             ds_read / s_waitcnt / SALU cost nothing), so the loop holds no VALU at all: the 36 read addresses of a row (3 rows x 3
+//             tap columns x 4 slot groups; the upper slot half is an immediate offset) are formed before its first MFMA;
+//             the epilogue (scale / shift, residual, ReLU, column sums, stores straight from the accumulator layout: a wave's element e is
+//             two pixels x 32 channels = two full 128-byte lines) follows the row;
+//   unit    : (image, strip, `rows` consecutive output rows); statistics: one partial row per unit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RF_PX = 72, RF_ROW_BYTES = RF_PX * 256, RF_NR = 5, RF_B_AGPR = 240;
+constexpr int RF_LDS_BYTES = RF_NR * RF_ROW_BYTES + 4 * 64 * 4;
+
+struct RowsArgsF {
+    const float* x;        // [B][H][W][64]
+    const float* w;        // [64][9][64] (forward: as stored; data-gradient: the transposed copy, taps walked backwards)
+    float* y;              // [B][H][W][64]
+    const float* scale;    // per output channel, or null
+    const float* shift;
+    const float* res;      // same shape as y, or null
+    float* stat;           // [nunits][2][64] column sums / sums of squares of the stored values, or null
+    int relu, flip;
+    int B, H, W, segs, rows, units_per_col, nunits;
+};
+
+template <bool B_IN_AGPR, bool ZERO>
+__device__ __forceinline__ void rf_mfma(f32x16& acc, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ZERO) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+#else
+    (void)acc; (void)a; (void)b;
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_conv3x3_c64_rows_f32(RowsArgsF p) {
+    extern __shared__ __attribute__((aligned(16))) float rf_lds[];
+    char* const ring = reinterpret_cast<char*>(rf_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave & 1, chh = wave >> 1;
+    float* const sred = reinterpret_cast<float*>(ring + RF_NR * RF_ROW_BYTES);                          // [4 waves][2][32]
+    const int fr = lane & 31, fh = lane >> 5;
+    const float* const zero_ = g_zero_line;
+
+    // ---- every B operand of the wave: lane (n = 32 chh + fr, k-half fh), tap t, k-step 4 q + e <-> input channel 8 q + 4 fh + e
+    float Bw[288];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p.w + ((chh * 32 + fr) * 9 + (p.flip ? 8 - t : t)) * 64 + 8 * q + 4 * fh);
+            Bw[t * 32 + 4 * q + 0] = v.x; Bw[t * 32 + 4 * q + 1] = v.y; Bw[t * 32 + 4 * q + 2] = v.z; Bw[t * 32 + 4 * q + 3] = v.w;
+        }
+    const float sc = p.scale ? p.scale[chh * 32 + fr] : 1.f, sh = p.shift ? p.shift[chh * 32 + fr] : 0.f;
+    // A read offsets inside a ring row: output pixel 32 ph + fr, tap column s -> ring pixel 32 ph + fr + s (ring pixel 0 = image column x0 - 1)
+    uint32_t aoff[3][4];                                   // slot group qq (k-steps q = qq and qq + 4: + 128 bytes) of tap column s3
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int pxr = ph * 32 + fr + s3;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) aoff[s3][qq] = (uint32_t)pxr * 256u + ((uint32_t)((2 * qq + fh) ^ (pxr & 7)) << 4);
+    }
+    const int dpx = lane >> 4, dslot = lane & 15;         // LDS-DMA: lane -> (pixel within a 4-pixel piece, physical 16-byte slot)
+
+    for (int unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
+        const int col = unit / p.units_per_col, yu = unit - col * p.units_per_col;
+        const int b = col / p.segs, x0 = (col - b * p.segs) * 64;
+        const int y0 = yu * p.rows, y1 = min(y0 + p.rows, p.H);
+        const float* const img = p.x + (int64_t)b * p.H * p.W * 64;
+        // input row iy -> ring slot (iy - y0 + 1) % 5; wave w loads pieces w, w + 4, ... of the row's 18
+        auto issue_row = [&](int iy) {
+            float* const dst = reinterpret_cast<float*>(ring + ((iy - y0 + 1) % RF_NR) * RF_ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pc = wave + 4 * j;
+                if (pc < 18) {
+                    const int pxr = pc * 4 + dpx, ix = x0 - 1 + pxr;
+                    const bool ok = pxr < 66 && (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+                    lds_dma16(ok ? img + ((int64_t)iy * p.W + ix) * 64 + ((dslot ^ (pxr & 7)) << 2) : zero_ + (dslot << 2), dst + pc * 256);
+                }
+            }
+        };
+        float ssum = 0.f, ssq = 0.f;
+        for (int iy = y0 - 1; iy <= min(y0 + 2, y1); ++iy) issue_row(iy);
+        wait_vmcnt<0>();
+        __syncthreads();
+        const uint32_t ring_base = lds_addr(ring);
+#ifdef SD_PP_TRACE
+        unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        for (int y = y0; y < y1; ++y) {
+            PP_T(r0_)
+            // the residual of this row: requested now, consumed after the MFMAs
+            float resv[16];
+            // accumulator layout: lane = (channel 32 chh + fr, pixels 4 fh + (e & 3) + 8 (e >> 2)); element e of a wave = two pixels x 32
+            // channels = two full 128-byte lines, so the row is stored (and its residual read) straight from that layout
+            const int64_t orow = (((int64_t)b * p.H + y) * p.W + x0 + ph * 32 + 4 * fh) * 64 + chh * 32 + fr;
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) resv[e] = p.res[orow + ((e & 3) + 8 * (e >> 2)) * 64];
+            }
+            // the LDS-DMA of input row y + 3 (this wave's pieces w, w + 4, ...): sources formed here, issued between the first MFMAs
+            const bool more = y + 3 <= y1;
+            float* const ddst = reinterpret_cast<float*>(ring + ((y + 3 - y0 + 1) % RF_NR) * RF_ROW_BYTES);
+            const float* dsrc[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pxr = (wave + 4 * j) * 4 + dpx, ix = x0 - 1 + pxr;
+                const bool ok = pxr < 66 && (unsigned)ix < (unsigned)p.W && (unsigned)(y + 3) < (unsigned)p.H;
+                dsrc[j] = ok ? img + ((int64_t)(y + 3) * p.W + ix) * 64 + ((dslot ^ (pxr & 7)) << 2) : zero_ + (dslot << 2);
+                asm volatile("" : "+v"(dsrc[j]));            // formed HERE: hipcc otherwise sinks these VALU instructions between the MFMAs
+            }
+            uint32_t ad[3][3][4];                                             // every read address of the row: no VALU between the MFMAs
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint32_t sb = ring_base + (uint32_t)((y - 1 + r - y0 + 1) % RF_NR) * RF_ROW_BYTES;
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) ad[r][s3][qq] = sb + aoff[s3][qq];
+            }
+            f32x16 acc;                                                       // (the first MFMA of the row starts it from 0)
+            // read i (tap i / 8, k-steps 4 (i % 8) ..) is issued three groups before its four MFMAs
+#define RF_RD(i) lds_read128_async<(((i) % 8) >> 2) * 128>(ad[((i) / 8) / 3][((i) / 8) % 3][(i) % 4])
+            f32x4 A[4];
+            PP_T(r1_)
+            A[0] = RF_RD(0); A[1] = RF_RD(1); A[2] = RF_RD(2);
+#define RF_STEP(i)                                                                                                     \
+            {                                                                                                          \
+                if ((i) + 3 < 72) A[((i) + 3) & 3] = RF_RD((i) + 3 < 72 ? (i) + 3 : 0);                                   \
+                /* LDS operations return in order: all but the three youngest are back */                              \
+                if ((i) + 3 < 72) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[(i) & 3]) :: "memory");                   \
+                else if ((i) == 69) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[(i) & 3]) :: "memory");                 \
+                else if ((i) == 70) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(A[(i) & 3]) :: "memory");                 \
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[(i) & 3]) :: "memory");                                \
+                if ((i) < 5 && more && wave + 4 * (i) < 18) lds_dma16(dsrc[(i) < 5 ? (i) : 0], ddst + (wave + 4 * (i)) * 256);  \
+                const f32x4 a_ = A[(i) & 3];                                                                           \
+                rf_mfma<(4 * (i) + 0 < RF_B_AGPR), (i) == 0>(acc, a_[0], Bw[4 * (i) + 0]);                              \
+                rf_mfma<(4 * (i) + 1 < RF_B_AGPR), false>(acc, a_[1], Bw[4 * (i) + 1]);                                 \
+                rf_mfma<(4 * (i) + 2 < RF_B_AGPR), false>(acc, a_[2], Bw[4 * (i) + 2]);                                 \
+                rf_mfma<(4 * (i) + 3 < RF_B_AGPR), false>(acc, a_[3], Bw[4 * (i) + 3]);                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }
+#define RF_TAP(t) RF_STEP(8 * (t)) RF_STEP(8 * (t) + 1) RF_STEP(8 * (t) + 2) RF_STEP(8 * (t) + 3) RF_STEP(8 * (t) + 4) RF_STEP(8 * (t) + 5) RF_STEP(8 * (t) + 6) RF_STEP(8 * (t) + 7)
+            RF_TAP(0) RF_TAP(1) RF_TAP(2) RF_TAP(3) RF_TAP(4) RF_TAP(5) RF_TAP(6) RF_TAP(7) RF_TAP(8)
+#undef RF_TAP
+#undef RF_STEP
+#undef RF_RD
+            // the asm MFMAs are invisible to the hazard recogniser: their results must not be read for 18 wait states
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            PP_T(r2_)
+            // Everything this wave has in flight is a row old by now (its pieces of row y + 3 and the residual from the row's start, the
+            // previous row's stores): this wait is free -- the stores below stay in flight across the barrier (waiting for THEM at the
+            // row's end cost a quarter of the row: a store round trip is ~4800 cycles)
+            wait_vmcnt<0>();
+            PP_T(r3_)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[e] * sc + sh;
+                if (p.res) v += resv[e];
+                if (p.relu) v = fmaxf(v, 0.f);
+                ssum += v; ssq += v * v;
+                p.y[orow + ((e & 3) + 8 * (e >> 2)) * 64] = v;
+            }
+            PP_T(r4_)
+            __builtin_amdgcn_s_barrier();    // every wave is done with input row y - 1 and has published its pieces of row y + 3
+            PP_T(r5_)
+            PP_ACC(0, r0_, r1_) PP_ACC(1, r1_, r2_) PP_ACC(2, r2_, r3_) PP_ACC(3, r3_, r4_) PP_ACC(4, r4_, r5_)
+#ifdef SD_PP_TRACE
+            tr[7] += 1;
+#endif
+        }
+#ifdef SD_PP_TRACE
+        if (blockIdx.x == 8 && lane == 0) { for (int kk = 0; kk < 8; ++kk) g_pp_trace[wave][kk] = tr[kk]; }
+#endif
+        if (p.stat) {
+            ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);
+            if (fh == 0) { sred[wave * 64 + fr] = ssum; sred[wave * 64 + 32 + fr] = ssq; }
+            __syncthreads();
+            if (tid < 128) {
+                const int which = tid >> 6, n = tid & 63, cw = (n >> 5) * 2;          // the two pixel-half waves of the channel half
+                p.stat[(int64_t)unit * 128 + tid] = sred[cw * 64 + which * 32 + (n & 31)] + sred[(cw + 1) * 64 + which * 32 + (n & 31)];
+            }
+        }
+        __syncthreads();                     // the ring and sred are reused by the next unit
+    }
+}
+
 #undef SD_BNRED_TERM
 
 // ---------------------------------------------------------------------------------------------
@@ -3175,6 +3376,26 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     return true;
 }
 
+// k_conv3x3_c64_rows_f32 applies: fp32, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
+// multiple of 64, plain or same-size residual, no fused BatchNorm-backward reduction, no split-K, and enough units to fill the chip.
+static int g_rowsf32_min_units = 192;   // sd_set_option("conv_rows_f32_min_units", n) (tests: 1; off: 1 << 30)
+static bool conv_rowsf32_geometry(const ConvArgs& a, int mode, RowsArgsF& r) {
+    if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
+    if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
+    if (a.Ho != a.Hi || a.Wo != a.Wi || a.Wo % 64 || a.res_up2 || a.bn_x) return false;
+    r = RowsArgsF{};
+    r.B = a.B; r.H = a.Ho; r.W = a.Wo; r.segs = a.Wo / 64;
+    const int cols = r.B * r.segs;
+    r.rows = std::min(r.H, std::max(8, cdiv(r.H * cols, 256)));        // ~256 units (one persistent block per CU), at least 8 rows each
+    r.units_per_col = cdiv(r.H, r.rows);
+    r.nunits = cols * r.units_per_col;
+    // a unit pays for 288 weight registers and four input rows before its first MFMA (g_rowsf32_min_units = 1 lifts both limits: tests)
+    if (r.nunits < g_rowsf32_min_units || (g_rowsf32_min_units > 1 && r.rows < 16)) return false;
+    r.x = (const float*)a.x; r.w = (const float*)a.w; r.y = (float*)a.y; r.scale = a.scale; r.shift = a.shift;
+    r.res = (const float*)a.res; r.stat = a.stat; r.relu = a.relu; r.flip = a.rsign < 0;
+    return true;
+}
+
 // k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered patch geometry (maps up to 64 pixels wide as whole
 // rows, wider ones as 64-pixel column strips), whole 512-pixel tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
 static int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
@@ -3249,6 +3470,19 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
                 raised = true;
             }
             hipLaunchKernelGGL(k_conv3x3_bf16_pp, dim3((pa.M / PP_BM) * (pa.Nn / 128)), dim3(512), PP_LDS_FLOATS * sizeof(float), st, pa);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (!stem && !bf16) {
+        RowsArgsF rf;
+        if (conv_rowsf32_geometry(a, mode, rf)) {
+            static thread_local bool raisedf = false;
+            if (!raisedf) {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_rows_f32), hipFuncAttributeMaxDynamicSharedMemorySize, RF_LDS_BYTES));
+                raisedf = true;
+            }
+            hipLaunchKernelGGL(k_conv3x3_c64_rows_f32, dim3(std::min(rf.nunits, 256)), dim3(256), RF_LDS_BYTES, st, rf);
             SD_LAUNCH_CHECK();
             return 0;
         }
@@ -3379,6 +3613,8 @@ static int fwd_stat_rows(const sd_conv_desc* d, bool bf16 = false) {
     ConvArgs t = a;
     RowsArgs ra;
     if (bf16 && conv_rows64_geometry(a, 0, ra)) return ra.nunits;
+    RowsArgsF rf;
+    if (!bf16 && conv_rowsf32_geometry(a, 0, rf)) return rf.nunits;
     if (bf16 && conv_pp_geometry(t, 0)) return a.M / PP_BM;
     t = a;
     return (patch_tile_bn(t, BN, 0, bf16) || (!bf16 && igemm_big_tiles(a, BN, 0))) ? cdiv(a.M, BMB) : cdiv(a.M, BM);
@@ -3944,6 +4180,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
+    if (name && !strcmp(name, "conv_rows_f32_min_units")) { g_rowsf32_min_units = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
@@ -3975,6 +4212,8 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
         return name;
     }
+    RowsArgsF rf;
+    if (conv_rowsf32_geometry(a, mode, rf)) return "k_conv3x3_c64_rows_f32";
     if (const int PBN = patch_tile_bn(t, BN, mode, false)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", PBN);
     else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);

@@ -527,6 +527,59 @@ def test_conv3x3_patch_kernel_with_fused_bn_statistics():
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 64), (1, 21, 128), (3, 9, 192), (2, 40, 64)])
+def test_conv3x3_row_stream_fp32_kernel(case):
+    """k_conv3x3_c64_rows_f32 (64 -> 64 channels, weights in registers, 64-pixel strips walked row by row; forced onto small problems
+    through sd_set_option): forward with the fused epilogue (scale / shift / residual / ReLU), forward with the fused BatchNorm
+    statistics, and the data-gradient with a residual, against torch; heights that are not multiples of the unit's row count, one
+    to three strips per row, several units per strip."""
+    from structuredetector_amd import _lib as L
+    B, H, W = case
+    cin = cout = 64
+    lib = L.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    d = make_desc(L, B, H, W, cin, cout, 3, 1, 1)
+    L.check(lib.sd_set_option(b"conv_rows_f32_min_units", 1))
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_c64_rows_f32"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 1).decode() == "k_conv3x3_c64_rows_f32"
+        xd, wd = nhwc(x), krsc(w)
+        y = torch.empty(B, H, W, cout, device=DEV)
+        scale_d, shift_d, res_d = scale.to(DEV), shift.to(DEV), nhwc(res)
+        L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
+                                  res_d.data_ptr(), 0, 1, 0, 0, L.stream()))
+        ref = F.conv2d(x, w, None, 1, 1)
+        close(from_nhwc(y), F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + res), 1e-5)
+        L.check(lib.sd_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, 0, 0, L.stream()))
+        close(from_nhwc(y), ref, 2e-6 * (cin * 9) ** 0.5)
+        mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        ws = torch.empty(max(lib.sd_conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+        y.zero_()
+        L.check(lib.sd_conv2d_fwd_bn_stats(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 1e-5, 0.1, 0, 0, mean.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+        close(from_nhwc(y), ref, 2e-6 * (cin * 9) ** 0.5)
+        close(mean.cpu(), ref.double().mean((0, 2, 3)).float(), 1e-5)
+        close(invstd.cpu(), (1.0 / torch.sqrt(ref.double().var((0, 2, 3), unbiased=False) + 1e-5)).float(), 1e-5)
+        dy = torch.randn(B, cout, H, W, generator=g)
+        skip = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.empty(cin * 9 * cout, device=DEV)
+        L.check(lib.sd_conv2d_transpose_weights(wd.data_ptr(), wt.data_ptr(), cout, 9, cin, L.stream()))
+        dx = torch.empty(B, H, W, cin, device=DEV)
+        L.check(lib.sd_conv2d_dgrad(nhwc(dy).data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), nhwc(skip).data_ptr(), L.stream()))
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, 1, 1).backward(dy)
+        close(from_nhwc(dx), xr.grad + skip, 1e-5)
+    finally:
+        L.check(lib.sd_set_option(b"conv_rows_f32_min_units", 192))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+
+
 def test_conv3x3_patch_kernel_narrow_tiles_for_wide_layers():
     """A layer whose 128-channel patch tiles do not fill the chip (layer4 at bs=64: 256 tiles) takes 64-channel tiles when those do
     (`conv_patch_narrow`): forward with the fused BatchNorm statistics (one partial row per 256-pixel tile row, eight channel tiles)

@@ -201,6 +201,13 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<128, false>"
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<128, false>"
     assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
+    # layer1 at bs=64 (128x128 maps, 64 channels): the fp32 row stream (256 units of 64 rows); small batches keep the tile kernel
+    d.Hi = d.Wi = d.Ho = d.Wo = 128; d.Cin = d.Cout = 64
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_c64_rows_f32"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_c64_rows_f32"
+    d.B = 8
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv_igemm<64, 0, false>"
+    d.B = 64
     # layer4 at bs=64 (16x16 maps, 512 channels): 256 patch tiles of 128 channels do not fill the chip, 512 tiles of 64 channels do
     d.Hi = d.Wi = d.Ho = d.Wo = 16; d.Cin = d.Cout = 512
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<64, false>"
