@@ -368,6 +368,44 @@ def test_network_train_forward_backward():
     assert torch.equal(net2.flat_grads, flat_before)
 
 
+def test_network_step_with_and_without_the_row_stream_and_narrow_tile_kernels():
+    """The dispatch rules that only engage at production batch sizes (layer1 on k_conv3x3_c64_rows_f32, layer4 / up2.conv on 64-channel
+    patch tiles), inside the whole network: training forward + backward at bs=64, 256x256 (layer1 maps 64 x 64: 256 row-stream units
+    of 16 rows) with those kernels on, against the same pass with them switched off -- outputs, BatchNorm statistics and every gradient
+    agree to fp32 summation-order accuracy (population: a ReLU input within an ulp of zero may flip, so the bulk is what is held)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(64, 3, 256, 256, generator=g).to(DEV)
+    dy = (torch.randn(64, 7, 64, 64, generator=g) * 0.1).to(DEV)
+    d = make_desc(L, 64, 64, 64, 64, 64, 3, 1, 1)
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 0).decode() == "k_conv3x3_c64_rows_f32"
+    res = {}
+    try:
+        for on in (True, False):
+            L.check(lib.sd_set_option(b"conv_rows_f32_min_units", 192 if on else 1 << 30))
+            L.check(lib.sd_set_option(b"conv_patch_narrow", NARROW_DEFAULT if on else 0))
+            _, net = _pair(seed=9)
+            net.train()
+            out, tape = net.forward_train(x)
+            net.backward_from(tape, dy)
+            torch.cuda.synchronize()
+            res[on] = (out.clone(), net.flat_grads.clone(), {k: v.clone() for k, v in net.named_buffers()})
+    finally:
+        L.check(lib.sd_set_option(b"conv_rows_f32_min_units", 192))
+        L.check(lib.sd_set_option(b"conv_patch_narrow", NARROW_DEFAULT))
+    (o1, g1, b1), (o0, g0, b0) = res[True], res[False]
+    close(o1.cpu(), o0.cpu(), 1e-4)
+    for k in b1:
+        if b1[k].dtype != torch.long:
+            close(b1[k].cpu(), b0[k].cpu(), 1e-5)
+    # gradients: a random-init network is chaotic under 1-ulp perturbations (ReLU inputs within an ulp of zero flip their mask: see
+    # test_network_full_resolution_vs_oracle), so the yardstick is the whole gradient vector, not its worst element
+    l2 = float((g1 - g0).norm() / g0.norm())
+    cos = float(torch.dot(g1, g0) / (g1.norm() * g0.norm()))
+    assert l2 < 2e-2 and cos > 0.9998, (l2, cos)
+
+
 def test_state_dict_roundtrip(tmp_path):
     ref, net = _pair(seed=5)
     net.save(tmp_path / "m.pth")
