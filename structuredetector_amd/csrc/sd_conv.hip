@@ -522,6 +522,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         // bf16: the residual rows of the whole wave tile are requested BEFORE the trip through LDS (one memory round trip per
         // tile instead of one per four rows: the residual convs were 25 % slower than the plain ones for nothing but this latency)
         uint2 rr[64 / RPI] = {};
+        float4 rf[64 / RPI];                           // the fp32 twin (FPN laterals: the upsample-add's rows come from a quarter-size map)
+        const bool pre32 = !BF16 && p.res != nullptr;
         if constexpr (BF16) {
             if (p.res) {
 #pragma unroll
@@ -532,6 +534,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                     // (no row: any valid address -- the value is dropped below; a select, not a branch around the load)
                     rr[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.res) + (rm >= 0 ? rm * p.Nn : 0) + n);
                 }
+            }
+        } else if (pre32) {
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + lane / LPR;
+                const int m = orow[wm0 + row];
+                const int64_t rm = m < 0 ? -1 : (p.res_up2 ? (int64_t)rrow[wm0 + row] : (int64_t)m);
+                rf[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (rm >= 0 ? rm * p.Nn : 0) + n);
             }
         }
 #pragma unroll
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
         BnRed4 br;
         if (bwd_red) bnred4_init(br, p, n);
-        auto out_row = [&](int it, uint2 r16) {
+        auto out_row = [&](int it, uint2 r16, const float4* r32) {
             const int row = it * RPI + lane / LPR;
             const int m = orow[wm0 + row];
             if (m < 0) return;
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
                         v.x += bf2f((uint16_t)(r16.x & 0xffff)); v.y += bf2f((uint16_t)(r16.x >> 16));
                         v.z += bf2f((uint16_t)(r16.y & 0xffff)); v.w += bf2f((uint16_t)(r16.y >> 16));
                     } else {
-                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
+                        const float4 r = r32 ? *r32 : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + rm * p.Nn + n);
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
                 }
@@ -576,10 +586,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
         };
         if constexpr (BF16) {
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it) out_row(it, rr[it]);
+            for (int it = 0; it < 64 / RPI; ++it) out_row(it, rr[it], nullptr);
+        } else if (pre32) {
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) out_row(it, make_uint2(0u, 0u), &rf[it]);
         } else {
 #pragma unroll 4
-            for (int it = 0; it < 64 / RPI; ++it) out_row(it, make_uint2(0u, 0u));
+            for (int it = 0; it < 64 / RPI; ++it) out_row(it, make_uint2(0u, 0u), nullptr);
         }
         if (bwd_red) {      // BatchNorm-backward reduction: lanes -> wave (64 rows) -> the two wave rows -> one partial row per tile
             bnred4_wave_sum<LPR>(br);
