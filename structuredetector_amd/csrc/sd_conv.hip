@@ -2238,25 +2238,37 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // Patch pieces of this wave (w, w + 4, ...): what depends on the lane only is formed ONCE -- the element offset of the lane's 16-byte
+    // slot from the chunk's first pixel, and which image borders can invalidate it.  (Per chunk and piece the source then takes 6 VALU
+    // instructions instead of 17: VALU work of either wave of a SIMD takes fp32-MFMA time, tools/micro/mfma_f32_mix.hip; staging was
+    // 127 VALU instructions per 144 MFMAs.)
+    int poff[W9_PIECES / 4];
+    unsigned pbits[W9_PIECES / 4];          // 1: first patch row, 2: last patch row, 4: first patch column, 8: last patch column, 16: past the patch, 32: always
+#pragma unroll
+    for (int j = 0; j < W9_PIECES / 4; ++j) {
+        const int sl = (wave + 4 * j) * 64 + lane;              // 16-byte slot inside the [rows][px][16] patch
+        const int r = sl / (W9_PX * 16), rem = sl - r * (W9_PX * 16), px = rem >> 4, c4 = rem & 15;
+        poff[j] = ((r - 1) * p.Wi + (px - 1)) * p.Ck + tc0 + c4 * 4;
+        pbits[j] = (r == 0 ? 1u : 0u) | (r == W9_ROWS - 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == W9_PX - 1 ? 8u : 0u) | (r >= W9_ROWS ? 16u : 0u) | 32u;
+    }
+    const int doff = (lane >> 4) * p.Nn + tn0 + (lane & 15) * 4;
     // stage chunk `ch` into (D, X): 8 + 26 pieces of 1 KB, wave w issues pieces w, w+4, ...
 #define W9_STAGE(ch, D, X)                                                                                        \
     {                                                                                                             \
         const int m0 = m_beg + (ch) * 32;                                                                         \
         const int ox0 = m0 % p.Wo, t_ = m0 / p.Wo, oy = t_ % p.Ho, b = t_ / p.Ho;                                 \
+        const bool live = m0 < m_end;                                                                             \
+        const float* const dbase = p.dy + (int64_t)m0 * p.Nn;                      /* wave-uniform */             \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
             const int q = wave + 4 * j;                                                                           \
-            const float* src = (m0 < m_end) ? p.dy + (int64_t)(m0 + q * 4 + (lane >> 4)) * p.Nn + tn0 + (lane & 15) * 4 : g_zero_line; \
-            lds_dma16(src, (D) + q * 256);                                                                        \
+            lds_dma16(live ? dbase + q * 4 * p.Nn + doff : g_zero_line, (D) + q * 256);                           \
         }                                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < W9_PIECES / 4; ++j) {                                               \
-            const int q = wave + 4 * j;                                                                           \
-            const int sl = q * 64 + lane;                       /* 16-byte slot inside the [rows][px][16] patch */ \
-            const int r = sl / (W9_PX * 16), rem = sl - r * (W9_PX * 16), px = rem >> 4, c4 = rem & 15;           \
-            const int iy = oy - 1 + r, ix = ox0 - 1 + px;                                                         \
-            const bool ok = m0 < m_end && r < W9_ROWS && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
-            const float* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + tc0 + c4 * 4 : g_zero_line; \
-            lds_dma16(src, (X) + q * 256);                                                                        \
-        }                                                                                                         \
+        /* borders this chunk touches (wave-uniform): a slot is zero when one of its bits is among them */       \
+        const unsigned cm = 16u | (live ? 0u : 32u) | (oy == 0 ? 1u : 0u) | (oy + W9_ROWS - 2 >= p.Hi ? 2u : 0u) | \
+                            (ox0 == 0 ? 4u : 0u) | (ox0 + ROWW >= p.Wi ? 8u : 0u);                                 \
+        const float* const xbase = p.x + (((int64_t)b * p.Hi + oy) * p.Wi + ox0) * p.Ck;                          \
+        _Pragma("unroll") for (int j = 0; j < W9_PIECES / 4; ++j)                                                 \
+            lds_dma16((pbits[j] & cm) ? g_zero_line : xbase + poff[j], (X) + (wave + 4 * j) * 256);                \
     }
     // 16 pixel pairs x 9 taps in four batches of four pairs.  A lane's B operand for (pair kk, tap r, s) is X[r][2 kk + s] (+ its
     // pixel parity in the base address): neighbouring pairs overlap, so a batch needs 3 x 9 X values + 4 dY values (31 LDS
