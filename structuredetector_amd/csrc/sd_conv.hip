@@ -18,6 +18,9 @@
 #include <string.h>
 #include "sd_common.h"
 
+#ifndef SD_S2_LPT
+#define SD_S2_LPT 1            // stride-2 data-gradient: parity classes in descending tap count (0: interleaved, the round-1 order)
+#endif
 namespace sd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -108,6 +111,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // tiles so that neighbouring tiles (shared input rows / weight panels) hit the same L2.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Stride-2 data-gradient (MODE 2): tile of block `bid`.  The four output-parity classes have 4, 2, 2 and 1 filter taps: with the classes
+// interleaved over the tile index the last blocks to start were as likely 4-tap tiles as 1-tap ones and ran next to idle slots.  Here
+// every XCD (blocks bid, bid + 8, ... in dispatch order) walks its share of the 4-tap class first, then the 2-tap classes, then the 1-tap
+// class -- longest first -- and inside a class a contiguous range of tiles (shared input rows hit the same L2).  `tile_m` keeps the old
+// numbering 4 * (tile inside the class) + class: it only names the tile's statistics row.
+__device__ __forceinline__ void s2_tile(int bid, int nwg, int n_tiles, int off, int& cls, int& tq, int& n_idx, int& tile_m) {
+    if (SD_S2_LPT && (nwg & 31) == 0) {
+        const int xcd = bid & 7, pos = bid >> 3, per = nwg >> 5;            // tiles per XCD and class
+        const int k4 = pos / per, within = xcd * per + (pos - k4 * per);   // position inside the class, n fastest
+        cls = (off & 1) ? (k4 == 0 ? 3 : k4 == 3 ? 0 : k4) : k4;           // taps per class: (2 - r0) * (2 - s0), r0 = (py + off) & 1
+        tq = within / n_tiles; n_idx = within - tq * n_tiles;
+    } else {
+        const int tile = xcd_remap(bid, nwg), tm = tile / n_tiles;
+        cls = tm & 3; tq = tm >> 2; n_idx = tile - tm * n_tiles;
+    }
+    tile_m = 4 * tq + cls;
 }
 
 // 16-byte LDS-DMA: each lane's global address is its own, the LDS destination is (wave-uniform base + 16 * lane).
@@ -201,16 +222,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Nn / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = tile / n_tiles;
-    const int n0 = (tile % n_tiles) * BN;                // n fastest: the A tile is reused from L2
+    int tile_m = tile / n_tiles;
+    int n0 = (tile % n_tiles) * BN;                      // n fastest: the A tile is reused from L2
     int m0 = tile_m * BM;
 
     int r0 = 0, s0 = 0, tstep = 1, nk = p.nk;
     int cls_base = 0, py = 0, px = 0;
     if (MODE == 2) {
-        // classes interleaved over the tile index so that every XCD gets the same mix of 1/2/2/4-tap tiles
-        const int Mq = p.M >> 2, cls = tile_m & 3;
-        cls_base = cls * Mq; m0 = cls_base + (tile_m >> 2) * BM;
+        int cls, tq, n_idx;
+        s2_tile(blockIdx.x, gridDim.x, n_tiles, p.off, cls, tq, n_idx, tile_m);
+        n0 = n_idx * BN;
+        const int Mq = p.M >> 2;
+        cls_base = cls * Mq; m0 = cls_base + tq * BM;
         py = cls >> 1; px = cls & 1;
         r0 = (py + p.off) & 1; s0 = (px + p.off) & 1; tstep = 2;         // r = oy + pad (mod 2), likewise s
         nk = ((p.R - r0 + 1) >> 1) * ((p.S - s0 + 1) >> 1) * p.kchunks;
@@ -889,14 +912,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = p.Nn / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = tile / n_tiles;
-    const int n0 = (tile % n_tiles) * BN;
+    int tile_m = tile / n_tiles;
+    int n0 = (tile % n_tiles) * BN;
     int m0 = tile_m * BMB;
     int r0 = 0, s0 = 0, tstep = 1, nk = p.nk * KSCALE;
     int cls_base = 0, py = 0, pxc = 0, m_end = p.M;
     if (MODE == 2) {
-        const int Mq = p.M >> 2, cls = tile_m & 3;
-        cls_base = cls * Mq; m0 = cls_base + (tile_m >> 2) * BMB; m_end = cls_base + Mq;
+        int cls, tq, n_idx;
+        s2_tile(blockIdx.x, gridDim.x, n_tiles, p.off, cls, tq, n_idx, tile_m);       // longest tiles first
+        n0 = n_idx * BN;
+        const int Mq = p.M >> 2;
+        cls_base = cls * Mq; m0 = cls_base + tq * BMB; m_end = cls_base + Mq;
         py = cls >> 1; pxc = cls & 1;
         r0 = (py + p.off) & 1; s0 = (pxc + p.off) & 1; tstep = 2;
         nk = ((p.R - r0 + 1) >> 1) * ((p.S - s0 + 1) >> 1) * p.kchunks * KSCALE;
