@@ -129,3 +129,39 @@ def assert_decode_matches_oracle(got, t, conf, sig_tol):
             np.testing.assert_array_equal(got["assign"][b][ps[b]], want_assign[b][ps[b]])
             strict += 1
     return int(ps.sum()), int(ps.size), strict
+
+
+# ---------------------------------------------------------------------------------------------
+# per-layer operands of an oracle run (tests/test_gpu_production_parity.py)
+# ---------------------------------------------------------------------------------------------
+def oracle_conv_trace(ref, x, dhead_of, device, skip=()):
+    """Run `ref(x)` (torch-CPU oracle network, training mode) and its backward from `dhead_of(head)`, capturing for every
+    Conv2d the tensors that layer saw: input x, output y, output gradient dy and input gradient dx (None where the input needs
+    no gradient), each moved to `device` as a contiguous NHWC tensor.  Returns (head.detach(), {module name: dict})."""
+    import torch
+    trace, handles = {}, []
+
+    def nhwc(t):
+        return t.detach().permute(0, 2, 3, 1).contiguous().to(device)
+
+    for name, m in ref.named_modules():
+        if not isinstance(m, torch.nn.Conv2d) or name in skip:
+            continue
+        rec = trace[name] = {"module": m}
+
+        def fwd_hook(mod, inp, out, rec=rec):
+            rec["x"], rec["y"] = nhwc(inp[0]), nhwc(out)
+
+        def bwd_hook(mod, gin, gout, rec=rec):
+            rec["dy"] = nhwc(gout[0])
+            rec["dx"] = nhwc(gin[0]) if gin[0] is not None else None
+
+        handles.append(m.register_forward_hook(fwd_hook))
+        handles.append(m.register_full_backward_hook(bwd_hook))
+    try:
+        head = ref(x)
+        head.backward(dhead_of(head))
+    finally:
+        for h in handles:
+            h.remove()
+    return head.detach(), trace

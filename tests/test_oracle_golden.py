@@ -136,3 +136,110 @@ def test_reference_network_schema():
     with torch.no_grad():
         y = net.eval()(torch.zeros(1, 3, 64, 64))
     assert y.shape == (1, 7, 16, 16)
+
+
+def _resnet34_fpn_schema(M, N, depth=128):
+    """Ordered (key, shape) list of the reference `Network`'s state_dict, written out from the PUBLISHED description of
+    torchvision's resnet34 (BasicBlock [3, 4, 6, 3], widths 64/128/256/512; state_dict order = registration order: conv1, bn1,
+    conv2, bn2, downsample) and from src/sdnet/model/network.py:41-57 -- a third statement, independent of oracle/ and of the product."""
+    out = []
+
+    def bn(prefix, c):
+        out.extend([(f"{prefix}.weight", (c,)), (f"{prefix}.bias", (c,)), (f"{prefix}.running_mean", (c,)), (f"{prefix}.running_var", (c,)),
+                    (f"{prefix}.num_batches_tracked", ())])
+
+    out.append(("adpater.0.weight", (64, 3, 7, 7))); bn("adpater.1", 64)                     # network.py:43-45 (sic)
+    cin = 64
+    for li, (n, c) in enumerate(((3, 64), (4, 128), (6, 256), (3, 512)), start=1):          # network.py:47-50
+        for b in range(n):
+            p = f"down{li}.{b}"
+            out.append((f"{p}.conv1.weight", (c, cin, 3, 3))); bn(f"{p}.bn1", c)
+            out.append((f"{p}.conv2.weight", (c, c, 3, 3))); bn(f"{p}.bn2", c)
+            if b == 0 and li > 1:
+                out.append((f"{p}.downsample.0.weight", (c, cin, 1, 1))); bn(f"{p}.downsample.1", c)
+            cin = c
+    out += [("up1.weight", (depth, 512, 1, 1)), ("up1.bias", (depth,))]                      # network.py:52
+    for name, c in (("up2", 256), ("up3", 128), ("up4", 64)):                                # network.py:53-55, 6-19
+        out += [(f"{name}.lateral.weight", (depth, c, 1, 1)), (f"{name}.lateral.bias", (depth,)), (f"{name}.conv.0.weight", (depth, depth, 3, 3))]
+        bn(f"{name}.conv.1", depth)
+    out += [("head.conv.weight", (M + N + 4, depth, 1, 1)), ("head.conv.bias", (M + N + 4,))]  # network.py:57, 22-29
+    return out
+
+
+def test_torchvision_boundary_structural_pin():
+    """a4 (torchvision resnet34 pieces, call sites src/sdnet/model/network.py:3,41,43-50): torchvision is absent, so arithmetic parity
+    stays unpinned there; everything that CAN be pinned without it is pinned here, for the oracle AND the product's parameter tree:
+    the full ordered state_dict schema (hash), BatchNorm eps / momentum, MaxPool2d(3, 2, 1), stride on conv1 of the first block,
+    no conv bias in the trunk, downsample exactly where stride != 1 or cin != cout, ReLU placement, nearest x2 upsampling."""
+    import hashlib
+    from argparse import Namespace
+
+    from structuredetector_amd.model import network as PN
+    M, N = 2, 1
+    want = _resnet34_fpn_schema(M, N)
+    digest = hashlib.sha256("\n".join(f"{k} {tuple(s)}" for k, s in want).encode()).hexdigest()
+    assert len(want) == 244 and digest == SCHEMA_SHA256, digest
+    ref = O.ReferenceNetwork(M, N)
+    prod = PN.Network(Namespace(labels={"a": 0, "b": 1}, parts={"p": 0}, fpn_depth=128), pretrained=False)
+    for net in (ref, prod):
+        got = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert got == [(k, tuple(s)) for k, s in want]
+        dtypes = {k: v.dtype for k, v in net.state_dict().items()}
+        assert all(dt == (torch.int64 if k.endswith("num_batches_tracked") else torch.float32) for k, dt in dtypes.items())
+    # --- oracle module hyper-parameters (what the restated trunk computes with) ---
+    nn = torch.nn
+    for m in ref.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            assert m.eps == 1e-5 and m.momentum == 0.1 and m.affine and m.track_running_stats
+        if isinstance(m, nn.ReLU):
+            assert m.inplace
+    conv1, _, relu, pool = ref.adpater
+    assert (conv1.kernel_size, conv1.stride, conv1.padding, conv1.bias) == ((7, 7), (2, 2), (3, 3), None) and isinstance(relu, nn.ReLU)
+    assert (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False)
+    cin = 64
+    for li, (n, c) in enumerate(((3, 64), (4, 128), (6, 256), (3, 512)), start=1):
+        layer = getattr(ref, f"down{li}")
+        assert len(layer) == n
+        for b, blk in enumerate(layer):
+            stride = 2 if (b == 0 and li > 1) else 1
+            assert (blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride, blk.conv1.padding) == (cin, c, (3, 3), (stride, stride), (1, 1))
+            assert (blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride, blk.conv2.padding) == (c, c, (3, 3), (1, 1), (1, 1))
+            assert blk.conv1.bias is None and blk.conv2.bias is None
+            assert (blk.downsample is not None) == (stride != 1 or cin != c)
+            if blk.downsample is not None:
+                ds = blk.downsample[0]
+                assert (ds.kernel_size, ds.stride, ds.padding, ds.bias) == ((1, 1), (2, 2), (0, 0), None) and isinstance(blk.downsample[1], nn.BatchNorm2d)
+            cin = c
+    for fpn in (ref.up2, ref.up3, ref.up4):
+        assert fpn.up.scale_factor == 2 and fpn.up.mode == "nearest"                        # network.py:10
+        assert fpn.lateral.bias is not None and fpn.conv[0].bias is None and fpn.conv[0].padding == (1, 1)
+    # BasicBlock dataflow: relu(bn2(conv2(relu(bn1(conv1(x))))) + identity_or_downsample(x)), checked on a block with hand-set weights
+    blk = O._BasicBlock(4, 4, 1).eval()
+    with torch.no_grad():
+        for conv in (blk.conv1, blk.conv2):
+            conv.weight.zero_(); conv.weight[:, :, 1, 1] = torch.eye(4)                      # identity convs
+        blk.bn1.weight.fill_(-1.0)                                                           # bn1 negates: relu(-x)
+    x = torch.tensor([[-2.0, -1.0, 1.0, 2.0]]).view(1, 4, 1, 1).expand(1, 4, 3, 3).contiguous()
+    s = 1.0 / (1.0 + 1e-5) ** 0.5                                                            # eval BatchNorm with running (0, 1)
+    want_y = torch.relu(torch.relu(-x * s) * s + x)
+    np.testing.assert_allclose(blk(x).detach().numpy(), want_y.numpy(), rtol=1e-6)
+    # --- product: the same hyper-parameters as constants / descriptors of the kernel schedule ---
+    assert PN.BN_EPS == 1e-5 and PN.BN_MOMENTUM == 0.1
+    st = prod.adpater[0]
+    assert (st.k, st.stride, st.pad, st.bias) == (7, 2, 3, None)
+    cin = 64
+    for li, (n, c) in enumerate(((3, 64), (4, 128), (6, 256), (3, 512)), start=1):
+        layer = getattr(prod, f"down{li}")
+        assert len(layer) == n
+        for b, blk in enumerate(layer):
+            stride = 2 if (b == 0 and li > 1) else 1
+            assert (blk.conv1.cin, blk.conv1.cout, blk.conv1.k, blk.conv1.stride, blk.conv1.pad, blk.conv1.bias) == (cin, c, 3, stride, 1, None)
+            assert (blk.conv2.cin, blk.conv2.cout, blk.conv2.k, blk.conv2.stride, blk.conv2.pad, blk.conv2.bias) == (c, c, 3, 1, 1, None)
+            assert (blk.downsample is not None) == (stride != 1 or cin != c)
+            if blk.downsample is not None:
+                ds = blk.downsample[0]
+                assert (ds.k, ds.stride, ds.pad, ds.bias) == (1, 2, 0, None)
+            cin = c
+
+
+SCHEMA_SHA256 = "df09e4ae27bca73d31fff2e2feb03c3a78219894d27e89d6d351cedad0b717cc"   # 244 entries, M=2, N=1, fpn_depth=128
