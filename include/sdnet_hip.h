@@ -227,6 +227,23 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, c
                        const float* scale, const float* shift, int relu, int out_bf16, void* workspace,
                        size_t workspace_bytes, sd_stream_t stream);
 
+/* Small-batch inference forward (the batch-1 evaluate loop, src/sdnet/cli/evaluate.py:34-45 -> network.py:59-84): same
+ * arithmetic and epilogue as sd_conv2d_fwd / sd_conv2d_fwd_bf16 (bf16 != 0: x, w, y, residual are bf16, accumulation and epilogue
+ * fp32) on 64-pixel x 64-channel tiles with the reduction split over blocks so that tiles x slices is about one block per CU; the
+ * partial tiles are combined INSIDE the launch by the block that arrives last for a tile (summed in slice order: results do not
+ * depend on the arrival order), so a conv is ONE launch.  sd_conv2d_fwd_sb_supported(): 1 for the geometries it is meant for
+ * (the 128-row tile grid of sd_conv2d_fwd would not fill the chip); any R == S conv with Cin % 32 (bf16: 64) == 0, Cout % 64 == 0
+ * is computed correctly.  `workspace`: sd_conv2d_fwd_sb_workspace_bytes() of scratch (partial tiles; no initialisation).
+ * `state`: sd_conv2d_fwd_sb_state_bytes() bytes owned by the caller, used by nothing else that may run concurrently, ZERO before
+ * the first call; every call leaves it zero again (back-to-back launches and hipGraph replays need no memset).  After a failed
+ * or aborted launch re-zero it.  Both may be null / 0 when sd_conv2d_fwd_sb_workspace_bytes() is 0 (no split). */
+int    sd_conv2d_fwd_sb_supported(const sd_conv_desc* d, int bf16);
+size_t sd_conv2d_fwd_sb_workspace_bytes(const sd_conv_desc* d, int bf16);
+size_t sd_conv2d_fwd_sb_state_bytes(const sd_conv_desc* d, int bf16);
+int sd_conv2d_fwd_sb(const void* x_nhwc, const void* w_krsc, void* y_nhwc, const sd_conv_desc* d, const float* scale, const float* shift,
+                     const void* residual, int res_up2, int relu, int bf16, void* workspace, size_t workspace_bytes, void* state,
+                     size_t state_bytes, sd_stream_t stream);
+
 /* The stem conv (7x7 / 2 / 3, NCHW image -> NHWC fp32) with the batch statistics of its output from the same launch
  * (as sd_conv2d_fwd_bn_stats; one pass over the 16.8 MB/img stem output less). */
 size_t sd_conv2d_stem_fwd_bn_stats_workspace_bytes(const sd_conv_desc* d);

@@ -78,6 +78,10 @@ _SIGNATURES = {
     "sd_loss_bwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_vp, c_vp]),
     "sd_conv2d_fwd_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_fwd_sb_supported": (c_int, [C.POINTER(ConvDesc), c_int]),
+    "sd_conv2d_fwd_sb_workspace_bytes": (c_size, [C.POINTER(ConvDesc), c_int]),
+    "sd_conv2d_fwd_sb_state_bytes": (c_size, [C.POINTER(ConvDesc), c_int]),
+    "sd_conv2d_fwd_sb": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_size, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_fwd_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_stem_fwd": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
     "sd_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
@@ -219,4 +223,20 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+    return buf
+
+
+_state_cache: dict = {}
+
+
+def zero_state(nbytes: int, device, tag: str = "conv") -> torch.Tensor:
+    """Per-(device, stream, tag) persistent ZEROED buffer for the kernels that keep arrival tickets / hand-off records in caller-owned
+    memory (sd_conv2d_fwd_sb, sd_decode_fused): zero at first use, left zero by every launch, never shared between streams."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream(), tag)
+    buf = _state_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            torch.cuda.current_stream().synchronize()      # a launch may still be using the old one
+        buf = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _state_cache[key] = buf
     return buf

@@ -128,6 +128,7 @@ class _Engine:
         # removes run at HBM speed anyway.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
         self.fuse_bn_bwd = False
         self._wt_plan, self._wt_flat, self._wt_valid = None, {}, None      # transposed data-gradient weights (see _transpose_all)
+        self.small_batch_kernel = True     # eval forward: sd_conv2d_fwd_sb where the 128-row tile grid cannot fill the chip (False: A/B)
 
     def _kname(self, d, which):
         """device kernel the C ABI will launch for this conv (profiling label; same names as the rocprofv3 kernel trace)"""
@@ -169,7 +170,17 @@ class _Engine:
         off, n = self.net._flat_off[id(conv.weight)]
         return self.net.flat_params_bf16[off:off + n]                 # physical [Cout][R][S][Cin] order, 8-byte aligned slots (off % 4 == 0)
 
-    def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False, amp=False):
+    def _conv_sb(self, x, w, y, d, scale, shift, res, res_up2, relu, bf16):
+        """Small-batch inference conv: one launch, split-K combined inside it (sd_conv2d_fwd_sb); the arrival tickets live in a
+        zeroed per-stream state buffer that every launch leaves zero."""
+        nws = self.lib.sd_conv2d_fwd_sb_workspace_bytes(C.byref(d), bf16)
+        ws = self._ws(nws, x.device) if nws else None
+        st = L.zero_state(self.lib.sd_conv2d_fwd_sb_state_bytes(C.byref(d), bf16), x.device) if nws else None
+        L.check(self.lib.sd_conv2d_fwd_sb(x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift), _ptr(res), int(res_up2),
+                                          int(relu), bf16, _ptr(ws), ws.numel() if nws else 0, _ptr(st), st.numel() if nws else 0, L.stream()),
+                "sd_conv2d_fwd_sb")
+
+    def conv(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False, amp=False, sb=False):
         d = _desc(B, Hi, Wi, conv)
         if amp:
             y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
@@ -180,6 +191,10 @@ class _Engine:
             return y, d
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.float32, device=x.device)
         flops = 2.0 * B * d.Ho * d.Wo * conv.cout * conv.cin * conv.k * conv.k
+        if sb and self.small_batch_kernel and self.lib.sd_conv2d_fwd_sb_supported(C.byref(d), 0):
+            self._timed("k_conv_fwd_sb<false>" if self.prof is not None else "", flops,
+                        lambda: self._conv_sb(x, conv.weight, y, d, scale, shift, res, res_up2, relu, 0))
+            return y, d
         nws = self.lib.sd_conv2d_fwd_workspace_bytes(C.byref(d))          # > 0 only for small batches (split-K)
         ws = self._ws(nws, x.device) if nws else None
         self._timed(self._kname(d, 0), flops, lambda: L.check(
@@ -320,23 +335,23 @@ class _Engine:
                         blocks_tape.append((blk, cur, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd, msk))
                 else:
                     s1, h1 = self.bn_fold(blk.bn1)
-                    a1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc, scale=s1, shift=h1, relu=True)
+                    a1, d1 = self.conv(cur, blk.conv1, B, Hc, Wc, scale=s1, shift=h1, relu=True, sb=True)
                     if blk.downsample is not None:
                         sd_, hd = self.bn_fold(blk.downsample[1])
-                        idt, _ = self.conv(cur, blk.downsample[0], B, Hc, Wc, scale=sd_, shift=hd)
+                        idt, _ = self.conv(cur, blk.downsample[0], B, Hc, Wc, scale=sd_, shift=hd, sb=True)
                     else:
                         idt = cur
                     s2, h2 = self.bn_fold(blk.bn2)
-                    out, _ = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo, scale=s2, shift=h2, res=idt, relu=True)
+                    out, _ = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo, scale=s2, shift=h2, res=idt, relu=True, sb=True)
                 cur, Hc, Wc = out, d1.Ho, d1.Wo
             feats.append((cur, Hc, Wc))
         (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
 
         # FPN (network.py:52-55,6-19): lateral 1x1 (+bias) with the x2-upsampled coarser map added in the epilogue
-        f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias, amp=amp)
+        f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias, amp=amp, sb=not training)
         fpn_tape = []
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
-            t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True, amp=amp)
+            t, dl = self.conv(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True, amp=amp, sb=not training)
             if training:
                 c, dc, stf = self.conv_stats(t, fpn.conv[0], B, Hs, Ws, fpn.conv[1], amp=amp)
                 fn, mf, if_ = self.bn_train(c, fpn.conv[1], stats=stf)
@@ -344,7 +359,7 @@ class _Engine:
                     fpn_tape.append((fpn, sc_t, (Hs, Ws), dl, t, dc, c, mf, if_, fn))
             else:
                 sf, hf = self.bn_fold(fpn.conv[1])
-                fn, _ = self.conv(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True)
+                fn, _ = self.conv(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True, sb=True)
             f = fn
 
         # head (network.py:57): NHWC -> NCHW
@@ -375,6 +390,9 @@ class _Engine:
     def conv_bf16(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
         d = _desc(B, Hi, Wi, conv)
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
+        if self.small_batch_kernel and self.lib.sd_conv2d_fwd_sb_supported(C.byref(d), 1):
+            self._conv_sb(x, self._w_bf16(conv), y, d, scale, shift, res, res_up2, relu, 1)
+            return y, d
         nws = self.lib.sd_conv2d_fwd_bf16_workspace_bytes(C.byref(d))
         ws = self._ws(nws, x.device) if nws else None
         L.check(self.lib.sd_conv2d_fwd_bf16(x.data_ptr(), self._w_bf16(conv).data_ptr(), y.data_ptr(), C.byref(d), _ptr(scale), _ptr(shift),

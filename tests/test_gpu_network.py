@@ -782,3 +782,81 @@ def test_stem_bn_relu_maxpool_fused_bf16(shape):
     assert float((diff > 0).float().mean()) < 0.02                           # the two forms agree bit for bit almost everywhere
     ref = F.max_pool2d(torch.relu(F.conv2d(img.bfloat16().float(), w.bfloat16().float(), None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
     close(f32.permute(0, 3, 1, 2), ref, 6e-3)
+
+
+SB_CASES = [  # B, H, W, cin, cout, k, stride, pad -- the bs=1 layer geometries of BASELINE configs[1] + ragged / multi-image ones
+    (1, 128, 128, 64, 64, 3, 1, 1),     # layer1: 256 tiles, no split
+    (1, 64, 64, 128, 128, 3, 1, 1),     # layer2: 128 tiles x 2 slices
+    (1, 32, 32, 256, 256, 3, 1, 1),     # layer3: 64 tiles x 4 slices, (channel tile, slice) pairs grouped per XCD
+    (1, 16, 16, 512, 512, 3, 1, 1),     # layer4: 32 tiles x 8 slices, grouped
+    (1, 128, 128, 64, 128, 3, 2, 1),    # strided 3x3
+    (1, 128, 128, 64, 128, 1, 2, 0),    # 1x1 / 2 downsample (two chunks, no split)
+    (1, 16, 16, 512, 128, 1, 1, 0),     # up1: 8 tiles x 8 slices of two chunks
+    (1, 32, 32, 256, 128, 1, 1, 0),     # FPN lateral (with the x2-upsampled residual below)
+    (2, 9, 7, 256, 256, 3, 1, 1),       # ragged last pixel tile (M = 126)
+    (3, 20, 12, 64, 64, 3, 1, 1),       # tiles cross image boundaries
+]
+
+
+@pytest.mark.parametrize("case", SB_CASES)
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_conv_fwd_small_batch_kernel(case, bf16):
+    """sd_conv2d_fwd_sb (64 x 64 tiles, split-K combined inside the launch by the last-arriving block) against torch: plain, and
+    with the fused epilogue (affine + residual or x2-upsampled residual + ReLU); launched repeatedly on alternating inputs through
+    the SAME workspace / ticket state (a stale slab line or a ticket left non-zero would show as a wrong second or third result),
+    and bit-identical between runs (the slices are summed in slice order, whichever block arrives last)."""
+    from structuredetector_amd import _lib as L
+    B, H, W, cin, cout, k, stride, pad = case
+    if bf16 and cin % 64:
+        pytest.skip("bf16 chunks are 64 channels")
+    lib = L.lib()
+    g = torch.Generator().manual_seed(sum(case) + 7 * bf16)
+    d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    q = (lambda t: t.bfloat16().float()) if bf16 else (lambda t: t)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    xs = [q(rnd(B, cin, H, W)) for _ in range(2)]
+    w = q(rnd(cout, cin, k, k) / (cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = rnd(cout)
+    up2 = d.Ho % 2 == 0 and d.Wo % 2 == 0 and k == 1
+    res = q(rnd(B, cout, d.Ho // 2, d.Wo // 2) if up2 else rnd(B, cout, d.Ho, d.Wo))
+    dev = lambda t: keep(t.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt))
+    xd, wd, rd = [dev(x) for x in xs], dev(w), dev(res)
+    sc, sh = keep(scale.to(DEV)), keep(shift.to(DEV))
+    nws, nst = lib.sd_conv2d_fwd_sb_workspace_bytes(C.byref(d), bf16), lib.sd_conv2d_fwd_sb_state_bytes(C.byref(d), bf16)
+    ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=DEV)
+    st = torch.zeros(max(nst, 256), dtype=torch.uint8, device=DEV)
+    tol = 6e-3 if bf16 else 2e-6 * (cin * k * k) ** 0.5
+    outs = []
+    for rep in range(5):
+        i = rep % 2
+        y = torch.empty(B, d.Ho, d.Wo, cout, dtype=dt, device=DEV)
+        plain = rep == 3
+        L.check(lib.sd_conv2d_fwd_sb(xd[i].data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0 if plain else sc.data_ptr(), 0 if plain else sh.data_ptr(),
+                                     0 if plain else rd.data_ptr(), 0 if plain else int(up2), 0 if plain else 1, bf16, ws.data_ptr(), ws.numel(),
+                                     st.data_ptr(), st.numel(), L.stream()), "sd_conv2d_fwd_sb")
+        ref = F.conv2d(xs[i], w, None, stride, pad)
+        if not plain:
+            r = F.interpolate(res, scale_factor=2) if up2 else res
+            ref = F.relu(ref * scale[None, :, None, None] + shift[None, :, None, None] + r)
+        close(y.float().permute(0, 3, 1, 2).cpu(), ref, max(tol, 1e-5))
+        outs.append(y)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
+    assert int(st.view(torch.int32).abs().sum()) == 0, "arrival tickets must be left zero"
+
+
+def test_network_bs1_small_batch_kernel_on_and_off():
+    """The bs=1 eval forward with sd_conv2d_fwd_sb (default) and with the two-launch split-K path it replaced: same head tensor to
+    fp32 summation-order accuracy, and the default path is bit-reproducible."""
+    ref, net = _pair(seed=17)
+    x = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        net.eval()
+        a = net(x).clone()
+        b = net(x).clone()
+        net._engine.small_batch_kernel = False
+        c = net(x).clone()
+        net._engine.small_batch_kernel = True
+    assert torch.equal(a, b)
+    close(a.cpu(), c.cpu(), 2e-5)
