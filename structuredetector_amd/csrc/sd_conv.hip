@@ -52,11 +52,11 @@ namespace sd {
 #else
 #define SD_TRACE_FLAG 0
 #endif
-#ifdef SD_PP_TRACE
+#if defined(SD_PP_TRACE) || defined(SD_SB_TRACE)
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-#if defined(SD_PP_ABL) || defined(SD_RS_ABL)
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL)
 #define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
 #else
 #define SD_EXPERIMENT_FLAG 0

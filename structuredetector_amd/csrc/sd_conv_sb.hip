@@ -19,6 +19,7 @@
 //     (layer4: 9.4 MB instead of 8 x 9.4 MB per conv).
 #include "sd_common.h"
 #include "sd_mfma.h"
+#include <stdlib.h>
 
 namespace sd {
 
@@ -33,11 +34,23 @@ struct SbArgs {
     unsigned* tickets;    // [tiles] arrival counters: zero before the first launch, left zero by every launch
     int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S, stride, pad;
     int relu, res_up2;
-    int M, nk, per;       // nk = R*S*(Ck / KE) chunks of 128 bytes per row; a slice multiplies `per` consecutive chunks
+    int M, nk, per;       // nk = R*S*(Ck / KE) chunks of 128 bytes per row; a slice multiplies `per` consecutive chunks (a multiple of R*S)
     int m_tiles, n_tiles, splits, grouped;
+    int cper;             // channel chunks per slice (per = R*S*cper)
+    unsigned mg_wo, mg_ho, mg_mt, mg_nt, mg_sp;   // ceil(2^32 / d) for d = Wo, Ho, m_tiles, n_tiles, splits: exact quotients by one multiply-high while n * d < 2^32 (d = 1: 0xffffffff, exact for n < 2^31 ... see sb_magic)
 };
 
-__device__ __attribute__((aligned(128))) float g_sb_zero_line[64];   // zero-initialised: source of padded rows and past-the-end chunks
+// zero-initialised: source of padded rows and past-the-end chunks (a padded row's pointer advances by the channel offset like a real one:
+// Ck * element size <= 4 KB)
+__device__ __attribute__((aligned(128))) float g_sb_zero[1024 + 32];
+
+#ifdef SD_SB_TRACE
+// timing experiment (make SUFFIX=_sbtrace EXTRA=-DSD_SB_TRACE): 100 MHz timestamps of every block's phases
+__device__ unsigned long long g_sb_trace[1024][8];
+#define SB_T(i) if (tid == 0 && blockIdx.x < 1024) g_sb_trace[blockIdx.x][i] = wall_clock64();
+#else
+#define SB_T(i)
+#endif
 
 constexpr int SB_ST = 64 * 32;          // floats per operand stage: 64 rows x 128 bytes
 constexpr int SB_TP = 36;               // row pitch (floats) of a wave's 32 x 32 transposition tile
@@ -52,55 +65,87 @@ __device__ __forceinline__ f32x4 sb_load16_sc1(const float* src) {
     return v;
 }
 #define SB_VM_WAIT4(a, b, c, d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+// end of a pipeline step: this wave's pieces of the chunk after next have landed (8 younger DMAs may be in flight) and the fragments
+// read during the step are in their registers
+#define SB_STEP_WAIT(f) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory")
 
-template <bool BF16>
+// n / d with magic = ceil(2^32 / d), exact while n * d < 2^32; d = 1 is encoded as magic 0 (2^32 does not fit)
+__device__ __forceinline__ int sb_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+
+// Reducer: sum of the slices' slab rows in slice order.  ITS rows of this lane x KP slices are in flight at once (ITS * KP = 16 or 32 sc1
+// loads of 16 bytes; every load of a handed-off byte is sc1, so no acquire is needed), then the next group of rows.
+template <int ITS, int KP>
+__device__ __forceinline__ void sb_reduce(const float* slab0, int splits, int er, f32x4 (&sum)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4 / ITS; ++g) {
+        f32x4 v[ITS * KP];
+#pragma unroll
+        for (int i = 0; i < ITS; ++i)
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                v[i * KP + k] = sb_load16_sc1(slab0 + ((g * ITS + i) * 8 + er) * 64 + (int64_t)min(k, splits - 1) * 4096);
+#pragma unroll
+        for (int q = 0; q < ITS * KP; q += 4) SB_VM_WAIT4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+#pragma unroll
+        for (int i = 0; i < ITS; ++i) {
+            f32x4 s = v[i * KP];
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+                if (k < splits) s += v[i * KP + k];
+            sum[g * ITS + i] = s;
+        }
+    }
+}
+
+// NTAP = R * S as a compile-time constant (9 or 1): the filter tap of every pipeline step is then a literal, and the per-row source
+// pointers of all taps (padding resolved: a padded tap points at the zero region) live in registers -- a chunk's four LDS-DMA
+// addresses cost four 64-bit adds.  NTAP = 0: any R == S filter, tap arithmetic at run time.
+template <bool BF16, int NTAP>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd_sb(SbArgs p) {
     using T = typename std::conditional<BF16, uint16_t, float>::type;
     constexpr int KE = BF16 ? 64 : 32;     // K elements per 128-byte chunk row
     constexpr int VE = BF16 ? 8 : 4;       // elements per 16-byte slot
-    __shared__ __attribute__((aligned(16))) float As0[SB_ST];
-    __shared__ __attribute__((aligned(16))) float As1[SB_ST];
-    __shared__ __attribute__((aligned(16))) float As2[SB_ST];
-    __shared__ __attribute__((aligned(16))) float As3[SB_ST];
-    __shared__ __attribute__((aligned(16))) float Bs0[SB_ST];
-    __shared__ __attribute__((aligned(16))) float Bs1[SB_ST];
-    __shared__ __attribute__((aligned(16))) float Bs2[SB_ST];
-    __shared__ __attribute__((aligned(16))) float Bs3[SB_ST];
+    constexpr int NT = NTAP ? NTAP : 1;
+    // ONE LDS object: stage i of A at float offset i * SB_ST, of B at (4 + i) * SB_ST, so that a stage is an immediate offset of the
+    // fragment reads (inline-asm ds_read_b128: the compiler's wait insertion never sees them beside the LDS-DMA in flight)
+    __shared__ __attribute__((aligned(16))) float lds[8 * SB_ST];
     __shared__ int orow[64];               // output pixel of each tile row, -1 = none
     __shared__ int rrow[64];               // its row in a half-size residual map (res_up2)
     __shared__ unsigned ticket_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SB_T(0)
     const T* const px_ = reinterpret_cast<const T*>(p.x);
     const T* const pw_ = reinterpret_cast<const T*>(p.w);
 
-    // ---- block -> (pixel tile, channel tile, K slice)
+    // ---- block -> (pixel tile, channel tile, K slice); quotients by multiply-high with host-made reciprocals (scalar unit)
     int mt, nt, sl;
     if (p.grouped) {
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        mt = i % p.m_tiles;
-        const int g = (i / p.m_tiles) * 8 + xcd;
-        nt = g % p.n_tiles; sl = g / p.n_tiles;
+        const int gq = sb_div(i, p.mg_mt);
+        mt = i - gq * p.m_tiles;
+        const int g = gq * 8 + xcd;
+        sl = sb_div(g, p.mg_nt); nt = g - sl * p.n_tiles;
     } else {
         const int t = xcd_remap(blockIdx.x, gridDim.x);      // XCD-contiguous pixel tiles: neighbours share input rows in L2
-        sl = t % p.splits;
-        const int u = t / p.splits;
-        nt = u % p.n_tiles; mt = u / p.n_tiles;
+        const int u = sb_div(t, p.mg_sp);
+        sl = t - u * p.splits;
+        mt = sb_div(u, p.mg_nt); nt = u - mt * p.n_tiles;
     }
     const int m0 = mt * 64, n0 = nt * 64;
     const int kbeg = sl * p.per, nkl = min(p.per, p.nk - kbeg);
+#ifdef SD_SB_TRACE
+    if (tid == 0 && blockIdx.x < 1024 && nkl > -5) g_sb_trace[blockIdx.x][7] = wall_clock64();     // (after the first uses of the kernel arguments)
+#endif
     const int ntap = p.R * p.S;
-    int ld_c0, ld_r, ld_s;
-    {
-        const int cc = kbeg / ntap, tap = kbeg - cc * ntap;    // chunk index = channel chunk * taps + tap (taps innermost: L2 reuse)
-        ld_c0 = cc * KE; ld_r = tap / p.S; ld_s = tap - ld_r * p.S;
-    }
+    int ic0 = sl * p.cper * KE;                                // channel offset of the next chunk to issue (a slice = whole channel chunks)
+    int itap = 0;                                              // NTAP == 0: its tap
 
     if (tid < 64) {
         const int m = m0 + tid;
         int pix = -1, rr = -1;
         if (m < p.M) {
-            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            const int t = sb_div(m, p.mg_wo), ox = m - t * p.Wo, b = sb_div(t, p.mg_ho), oy = t - b * p.Ho;
             pix = m;
             rr = (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
         }
@@ -111,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_sb(SbArgs p) {
     // wave-instruction of LDS-DMA: lane l -> row l/8, physical 16-byte slot l%8).  LDS image: row r keeps logical slot q at
     // physical slot q ^ ((r >> 1) & 7) (conflict-free ds_read_b128), so the swizzle goes on the SOURCE address.
     const int prow = lane >> 3, pslot = lane & 7;
-    const T* const zsrc = reinterpret_cast<const T*>(g_sb_zero_line);
-    const T* abase[2];
+    const T* const zsrc = reinterpret_cast<const T*>(g_sb_zero);
+    const T* aptr[2][NT];                  // NTAP > 0: source of (row j, tap) at channel 0, or the zero region
+    const T* abase[2];                     // NTAP == 0: image base + slot; coordinates checked per chunk
     int aty[2], atx[2], aq[2];
     const T* bbase[2];
     const int wk = ntap * p.Ck;
@@ -124,147 +170,195 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_sb(SbArgs p) {
         const int m = m0 + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        aty[j] = ok ? oy * p.stride - p.pad : -(1 << 28);       // rows past the end fail every range check
+        const int t = sb_div(mm, p.mg_wo), ox = mm - t * p.Wo, b = sb_div(t, p.mg_ho), oy = t - b * p.Ho;
+        aty[j] = ok ? oy * p.stride - p.pad : -64;             // rows past the end fail every range check (R <= 32)
         atx[j] = ox * p.stride - p.pad;
         abase[j] = px_ + (int64_t)b * p.Hi * p.Wi * p.Ck + q;
         bbase[j] = pw_ + (int64_t)(n0 + row) * wk + q;
+        if (NTAP) {
+            // tap (r, s): pointer of tap (0, 0) + a wave-uniform offset; padding by three row checks x three column checks
+            const T* const p00 = abase[j] + (int64_t)(aty[j] * p.Wi + atx[j]) * p.Ck;
+            bool vr[3], vc[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { vr[r] = (unsigned)(aty[j] + r) < (unsigned)p.Hi; vc[r] = (unsigned)(atx[j] + r) < (unsigned)p.Wi; }
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                const int r = NTAP == 9 ? tp / 3 : 0, s_ = NTAP == 9 ? tp % 3 : 0;
+                aptr[j][tp] = (vr[r] && vc[s_]) ? p00 + (int64_t)(r * p.Wi + s_) * p.Ck : zsrc + q;
+            }
+        }
     }
-    int issued = 0;
-#define SB_ISSUE(AD, BD)                                                                           \
+    const int cmax = p.Ck - KE;
+    float* const ldsA = lds + wave * 512;                      // this wave's first piece inside stage 0 of A (B: + 4 * SB_ST)
+    // The next chunk (filter tap TP when NTAP > 0) into stage ST, one LDS-DMA piece at a time (J = 0, 1: the wave's A pieces, 2, 3: its B
+    // pieces) so that the pipeline steps can put ONE piece into each MFMA shadow (one wave gets a piece out per ~66 cycles).  Every step
+    // issues its four pieces, also past the end of the slice (the counted waits rely on it, and a conditional issue costs selects or
+    // branches between the MFMAs): the channel offset is clamped to the last chunk, so those pieces re-read valid data that no MFMA uses.
+#define SB_ISSUE_J(TP, ST, J)                                                                      \
     {                                                                                              \
-        if (issued < nkl) {                                                                        \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                        \
-                const int ty = aty[j] + ld_r, tx = atx[j] + ld_s;                                  \
-                const bool ok = (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;    \
-                const T* src = ok ? abase[j] + ((int64_t)(ty * p.Wi + tx) * p.Ck + ld_c0) : zsrc + aq[j]; \
-                lds_dma16(src, (AD) + (wave * 2 + j) * 256);                                       \
-            }                                                                                      \
-            const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0;                                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) lds_dma16(bbase[j] + woff, (BD) + (wave * 2 + j) * 256); \
-            if (++ld_s >= p.S) { ld_s = 0; if (++ld_r >= p.R) { ld_r = 0; ld_c0 += KE; } }        \
-        } else {      /* past the end: keep the per-iteration DMA count (the counted waits rely on it) */ \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) lds_dma16(zsrc + aq[j], (AD) + (wave * 2 + j) * 256); \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) lds_dma16(zsrc + aq[j], (BD) + (wave * 2 + j) * 256); \
+        float* const dst = ldsA + (ST) * SB_ST + ((J) >> 1) * 4 * SB_ST + ((J) & 1) * 256;         \
+        if (NTAP) {                                                                                \
+            if ((J) < 2) lds_dma16(aptr[(J) & 1][(TP) % NT] + ic0, dst);                           \
+            else lds_dma16(bbase[(J) & 1] + (((TP) % NT) * p.Ck + ic0), dst);                      \
+            if ((J) == 3 && (TP) % NT == NT - 1) ic0 = min(ic0 + KE, cmax);                        \
+        } else {                                                                                   \
+            if ((J) < 2) {                                                                         \
+                const int r = itap / p.S, s_ = itap - r * p.S;                                     \
+                const int ty = aty[(J) & 1] + r, tx = atx[(J) & 1] + s_;                           \
+                const bool in = (unsigned)ty < (unsigned)p.Hi && (unsigned)tx < (unsigned)p.Wi;    \
+                lds_dma16(in ? abase[(J) & 1] + ((int64_t)(ty * p.Wi + tx) * p.Ck + ic0) : zsrc + aq[(J) & 1], dst); \
+            } else lds_dma16(bbase[(J) & 1] + (itap * p.Ck + ic0), dst);                           \
+            if ((J) == 3 && ++itap == ntap) { itap = 0; ic0 = min(ic0 + KE, cmax); }               \
         }                                                                                          \
-        ++issued;                                                                                  \
     }
+#define SB_ISSUE(TP, ST) SB_ISSUE_J(TP, ST, 0) SB_ISSUE_J(TP, ST, 1) SB_ISSUE_J(TP, ST, 2) SB_ISSUE_J(TP, ST, 3)
 
     // ---- wave tile: 32 (m) x 32 (n)
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
     const int rd_swz = (fr >> 1) & 7;
-    f32x16 acc;
+    // two accumulators, alternating k-steps: a dependent v_mfma issues a few cycles after its predecessor has left the pipe (measured:
+    // 1253 instead of 1024 cycles per chunk with one accumulator), two independent chains keep it full; summed once at the end
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // per-lane byte offsets of the four k-groups' 16-byte fragments inside a stage (A row wm*32 + fr, B row wn*32 + fr)
-    uint32_t fo[4];
+    for (int e = 0; e < 16; ++e) acc[e] = acc1[e] = 0.f;
+    // LDS byte addresses (stage 0) of the four k-groups' 16-byte fragments: A row wm*32 + fr, B row wn*32 + fr
+    uint32_t fa[4], fb[4];
+    {
+        const uint32_t base = lds_addr(lds);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fo[ks] = (uint32_t)((((ks * 2 + fh) ^ rd_swz) << 2) * 4);
-    const uint32_t a_row = (uint32_t)((wm * 32 + fr) * 32 * 4), b_row = (uint32_t)((wn * 32 + fr) * 32 * 4);
-
-    SB_ISSUE(As0, Bs0)
-    SB_ISSUE(As1, Bs1)
-    SB_ISSUE(As2, Bs2)
-    wait_vmcnt<8>();                                          // chunk 0 has landed (chunks 1, 2 may be in flight)
-    __builtin_amdgcn_s_barrier();
-
-#define SB_COMPUTE(AB, BB)                                                                         \
-    {                                                                                              \
-        const uint32_t ab = lds_addr(AB) + a_row, bb = lds_addr(BB) + b_row;                       \
-        f32x4 a0 = lds_read128_async<0>(ab + fo[0]), b0 = lds_read128_async<0>(bb + fo[0]);        \
-        f32x4 a1 = lds_read128_async<0>(ab + fo[1]), b1 = lds_read128_async<0>(bb + fo[1]);        \
-        f32x4 a2 = lds_read128_async<0>(ab + fo[2]), b2 = lds_read128_async<0>(bb + fo[2]);        \
-        f32x4 a3 = lds_read128_async<0>(ab + fo[3]), b3 = lds_read128_async<0>(bb + fo[3]);        \
-        SD_LDS_WAIT2(6, a0, b0); SB_MFMA(a0, b0)                                                   \
-        SD_LDS_WAIT2(4, a1, b1); SB_MFMA(a1, b1)                                                   \
-        SD_LDS_WAIT2(2, a2, b2); SB_MFMA(a2, b2)                                                   \
-        SD_LDS_WAIT2(0, a3, b3); SB_MFMA(a3, b3)                                                   \
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t slot = (uint32_t)((((ks * 2 + fh) ^ rd_swz) << 2) * 4);
+            fa[ks] = base + (uint32_t)((wm * 32 + fr) * 128) + slot;
+            fb[ks] = base + (uint32_t)(4 * SB_ST * 4 + (wn * 32 + fr) * 128) + slot;
+        }
     }
-#define SB_MFMA(FA, FB)                                                                            \
+    // fragment registers of two chunks: set 0 / 1, [0..3] = A k-groups, [4..7] = B k-groups
+    f32x4 fx[2][8];
+#define SB_READ1(SET, ST, KS)                                                                       \
+    { fx[SET][KS] = lds_read128_async<(ST) * SB_ST * 4>(fa[KS]); fx[SET][4 + (KS)] = lds_read128_async<(ST) * SB_ST * 4>(fb[KS]); }
+#define SB_READ(SET, ST) SB_READ1(SET, ST, 0) SB_READ1(SET, ST, 1) SB_READ1(SET, ST, 2) SB_READ1(SET, ST, 3)
+    // MFMA(s) of k-group KS: fp32 = four dependent v_mfma_f32_32x32x2_f32 (T = 0 .. 3 singly), bf16 = one v_mfma_f32_32x32x16_bf16 (at T = 0)
+#define SB_MFMA1(SET, KS, T_)                                                                      \
     if (BF16) {                                                                                    \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FA), __builtin_bit_cast(bf16x8, FB), acc, 0, 0, 0); \
-    } else {                                                                                       \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[t], FB[t], acc, 0, 0, 0); \
-    }
-    // one pipeline step, stage names literal: issue chunk kc+3 into the stage read at step kc-1, multiply chunk kc, then make sure
-    // this wave's pieces of chunk kc+1 have landed (two younger chunks = 8 DMAs may stay in flight) before the barrier publishes them
-#define SB_ITER(AC, BC, AN, BN_)                                                                   \
+        if ((T_) == 0) {                                                                           \
+            if ((KS) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fx[SET][KS]), __builtin_bit_cast(bf16x8, fx[SET][4 + (KS)]), acc1, 0, 0, 0); \
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fx[SET][KS]), __builtin_bit_cast(bf16x8, fx[SET][4 + (KS)]), acc, 0, 0, 0); \
+        }                                                                                          \
+    } else if ((T_) & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fx[SET][KS][T_], fx[SET][4 + (KS)][T_], acc1, 0, 0, 0); \
+    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fx[SET][KS][T_], fx[SET][4 + (KS)][T_], acc, 0, 0, 0);
+#define SB_PIN __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: chunks 0 .. 3 on their way, chunk 0 in registers, chunk 1 published
+    SB_ISSUE(0, 0)
+    SB_ISSUE(1, 1)
+    SB_ISSUE(2, 2)
+    SB_ISSUE(3, 3)
+    SB_T(1)
+    wait_vmcnt<12>();                                         // chunk 0 has landed
+    __builtin_amdgcn_s_barrier();
+    SB_READ(0, 0)
+    SB_STEP_WAIT(fx[0]);                                      // chunk 0 in registers, this wave's pieces of chunk 1 landed
+    __builtin_amdgcn_s_barrier();                             // chunk 1 published; every wave is done with stage 0
+    SB_T(2)
+#ifdef SD_SB_TRACE
+    const long long cyc0 = clock64();
+#endif
+
+    // One pipeline step (I literal): multiply chunk I from register set I & 1 while the fragments of chunk I+1 are read into the other
+    // set and chunk I+4 is issued into the stage chunk I came from (free: every wave had chunk I in registers before the last barrier).
+    // The LDS reads and the LDS-DMA issue sit between the MFMAs (a dependent MFMA issues 64 cycles after its predecessor: what stands
+    // between them runs in that shadow); sched_barrier pins that order.
+#ifndef SD_SB_ABL
+#define SD_SB_ABL 0     // timing-only ablations of the pipeline step (WRONG RESULTS): 1 no LDS-DMA, 2 no barrier, 3 no fragment reads, 4 no MFMA
+#endif
+#define SB_ABL_DMA(x) if (SD_SB_ABL != 1) { x }
+#define SB_ABL_RD(x) if (SD_SB_ABL != 3) { x }
+#define SB_ABL_MM(x) if (SD_SB_ABL != 4) { x }
+#define SB_STEP(I)                                                                                 \
     {                                                                                              \
-        SB_ISSUE(AN, BN_)                                                                          \
-        SB_COMPUTE(AC, BC)                                                                         \
-        wait_vmcnt_and_lds<8>();                                                                   \
-        __builtin_amdgcn_s_barrier();                                                              \
-        ++kc;                                                                                      \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 0, 0)) SB_PIN SB_ABL_RD(SB_READ1(((I) + 1) & 1, ((I) + 1) & 3, 0)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 0, 1)) SB_PIN SB_ABL_RD(SB_READ1(((I) + 1) & 1, ((I) + 1) & 3, 1)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 0, 2)) SB_PIN SB_ABL_RD(SB_READ1(((I) + 1) & 1, ((I) + 1) & 3, 2)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 0, 3)) SB_PIN SB_ABL_RD(SB_READ1(((I) + 1) & 1, ((I) + 1) & 3, 3)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 1, 0)) SB_PIN SB_ABL_DMA(SB_ISSUE_J((I) + 4, (I) & 3, 0)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 1, 1) SB_MFMA1((I) & 1, 1, 2) SB_MFMA1((I) & 1, 1, 3))         \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 2, 0)) SB_PIN SB_ABL_DMA(SB_ISSUE_J((I) + 4, (I) & 3, 1)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 2, 1)) SB_PIN SB_ABL_DMA(SB_ISSUE_J((I) + 4, (I) & 3, 2)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 2, 2) SB_MFMA1((I) & 1, 2, 3))                                 \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 3, 0)) SB_PIN SB_ABL_DMA(SB_ISSUE_J((I) + 4, (I) & 3, 3)) SB_PIN  \
+        SB_ABL_MM(SB_MFMA1((I) & 1, 3, 1) SB_MFMA1((I) & 1, 3, 2) SB_MFMA1((I) & 1, 3, 3))         \
+        SB_PIN                                                                                     \
+        SB_STEP_WAIT(fx[((I) + 1) & 1]);                                                           \
+        if (SD_SB_ABL != 2) __builtin_amdgcn_s_barrier();                                          \
+        if (++kc >= nkl) break;                                                                    \
     }
+#define SB_STEP4(I) SB_STEP(I) SB_STEP((I) + 1) SB_STEP((I) + 2) SB_STEP((I) + 3)
     int kc = 0;
-    while (kc < nkl) {
-        SB_ITER(As0, Bs0, As3, Bs3)
-        if (kc < nkl) SB_ITER(As1, Bs1, As0, Bs0)
-        if (kc < nkl) SB_ITER(As2, Bs2, As1, Bs1)
-        if (kc < nkl) SB_ITER(As3, Bs3, As2, Bs2)
+    for (;;) {
+        if (NTAP == 9) {
+            SB_STEP4(0) SB_STEP4(4) SB_STEP4(8) SB_STEP4(12) SB_STEP4(16) SB_STEP4(20) SB_STEP4(24) SB_STEP4(28) SB_STEP4(32)
+        } else {
+            SB_STEP4(0)
+        }
     }
     wait_vmcnt<0>();
-#undef SB_ITER
-#undef SB_COMPUTE
-#undef SB_MFMA
+#undef SB_STEP4
+#undef SB_STEP
+#undef SB_MFMA1
+#undef SB_READ
+#undef SB_READ1
 #undef SB_ISSUE
+#undef SB_ISSUE_J
+#undef SB_PIN
     __syncthreads();                                          // every (past-the-end) DMA has landed: the stages are free
+    SB_T(3)
+#ifdef SD_SB_TRACE
+    if (tid == 0 && blockIdx.x < 1024) g_sb_trace[blockIdx.x][4] = (unsigned long long)(clock64() - cyc0);      // (splits == 1 only: slot 4 is rewritten below)
+#endif
 
     // ---- the wave's 32 x 32 accumulator -> rows, through a wave-private LDS tile (C/D map: n = lane & 31,
     // m = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)); afterwards lane -> (row it*8 + lane/8, four channels (lane%8)*4)
-    float* const Tw = wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? As2 : As3;
+    float* const Tw = lds + wave * SB_ST;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Tw[((e & 3) + 8 * (e >> 2) + 4 * fh) * SB_TP + fr] = acc[e];
+    for (int e = 0; e < 16; ++e) Tw[((e & 3) + 8 * (e >> 2) + 4 * fh) * SB_TP + fr] = acc[e] + acc1[e];
     const int er = lane >> 3, c4 = (lane & 7) * 4;
     const int n = n0 + wn * 32 + c4;
     const int tile = mt * p.n_tiles + nt;
+    f32x4 out[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(Tw + (it * 8 + er) * SB_TP + c4);
+        out[it][0] = v.x; out[it][1] = v.y; out[it][2] = v.z; out[it][3] = v.w;
+    }
 
     if (p.splits > 1) {
         float* const slab = p.slabs + ((int64_t)tile * p.splits + sl) * 4096 + (wm * 32) * 64 + wn * 32 + c4;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + er;
-            const float4 v = *reinterpret_cast<const float4*>(Tw + row * SB_TP + c4);
-            f32x4 vv; vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
-            sb_store16_sc1(slab + row * 64, vv);
-        }
+        for (int it = 0; it < 4; ++it) sb_store16_sc1(slab + (it * 8 + er) * 64, out[it]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
         __syncthreads();                                      // ... before ONE lane signals for the block
+        SB_T(4)
         if (tid == 0) ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        SB_T(5)
         if (ticket_s != (unsigned)(p.splits - 1)) return;     // not the last slice of this tile to arrive
         if (tid == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // state left zero
+        const float* const slab0 = p.slabs + (int64_t)tile * p.splits * 4096 + (wm * 32) * 64 + wn * 32 + c4;
+        if (p.splits <= 4) sb_reduce<4, 4>(slab0, p.splits, er, out);
+        else if (p.splits <= 8) sb_reduce<4, 8>(slab0, p.splits, er, out);      // 32 loads in flight (the fragment registers are dead)
+        else sb_reduce<2, 16>(slab0, p.splits, er, out);
     }
 
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + n);
     if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + n);
-    const float* const slab0 = p.slabs + (int64_t)tile * p.splits * 4096 + (wm * 32) * 64 + wn * 32 + c4;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + er, trow = wm * 32 + row;
+        const int trow = wm * 32 + it * 8 + er;
         const int m = orow[trow];
-        float4 v;
-        if (p.splits > 1) {
-            // sum of the slices in slice order, four sc1 loads in flight (every load of a handed-off byte is sc1: no acquire needed)
-            f32x4 s; s[0] = s[1] = s[2] = s[3] = 0.f;
-            const float* src = slab0 + row * 64;
-            for (int k = 0; k < p.splits; k += 4) {
-                const int k1 = min(k + 1, p.splits - 1), k2 = min(k + 2, p.splits - 1), k3 = min(k + 3, p.splits - 1);
-                f32x4 v0 = sb_load16_sc1(src + (int64_t)k * 4096), v1 = sb_load16_sc1(src + (int64_t)k1 * 4096);
-                f32x4 v2 = sb_load16_sc1(src + (int64_t)k2 * 4096), v3 = sb_load16_sc1(src + (int64_t)k3 * 4096);
-                SB_VM_WAIT4(v0, v1, v2, v3);
-                s += v0;
-                if (k + 1 < p.splits) s += v1;
-                if (k + 2 < p.splits) s += v2;
-                if (k + 3 < p.splits) s += v3;
-            }
-            v = make_float4(s[0], s[1], s[2], s[3]);
-        } else {
-            v = *reinterpret_cast<const float4*>(Tw + row * SB_TP + c4);
-        }
         if (m < 0) continue;
+        float4 v = make_float4(out[it][0], out[it][1], out[it][2], out[it][3]);
         v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
         if (p.res) {
             const int64_t rm = p.res_up2 ? (int64_t)rrow[trow] : (int64_t)m;
@@ -287,24 +381,37 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_sb(SbArgs p) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * p.Nn + n) = v;
         }
     }
+#ifdef SD_SB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SB_T(6)
+#endif
 }
 
 // Decomposition (host): K slices so that tiles x slices is about one block per CU, at least two chunks per slice, at most 16 slabs
 // for the reducer to read.
 static bool sb_plan(SbArgs& a, const sd_conv_desc* d, bool bf16) {
     const int KE = bf16 ? 64 : 32;
-    if (d->Cin % KE || d->Cout % 64) return false;
+    if (d->Cin % KE || d->Cout % 64 || d->Cin * (bf16 ? 2 : 4) > 4096 || d->R != d->S || d->R > 32) return false;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
     a.stride = d->stride; a.pad = d->pad;
     a.M = d->B * d->Ho * d->Wo;
-    a.nk = d->R * d->S * (d->Cin / KE);
+    const int ntap = d->R * d->S, kchunks = d->Cin / KE;
+    a.nk = ntap * kchunks;
     a.m_tiles = cdiv(a.M, 64); a.n_tiles = d->Cout / 64;
     const int tiles = a.m_tiles * a.n_tiles;
     int s = 1;
-    if (tiles < 192) s = std::max(1, std::min(std::min(16, a.nk / 2), (256 + tiles / 2) / tiles));
-    a.per = cdiv(a.nk, s);
+    static const int target = getenv("SD_SB_TARGET") ? atoi(getenv("SD_SB_TARGET")) : 256;      // EXPERIMENT (A/B of the block count)
+    static const int smax = getenv("SD_SB_SMAX") ? atoi(getenv("SD_SB_SMAX")) : 16;
+    if (tiles < target * 3 / 4) s = std::max(1, std::min(std::min(smax, a.nk / 2), (target + tiles / 2) / tiles));
+    if (bf16 && tiles >= 128) s = 1;                         // bf16: the loop is a fraction of a split's combine (measured: 1.8 vs 3.4 us)
+    a.cper = cdiv(kchunks, std::min(s, kchunks));            // whole channel chunks per slice: every slice starts at filter tap 0
+    a.per = ntap * a.cper;
     a.splits = cdiv(a.nk, a.per);
     a.grouped = (a.n_tiles * a.splits) % 8 == 0 && a.splits > 1;
+    // quotients by multiply-high: exact while n * d < 2^32 (pixels: n < M <= 2^20, 2 <= d <= 2^12; blocks: n, d <= 2^15)
+    if (a.M > (1 << 20) || d->Wo < 2 || d->Wo > 4096 || d->Ho < 2 || d->Ho > 4096 || (int64_t)tiles * a.splits > (1 << 15)) return false;
+    auto magic = [](int dd) { return dd <= 1 ? 0u : (unsigned)(((1ull << 32) + dd - 1) / dd); };
+    a.mg_wo = magic(d->Wo); a.mg_ho = magic(d->Ho); a.mg_mt = magic(a.m_tiles); a.mg_nt = magic(a.n_tiles); a.mg_sp = magic(a.splits);
     return true;
 }
 
@@ -319,7 +426,8 @@ int sd_conv2d_fwd_sb_supported(const sd_conv_desc* d, int bf16) {
     if (!d || d->B <= 0 || d->Cin % (bf16 ? 64 : 32) || d->Cout % 64 || d->R != d->S || d->R < 1 || d->stride < 1) return 0;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     const int BN = (d->Cout % 128 == 0) ? 128 : 64;
-    return cdiv(M, 128) * (d->Cout / BN) < 256 ? 1 : 0;
+    SbArgs a{};
+    return (cdiv(M, 128) * (d->Cout / BN) < 256 && M <= (1 << 20) && sb_plan(a, d, bf16 != 0)) ? 1 : 0;
 }
 
 size_t sd_conv2d_fwd_sb_workspace_bytes(const sd_conv_desc* d, int bf16) {
@@ -344,8 +452,8 @@ int sd_conv2d_fwd_sb(const void* x, const void* w, void* y, const sd_conv_desc* 
     SD_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->B * d->Hi * d->Wi * d->Cin < (1ll << 31), SD_ERR_INVALID,
                "sd_conv2d_fwd_sb: tensor too large for 32-bit element offsets (this is the small-batch kernel)");
     SbArgs a{};
-    SD_REQUIRE(sb_plan(a, d, bf16 != 0), SD_ERR_INVALID, "sd_conv2d_fwd_sb: needs Cin %% %d == 0 and Cout %% 64 == 0 (got %d, %d)", bf16 ? 64 : 32,
-               d->Cin, d->Cout);
+    SD_REQUIRE(sb_plan(a, d, bf16 != 0), SD_ERR_INVALID, "sd_conv2d_fwd_sb: needs Cin %% %d == 0, Cin <= %d, Cout %% 64 == 0, at most 2^20 output pixels and "
+               "2 <= Ho, Wo <= 4096 (got Cin %d, Cout %d, %d x %d x %d)", bf16 ? 64 : 32, bf16 ? 2048 : 1024, d->Cin, d->Cout, d->B, d->Ho, d->Wo);
     SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(residual) && aligned16(workspace),
                SD_ERR_ALIGN, "sd_conv2d_fwd_sb: pointers must be 16-byte aligned");
     SD_REQUIRE(!res_up2 || (residual && d->Ho % 2 == 0 && d->Wo % 2 == 0), SD_ERR_INVALID, "sd_conv2d_fwd_sb: res_up2 needs a residual and even Ho, Wo");
@@ -356,10 +464,19 @@ int sd_conv2d_fwd_sb(const void* x, const void* w, void* y, const sd_conv_desc* 
     a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu; a.res_up2 = res_up2;
     a.slabs = (float*)workspace; a.tickets = (unsigned*)state;
     const int blocks = a.m_tiles * a.n_tiles * a.splits;
-    if (bf16) hipLaunchKernelGGL(k_conv_fwd_sb<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_conv_fwd_sb<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const int ntap = d->R * d->S;
+#define SB_LAUNCH(BF, NTAP) hipLaunchKernelGGL((k_conv_fwd_sb<BF, NTAP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a)
+    if (bf16) { if (ntap == 9) SB_LAUNCH(true, 9); else if (ntap == 1) SB_LAUNCH(true, 1); else SB_LAUNCH(true, 0); }
+    else { if (ntap == 9) SB_LAUNCH(false, 9); else if (ntap == 1) SB_LAUNCH(false, 1); else SB_LAUNCH(false, 0); }
+#undef SB_LAUNCH
     SD_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SD_SB_TRACE
+int sd_debug_sb_trace(unsigned long long* out, int blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::g_sb_trace), sizeof(unsigned long long) * 8 * (blocks < 1024 ? blocks : 1024));
+}
+#endif
 
 }  // extern "C"
