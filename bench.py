@@ -193,7 +193,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="run the weight-gradient GEMMs on a side stream (+3.5 %% images/s; per-kernel durations then overlap)")
+                    help="experiment: run the weight-gradient GEMMs on a side stream (measured in round 2: fp32 step 6 %% SLOWER, mixed "
+                         "precision -0.3 %%: both streams are MFMA-bound and share the power budget; per-kernel durations then overlap)")
     ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
                     help="gradient all-reduce binding for --gpus > 1: torch.distributed's RCCL (default) or the C-ABI sd_allreduce_*")
     ap.add_argument("--fuse-bn-bwd", dest="fuse_bn_bwd", action="store_true", default=None,
@@ -218,10 +219,21 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X visible as torch device 'cuda' (there is no CPU path to measure)")
-    dev = torch.device("cuda", local if local < torch.cuda.device_count() else 0)    # (rehearsal: several ranks on one GPU)
+    backend = os.environ.get("SDNET_DIST_BACKEND", "nccl")          # "gloo": rehearsal of the multi-rank path on one GPU / on CPU hosts
+    if local >= torch.cuda.device_count():
+        # RCCL needs one device per rank: a rank silently sharing device 0 would time a different experiment
+        if world > 1 and backend == "nccl":
+            raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} visible device(s); the RCCL run needs one "
+                             "GPU per rank (set SDNET_DIST_BACKEND=gloo to rehearse several ranks on one GPU)")
+        local = 0                                                    # (gloo rehearsal: several ranks on one GPU)
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
-        backend = os.environ.get("SDNET_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the multi-rank path on one GPU / on CPU hosts
+        # eight ranks share the host: cap each rank's CPU pools (the Encode planner and torch's intra-op pool) at its share of the cores
+        share = max(1, (os.cpu_count() or 8) // world)
+        torch.set_num_threads(min(torch.get_num_threads(), share))
+        os.environ.setdefault("OMP_NUM_THREADS", str(share))
+    if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -276,6 +288,8 @@ def main():
         dist.all_gather(gathered, devs)
         rccl["device_of_rank"] = [int(g[0]) for g in gathered]
         rccl["distinct_devices"] = len({int(g[0]) for g in gathered})
+        if backend == "nccl" and rccl["distinct_devices"] != world:
+            raise SystemExit(f"bench.py: {world} ranks over RCCL but {rccl['distinct_devices']} distinct devices ({rccl['device_of_rank']})")
 
     for i in range(a.warmup):
         loss = run_step(i)

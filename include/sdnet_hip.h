@@ -114,7 +114,11 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
  * (e.g. 2048x2048 inputs with 16 maps) are rejected with SD_ERR_INVALID: use sd_decode for those.
  * Replaces decoders.py:41-100 like sd_decode; exists because bs = 1 inference is launch-latency-bound. */
 size_t sd_decode_state_bytes(int B, int M, int N, int h, int w);
-int    sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P);   /* 1 when sd_decode_fused accepts this geometry */
+int    sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P);   /* 1 when sd_decode_fused can compute this geometry */
+/* 1 where ONE launch is also the FASTER decoder (at most 256 tile blocks per image: 512x512 with 2 + 1 maps has 48; exact top-k: batches
+ * up to 8).  Elsewhere call sd_decode: at 1024x1024 / 8 + 8 maps / K = 128 / P = 512 the one-launch form takes 451 us against 116 us.
+ * sd_decode_fused REFUSES (SD_ERR_INVALID) image geometries beyond 256 tile blocks unless bit 1 of `exact_topk` (value 2) is set. */
+int    sd_decode_fused_recommended(int B, int M, int N, int h, int w, int K, int P, int exact_topk);
 size_t sd_decode_fused_workspace_bytes(int B, int M, int N, int h, int w, int K, int P);
 int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
                     const float* part_hm, int64_t p_sb, int64_t p_sc,
@@ -122,9 +126,11 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
                     const float* embeddings, int64_t e_sb, int64_t e_sc,
                     int B, int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk,
                     void* packed, void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, sd_stream_t stream);
-/* Tuning knob of sd_decode_fused (process-wide, not a result-changing setting): "tall_tiles_from" = number of 64x16-pixel tile
- * blocks of a launch (B x (M+N) x tiles) from which the NMS runs on 64x32 tiles instead (default 2688: batches of 56 and more
- * at 128x128 maps; 1 = always, 1 << 30 = never).  The sizes returned by sd_decode_state_bytes / _workspace_bytes cover both. */
+/* Tuning knob of sd_decode_fused (not a result-changing setting; THREAD-LOCAL: it applies to calls made by the host thread that set
+ * it, every thread starts from the default, so two engines in two threads of one process cannot disturb each other):
+ * "tall_tiles_from" = number of 64x16-pixel tile blocks of a launch (B x (M+N) x tiles) from which the NMS runs on 64x32 tiles instead
+ * (default 2688: batches of 56 and more at 128x128 maps; 1 = always, 1 << 30 = never).  The sizes returned by sd_decode_state_bytes /
+ * _workspace_bytes cover both. */
 int sd_decode_set_option(const char* name, int value);
 
 /* Explicit host wait for everything queued on `stream` (hipStreamSynchronize): the ONE blocking call of the decoder's host side,
@@ -282,7 +288,10 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
                     const float* invstd, const float* gamma, const float* beta, const float* means, float* dx, float* g_out,
                     sd_stream_t stream);
 
-/* Process-wide tuning / test switches.  "conv_patch_min_tiles": smallest tile grid for which the 3x3 stride-1 convs take the
+/* Kernel-selection thresholds (tuning / test switches; they never change results beyond fp32 summation order).  THREAD-LOCAL: a value
+ * applies to the calls made by the host thread that set it and every thread starts from the defaults -- two engines driven from two
+ * threads of one process (training + evaluation) cannot change each other's kernel choice; the library keeps no process-global
+ * mutable state.  sd_conv2d_kernel_name() reports the choice the CALLING thread would get.  "conv_patch_min_tiles": smallest tile grid for which the 3x3 stride-1 convs take the
  * patch-staging kernel (default 512 = two resident blocks per CU; 1 = always, for tests; 1 << 30 = never);
  * "conv_patch_bn64": 1 = also for layers with 64 output channels (default 0: slower inside the training step);
  * "conv_pp_min_tiles": smallest grid of 512-pixel x 128-channel tiles for which the bf16 3x3 stride-1 convs take the two-group

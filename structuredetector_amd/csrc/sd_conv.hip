@@ -3313,9 +3313,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(ConvArgs p) {
 #define SD_CONV_PATCH 1        // 1 = 3x3 / stride 1 / pad 1 convs (forward and data-gradient) run k_conv3x3_patch where its geometry fits
 #endif
 
-static int g_patch_bn64 = 0;            // 64-channel layers: the patch kernel wins the isolated layer benchmark (+4 %) but loses inside the
+static thread_local int g_patch_bn64 = 0;            // 64-channel layers: the patch kernel wins the isolated layer benchmark (+4 %) but loses inside the
                                         // training step (754 vs 720 us per launch), so it is off; sd_set_option("conv_patch_bn64", 1)
-static int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_option("conv_patch_min_tiles", n) (tests: 1; off: 1 << 30)
+static thread_local int g_patch_min_tiles = 512;     // two resident blocks per CU; sd_set_option("conv_patch_min_tiles", n) (tests: 1; off: 1 << 30)
 
 // k_conv3x3_patch applies: unit-stride 3x3 with pad 1 (fwd: rsign +1, off -1; dgrad: rsign -1, off +1), map width 16..128 (power
 // of two), images that are whole 256-pixel tiles, no split-K, and a grid that fills the chip.  Fills the geometry fields.
@@ -3340,7 +3340,7 @@ static bool conv_patch_geometry(ConvArgs& a, int BN, int mode, bool bf16 = false
 // Output-channel width of the patch-staging tile that takes this conv (0: none; fills the geometry fields).  128-channel tiles when
 // they fill the chip; a layer whose 128-channel tiles do not (layer4 at bs=64: 256 tiles) takes 64-channel tiles if those do
 // (sd_set_option("conv_patch_narrow", n): 0 off, 1 fp32 only, 2 fp32 and bf16).
-static int g_patch_narrow = 2;            // 1: fp32 only, 2: bf16 too.  Same-box A/B (tools/ab_option.py): fp32 step -0.4 % (layer4: k_conv_igemm<128> -> k_conv3x3_patch<64>), bf16 eval forward -1.6 %, mixed-precision step -0.7 %
+static thread_local int g_patch_narrow = 2;            // 1: fp32 only, 2: bf16 too.  Same-box A/B (tools/ab_option.py): fp32 step -0.4 % (layer4: k_conv_igemm<128> -> k_conv3x3_patch<64>), bf16 eval forward -1.6 %, mixed-precision step -0.7 %
 static int patch_tile_bn(ConvArgs& a, int BN, int mode, bool bf16) {
     ConvArgs t = a;
     if (conv_patch_geometry(t, BN, mode, bf16)) { a = t; return BN; }
@@ -3353,7 +3353,7 @@ static int patch_tile_bn(ConvArgs& a, int BN, int mode, bool bf16) {
 
 // k_conv3x3_c64_rows_bf16 applies: bf16, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
 // multiple of 128, plain or same-size residual, no split-K, and enough (image, strip, row range) units to fill the chip.
-static int g_rows64_min_units = 192;    // sd_set_option("conv_rows64_min_units", n) (tests: 1; off: 1 << 30)
+static thread_local int g_rows64_min_units = 192;    // sd_set_option("conv_rows64_min_units", n) (tests: 1; off: 1 << 30)
 static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
@@ -3374,7 +3374,7 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
 
 // k_conv3x3_c64_rows_f32 applies: fp32, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
 // multiple of 64, plain or same-size residual, no fused BatchNorm-backward reduction, no split-K, and enough units to fill the chip.
-static int g_rowsf32_min_units = 192;   // sd_set_option("conv_rows_f32_min_units", n) (tests: 1; off: 1 << 30)
+static thread_local int g_rowsf32_min_units = 192;   // sd_set_option("conv_rows_f32_min_units", n) (tests: 1; off: 1 << 30)
 static bool conv_rowsf32_geometry(const ConvArgs& a, int mode, RowsArgsF& r) {
     if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
@@ -3394,8 +3394,8 @@ static bool conv_rowsf32_geometry(const ConvArgs& a, int mode, RowsArgsF& r) {
 
 // k_conv3x3_bf16_pp applies: bf16, 128-channel output tiles, the double-buffered patch geometry (maps up to 64 pixels wide as whole
 // rows, wider ones as 64-pixel column strips), whole 512-pixel tiles and a grid of at least g_pp_min_tiles blocks (one 512-thread block per CU).  Fills the geometry fields.
-static int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
-static int g_pp_strips = 1;             // sd_set_option("conv_pp_strips", 0): maps of 128 pixels and wider stay on k_conv3x3_patch (A/B)
+static thread_local int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
+static thread_local int g_pp_strips = 1;             // sd_set_option("conv_pp_strips", 0): maps of 128 pixels and wider stay on k_conv3x3_patch (A/B)
 static bool conv_pp_geometry(ConvArgs& a, int mode) {
     if (a.Nn % 128 || a.M % PP_BM || (a.M / PP_BM) * (a.Nn / 128) < g_pp_min_tiles) return false;
     a.pt_strip_log2 = 0;
@@ -3529,7 +3529,7 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
 }
 
 // Split-K factor of the forward conv: only when the tile grid cannot fill the chip (small batch).
-static int g_fwd_split_k = 1;           // sd_set_option("conv_fwd_split_k", 0): small grids keep the single-pass kernels (tests of those kernels)
+static thread_local int g_fwd_split_k = 1;           // sd_set_option("conv_fwd_split_k", 0): small grids keep the single-pass kernels (tests of those kernels)
 static int fwd_splits(const sd_conv_desc* d, int ke = BK) {
     if (!g_fwd_split_k) return 1;
     const int M = d->B * d->Ho * d->Wo;
@@ -4168,6 +4168,8 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
 int sd_debug_pp_trace(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(sd::g_pp_trace), sizeof(unsigned long long) * 64); }
 #endif
 
+// Dispatch thresholds are THREAD-LOCAL (default-initialised in every host thread): two engines driven from two threads of one process
+// cannot change each other's kernel choice.
 int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_min_tiles")) { g_patch_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }

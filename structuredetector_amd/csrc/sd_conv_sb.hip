@@ -19,7 +19,6 @@
 //     (layer4: 9.4 MB instead of 8 x 9.4 MB per conv).
 #include "sd_common.h"
 #include "sd_mfma.h"
-#include <stdlib.h>
 
 namespace sd {
 
@@ -400,9 +399,9 @@ static bool sb_plan(SbArgs& a, const sd_conv_desc* d, bool bf16) {
     a.m_tiles = cdiv(a.M, 64); a.n_tiles = d->Cout / 64;
     const int tiles = a.m_tiles * a.n_tiles;
     int s = 1;
-    static const int target = getenv("SD_SB_TARGET") ? atoi(getenv("SD_SB_TARGET")) : 256;      // EXPERIMENT (A/B of the block count)
-    static const int smax = getenv("SD_SB_SMAX") ? atoi(getenv("SD_SB_SMAX")) : 16;
-    if (tiles < target * 3 / 4) s = std::max(1, std::min(std::min(smax, a.nk / 2), (target + tiles / 2) / tiles));
+    // about one block per CU (measured: 512 blocks of half the work are 5 % slower, the combine grows with the slices), at least two
+    // chunks per slice, at most 16 slabs for the reducer
+    if (tiles < 192) s = std::max(1, std::min(std::min(16, a.nk / 2), (256 + tiles / 2) / tiles));
     if (bf16 && tiles >= 128) s = 1;                         // bf16: the loop is a fraction of a split's combine (measured: 1.8 vs 3.4 us)
     a.cper = cdiv(kchunks, std::min(s, kchunks));            // whole channel chunks per slice: every slice starts at filter tap 0
     a.per = ntap * a.cper;

@@ -1119,15 +1119,15 @@ static int next_pow2_host(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // half the blocks, half the records the selectors wait for, 36 halo rows per 32 instead of 20 per 16 -- finish sooner.  Measured
 // (tools/decode_tile_sweep.py, 3 maps of 128x128, us per launch 64x16 / 64x32): bs=1 12.8 / 14.0, bs=16 14.6 / 15.2, bs=32 16.6 / 16.7,
 // bs=48 18.7 / 18.9, bs=64 21.1 / 20.1, bs=96 25.3 / 23.6, bs=128 29.6 / 27.1: the switch sits at 2688 blocks (bs=56).  sd_decode_set_option("tall_tiles_from", n) moves the switch.
-static std::atomic<int> g_tall_tiles_from{2688};
+static thread_local int g_tall_tiles_from = 2688;      // per host thread, like the conv dispatch thresholds
 int sd_decode_set_option(const char* name, int value) {
-    if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from.store(value); return 0; }
+    if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
 static int fused_tile_height(int B, int M, int N, int h, int w) {
     const int64_t blocks16 = (int64_t)std::max(B, 1) * (M + N) * cdiv(w, TW) * cdiv(h, 16);
-    return blocks16 >= g_tall_tiles_from.load(std::memory_order_relaxed) ? 32 : 16;
+    return blocks16 >= g_tall_tiles_from ? 32 : 16;
 }
 static size_t fused_tiles(int h, int w, int th) { return (size_t)cdiv(w, TW) * cdiv(h, th); }
 
@@ -1163,6 +1163,15 @@ int sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P) {
            fused_lds(K, P, (int)nti, std::max(FUSED_CAP_EXACT, 2 * next_pow2_host(std::max(K, P))), 32).total <= FUSED_LDS_LIMIT;
 }
 
+// Where ONE launch is the faster decoder (measured: profiles/r02_decode_variants.txt): image geometries of at most 256 tile blocks
+// (512x512 with 2 + 1 maps = 48; the selector's LDS is paid by every tile block of the grid, and with ~1000 tiles per image -- 1024x1024,
+// 8 + 8 maps -- it halves the occupancy of the 16 k tile blocks: 451 us vs 116 us for sd_decode at K = 128, P = 512), and for the exact
+// top-k only small batches (bs = 64: 39.0 vs 31.3 us, its two 2048-key sort buffers cost the tile blocks occupancy).
+static int64_t fused_image_tiles(int M, int N, int h, int w) { return (int64_t)(M + N) * fused_tiles(h, w, 16); }
+int sd_decode_fused_recommended(int B, int M, int N, int h, int w, int K, int P, int exact_topk) {
+    return sd_decode_fused_supported(B, M, N, h, w, K, P) && fused_image_tiles(M, N, h, w) <= 256 && (!(exact_topk & 1) || B <= 8);
+}
+
 int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* part_hm, int64_t p_sb, int64_t p_sc,
                     const float* offsets, int64_t o_sb, int64_t o_sc, const float* embeddings, int64_t e_sb, int64_t e_sc, int B,
                     int M, int N, int h, int w, int K, int P, float conf, float dist_px, int exact_topk, void* packed, void* state,
@@ -1178,6 +1187,12 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const fl
     // at most B selector blocks wait inside the grid: keep them far below the resident block slots of the chip (256 CUs x >= 2)
     SD_REQUIRE(B <= 256, SD_ERR_INVALID, "sd_decode_fused: batch %d > 256 (selector blocks must stay resident); use sd_decode", B);
     SD_REQUIRE(packed && workspace && state, SD_ERR_INVALID, "sd_decode_fused: null pointer");
+    // exact_topk bit 1 (value 2): accept geometries where the two-launch sd_decode is the faster decoder (tests of this kernel)
+    const bool force = (exact_topk & 2) != 0;
+    exact_topk &= 1;
+    SD_REQUIRE(force || (M > 0 && N > 0 && fused_image_tiles(M, N, h, w) <= 256), SD_ERR_INVALID,
+               "sd_decode_fused: %lld tile blocks per image (> 256): sd_decode is several times faster for this geometry "
+               "(sd_decode_fused_recommended() == 0); pass exact_topk | 2 to run it here anyway", (long long)fused_image_tiles(std::max(M, 1), std::max(N, 1), h, w));
     const int th = fused_tile_height(B, M, N, h, w);
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, th);
     const int tiles = tiles_x * tiles_y;

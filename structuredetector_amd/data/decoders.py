@@ -27,6 +27,7 @@ class Decoder:
         self._state = {}
         self._plans = {}
         self._thresholds = {}
+        self.selector_timeouts = 0       # sd_decode_fused calls that were redone by the two-launch decoder (a tile block was delayed)
 
     # ------------------------------------------------------------------ device stage
     def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None):
@@ -45,20 +46,17 @@ class Decoder:
         packed = torch.empty(lib.sd_decode_packed_words(B, K, P), dtype=torch.int32, device=a.device)
         conf32 = float(np.float32(conf_thresh))                       # tensor-vs-scalar compares run in fp32
         dist32 = float(np.float32(dist_thresh * min(w, h)))           # decoders.py:100
+        force = 2 if fused else 0            # an explicit fused=True runs the one-launch kernel also where the launch pair is faster (tests)
         if fused is None:
-            # one launch for image geometries up to 256 tiles (512x512 with 2 + 1 maps = 48): the selector's LDS is paid by every
-            # tile block of the grid, and with the bookkeeping of ~1000 tiles per image (stress config) it halves the occupancy
-            # of the 16 k tile blocks -- there the NMS launch + select launch pair is faster
-            # (measured device span per call, 512x512 2+1 maps: bs=1 13.5 us vs 21.7 us for the launch pair; bs=64 23.1 vs 25.9;
-            #  exact top-k at bs=64: 39.0 vs 31.3 -- its 2 x 2048-key sort buffers cost the tile blocks occupancy -> launch pair)
-            tiles = (M + N) * (-(-w // 64)) * (-(-h // 16))
-            fused = tiles <= 256 and (not exact_topk or B <= 8) and bool(lib.sd_decode_fused_supported(B, M, N, h, w, K, P))
+            # the measured rule lives behind the C ABI (sd_decode_fused_recommended): one launch for image geometries up to 256 tile
+            # blocks, and for the exact top-k only up to batch 8
+            fused = bool(lib.sd_decode_fused_recommended(B, M, N, h, w, K, P, int(exact_topk)))
         if fused:
             ws = L.workspace(lib.sd_decode_fused_workspace_bytes(B, M, N, h, w, K, P), a.device)
             state = self._fused_state(a.device, lib.sd_decode_state_bytes(B, M, N, h, w))
             try:
                 L.check(lib.sd_decode_fused(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
-                                            conf32, dist32, int(bool(exact_topk)), packed.data_ptr(), state.data_ptr(), state.numel(),
+                                            conf32, dist32, int(bool(exact_topk)) | force, packed.data_ptr(), state.data_ptr(), state.numel(),
                                             ws.data_ptr(), ws.numel(), L.stream()), "sd_decode_fused")
             except L.SdError:
                 state.zero_()                                         # contract: re-zero the state after a failed call
@@ -113,8 +111,7 @@ class Decoder:
         plan = self._plans.get(key)
         lib = L.lib()
         if plan is None:
-            tiles = (M + N) * (-(-w // 64)) * (-(-h // 16))
-            if not (tiles <= 256 and lib.sd_decode_fused_supported(B, M, N, h, w, K, P)):
+            if not lib.sd_decode_fused_recommended(B, M, N, h, w, K, P, 0):
                 self._plans[key] = False
                 return None
             host = torch.empty(lib.sd_decode_packed_words(B, K, P), dtype=torch.int32, pin_memory=True)
@@ -137,9 +134,12 @@ class Decoder:
             rc = lib.sd_stream_synchronize(stream)                                     # the one host wait
         status = v_status.tolist()
         if rc or any(status):
-            keep[2].zero_()                                                            # contract: re-zero the state after a failed call
+            # a selector gave up its bounded wait for a tile block (e.g. another process or stream held the GPU): re-zero THIS call's
+            # hand-off state -- the stream is idle, nothing else uses the buffer -- and let the caller take the two-launch path once
+            keep[2].zero_()
             L.check(rc, "sd_decode_fused")
-            raise L.SdError(f"sd_decode_fused: the selector of image(s) {[i for i, v in enumerate(status) if v]} gave up waiting for a tile block")
+            self.selector_timeouts += 1
+            return None
         in_h, in_w = int(self.down_ratio * h), int(self.down_ratio * w)                # decoders.py:41
         sx, sy = in_w / w, in_h / h                                                    # utils.py:19-26
         anchor_all, part_all, assign_all = v_anchor.tolist(), v_part.tolist(), v_assign.tolist()
@@ -175,9 +175,14 @@ class Decoder:
         in_h, in_w = int(self.down_ratio * out_h), int(self.down_ratio * out_w)       # decoders.py:41
         host = self.split_packed(packed.cpu().numpy(), B, K, P)                        # the one D2H (+ sync)
         if host["status"].any():
-            for st in self._state.values():
-                st.zero_()
-            raise L.SdError(f"sd_decode_fused: the selector of image(s) {np.nonzero(host['status'])[0].tolist()} gave up waiting for a tile block")
+            # transient (a tile block was delayed past the selector's bounded wait): the D2H above has synchronised this stream, so its
+            # state buffer -- and only its -- can be re-zeroed; the two-launch decoder has no cross-block wait, retry once through it
+            self.selector_timeouts += 1
+            self._fused_state(packed.device, 0).zero_()
+            packed, _ = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=return_metadata, fused=False)
+            host = self.split_packed(packed.cpu().numpy(), B, K, P)
+            if host["status"].any():
+                raise L.SdError(f"sd_decode: non-zero status for image(s) {np.nonzero(host['status'])[0].tolist()}")
         sx, sy = in_w / out_w, in_h / out_h                                            # utils.py:19-26
 
         anchor_out = host["anchor_out"].astype(np.float64)        # float(np.float32) == tensor.item()

@@ -108,3 +108,75 @@ def test_dataset_shards_are_disjoint_and_step_aligned_gloo():
     out = mp.Manager().dict()
     mp.spawn(_shard_worker, args=(world, port, n, batch, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world))
+
+
+# ---------------------------------------------------------------------------------------------
+# world = 8 rehearsal (the driver's 8-GPU run is the first contact with eight ranks: make it boring)
+# ---------------------------------------------------------------------------------------------
+def _flat_ranges():
+    from structuredetector_amd.model import Network
+    net = Network(Namespace(labels={"a": 0, "b": 1}, parts={"l": 0}, fpn_depth=128), pretrained=False)
+    offs, total = {}, 0
+    for p in net.parameters():
+        offs[id(p)] = (total, p.numel())
+        total += (p.numel() + 3) // 4 * 4
+    net._flat_off = offs
+    return net.stage_ranges(), total
+
+
+def _verify8_worker(rank, world, port, ranges, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)                                   # eight ranks on eight cores
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from structuredetector_amd.model.trainer import TrainStep
+        # the REAL TrainStep.verify_exchange / _exchange_hooks code over gloo on a CPU flat buffer (a TrainStep proper needs a GPU network)
+        step = object.__new__(TrainStep)
+        step.net = Namespace(flat_grads=torch.zeros(total))
+        step.ranges, step.world, step.pg, step.rccl, step.exchange_enabled = ranges, world, None, None, True
+        report = step.verify_exchange()
+        ok = report["ranks"] == world and report["check"].startswith(f"ok: sum(rank+1) == {world * (world + 1) // 2:g}")
+        ok = ok and sum(report["buckets"].values()) == total and float(step.net.flat_grads.abs().max()) == 0.0
+        # a rank that contributes nothing must be caught: rank 3 zeroes its buffer inside the exchange
+        step2 = object.__new__(TrainStep)
+        step2.net = Namespace(flat_grads=torch.zeros(total))
+        step2.ranges, step2.world, step2.pg, step2.rccl, step2.exchange_enabled = ranges, world, None, None, True
+        hooks = step2._exchange_hooks
+
+        def broken():
+            on_stage, finish = hooks()
+
+            def on(name):
+                if rank == 3:
+                    lo, hi = ranges[name]
+                    step2.net.flat_grads[lo:hi] = 0.0
+                on_stage(name)
+            return on, finish
+        step2._exchange_hooks = broken
+        try:
+            step2.verify_exchange()
+            ok = False
+        except Exception as err:
+            ok = ok and "gradient exchange check failed" in str(err)
+        out[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_verify_exchange_world8_gloo():
+    """TrainStep.verify_exchange with eight ranks: every element of all five buckets reads 36 on every rank, the buckets tile the flat
+    buffer, and a rank that drops out of the sum is detected on every rank."""
+    ranges, total = _flat_ranges()
+    world, port = 8, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_verify8_worker, args=(world, port, ranges, total, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)
+
+
+def test_dataset_shards_world8_gloo():
+    """shard_indices at world = 8 with n = 8*B*k - 1: same step count on every rank, disjoint, covering the truncated permutation."""
+    world, port, batch = 8, _free_port(), 4
+    n = 8 * batch * 3 - 1
+    out = mp.Manager().dict()
+    mp.spawn(_shard_worker, args=(world, port, n, batch, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world))

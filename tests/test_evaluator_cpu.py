@@ -7,7 +7,7 @@ import numpy as np
 from tests.helpers import scene_from_flat
 
 
-def build(golden_dir):
+def build(golden_dir, keep=None):
     from structuredetector_amd.model import Evaluator
     from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object
     g = np.load(golden_dir / "evaluator.npz")
@@ -27,7 +27,8 @@ def build(golden_dir):
             objs.append(Object(rl[int(l)], Keypoint("stem", x, y, s), kps))
         pred = ImageAnnotation(f"p{n}", objs)
         raw = [Keypoint(rp[int(k)], x, y, s) for (k, x, y, s) in g[f"raw{n}"]]
-        ev.accumulate(pred, gt, raw, True, True)
+        if keep is None or keep(n):
+            ev.accumulate(pred, gt, raw, True, True)
         n += 1
     assert n == 6
     return g, ev
@@ -62,6 +63,24 @@ def test_evaluator_merge_is_associative(golden_dir):
     assert Evaluation(0, 0, 3).precision == 0 and Evaluation(0, 3, 0).recall == 0
     u = Evaluations(["a"]) | Evaluations(["b"])
     assert set(u.labels) == {"a", "b"}
+
+
+def test_evaluator_merge_over_8_shards_equals_single_evaluator(golden_dir):
+    """World = 8 rehearsal of data-parallel evaluation: the images sharded [rank::8] (two ranks get none), one Evaluator per rank,
+    merged on rank 0 == one Evaluator over all images (counters exactly, accuracy lists as multisets, the same metrics)."""
+    _, whole = build(golden_dir)
+    shards = [build(golden_dir, keep=lambda n, r=r: n % 8 == r)[1] for r in range(8)]
+    merged = shards[0]
+    for other in shards[1:]:
+        merged.merge(other)
+    for a, b in ((whole.anchor_eval, merged.anchor_eval), (whole.part_eval, merged.part_eval), (whole.csi_eval, merged.csi_eval),
+                 (whole.classification_eval, merged.classification_eval)):
+        assert list(a.labels) == list(b.labels)
+        for label in a.labels:
+            assert (a[label].tp, a[label].npos, a[label].ndet) == (b[label].tp, b[label].npos, b[label].ndet), label
+            assert sorted(a[label].acc) == sorted(b[label].acc), label
+        assert a.reduce().f1_score == b.reduce().f1_score
+    assert whole._csv_kps_str() == merged._csv_kps_str()
 
 
 def test_evaluate16_directory_reader_and_evaluator_vs_reference(golden_dir, tmp_path):
