@@ -172,6 +172,17 @@ int sd_preprocess_images(const uint8_t* images, int B, int Hin, int Win, int Hou
                          const uint8_t* flips, const float* mean3, const float* std3, float* out,
                          void* workspace, size_t workspace_bytes, sd_stream_t stream);
 
+/* The same with the reference's RandomColorJitter (src/sdnet/data/transforms.py:37-47: torchvision ColorJitter(0.25, 0.25, 0.15, 0.05) on the
+ * RESIZED PIL image, before the flips and Normalize) applied per image on the device, byte for byte what Pillow computes
+ * (ImageEnhance.Brightness / Contrast / Color and the HSV round trip of adjust_hue).  jitter_order (B) int32: bits 0-7 = the four op ids in
+ * application order, 2 bits each (0 brightness, 1 contrast, 2 saturation, 3 hue), bits 8-15 = the hue shift byte uint8(hue_factor * 255);
+ * jitter_factors (B, 3) fp32 = brightness, contrast, saturation factors.  The random draws stay with the caller. */
+size_t sd_preprocess_jitter_workspace_bytes(int B, int Hin, int Win, int Hout, int Wout);
+int sd_preprocess_images_jitter(const uint8_t* images, int B, int Hin, int Win, int Hout, int Wout, const int* h_bounds, const int* h_kk,
+                                int h_ksize, const int* v_bounds, const int* v_kk, int v_ksize, const uint8_t* flips, const int* jitter_order,
+                                const float* jitter_factors, const float* mean3, const float* std3, float* out, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream);
+
 /* ---- loss: src/sdnet/model/loss.py:17-64,91-117 ------------------------------------------- */
 
 #define SD_HM_MSE   0

@@ -73,6 +73,9 @@ _SIGNATURES = {
     "sd_preprocess_workspace_bytes": (c_size, [c_int] * 4),
     "sd_preprocess_images": (c_int, [c_vp] + [c_int] * 5 + [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, C.POINTER(c_float), C.POINTER(c_float),
                                                 c_vp, c_vp, c_size, c_vp]),
+    "sd_preprocess_jitter_workspace_bytes": (c_size, [c_int] * 5),
+    "sd_preprocess_images_jitter": (c_int, [c_vp] + [c_int] * 5 + [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, C.POINTER(c_float), C.POINTER(c_float),
+                                            c_vp, c_vp, c_size, c_vp]),
     "sd_render_targets": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp]),
     "sd_loss_workspace_bytes": (c_size, [c_int] * 5),
     "sd_loss_fwd": (c_int, [C.POINTER(LossDesc), c_vp, c_vp, c_size, c_vp]),

@@ -6,8 +6,12 @@ src/sdnet/utils/utils.py:384-415 on the host and the per-epoch multi-scale shape
 Resize parity: `F.resize` of a PIL image is Pillow's separable 8-bit fixed-point resampling; `pil_bilinear_coeffs` reproduces
 Pillow's coefficient tables (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc) and the kernels its integer
 arithmetic, so the resized bytes equal `Image.resize(size, BILINEAR)` and the normalised tensor equals the reference's bit for bit.
-ColorJitter (transforms.py:37-44: random photometric noise from torchvision) is not reproduced: with `--no_augmentation` the two
-pipelines are identical; with augmentation this one applies the geometric part (flips + multi-scale) only.
+ColorJitter parity (transforms.py:37-47): torchvision's ColorJitter on a PIL image is Pillow's ImageEnhance.Brightness / Contrast /
+Color plus an HSV round trip for the hue, in a random order; `sd_preprocess_images_jitter` reproduces Pillow's byte arithmetic on the
+resized image (oracle/pil_photometric.py is the restatement, pinned against Pillow over all 2^24 colours; torchvision itself is absent
+here, its PIL code path is restated from the published 0.20.1 source), so with the same random draws the normalised tensor equals the
+reference's bit for bit.  The draws (`torch.randperm(4)`, four `uniform_`s, two `randn`s per sample, in the reference's order) come
+from torch's global generator on the host.
 """
 from __future__ import annotations
 
@@ -83,9 +87,10 @@ class _Tables:
 _tables = _Tables()
 
 
-def preprocess_images(images: torch.Tensor, out_size, flips=None, mean=_MEAN, std=_STD) -> torch.Tensor:
+def preprocess_images(images: torch.Tensor, out_size, flips=None, mean=_MEAN, std=_STD, jitter=None) -> torch.Tensor:
     """images: (B, Hin, Win, 3) uint8 on the GPU; out_size = (width, height); flips: (B,) uint8 (bit 0 horizontal, bit 1 vertical)
-    or None.  Returns (B, 3, height, width) fp32 = Normalize(to_tensor(flip(resize(image)))) of transforms.py."""
+    or None; jitter: None or (order words (B,) int32, factors (B, 3) fp32) as `jitter_words` makes them.
+    Returns (B, 3, height, width) fp32 = Normalize(to_tensor(flip(jitter(resize(image))))) of transforms.py:217-226."""
     L.require_cuda(images)
     if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
         raise L.SdError(f"preprocess_images expects (B, H, W, 3) uint8, got {tuple(images.shape)} {images.dtype}")
@@ -96,17 +101,35 @@ def preprocess_images(images: torch.Tensor, out_size, flips=None, mean=_MEAN, st
     vb, vk, vks = _tables.get(Hin, Hout, images.device)
     out = torch.empty((B, 3, Hout, Wout), dtype=torch.float32, device=images.device)
     lib = L.lib()
-    ws = L.workspace(lib.sd_preprocess_workspace_bytes(B, Hin, Win, Wout), images.device)
     fl = None
     if flips is not None:
-        fl = torch.as_tensor(flips, dtype=torch.uint8).to(images.device)
+        fl = torch.as_tensor(flips, dtype=torch.uint8).to(images.device, non_blocking=True)
         if fl.numel() != B:
             raise L.SdError("flips must have one entry per image")
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    if jitter is not None:
+        order = torch.as_tensor(jitter[0], dtype=torch.int32).to(images.device, non_blocking=True)
+        factors = torch.as_tensor(jitter[1], dtype=torch.float32).reshape(-1, 3).contiguous().to(images.device, non_blocking=True)
+        if order.numel() != B or factors.shape[0] != B:
+            raise L.SdError("jitter parameters must have one row per image")
+        ws = L.workspace(lib.sd_preprocess_jitter_workspace_bytes(B, Hin, Win, Hout, Wout), images.device)
+        L.check(lib.sd_preprocess_images_jitter(images.data_ptr(), B, Hin, Win, Hout, Wout, hb.data_ptr(), hk.data_ptr(), hks, vb.data_ptr(),
+                                                vk.data_ptr(), vks, fl.data_ptr() if fl is not None else 0, order.data_ptr(), factors.data_ptr(),
+                                                m3, s3, out.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()), "sd_preprocess_images_jitter")
+        return out
+    ws = L.workspace(lib.sd_preprocess_workspace_bytes(B, Hin, Win, Wout), images.device)
     L.check(lib.sd_preprocess_images(images.data_ptr(), B, Hin, Win, Hout, Wout, hb.data_ptr(), hk.data_ptr(), hks, vb.data_ptr(),
                                      vk.data_ptr(), vks, fl.data_ptr() if fl is not None else 0, m3, s3, out.data_ptr(), ws.data_ptr(),
                                      ws.numel(), L.stream()), "sd_preprocess_images")
     return out
+
+
+def jitter_words(order, brightness, contrast, saturation, hue):
+    """One image's ColorJitter parameters in the form `sd_preprocess_images_jitter` takes: the op order (a permutation of
+    0 brightness, 1 contrast, 2 saturation, 3 hue) packed two bits each, the hue shift byte `uint8(hue * 255)` torchvision's adjust_hue
+    adds to the H channel (truncation toward zero, wrap-around) in bits 8-15, and the three blend factors."""
+    word = sum(int(op) << (2 * k) for k, op in enumerate(order)) | ((int(hue * 255) & 0xFF) << 8)
+    return word, (float(brightness), float(contrast), float(saturation))
 
 
 class ValidationAugmentation:
@@ -116,8 +139,9 @@ class ValidationAugmentation:
         self.args = args
         self.size = (args.width, args.height)
 
-    def flips_for(self, n):
-        return None
+    def draws_for(self, n):
+        """(flips, jitter) for n samples: validation draws nothing."""
+        return None, None
 
     def __call__(self, images, annotations):
         """images: list of (H, W, 3) uint8 arrays / tensors (any sizes) or one (B, H, W, 3) tensor; annotations: list of
@@ -125,7 +149,9 @@ class ValidationAugmentation:
         copies).  Returns ((B, 3, height, width) fp32 device tensor, annotations in network-input pixels)."""
         dev = self.args.device
         W, H = self.size
-        if isinstance(images, torch.Tensor) and images.dim() == 4:
+        if hasattr(images, "groups"):                                # data/feeder.py GroupedBatch: grouped by size and uploaded already
+            groups = images.groups
+        elif isinstance(images, torch.Tensor) and images.dim() == 4:
             groups = {tuple(images.shape[1:3]): (list(range(images.shape[0])), images)}
         else:
             by_size = {}
@@ -134,11 +160,12 @@ class ValidationAugmentation:
                 by_size.setdefault(tuple(t.shape[:2]), []).append((i, t))
             groups = {k: ([i for i, _ in v], torch.stack([t for _, t in v])) for k, v in by_size.items()}
         n = sum(len(idx) for idx, _ in groups.values())
-        flips = self.flips_for(n)
+        flips, jitter = self.draws_for(n)
         out = torch.empty((n, 3, H, W), dtype=torch.float32, device=dev)
         for (hin, win), (idx, stack) in groups.items():
             f = None if flips is None else [flips[i] for i in idx]
-            res = preprocess_images(stack.to(dev, non_blocking=True), (W, H), f)
+            j = None if jitter is None else ([jitter[0][i] for i in idx], [jitter[1][i] for i in idx])
+            res = preprocess_images(stack.to(dev, non_blocking=True), (W, H), f, jitter=j)
             if len(groups) == 1:
                 out = res
             else:
@@ -156,26 +183,36 @@ class ValidationAugmentation:
 
 
 class TrainAugmentation(ValidationAugmentation):
-    """transforms.py:211-247: Resize + RandomHorizontalFlip + RandomVerticalFlip + Normalize, and the per-epoch multi-scale
-    `trigger_random_resize` (ratios 0.75 .. 1.25 in steps of 1/16, sizes rounded down to multiples of 32).  Random decisions are
-    drawn like the reference draws them -- `torch.randn(1).item() < prob` (transforms.py:14,27: a normal, not a uniform, draw:
-    the flip probability is Phi(0.5) = 0.69) and `torch.randint` for the ratio -- from torch's global generator."""
+    """transforms.py:211-247: Resize + RandomColorJitter + RandomHorizontalFlip + RandomVerticalFlip + Normalize, and the per-epoch
+    multi-scale `trigger_random_resize` (ratios 0.75 .. 1.25 in steps of 1/16, sizes rounded down to multiples of 32).  Random decisions
+    are drawn like the reference draws them, per sample and in its order -- ColorJitter.get_params (`torch.randperm(4)`, then the
+    brightness / contrast / saturation factors uniformly from [1 - x, 1 + x] and the hue from [-x, x]), then `torch.randn(1).item() <
+    prob` for each flip (transforms.py:14,27: a normal, not a uniform, draw: the flip probability is Phi(0.5) = 0.69) -- and
+    `torch.randint` for the ratio, from torch's global generator."""
 
     ratios = (0.75, 0.8125, 0.875, 0.9375, 1, 1.0625, 1.125, 1.1875, 1.25)
+    brightness, contrast, saturation, hue = 0.25, 0.25, 0.15, 0.05            # transforms.py:38
 
     def __init__(self, args, prob=0.5):
         super().__init__(args)
         self.prob = prob
 
-    def flips_for(self, n):
+    def draws_for(self, n):
         if self.args.no_augmentation:
-            return None
-        out = []
+            return None, None
+        flips, words, factors = [], [], []
         for _ in range(n):
-            h = torch.randn(1).item() < self.prob
-            v = torch.randn(1).item() < self.prob
-            out.append(int(h) | (int(v) << 1))
-        return out
+            order = torch.randperm(4).tolist()                                                     # ColorJitter.get_params
+            b = float(torch.empty(1).uniform_(max(0.0, 1 - self.brightness), 1 + self.brightness))
+            c = float(torch.empty(1).uniform_(max(0.0, 1 - self.contrast), 1 + self.contrast))
+            s = float(torch.empty(1).uniform_(max(0.0, 1 - self.saturation), 1 + self.saturation))
+            h = float(torch.empty(1).uniform_(-self.hue, self.hue))
+            w, f3 = jitter_words(order, b, c, s, h)
+            words.append(w); factors.append(f3)
+            hf = torch.randn(1).item() < self.prob                                                 # RandomHorizontalFlip, then Vertical
+            vf = torch.randn(1).item() < self.prob
+            flips.append(int(hf) | (int(vf) << 1))
+        return flips, (words, factors)
 
     def trigger_random_resize(self):
         if self.args.no_augmentation:

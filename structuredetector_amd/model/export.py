@@ -65,7 +65,7 @@ class FusedInferenceModel(torch.nn.Module):
     @classmethod
     def load(cls, path, device="cuda"):
         from argparse import Namespace
-        blob = torch.load(path, map_location="cpu", weights_only=False)
+        blob = torch.load(path, map_location="cpu", weights_only=True)      # tensors, dicts, tuples, strings and numbers only
         if blob.get("format") != cls.FORMAT:
             raise L.SdError(f"{path}: not a {cls.FORMAT} file")
         args = Namespace(labels=blob["meta"]["labels"], parts=blob["meta"]["parts"], fpn_depth=blob["meta"]["fpn_depth"],

@@ -168,7 +168,7 @@ class _Engine:
 
     def _w16(self, conv):
         off, n = self.net._flat_off[id(conv.weight)]
-        return self.net.flat_params_bf16[off:off + n]                 # physical [Cout][R][S][Cin] order, 8-byte aligned slots (off % 4 == 0)
+        return self.net.flat_params_bf16[off:off + n]                 # physical [Cout][R][S][Cin] order; off % 8 == 0 (32-byte slots): 16-byte aligned
 
     def _conv_sb(self, x, w, y, d, scale, shift, res, res_up2, relu, bf16):
         """Small-batch inference conv: one launch, split-K combined inside it (sd_conv2d_fwd_sb); the arrival tickets live in a
@@ -799,7 +799,7 @@ class Network(nn.Module):
         offs, total = [], 0
         for p in params:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += (p.numel() + 7) // 8 * 8          # 32-byte slots: the bf16 view of a conv weight (same element offset, _w16) stays 16-byte aligned
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         grads = torch.zeros(total, dtype=torch.float32, device=dev)
         self._flat_order, self._flat_off = params, {}
@@ -898,6 +898,6 @@ class Network(nn.Module):
         """Flat-buffer [lo, hi) element ranges of the gradient groups reported by `backward_from(on_stage=...)`."""
         def span(mods):
             offs = [self._flat_off[id(p)] for m in mods for p in m.parameters()]
-            return (min(o for o, _ in offs), max((o + n + 3) // 4 * 4 for o, n in offs))
+            return (min(o for o, _ in offs), max((o + n + 7) // 8 * 8 for o, n in offs))
         return {"fpn_head": span([self.up1, self.up2, self.up3, self.up4, self.head]), "down4": span([self.down4]),
                 "down3": span([self.down3]), "down2": span([self.down2]), "down1_stem": span([self.adpater, self.down1])}

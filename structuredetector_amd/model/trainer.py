@@ -288,9 +288,13 @@ class Trainer:
                 images = torch.randn(B, 3, a.height, a.width, device=a.device, generator=gen)
                 yield images, self.encode.render(self.encode.plan(a.width, a.height, *flat), a.device)
         else:
-            for idx in shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch):
-                items = [self.dataset[int(j)] for j in idx]
-                images, anns = self.augment([im for im, _ in items], [an for _, an in items])
+            # decode threads + pinned staging + side-stream upload, `prefetch` batches ahead of the step (data/feeder.py); resize, jitter,
+            # flips, normalisation and the targets for the whole batch on the GPU (the reference: trainer.py:62-72, dataset.py:41-49)
+            from ..data.feeder import BatchFeeder
+            shards = shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch)
+            workers = getattr(a, "decode_workers", 0) or max(1, min(16, (os.cpu_count() or 4) // world))
+            for batch in BatchFeeder(self.dataset, shards, a.device, workers=workers, depth=getattr(a, "prefetch", 3)):
+                images, anns = self.augment(batch, batch.annotations)
                 yield images, self.encode.batch(self.augment.size, anns, a.device)
 
     def valid_samples(self):
@@ -334,18 +338,30 @@ class Trainer:
 
     # ---- true resume: weights + BatchNorm buffers + Adam moments / step + StepLR epoch + best-so-far metrics + epoch counter ----
     def save_resume(self, path):
+        """Everything the next epoch depends on: weights + BatchNorm buffers, Adam moments / step / lr, StepLR epoch, best-so-far
+        metrics, the multi-scale input size drawn for the next epoch (trainer.py:135), the random streams the augmentation and the
+        synthetic scenes draw from (torch's global generator, this rank's numpy generator) and the run's save directory -- tensors
+        and plain Python values only, so that the file loads with `weights_only=True`."""
         torch.save({"model": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
                     "optimizer": self.step.state_dict(), "scheduler": self.scheduler.state_dict(), "epoch": self.epoch,
-                    "best": {k: getattr(self, k) for k in ("best_loss", "best_csi", "best_classif", "best_kp_reg")}}, path)
+                    "best": {k: getattr(self, k) for k in ("best_loss", "best_csi", "best_classif", "best_kp_reg")},
+                    "augment_size": tuple(int(v) for v in self.augment.size), "torch_rng": torch.get_rng_state(),
+                    "numpy_rng": self.rng.bit_generator.state, "save_dir": str(self.save_dir)}, path)
 
     def load_resume(self, path):
-        state = torch.load(path, map_location="cpu", weights_only=False)
+        from pathlib import Path
+        state = torch.load(path, map_location="cpu", weights_only=True)
         self.net.load_state_dict(state["model"])
         self.step.load_state_dict(state["optimizer"])
         self.scheduler.load_state_dict(state["scheduler"])
         self.start_epoch = int(state["epoch"]) + 1
         for k, v in state["best"].items():
             setattr(self, k, v)
+        if "augment_size" in state:                     # (files written before round 3 carry the weights / optimizer part only)
+            self.augment.size = tuple(int(v) for v in state["augment_size"])
+            torch.set_rng_state(state["torch_rng"])
+            self.rng.bit_generator.state = state["numpy_rng"]
+            self.save_dir = Path(state["save_dir"])     # model_best_* and resume.pth of one run stay in one directory
 
     def train(self):
         steps = 0

@@ -50,6 +50,8 @@ _FLAGS = [
     (("--steps",), dict(type=int, default=0, help="Stop training after this many optimizer steps (0 = full epochs).")),
     (("--bf16_inference",), dict(action="store_true", help="Eval-mode forward on the bf16 backbone (fp32 decode); training unaffected.")),
     (("--resume",), dict(type=str, default=None, help="Continue a run from trainings/<stamp>/resume.pth (weights, Adam state, scheduler, epoch).")),
+    (("--decode_workers",), dict(type=int, default=0, help="Image decode threads of the directory feed (0 = min(16, cores)).")),
+    (("--prefetch",), dict(type=int, default=3, help="Batches decoded and uploaded ahead of the training step.")),
 ]
 
 _POSITIVE = ["in_channels", "fpn_depth", "batch_size", "epochs", "learning_rate", "down_ratio", "max_objects", "max_parts"]
@@ -92,7 +94,7 @@ def finalize(args):
     if not args.use_cuda:
         raise RuntimeError("structuredetector_amd needs an MI355X visible as torch device 'cuda' (no CPU path)")
     args.device = torch.device("cuda", torch.cuda.current_device())
-    args.num_workers = min(cpu_count(), 4)
+    args.num_workers = min(cpu_count(), 4)          # (args.py:251: the reference's DataLoader workers; the decode threads here: --decode_workers)
     set_seed(926354916)
 
     if args.hm_loss_fn.lower() not in {"focal", "mse"}:

@@ -55,7 +55,7 @@ def test_bucketed_allreduce_matches_flat_gloo():
     offs, total = {}, 0
     for p in net.parameters():
         offs[id(p)] = (total, p.numel())
-        total += (p.numel() + 3) // 4 * 4
+        total += (p.numel() + 7) // 8 * 8
     net._flat_off = offs
     ranges = net.stage_ranges()
     order = ["fpn_head", "down4", "down3", "down2", "down1_stem"]
@@ -119,7 +119,7 @@ def _flat_ranges():
     offs, total = {}, 0
     for p in net.parameters():
         offs[id(p)] = (total, p.numel())
-        total += (p.numel() + 3) // 4 * 4
+        total += (p.numel() + 7) // 8 * 8
     net._flat_off = offs
     return net.stage_ranges(), total
 

@@ -243,3 +243,36 @@ def test_torchvision_boundary_structural_pin():
 
 
 SCHEMA_SHA256 = "df09e4ae27bca73d31fff2e2feb03c3a78219894d27e89d6d351cedad0b717cc"   # 244 entries, M=2, N=1, fpn_depth=128
+
+
+def test_photometric_restatement_equals_pillow_exhaustively():
+    """oracle/pil_photometric.py (what the GPU ColorJitter is checked against in its arithmetic) == the installed Pillow, bit for bit:
+    all 2^24 RGB triples through convert("HSV") and convert("L"), all 2^24 HSV triples through convert("RGB"), Image.blend for every
+    (degenerate, value) byte pair over factors inside / outside / at the ends of [0, 1], and the four ops on a noise image the way
+    torchvision's _functional_pil.py (0.20.1) calls them (transforms.py:37-47)."""
+    from PIL import Image, ImageEnhance
+
+    from oracle import pil_photometric as PP
+    v = np.arange(1 << 24, dtype=np.uint32)
+    cube = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    img = Image.fromarray(cube, "RGB")
+    assert np.array_equal(np.asarray(img.convert("HSV")), PP.rgb_to_hsv(cube))
+    assert np.array_equal(np.asarray(img.convert("L")), PP.rgb_to_l(cube))
+    assert np.array_equal(np.asarray(Image.fromarray(cube, "HSV").convert("RGB")), PP.hsv_to_rgb(cube))
+    d, x = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    for f in (0.0, 0.3333333, 0.75, 0.8, 0.85, 0.9123456, 1.0, 1.0000001, 1.05, 1.15, 1.249999, 1.25, 1.7):
+        assert np.array_equal(PP.blend(d, x, f), np.asarray(Image.blend(Image.fromarray(d, "L"), Image.fromarray(x, "L"), f))), f
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    pil = Image.fromarray(im)
+    for f in (0.75, 0.93, 1.0, 1.17, 1.25):
+        assert np.array_equal(np.asarray(ImageEnhance.Brightness(pil).enhance(f)), PP.adjust_brightness(im, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Contrast(pil).enhance(f)), PP.adjust_contrast(im, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Color(pil).enhance(f)), PP.adjust_saturation(im, f))
+    for hf in (-0.05, -0.0123, 0.0, 0.02, 0.05):
+        h, s_, v_ = pil.convert("HSV").split()
+        nh = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            nh += np.array(hf * 255).astype(np.uint8)
+        want = np.asarray(Image.merge("HSV", (Image.fromarray(nh, "L"), s_, v_)).convert("RGB"))
+        assert np.array_equal(want, PP.adjust_hue(im, hf)), hf

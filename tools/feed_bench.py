@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""`train --train_dir` throughput (VERDICT r2 task 4): N synthetic PNG + JSON samples on disk (schema of the
+reference's README.md:40-71), decoded by the thread-pool feed, resized / jittered / flipped / normalised and encoded on the GPU, through
+the real TrainStep -- images/s next to the synthetic-tensor step of the same batch (what bench.py times).
+usage: feed_bench.py [--n 512] [--batch 64] [--steps 24] [--workers 0] [--amp] [--no_augmentation] [--dir /tmp/sd_feed]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def write_samples(directory, n, size, seed=7):
+    """photo-like content (smooth fields + fine noise: PNGs of ~1/2 the raw size, like camera images, not blocky noise that inflates fast)"""
+    from PIL import Image
+
+    from oracle import sdnet_oracle as O
+    directory.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    labels, parts = ["bean", "maize"], ["leaf"]
+    for i in range(n):
+        low = rng.integers(0, 256, (size // 32, size // 32, 3), dtype=np.uint8)
+        img = np.asarray(Image.fromarray(low).resize((size, size), Image.BICUBIC), np.int16) + rng.integers(-12, 13, (size, size, 3), dtype=np.int16)
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(directory / f"img_{i:04d}.png", compress_level=3)
+        objs = O.synthetic_scene(rng, size, size, 2, 1)
+        js = {"image_path": str(directory / f"img_{i:04d}.png"), "img_size": [size, size],
+              "objects": [{"label": labels[l], "box": None,
+                           "parts": [{"kind": "stem", "location": {"x": x, "y": y}}] + [{"kind": parts[k], "location": {"x": px, "y": py}} for (k, px, py) in ps]}
+                          for (l, x, y, ps) in objs]}
+        (directory / f"img_{i:04d}.json").write_text(json.dumps(js))
+    (directory.parent / "feed_labels.json").write_text(json.dumps({"labels": labels, "parts": parts}))
+    return directory.parent / "feed_labels.json"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=24); ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--amp", action="store_true"); ap.add_argument("--no_augmentation", action="store_true")
+    ap.add_argument("--dir", default="/tmp/sd_feed")
+    a = ap.parse_args()
+    from structuredetector_amd.model.trainer import Trainer
+    from structuredetector_amd.utils.args import Arguments
+    root = Path(a.dir)
+    t0 = time.perf_counter()
+    labels = write_samples(root / "train", a.n, a.size)
+    t_write = time.perf_counter() - t0
+    png_mb = sum(f.stat().st_size for f in (root / "train").glob("*.png")) / a.n / 1e6
+    common = ["--labels", str(labels), "-s", "stem", "-b", str(a.batch), "-W", str(a.size), "-H", str(a.size), "-e", "1000"] + (["--amp"] if a.amp else []) + \
+             (["-a"] if a.no_augmentation else [])
+    out = {"samples": a.n, "png_mb_each": round(png_mb, 3), "write_s": round(t_write, 1), "batch": a.batch, "amp": a.amp, "augmentation": not a.no_augmentation}
+
+    def rate(argv, label):
+        args = Arguments().parse(argv)
+        tr = Trainer(args)
+        if not args.synthetic and not args.no_augmentation:
+            assert type(tr.augment).__name__ == "TrainAugmentation"
+        it = tr.batches()
+        n, t_start = 0, None
+        warm = 4
+        while n < warm + a.steps:
+            try:
+                images, targets = next(it)
+            except StopIteration:
+                tr.epoch += 1
+                it = tr.batches()
+                continue
+            tr.step(images, targets)
+            n += 1
+            if n == warm:
+                torch.cuda.synchronize(); t_start = time.perf_counter()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_start
+        it.close()
+        out[label] = round(a.steps * a.batch / dt, 1)
+        out[label.replace("img_s", "ms_per_step")] = round(dt / a.steps * 1e3, 2)
+
+    rate(common + ["--synthetic", str(a.batch * 8)], "synthetic_img_s")
+    rate(common + ["--train_dir", str(root / "train"), "--decode_workers", str(a.workers)], "directory_img_s")
+    out["directory_over_synthetic"] = round(out["directory_img_s"] / out["synthetic_img_s"], 3)
+    # decode alone (what the pool sustains without the GPU step): every sample once through the dataset reader on the pool
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    from structuredetector_amd.data import CropDataset
+    args = Arguments().parse(common + ["--train_dir", str(root / "train")])
+    ds = CropDataset(args, root / "train", raw=True)
+    workers = a.workers or min(16, os.cpu_count() or 4)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(ds.__getitem__, range(len(ds))))
+    out["decode_only_img_s"] = round(len(ds) / (time.perf_counter() - t0), 1)
+    out["decode_workers"] = workers
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
