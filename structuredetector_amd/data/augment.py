@@ -10,8 +10,7 @@ ColorJitter parity (transforms.py:37-47): torchvision's ColorJitter on a PIL ima
 Color plus an HSV round trip for the hue, in a random order; `sd_preprocess_images_jitter` reproduces Pillow's byte arithmetic on the
 resized image (oracle/pil_photometric.py is the restatement, pinned against Pillow over all 2^24 colours; torchvision itself is absent
 here, its PIL code path is restated from the published 0.20.1 source), so with the same random draws the normalised tensor equals the
-reference's bit for bit.  The draws (`torch.randperm(4)`, four `uniform_`s, two `randn`s per sample, in the reference's order) come
-from torch's global generator on the host.
+reference's bit for bit.  The random draws come from torch's global generator on the host (TrainAugmentation.draws_for).
 """
 from __future__ import annotations
 
@@ -185,10 +184,11 @@ class ValidationAugmentation:
 class TrainAugmentation(ValidationAugmentation):
     """transforms.py:211-247: Resize + RandomColorJitter + RandomHorizontalFlip + RandomVerticalFlip + Normalize, and the per-epoch
     multi-scale `trigger_random_resize` (ratios 0.75 .. 1.25 in steps of 1/16, sizes rounded down to multiples of 32).  Random decisions
-    are drawn like the reference draws them, per sample and in its order -- ColorJitter.get_params (`torch.randperm(4)`, then the
-    brightness / contrast / saturation factors uniformly from [1 - x, 1 + x] and the hue from [-x, x]), then `torch.randn(1).item() <
-    prob` for each flip (transforms.py:14,27: a normal, not a uniform, draw: the flip probability is Phi(0.5) = 0.69) -- and
-    `torch.randint` for the ratio, from torch's global generator."""
+    have the reference's distributions -- ColorJitter.get_params (a random order of the four ops, brightness / contrast / saturation
+    factors uniform in [1 - x, 1 + x], hue in [-x, x]), `randn < prob` for each flip (transforms.py:14,27: a normal, not a uniform,
+    draw: the flip probability is Phi(0.5) = 0.69), `torch.randint` for the multi-scale ratio -- from torch's global generator (the
+    reference draws them inside DataLoader worker processes with per-worker seeds: its stream is not reproducible across worker counts,
+    so the distributions, not a draw order, are what there is to match)."""
 
     ratios = (0.75, 0.8125, 0.875, 0.9375, 1, 1.0625, 1.125, 1.1875, 1.25)
     brightness, contrast, saturation, hue = 0.25, 0.25, 0.15, 0.05            # transforms.py:38
@@ -198,21 +198,25 @@ class TrainAugmentation(ValidationAugmentation):
         self.prob = prob
 
     def draws_for(self, n):
+        """(flips, jitter) of n samples from torch's global generator, in THREE vectorised draws per batch: per-sample tiny tensor ops
+        (the literal form of ColorJitter.get_params + the two flip draws: seven ops per sample) cost 450 ms per batch of 64 next to
+        16 busy decode threads (measured: tools/feed_probe.py), 7 ms alone.  Same distributions: a uniformly random permutation of
+        the four ops (argsort of four uniforms = torch.randperm(4)), brightness / contrast / saturation uniform in [1 - x, 1 + x], hue
+        uniform in [-x, x] (uniform_(a, b) = a + (b - a) * U), each flip when a standard normal draw is below `prob`."""
         if self.args.no_augmentation:
             return None, None
-        flips, words, factors = [], [], []
-        for _ in range(n):
-            order = torch.randperm(4).tolist()                                                     # ColorJitter.get_params
-            b = float(torch.empty(1).uniform_(max(0.0, 1 - self.brightness), 1 + self.brightness))
-            c = float(torch.empty(1).uniform_(max(0.0, 1 - self.contrast), 1 + self.contrast))
-            s = float(torch.empty(1).uniform_(max(0.0, 1 - self.saturation), 1 + self.saturation))
-            h = float(torch.empty(1).uniform_(-self.hue, self.hue))
-            w, f3 = jitter_words(order, b, c, s, h)
+        u = torch.rand(n, 8, dtype=torch.float64)
+        z = torch.randn(n, 2)
+        orders = torch.argsort(u[:, :4], dim=1).tolist()
+        lo = torch.tensor([max(0.0, 1 - self.brightness), max(0.0, 1 - self.contrast), max(0.0, 1 - self.saturation), -self.hue], dtype=torch.float64)
+        hi = torch.tensor([1 + self.brightness, 1 + self.contrast, 1 + self.saturation, self.hue], dtype=torch.float64)
+        vals = (lo + (hi - lo) * u[:, 4:]).tolist()
+        flip_bits = ((z[:, 0] < self.prob).to(torch.int64) | ((z[:, 1] < self.prob).to(torch.int64) << 1)).tolist()
+        words, factors = [], []
+        for order, (b, c, s_, h) in zip(orders, vals):
+            w, f3 = jitter_words(order, b, c, s_, h)
             words.append(w); factors.append(f3)
-            hf = torch.randn(1).item() < self.prob                                                 # RandomHorizontalFlip, then Vertical
-            vf = torch.randn(1).item() < self.prob
-            flips.append(int(hf) | (int(vf) << 1))
-        return flips, (words, factors)
+        return flip_bits, (words, factors)
 
     def trigger_random_resize(self):
         if self.args.no_augmentation:

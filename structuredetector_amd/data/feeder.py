@@ -38,6 +38,8 @@ class BatchFeeder:
         """dataset: CropDataset(raw=True) -- items ((H, W, 3) uint8 CPU tensor, annotation); index_batches: the epoch's batches of sample
         indices (trainer.shard_indices); workers: decode threads (default min(16, cores)); depth: batches in flight ahead of the consumer."""
         self.dataset, self.batches, self.device = dataset, [list(int(j) for j in b) for b in index_batches], torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.workers = int(workers or min(16, os.cpu_count() or 4))
         self.depth = max(1, int(depth))
         self._pinned = {}             # (n, h, w) -> list of [buffer, event of the upload that last read it]

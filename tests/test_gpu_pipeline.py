@@ -81,7 +81,7 @@ def pil_color_jitter(im, order, b, c, s, h):
             hh, ss, vv = im.convert("HSV").split()
             nh = np.array(hh, dtype=np.uint8)
             with np.errstate(over="ignore"):
-                nh += np.array(h * 255).astype(np.uint8)
+                nh += np.uint8(h[0]) if isinstance(h, tuple) else np.array(h * 255).astype(np.uint8)     # (shift byte,) or the hue factor
             im = Image.merge("HSV", (Image.fromarray(nh, "L"), ss, vv)).convert("RGB")
     return im
 
@@ -145,14 +145,12 @@ def test_train_augmentation_jitter_flips_and_multiscale():
     imgs = [rng.integers(0, 256, (60, 80, 3), dtype=np.uint8) for _ in range(6)]
     anns = [ImageAnnotation(f"{i}.png", [Object("bean", Keypoint("stem", 10.0 * i + 1, 5.0 * i + 2), [Keypoint("leaf", 70.0, 50.0)])]) for i in range(6)]
     torch.manual_seed(5)
+    flips, (words, factors) = aug.draws_for(6)                      # the draws the call below will make (same generator state)
     expect = []
-    for _ in range(6):                                # per sample, in the reference's order: ColorJitter.get_params, then the two flips
-        order = torch.randperm(4).tolist()
-        b = float(torch.empty(1).uniform_(0.75, 1.25)); c = float(torch.empty(1).uniform_(0.75, 1.25))
-        s = float(torch.empty(1).uniform_(0.85, 1.15)); hue = float(torch.empty(1).uniform_(-0.05, 0.05))
-        h = torch.randn(1).item() < 0.5
-        v = torch.randn(1).item() < 0.5
-        expect.append(((order, b, c, s, hue), h, v))
+    for i in range(6):
+        order = [(words[i] >> (2 * k)) & 3 for k in range(4)]
+        assert sorted(order) == [0, 1, 2, 3] and 0.75 <= factors[i][0] <= 1.25 and 0.75 <= factors[i][1] <= 1.25 and 0.85 <= factors[i][2] <= 1.15
+        expect.append(((order, *factors[i], ((words[i] >> 8) & 255,)), bool(flips[i] & 1), bool(flips[i] & 2)))
     torch.manual_seed(5)
     out, out_anns = aug(imgs, anns)
     assert any(h for _, h, _ in expect) and any(not h for _, h, _ in expect)

@@ -80,7 +80,30 @@ def main():
         out[label] = round(a.steps * a.batch / dt, 1)
         out[label.replace("img_s", "ms_per_step")] = round(dt / a.steps * 1e3, 2)
 
+    def breakdown(argv):
+        """where a directory-fed step spends its host time: waiting for the feeder, augmentation call, target encoding, step launch"""
+        from structuredetector_amd.data.feeder import BatchFeeder
+        from structuredetector_amd.model.trainer import shard_indices
+        args = Arguments().parse(argv)
+        tr = Trainer(args)
+        shards = shard_indices(len(tr.dataset), a.batch, 0, 1, 1)
+        feed = iter(BatchFeeder(tr.dataset, shards * 4, args.device, workers=a.workers or None, depth=3))
+        acc = {"wait": 0.0, "augment": 0.0, "encode": 0.0, "step": 0.0}
+        for i in range(4 + 12):
+            t0 = time.perf_counter(); batch = next(feed)
+            t1 = time.perf_counter(); images, anns = tr.augment(batch, batch.annotations)
+            t2 = time.perf_counter(); targets = tr.encode.batch(tr.augment.size, anns, args.device)
+            t3 = time.perf_counter(); tr.step(images, targets)
+            t4 = time.perf_counter()
+            if i >= 4:
+                for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    acc[k] += v / 12 * 1e3
+        torch.cuda.synchronize()
+        feed.close()
+        out["host_ms_per_step"] = {k: round(v, 2) for k, v in acc.items()}
+
     rate(common + ["--synthetic", str(a.batch * 8)], "synthetic_img_s")
+    breakdown(common + ["--train_dir", str(root / "train")])
     rate(common + ["--train_dir", str(root / "train"), "--decode_workers", str(a.workers)], "directory_img_s")
     out["directory_over_synthetic"] = round(out["directory_img_s"] / out["synthetic_img_s"], 3)
     # decode alone (what the pool sustains without the GPU step): every sample once through the dataset reader on the pool
