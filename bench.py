@@ -463,6 +463,20 @@ def main():
         if not a.amp:
             guarded(ns, "train_step_amp_bf16", fig_amp)
         guarded(ns, "stress_1024_8x8_bf16", fig_stress)
+
+        def fig_directory_feed():
+            # `train --train_dir`: 512 PNG + JSON samples on disk -> decode threads -> pinned staging -> side-stream upload ->
+            # GPU resize / ColorJitter / flips / Normalize / targets -> the same TrainStep; beside the synthetic-tensor step timed above
+            import tempfile
+
+            from tools.feed_bench import run as feed_run
+            with tempfile.TemporaryDirectory(prefix="sd_feed_") as tmp:
+                r = feed_run(n=512, batch=B, size=img, steps=16, amp=bool(a.amp), directory=tmp, breakdown=False, synthetic=False)
+            r["synthetic_tensor_img_s"] = round(B * a.steps / dt, 1)
+            r["directory_over_synthetic"] = round(r["directory_img_s"] / r["synthetic_tensor_img_s"], 3)
+            return r
+        if (B, img) == (64, 512):
+            guarded(ns, "directory_feed", fig_directory_feed)
         extra["north_star"] = ns
     if rank == 0:
         try:

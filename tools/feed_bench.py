@@ -37,33 +37,32 @@ def write_samples(directory, n, size, seed=7):
     return directory.parent / "feed_labels.json"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=512); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--steps", type=int, default=24); ap.add_argument("--workers", type=int, default=0)
-    ap.add_argument("--amp", action="store_true"); ap.add_argument("--no_augmentation", action="store_true")
-    ap.add_argument("--dir", default="/tmp/sd_feed")
-    a = ap.parse_args()
-    from structuredetector_amd.model.trainer import Trainer
+def run(n=512, batch=64, size=512, steps=24, workers=0, amp=False, no_augmentation=False, directory="/tmp/sd_feed", breakdown=True, synthetic=True):
+    """Returns the figures as a dict (bench.py's `directory_feed` extra calls this with breakdown / synthetic off)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from structuredetector_amd.data import CropDataset
+    from structuredetector_amd.data.feeder import BatchFeeder
+    from structuredetector_amd.model.trainer import Trainer, shard_indices
     from structuredetector_amd.utils.args import Arguments
-    root = Path(a.dir)
+    root = Path(directory)
     t0 = time.perf_counter()
-    labels = write_samples(root / "train", a.n, a.size)
+    labels = write_samples(root / "train", n, size)
     t_write = time.perf_counter() - t0
-    png_mb = sum(f.stat().st_size for f in (root / "train").glob("*.png")) / a.n / 1e6
-    common = ["--labels", str(labels), "-s", "stem", "-b", str(a.batch), "-W", str(a.size), "-H", str(a.size), "-e", "1000"] + (["--amp"] if a.amp else []) + \
-             (["-a"] if a.no_augmentation else [])
-    out = {"samples": a.n, "png_mb_each": round(png_mb, 3), "write_s": round(t_write, 1), "batch": a.batch, "amp": a.amp, "augmentation": not a.no_augmentation}
+    png_mb = sum(f.stat().st_size for f in (root / "train").glob("*.png")) / n / 1e6
+    common = ["--labels", str(labels), "-s", "stem", "-b", str(batch), "-W", str(size), "-H", str(size), "-e", "1000"] + (["--amp"] if amp else []) + \
+             (["-a"] if no_augmentation else [])
+    out = {"samples": n, "png_mb_each": round(png_mb, 3), "write_s": round(t_write, 1), "batch": batch, "amp": amp, "augmentation": not no_augmentation}
+    threads_before = torch.get_num_threads()
 
     def rate(argv, label):
         args = Arguments().parse(argv)
         tr = Trainer(args)
-        if not args.synthetic and not args.no_augmentation:
-            assert type(tr.augment).__name__ == "TrainAugmentation"
         it = tr.batches()
-        n, t_start = 0, None
+        k, t_start = 0, None
         warm = 4
-        while n < warm + a.steps:
+        while k < warm + steps:
             try:
                 images, targets = next(it)
             except StopIteration:
@@ -71,54 +70,65 @@ def main():
                 it = tr.batches()
                 continue
             tr.step(images, targets)
-            n += 1
-            if n == warm:
+            k += 1
+            if k == warm:
                 torch.cuda.synchronize(); t_start = time.perf_counter()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t_start
         it.close()
-        out[label] = round(a.steps * a.batch / dt, 1)
-        out[label.replace("img_s", "ms_per_step")] = round(dt / a.steps * 1e3, 2)
+        out[label] = round(steps * batch / dt, 1)
+        out[label.replace("img_s", "ms_per_step")] = round(dt / steps * 1e3, 2)
 
-    def breakdown(argv):
+    def host_breakdown(argv):
         """where a directory-fed step spends its host time: waiting for the feeder, augmentation call, target encoding, step launch"""
-        from structuredetector_amd.data.feeder import BatchFeeder
-        from structuredetector_amd.model.trainer import shard_indices
         args = Arguments().parse(argv)
         tr = Trainer(args)
-        shards = shard_indices(len(tr.dataset), a.batch, 0, 1, 1)
-        feed = iter(BatchFeeder(tr.dataset, shards * 4, args.device, workers=a.workers or None, depth=3))
+        shards = shard_indices(len(tr.dataset), batch, 0, 1, 1)
+        feed = iter(BatchFeeder(tr.dataset, shards * 4, args.device, workers=workers or None, depth=3))
         acc = {"wait": 0.0, "augment": 0.0, "encode": 0.0, "step": 0.0}
         for i in range(4 + 12):
-            t0 = time.perf_counter(); batch = next(feed)
-            t1 = time.perf_counter(); images, anns = tr.augment(batch, batch.annotations)
+            t0 = time.perf_counter(); b = next(feed)
+            t1 = time.perf_counter(); images, anns = tr.augment(b, b.annotations)
             t2 = time.perf_counter(); targets = tr.encode.batch(tr.augment.size, anns, args.device)
             t3 = time.perf_counter(); tr.step(images, targets)
             t4 = time.perf_counter()
             if i >= 4:
-                for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
-                    acc[k] += v / 12 * 1e3
+                for key, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    acc[key] += v / 12 * 1e3
         torch.cuda.synchronize()
         feed.close()
-        out["host_ms_per_step"] = {k: round(v, 2) for k, v in acc.items()}
+        out["host_ms_per_step"] = {key: round(v, 2) for key, v in acc.items()}
 
-    rate(common + ["--synthetic", str(a.batch * 8)], "synthetic_img_s")
-    breakdown(common + ["--train_dir", str(root / "train")])
-    rate(common + ["--train_dir", str(root / "train"), "--decode_workers", str(a.workers)], "directory_img_s")
-    out["directory_over_synthetic"] = round(out["directory_img_s"] / out["synthetic_img_s"], 3)
-    # decode alone (what the pool sustains without the GPU step): every sample once through the dataset reader on the pool
-    from concurrent.futures import ThreadPoolExecutor
-    import os
-    from structuredetector_amd.data import CropDataset
-    args = Arguments().parse(common + ["--train_dir", str(root / "train")])
-    ds = CropDataset(args, root / "train", raw=True)
-    workers = a.workers or min(16, os.cpu_count() or 4)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(workers) as pool:
-        list(pool.map(ds.__getitem__, range(len(ds))))
-    out["decode_only_img_s"] = round(len(ds) / (time.perf_counter() - t0), 1)
-    out["decode_workers"] = workers
-    print(json.dumps(out))
+    try:
+        if synthetic:
+            rate(common + ["--synthetic", str(batch * 8)], "synthetic_img_s")
+        if breakdown:
+            host_breakdown(common + ["--train_dir", str(root / "train")])
+        rate(common + ["--train_dir", str(root / "train"), "--decode_workers", str(workers)], "directory_img_s")
+        if synthetic:
+            out["directory_over_synthetic"] = round(out["directory_img_s"] / out["synthetic_img_s"], 3)
+        # decode alone (what the pool sustains without the GPU step): every sample once through the dataset reader on the pool
+        args = Arguments().parse(common + ["--train_dir", str(root / "train")])
+        ds = CropDataset(args, root / "train", raw=True)
+        nw = workers or min(16, os.cpu_count() or 4)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nw) as pool:
+            list(pool.map(ds.__getitem__, range(len(ds))))
+        out["decode_only_img_s"] = round(len(ds) / (time.perf_counter() - t0), 1)
+        out["decode_workers"] = nw
+    finally:
+        torch.set_num_threads(threads_before)          # (the directory Trainer runs torch's intra-op pool single-threaded)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=24); ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--amp", action="store_true"); ap.add_argument("--no_augmentation", action="store_true")
+    ap.add_argument("--dir", default="/tmp/sd_feed")
+    a = ap.parse_args()
+    print(json.dumps(run(a.n, a.batch, a.size, a.steps, a.workers, a.amp, a.no_augmentation, a.dir)))
 
 
 if __name__ == "__main__":
