@@ -264,11 +264,6 @@ class Trainer:
         # directory data: decode on the host (PIL), resize + flips + normalisation for the whole batch on the GPU
         from ..data.augment import TrainAugmentation
         self.dataset = None if args.synthetic else CropDataset(args, args.train_dir, raw=True)
-        if self.dataset is not None:
-            # the loop's host work is thousands of tiny tensor ops and kernel launches: torch's intra-op pool gives them nothing, and its
-            # workers spin against the decode threads (measured: 64 x 7 scalar draws 450 ms next to 16 decoders, 7 ms alone).  The
-            # reference's DataLoader workers run single-threaded for the same reason (torch.utils.data sets one thread per worker).
-            torch.set_num_threads(1)
         self.augment = TrainAugmentation(args)
         self.save_dir = Path("trainings") / f"{datetime.now():%Y-%m-%d_%H-%M-%S}"
         self.best_loss = float("inf")
@@ -298,9 +293,17 @@ class Trainer:
             from ..data.feeder import BatchFeeder
             shards = shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch)
             workers = getattr(a, "decode_workers", 0) or max(1, min(16, (os.cpu_count() or 4) // world))
-            for batch in BatchFeeder(self.dataset, shards, a.device, workers=workers, depth=getattr(a, "prefetch", 3)):
-                images, anns = self.augment(batch, batch.annotations)
-                yield images, self.encode.batch(self.augment.size, anns, a.device)
+            # While the feed runs, torch's intra-op pool is single-threaded: the loop's host work is thousands of tiny tensor ops and kernel
+            # launches, the pool gives them nothing and its workers spin against the decode threads (measured: 64 x 7 scalar draws 450 ms
+            # next to 16 decoders, 7 ms alone).  The reference's DataLoader workers run single-threaded for the same reason.
+            threads = torch.get_num_threads()
+            torch.set_num_threads(1)
+            try:
+                for batch in BatchFeeder(self.dataset, shards, a.device, workers=workers, depth=getattr(a, "prefetch", 3)):
+                    images, anns = self.augment(batch, batch.annotations)
+                    yield images, self.encode.batch(self.augment.size, anns, a.device)
+            finally:
+                torch.set_num_threads(threads)
 
     def valid_samples(self):
         if self.valid_set is not None:

@@ -14,6 +14,7 @@ Two layers of evidence:
 """
 import copy
 import ctypes as C
+import os
 import time
 from argparse import Namespace
 
@@ -60,7 +61,7 @@ def test_train_step_bs64_512_vs_oracle_per_kernel_family():
     lib = L.lib()
     B, S, M, N, K, P = 64, 512, 2, 1, 20, 40
     t0 = time.time()
-    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     ref = O.build_reference_network(M, N, seed=31).train()
     ref64 = copy.deepcopy(ref).double()
     args = make_args(M, N, K, P, device=torch.device(DEV), learning_rate=1e-3)
@@ -268,7 +269,7 @@ def test_stress_geometry_bf16_forward_bs16_1024_vs_autocast_oracle():
     from structuredetector_amd.model import Network
     lib = L.lib()
     B, S, M, N = 16, 1024, 8, 8
-    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     ref = O.build_reference_network(M, N, seed=41).eval()
     args = Namespace(labels={f"l{i}": i for i in range(M)}, parts={f"p{i}": i for i in range(N)}, fpn_depth=128, use_amp=True)
     net = Network(args, pretrained=False, raw_output=True)
