@@ -249,7 +249,7 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w_krsc, void* y_nhwc, c
  * fp32) on 64-pixel x 64-channel tiles with the reduction split over blocks so that tiles x slices is about one block per CU; the
  * partial tiles are combined INSIDE the launch by the block that arrives last for a tile (summed in slice order: results do not
  * depend on the arrival order), so a conv is ONE launch.  sd_conv2d_fwd_sb_supported(): 1 for the geometries it is meant for
- * (the 128-row tile grid of sd_conv2d_fwd would not fill the chip); any R == S conv with Cin % 32 (bf16: 64) == 0, Cout % 64 == 0
+ * (the 128-row tile grid of sd_conv2d_fwd would not fill the chip twice: batches up to ~16 at 512x512); any R == S conv with Cin % 32 (bf16: 64) == 0, Cout % 64 == 0
  * is computed correctly.  `workspace`: sd_conv2d_fwd_sb_workspace_bytes() of scratch (partial tiles; no initialisation).
  * `state`: sd_conv2d_fwd_sb_state_bytes() bytes owned by the caller, used by nothing else that may run concurrently, ZERO before
  * the first call; every call leaves it zero again (back-to-back launches and hipGraph replays need no memset).  After a failed

@@ -420,13 +420,15 @@ using namespace sd;
 
 extern "C" {
 
-// Geometries the small-batch kernel takes: where the 128-row tile grid of sd_conv2d_fwd cannot fill the chip (< 256 tiles).
+// Geometries the small-batch kernel takes: where the 128-row tile grid of sd_conv2d_fwd does not fill the chip twice (< 512 tiles).
 int sd_conv2d_fwd_sb_supported(const sd_conv_desc* d, int bf16) {
     if (!d || d->B <= 0 || d->Cin % (bf16 ? 64 : 32) || d->Cout % 64 || d->R != d->S || d->R < 1 || d->stride < 1) return 0;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     const int BN = (d->Cout % 128 == 0) ? 128 : 64;
     SbArgs a{};
-    return (cdiv(M, 128) * (d->Cout / BN) < 256 && M <= (1 << 20) && sb_plan(a, d, bf16 != 0)) ? 1 : 0;
+    // < 512 tiles of 128 rows (two resident blocks per CU): measured on the whole eval forward, bs = 2 .. 16 (tools/bs1_bench.py): 256 -> 512
+    // is 2-4 % faster at every batch, 1024 the same, 4096 mixed
+    return (cdiv(M, 128) * (d->Cout / BN) < 512 && M <= (1 << 20) && sb_plan(a, d, bf16 != 0)) ? 1 : 0;
 }
 
 size_t sd_conv2d_fwd_sb_workspace_bytes(const sd_conv_desc* d, int bf16) {

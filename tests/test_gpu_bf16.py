@@ -148,3 +148,26 @@ def test_stress_config_bf16_backbone_fp32_decode():
     from tests.helpers import assert_decode_matches_oracle
     # (a random-init network saturates many logits: clamp plateaus leave few tie-free ranks here, so no coverage floor)
     assert_decode_matches_oracle(got, t, 0.5, dict(rtol=4e-7, atol=0))
+
+
+def test_network_bf16_bs1_512_small_batch_kernel_vs_autocast_oracle():
+    """BASELINE configs[1] on the bf16 backbone: batch 1, 512x512 -- every conv on sd_conv2d_fwd_sb (bf16 MFMA, K split over blocks and
+    combined inside the launch) -- against the oracle's fp32 forward, with torch.autocast(cpu, bfloat16) of the same oracle as the
+    yardstick; also the same image inside a batch of 3 (other tile / slice decomposition) and bit-reproducibility."""
+    ref, net = _pair(seed=5)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 3, 512, 512, generator=g)
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        want32 = ref(x)
+        with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+            want16 = ref(x).float()
+        one = net(x[:1].to(DEV)).cpu()
+        again = net(x[:1].to(DEV)).cpu()
+        three = net(x.to(DEV)).cpu()
+    assert torch.equal(one, again)
+    scale = want32.abs().max().item()
+    err_auto = (want16 - want32).abs().max().item() / scale
+    for got, want in ((one, want32[:1]), (three, want32)):
+        err = (got - want).abs().max().item() / scale
+        assert err <= max(1.5 * err_auto, 2e-2), (err, err_auto)
