@@ -2,7 +2,7 @@
 # Regenerates every profile artefact of a round in ONE gpurun call; results land in gpurun_out/profiles_<tag>/ (copy to profiles/).
 # usage: bash tools/make_profiles.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
@@ -23,6 +23,7 @@ stats train_fp32 tools/prof_train.py 4
 stats train_amp tools/prof_train.py 4 amp
 stats fwd_bf16 tools/prof_bf16_fwd.py 6
 stats fwd_bf16_stress tools/prof_bf16_fwd.py 6 stress
+stats fwd_bs1 tools/prof_fwd1.py 20
 # 4. decoder variants (per-kernel durations + device span per call)
 bash tools/decode_prof.sh $TAG > /dev/null 2>&1 && cp gpurun_out/decode_prof_$TAG.txt $OUT/${TAG}_decode_variants.txt
 # 5. HBM traffic of the conv kernels (PMC, separate passes)
