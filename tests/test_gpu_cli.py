@@ -180,9 +180,45 @@ def test_resume_is_bit_identical(tmp_path, monkeypatch):
     train.main(common + ["-e", "1"])
     resume = list((tmp_path / "trainings").glob("*/resume.pth"))
     assert len(resume) == 1
-    st = torch.load(resume[0], map_location="cpu", weights_only=False)
+    st = torch.load(resume[0], map_location="cpu", weights_only=True)
     assert st["epoch"] == 0 and st["optimizer"]["step_count"] == 2 and st["scheduler"]["epoch"] == 1
     train.main(common + ["-e", "2", "--resume", str(resume[0])])
+
+
+def test_resume_restores_augmentation_state_over_a_directory(golden_dir, tmp_path, monkeypatch):
+    """`resume.pth` also carries the multi-scale size drawn for the next epoch, the random streams (torch's global generator,
+    the rank's numpy generator) and the run's save directory, and loads with weights_only=True: a resumed run continues with the input
+    size and the draws the uninterrupted run would have had, and keeps writing into the same trainings/<stamp>/."""
+    from structuredetector_amd.model.trainer import Trainer
+    from structuredetector_amd.utils.args import Arguments
+    from tests.helpers import write_evaluate16_dir
+    g = np.load(golden_dir / "evaluate16.npz")
+    write_evaluate16_dir(g, tmp_path / "train")
+    (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
+    monkeypatch.chdir(tmp_path)
+    argv = ["--train_dir", str(tmp_path / "train"), "-W", "128", "-H", "128", "-s", "stem", "--labels", str(tmp_path / "labels.json"), "-b", "8", "-e", "3"]
+    args = Arguments().parse(argv)
+    torch.manual_seed(77)
+    tr = Trainer(args)
+    sizes = []
+    orig = type(tr.augment).trigger_random_resize
+
+    def spy(self):
+        sizes.append(orig(self))
+        return sizes[-1]
+    monkeypatch.setattr(type(tr.augment), "trigger_random_resize", spy)
+    args.epochs = 1
+    tr.train()                                              # epoch 0, then the size of epoch 1 is drawn and resume.pth written
+    resume = tr.save_dir / "resume.pth"
+    state = torch.load(resume, map_location="cpu", weights_only=True)
+    assert tuple(state["augment_size"]) == tuple(sizes[-1]) == tuple(tr.augment.size)
+    want_draw, want_np = torch.rand(3), tr.rng.random(3)    # what the uninterrupted run would draw next
+    torch.manual_seed(1234)                                 # a fresh process would start from other streams
+    args2 = Arguments().parse(argv + ["--resume", str(resume)])
+    tr2 = Trainer(args2)
+    assert tr2.start_epoch == 1 and tuple(tr2.augment.size) == tuple(sizes[-1]) and tr2.save_dir == tr.save_dir
+    assert torch.equal(torch.rand(3), want_draw) and np.array_equal(tr2.rng.random(3), want_np)
+    assert tr2.step.step_count == tr.step.step_count and torch.equal(tr2.net.flat_params, tr.net.flat_params)
 
 
 def test_fused_inference_export_and_detect(tmp_path, monkeypatch):
