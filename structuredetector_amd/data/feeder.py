@@ -22,6 +22,35 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 
+def cpu_share():
+    """Cores this process may really use: the cgroup CPU quota where there is one (a container sees all host cores in
+    os.cpu_count()), else the scheduler affinity, else the core count."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                         # cgroup v1
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            return max(1, quota // period)
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 4
+
+
+def default_decode_workers(world=1):
+    """Half of this rank's cores, 2 .. 16: PNG / JPEG decoding is CPU work (~9 ms per 512x512 PNG), and the training loop's launch thread
+    and the producer need cores of their own -- measured on a 16-core share, fp32 step of 76 ms: 8 workers 841 img/s (99 % of the
+    synthetic-tensor step), 12: 822, 16: 815, 24: 732."""
+    return max(2, min(16, cpu_share() // max(world, 1) // 2))
+
+
 class GroupedBatch:
     """One batch as the GPU pipeline wants it: `groups` = {(height, width): (sample positions, (n, height, width, 3) uint8 DEVICE tensor)},
     `annotations` in sample order (ORIGINAL image pixels), `ready` = event after which the device tensors are complete."""
@@ -36,11 +65,11 @@ class GroupedBatch:
 class BatchFeeder:
     def __init__(self, dataset, index_batches, device, workers=None, depth=3):
         """dataset: CropDataset(raw=True) -- items ((H, W, 3) uint8 CPU tensor, annotation); index_batches: the epoch's batches of sample
-        indices (trainer.shard_indices); workers: decode threads (default min(16, cores)); depth: batches in flight ahead of the consumer."""
+        indices (trainer.shard_indices); workers: decode threads (default: default_decode_workers()); depth: batches in flight ahead of the consumer."""
         self.dataset, self.batches, self.device = dataset, [list(int(j) for j in b) for b in index_batches], torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.workers = int(workers or min(16, os.cpu_count() or 4))
+        self.workers = int(workers or default_decode_workers())
         self.depth = max(1, int(depth))
         self._pinned = {}             # (n, h, w) -> list of [buffer, event of the upload that last read it]
         self._stop = threading.Event()

@@ -290,9 +290,9 @@ class Trainer:
         else:
             # decode threads + pinned staging + side-stream upload, `prefetch` batches ahead of the step (data/feeder.py); resize, jitter,
             # flips, normalisation and the targets for the whole batch on the GPU (the reference: trainer.py:62-72, dataset.py:41-49)
-            from ..data.feeder import BatchFeeder
+            from ..data.feeder import BatchFeeder, default_decode_workers
             shards = shard_indices(len(self.dataset), B, self.rank, world, 926354916 + self.epoch)
-            workers = getattr(a, "decode_workers", 0) or max(1, min(16, (os.cpu_count() or 4) // world))
+            workers = getattr(a, "decode_workers", 0) or default_decode_workers(world)
             # While the feed runs, torch's intra-op pool is single-threaded: the loop's host work is thousands of tiny tensor ops and kernel
             # launches, the pool gives them nothing and its workers spin against the decode threads (measured: 64 x 7 scalar draws 450 ms
             # next to 16 decoders, 7 ms alone).  The reference's DataLoader workers run single-threaded for the same reason.

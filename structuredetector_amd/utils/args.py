@@ -50,7 +50,7 @@ _FLAGS = [
     (("--steps",), dict(type=int, default=0, help="Stop training after this many optimizer steps (0 = full epochs).")),
     (("--bf16_inference",), dict(action="store_true", help="Eval-mode forward on the bf16 backbone (fp32 decode); training unaffected.")),
     (("--resume",), dict(type=str, default=None, help="Continue a run from trainings/<stamp>/resume.pth (weights, Adam state, scheduler, epoch).")),
-    (("--decode_workers",), dict(type=int, default=0, help="Image decode threads of the directory feed (0 = min(16, cores)).")),
+    (("--decode_workers",), dict(type=int, default=0, help="Image decode threads of the directory feed (0 = half of this rank's CPU share, 2 .. 16).")),
     (("--prefetch",), dict(type=int, default=3, help="Batches decoded and uploaded ahead of the training step.")),
 ]
 

@@ -48,7 +48,10 @@ def run(n=512, batch=64, size=512, steps=24, workers=0, amp=False, no_augmentati
     from structuredetector_amd.utils.args import Arguments
     root = Path(directory)
     t0 = time.perf_counter()
-    labels = write_samples(root / "train", n, size)
+    if len(list((root / "train").glob("*.png"))) == n and (root / "feed_labels.json").exists():
+        labels = root / "feed_labels.json"                  # (a previous run's samples: same seed, same files)
+    else:
+        labels = write_samples(root / "train", n, size)
     t_write = time.perf_counter() - t0
     png_mb = sum(f.stat().st_size for f in (root / "train").glob("*.png")) / n / 1e6
     common = ["--labels", str(labels), "-s", "stem", "-b", str(batch), "-W", str(size), "-H", str(size), "-e", "1000"] + (["--amp"] if amp else []) + \
@@ -110,7 +113,8 @@ def run(n=512, batch=64, size=512, steps=24, workers=0, amp=False, no_augmentati
         # decode alone (what the pool sustains without the GPU step): every sample once through the dataset reader on the pool
         args = Arguments().parse(common + ["--train_dir", str(root / "train")])
         ds = CropDataset(args, root / "train", raw=True)
-        nw = workers or min(16, os.cpu_count() or 4)
+        from structuredetector_amd.data.feeder import default_decode_workers
+        nw = workers or default_decode_workers()
         t0 = time.perf_counter()
         with ThreadPoolExecutor(nw) as pool:
             list(pool.map(ds.__getitem__, range(len(ds))))
