@@ -6,10 +6,16 @@
 // Why a kernel of its own: at one image the trunk's GEMMs are 16384 x 64 x 576 ... 256 x 512 x 4608 (pixels x Cout x K): the
 // 128 x 128 tiles of k_conv_igemm give 8 ... 128 blocks, so K was split 4 ... 36 ways into 288 unbalanced blocks whose 17-19 MB of
 // partial tiles a second launch (k_splitk_reduce) summed: 26 + 6.7 us per conv for 7.7 us of MFMA work.  Here
-//   * tile 64 (pixels) x 64 (channels), four waves, one 32 x 32 accumulator each: 256 / 128 / 64 / 32 tiles for layer1 .. layer4,
-//     so K splits 1 / 2 / 4 / 8 ways give 256 equal blocks (one per CU) of 18 chunks each;
-//   * four LDS stages of 16 KB (64 rows x 128 B per operand), filled by LDS-DMA three chunks ahead, counted vmcnt waits and a bare
-//     s_barrier per chunk (a __syncthreads() would drain the DMAs in flight); fragment reads are inline-asm ds_read_b128;
+//   * tile 64 (pixels) x 64 (channels), four waves of one 32 x 32 output tile each: 256 / 128 / 64 / 32 tiles for layer1 .. layer4,
+//     so K splits 1 / 2 / 4 / 8 ways give 256 equal blocks (one per CU) of 18 chunks each; taken up to 512 tiles of 128 rows (bs ~16);
+//   * four LDS stages of 16 KB (64 rows x 128 B per operand) filled by LDS-DMA FOUR chunks ahead, a counted vmcnt(8) + lgkmcnt(0)
+//     wait and a bare s_barrier per chunk (a __syncthreads() would drain the DMAs in flight);
+//   * software-pipelined steps: while the MFMAs of chunk i run from one register set, the fragments of chunk i+1 are read
+//     (inline-asm ds_read_b128, the stage an immediate offset of ONE LDS array) into the other and the four LDS-DMA pieces of chunk
+//     i+4 are issued one per MFMA shadow; the filter tap of every step is a compile-time literal (36-step unrolled body for 3x3
+//     filters) and the per-row source pointers of all taps live in registers (padding = pointer into a zero region): a chunk's
+//     addresses cost four 64-bit adds.  In-kernel clocks: 1253 cycles per chunk of 1024 MFMA cycles (each LDS-DMA instruction costs
+//     the issuing wave ~35 of them: one wave per SIMD); DESIGN.md section 7 has the ablations;
 //   * the split-K combine happens INSIDE the launch: every slice block stores its 16 KB fp32 slab write-through (sc1), drains,
 //     and draws an arrival ticket (agent-scope atomic add); the block that draws the last ticket sums the slabs IN SLICE ORDER
 //     (deterministic: the order does not depend on which block arrives last) with sc1 loads and runs the epilogue.  No second
