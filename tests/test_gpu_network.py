@@ -795,6 +795,8 @@ SB_CASES = [  # B, H, W, cin, cout, k, stride, pad -- the bs=1 layer geometries 
     (1, 32, 32, 256, 128, 1, 1, 0),     # FPN lateral (with the x2-upsampled residual below)
     (2, 9, 7, 256, 256, 3, 1, 1),       # ragged last pixel tile (M = 126)
     (3, 20, 12, 64, 64, 3, 1, 1),       # tiles cross image boundaries
+    (1, 24, 40, 64, 64, 5, 1, 2),       # 5x5 filter: the run-time-tap instantiation (NTAP = 0), 50 chunks in 5 slices
+    (2, 32, 32, 64, 128, 7, 2, 3),      # 7x7 / stride 2 (run-time taps, strided, 98 chunks)
 ]
 
 
