@@ -862,3 +862,28 @@ def test_network_bs1_small_batch_kernel_on_and_off():
         net._engine.small_batch_kernel = True
     assert torch.equal(a, b)
     close(a.cpu(), c.cpu(), 2e-5)
+
+
+def test_small_batch_forward_on_two_streams_concurrently():
+    """The split-K tickets of sd_conv2d_fwd_sb live in a caller-owned state buffer PER STREAM (`_lib.zero_state`): two networks run
+    their bs = 1 forwards on two streams at the same time, many times over, and each result equals the one computed alone."""
+    from structuredetector_amd import _lib as L
+    _, net_a = _pair(seed=23)
+    _, net_b = _pair(seed=29)
+    xa = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(1)).to(DEV)
+    xb = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        net_a.eval(); net_b.eval()
+        want_a, want_b = net_a(xa).clone(), net_b(xb).clone()
+        torch.cuda.synchronize()
+        sa, sb_ = torch.cuda.Stream(), torch.cuda.Stream()
+        outs_a, outs_b = [], []
+        for _ in range(10):
+            with torch.cuda.stream(sa):
+                outs_a.append(net_a(xa))
+            with torch.cuda.stream(sb_):
+                outs_b.append(net_b(xb))
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, want_a) for o in outs_a) and all(torch.equal(o, want_b) for o in outs_b)
+    states = [v for (d, s, tag), v in L._state_cache.items() if tag == "conv"]
+    assert len(states) >= 3 and all(int(v.view(torch.int32).abs().sum()) == 0 for v in states)     # default + two side streams, all left zero
