@@ -16,10 +16,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
 def write_samples(directory, n, size, seed=7):
-    """photo-like content (smooth fields + fine noise: PNGs of ~1/2 the raw size, like camera images, not blocky noise that inflates fast)"""
+    """photo-like content (smooth fields + fine noise: PNGs of ~1/2 the raw size, like camera images, not blocky noise that inflates fast);
+    scenes from the product's own seeded generator (data/synthetic.py)"""
     from PIL import Image
 
-    from oracle import sdnet_oracle as O
+    from structuredetector_amd.data.synthetic import synthetic_batch
     directory.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(seed)
     labels, parts = ["bean", "maize"], ["leaf"]
@@ -27,11 +28,14 @@ def write_samples(directory, n, size, seed=7):
         low = rng.integers(0, 256, (size // 32, size // 32, 3), dtype=np.uint8)
         img = np.asarray(Image.fromarray(low).resize((size, size), Image.BICUBIC), np.int16) + rng.integers(-12, 13, (size, size, 3), dtype=np.int16)
         Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(directory / f"img_{i:04d}.png", compress_level=3)
-        objs = O.synthetic_scene(rng, size, size, 2, 1)
-        js = {"image_path": str(directory / f"img_{i:04d}.png"), "img_size": [size, size],
-              "objects": [{"label": labels[l], "box": None,
-                           "parts": [{"kind": "stem", "location": {"x": x, "y": y}}] + [{"kind": parts[k], "location": {"x": px, "y": py}} for (k, px, py) in ps]}
-                          for (l, x, y, ps) in objs]}
+        n_obj, o_lab, o_xy, o_np, p_kind, p_xy = synthetic_batch(rng, 1, size, size, len(labels), len(parts))
+        objs, j = [], 0
+        for k in range(int(n_obj[0])):
+            ps = [{"kind": parts[int(p_kind[j + q])], "location": {"x": float(p_xy[j + q][0]), "y": float(p_xy[j + q][1])}} for q in range(int(o_np[k]))]
+            j += int(o_np[k])
+            objs.append({"label": labels[int(o_lab[k])], "box": None,
+                         "parts": [{"kind": "stem", "location": {"x": float(o_xy[k][0]), "y": float(o_xy[k][1])}}] + ps})
+        js = {"image_path": str(directory / f"img_{i:04d}.png"), "img_size": [size, size], "objects": objs}
         (directory / f"img_{i:04d}.json").write_text(json.dumps(js))
     (directory.parent / "feed_labels.json").write_text(json.dumps({"labels": labels, "parts": parts}))
     return directory.parent / "feed_labels.json"
