@@ -2604,27 +2604,51 @@ __device__ __forceinline__ int stem_koff(int k) {      // patch offset of reduct
 }
 
 // All global loads of a staging pass are issued before the first LDS store (fully unrolled, values in registers):
-// a load-store-load-store loop would expose one global round trip per element.
-__device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* patch, int b, int oy, int ox0) {
-    constexpr int TOTAL = SP_ROWS * SP_PITCH, NLD = (TOTAL + 255) / 256;
-    const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 3;
+// a load-store-load-store loop would expose one global round trip per element.  Split in two halves so that a persistent block
+// can have the NEXT tile's patch in flight (stem_fetch_patch) while the MFMAs of the current one run, and only store it
+// (stem_commit_patch) once every wave is done with the current patch.
+constexpr int SP_NLD = SP_ROWS + 1;
+// Thread t fetches patch column t of all 21 (ci, r) rows (row addresses are wave-uniform: scalar arithmetic, one vector offset) and,
+// for t < 105, one element of columns 256 .. 260.  Out-of-image rows / columns are fetched from the clamped coordinate and zeroed at
+// commit time (no branch around a load, no per-element address registers carried across the tile loop).
+__device__ __forceinline__ void stem_fetch_patch(const StemArgs& p, float (&v)[SP_NLD], int b, int oy, int ox0) {
+    const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 3, tid = threadIdx.x;
     const float* img = p.x + (int64_t)b * 3 * p.H * p.W;
-    float v[NLD];
+    const int ixc = min(max(ix0 + tid, 0), p.W - 1);
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        const int row = i / SP_PITCH, col = i - row * SP_PITCH;
+    for (int row = 0; row < SP_ROWS; ++row) {
         const int ci = row / 7, r = row - ci * 7;
-        const int iy = iy0 + r, ix = ix0 + col;
-        const bool ok = i < TOTAL && col < SP_USED && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float* src = ok ? img + (ci * p.H + iy) * p.W + ix : g_zero_line;
-        v[j] = *src;
+        const int iyc = min(max(iy0 + r, 0), p.H - 1);
+        v[row] = img[(ci * p.H + iyc) * p.W + ixc];
     }
+    const int e = min(tid, SP_ROWS * 5 - 1), row = e / 5, c = 256 + e - row * 5, ci = row / 7, r = row - ci * 7;
+    v[SP_ROWS] = img[(ci * p.H + min(max(iy0 + r, 0), p.H - 1)) * p.W + min(max(ix0 + c, 0), p.W - 1)];
+}
+__device__ __forceinline__ void stem_commit_patch(const StemArgs& p, float* patch, const float (&v)[SP_NLD], int oy, int ox0) {
+    const int iy0 = 2 * oy - 3, ix0 = 2 * ox0 - 3, tid = threadIdx.x;
+    const bool cok = (unsigned)(ix0 + tid) < (unsigned)p.W;
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        if (i < TOTAL) patch[i] = v[j];
+    for (int row = 0; row < SP_ROWS; ++row) {
+        const int r = row % 7;
+        patch[row * SP_PITCH + tid] = (cok && (unsigned)(iy0 + r) < (unsigned)p.H) ? v[row] : 0.f;
     }
+    if (tid < SP_ROWS * 5) {
+        const int row = tid / 5, c = 256 + tid - row * 5, r = row % 7;
+        patch[row * SP_PITCH + c] = ((unsigned)(ix0 + c) < (unsigned)p.W && (unsigned)(iy0 + r) < (unsigned)p.H) ? v[SP_ROWS] : 0.f;
+    }
+}
+__device__ __forceinline__ void stem_fetch_dy(const StemArgs& p, f32x4 (&dv)[8], int64_t row0, int ox0) {     // 128 x 64 tile of dy
+    // (f32x4, not HIP's float4: an array of that struct type carried across the tile loop stays in scratch memory)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = threadIdx.x + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
+        const float* src = (ox0 + px < p.Wo) ? p.dy + (row0 + px) * 64 + c4 : g_zero_line;
+        dv[j] = *reinterpret_cast<const f32x4*>(src);
+    }
+}
+__device__ __forceinline__ void stem_tile_coords(const StemArgs& p, int tile, int& b, int& oy, int& ox0) {
+    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
+    oy = t2 % p.Ho; b = t2 / p.Ho; ox0 = tx * 128;
 }
 
 // BF16MM: the product runs on the bf16 MFMA (inference with the bf16 backbone): image patch and weights are rounded to bf16 on the
@@ -2680,11 +2704,23 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
     if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + c4);
     float* T = Tall + wave * 1024;
 
+    // the patch of tile t+1 is fetched into registers while tile t is multiplied: a tile never waits for a global round trip
+    float pv[SP_NLD];
+    if ((int)blockIdx.x < p.ntiles) {
+        int b, oy, ox0;
+        stem_tile_coords(p, blockIdx.x, b, oy, ox0);
+        stem_fetch_patch(p, pv, b, oy, ox0);
+    }
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
-        const int ox0 = tx * 128;
-        stem_load_patch(p, patch, b, oy, ox0);
+        int b, oy, ox0;
+        stem_tile_coords(p, tile, b, oy, ox0);
+        stem_commit_patch(p, patch, pv, oy, ox0);
         __syncthreads();                                 // patch (and, the first time, the weights) staged
+        if (tile + (int)gridDim.x < p.ntiles) {
+            int nb, noy, nox0;
+            stem_tile_coords(p, tile + gridDim.x, nb, noy, nox0);
+            stem_fetch_patch(p, pv, nb, noy, nox0);
+        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -2984,27 +3020,33 @@ __global__ __launch_bounds__(256, 1) void k_stem_wgrad2(StemArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // patch and dy tile of tile t+1 are fetched into registers while tile t is multiplied (one block per CU: nothing else would
+    // cover the global round trip of a staging pass)
+    float pv[SP_NLD];
+    f32x4 dv[8];
+#define SW2_FETCH(tile_)                                                                                         \
+    {                                                                                                            \
+        int b_, oy_, ox0_;                                                                                       \
+        stem_tile_coords(p, (tile_), b_, oy_, ox0_);                                                             \
+        stem_fetch_patch(p, pv, b_, oy_, ox0_);                                                                  \
+        stem_fetch_dy(p, dv, ((int64_t)b_ * p.Ho + oy_) * p.Wo + ox0_, ox0_);                                    \
+    }
+    if ((int)blockIdx.x < p.ntiles) SW2_FETCH(blockIdx.x)
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, oy = t2 % p.Ho, b = t2 / p.Ho;
-        const int ox0 = tx * 128;
-        __syncthreads();
-        stem_load_patch(p, patch, b, oy, ox0);
-        const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo + ox0;
+        __syncthreads();                                 // every wave is done with the previous tile's operands
         {
-            float4 dv[8];
+            int b, oy, ox0;
+            stem_tile_coords(p, tile, b, oy, ox0);
+            stem_commit_patch(p, patch, pv, oy, ox0);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
-                const float* src = (ox0 + px < p.Wo) ? p.dy + (row0 + px) * 64 + c4 : g_zero_line;
-                dv[j] = *reinterpret_cast<const float4*>(src);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = tid + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
-                *reinterpret_cast<float4*>(dys + px * 64 + c4) = dv[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, px = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(dys + px * 64 + c4) = dv[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < p.ntiles) SW2_FETCH(tile + gridDim.x)
+#undef SW2_FETCH
         const float* da = dys + (wave * 32 + fh) * 64 + fr;
         const float* xb = patch + 2 * (wave * 32 + fh);
 #pragma unroll 4

@@ -114,6 +114,7 @@ class _Engine:
         self.net = net
         self.lib = L.lib()
         self.prof = None      # list -> every conv launch appends (kernel, algorithmic flops, start event, end event, phase)
+        self.prof_shapes = None   # list -> the geometry of every labelled launch, in the order of `prof` (tools/step_layers.py)
         self._nbt = []        # num_batches_tracked counters touched by the running forward (bumped with one launch)
         # Optional: weight-gradient GEMMs on a side stream (they only depend on the layer's output gradient), free-running
         # beside the data-gradient chain.  Measured +3.5 % images/s at bs=64; OFF by default because concurrent kernels
@@ -132,7 +133,11 @@ class _Engine:
 
     def _kname(self, d, which):
         """device kernel the C ABI will launch for this conv (profiling label; same names as the rocprofv3 kernel trace)"""
-        return self.lib.sd_conv2d_kernel_name(C.byref(d), which).decode() if self.prof is not None else ""
+        if self.prof is None:
+            return ""
+        if self.prof_shapes is not None:
+            self.prof_shapes.append((d.B, d.Hi, d.Wi, d.Cin, d.Cout, d.R, d.stride, d.Ho, d.Wo))
+        return self.lib.sd_conv2d_kernel_name(C.byref(d), which).decode()
 
     def _timed(self, kind, flops, fn, phase="fwd"):
         if self.prof is None:
