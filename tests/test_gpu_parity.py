@@ -489,3 +489,66 @@ def test_fused_decoder_limits_and_fallback():
     assert torch.equal(a, b) and not dec._state
     with pytest.raises(L.SdError, match="out of range"):
         dec.decode_packed(head_views(head, 1, 1), 0.5, 0.1, fused=True)
+
+
+# ------------------------------------------------------------------------------------------ empty and ragged inputs
+@pytest.mark.parametrize("hm_fn", ["mse", "focal"])
+def test_empty_and_ragged_batch_encode_loss_decode_vs_oracle(hm_fn):
+    """One batch with every ragged case the reference's collate can produce (dataset.py:58-87 stacks fixed-size fields whatever the
+    annotation holds): an image with NO objects, an object with NO parts, objects whose parts are all outside the image (clipped to the
+    border, utils.py:364-381), and an ordinary scene.  Encode vs the oracle (indices / masks bit-exact), the loss on a seeded head
+    (value and gradient; the empty image contributes no L1 terms), the decoder on the rendered targets (the empty image decodes to NO
+    objects) and on a head that is below the threshold everywhere (all annotations empty)."""
+    from structuredetector_amd.data import Decoder, Encode
+    from structuredetector_amd.model import Loss
+    W = H = 128
+    M, N, K, P = 2, 2, 6, 9
+    args = make_args(M, N, K, P, device=torch.device(DEV), hm_loss_fn=hm_fn)
+    scenes = [
+        [],                                                                                   # no objects at all
+        [(0, 40.25, 70.5, [])],                                                               # an anchor without parts
+        [(1, 20.0, 20.0, [(0, -15.0, 300.0), (1, 500.0, -3.0)]), (0, 127.9, 0.0, [])],        # parts outside the image: clipped
+        [(0, 30.5, 31.5, [(0, 50.0, 60.0), (1, 12.0, 90.75)]), (1, 99.0, 64.0, [(1, 101.5, 80.0)])],
+    ]
+    anns = [to_annotation(args, s, f"img{i}.png") for i, s in enumerate(scenes)]
+    out = Encode(args).batch((W, H), anns)
+    want = O.collate([O.encode(W, H, s, M, N, K, P, 4.0, 0.1) for s in scenes])
+    for k in ENC_KEYS:
+        got = out[k].cpu().numpy()
+        assert got.shape == want[k].shape and got.dtype == want[k].dtype, k
+        if k.endswith("_hm"):
+            np.testing.assert_allclose(got, want[k], rtol=1e-5, atol=1e-7, err_msg=k)
+            np.testing.assert_array_equal(got == 1.0, want[k] == 1.0)
+        else:
+            np.testing.assert_array_equal(got, want[k], err_msg=k)
+    assert not out["anchor_mask"][0].any() and not out["part_mask"][0].any() and float(out["anchor_hm"][0].abs().sum()) == 0.0
+    assert int(out["anchor_mask"][1].sum()) == 1 and not out["part_mask"][1].any()
+
+    # loss: value + gradient vs the oracle on a seeded head
+    rng = np.random.default_rng(11)
+    head = rng.standard_normal((4, M + N + 4, H // 4, W // 4)).astype(np.float32)
+    ref = O.loss(head, want, M, N, hm_loss_fn=hm_fn, want_grad=True)
+    hd = dev(head).requires_grad_(True)
+    crit = Loss(args)
+    val = crit(head_views(hd * 1.0, M, N), out)
+    val.backward()
+    np.testing.assert_allclose([val.item(), float(crit.stats.hm_loss), float(crit.stats.offset_loss), float(crit.stats.embedding_loss)],
+                               [ref["total"], ref["hm"], ref["offset"], ref["embedding"]], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(hd.grad.cpu().numpy(), ref["grad"], rtol=1e-4, atol=1e-4 * np.abs(ref["grad"]).max())
+
+    # decoder on heads synthesised from these targets: the empty image yields no objects, the part-less anchor an object without parts
+    heads = np.stack([O.head_from_targets(rng, {k: v[b] for k, v in want.items()}, M, N, noise=0.0) for b in range(4)])
+    dec = Decoder(args)
+    got_anns = dec(head_views(dev(heads), M, N))
+    t = O.decode_tensors(heads[:, :M], heads[:, M:M + N], heads[:, M + N:M + N + 2], heads[:, M + N + 2:], K, P, args.conf_threshold,
+                         args.decoder_dist_thresh)
+    for b in range(4):
+        o, p = annotation_arrays(args, got_anns[b])
+        ro, rp = objects_to_arrays(O.assemble_objects(t, b, args.conf_threshold, 4.0, W // 4, H // 4))
+        assert o.shape == ro.shape and p.shape == rp.shape, (b, o.shape, ro.shape, p.shape, rp.shape)
+        np.testing.assert_array_equal(o[:, :3], ro[:, :3]); np.testing.assert_array_equal(p[:, :4], rp[:, :4])
+    assert len(got_anns[0].objects) == 0
+    assert len(got_anns[1].objects) == 1 and len(got_anns[1].objects[0].parts) == 0
+    # a head below the threshold everywhere (and one of all zeros: sigmoid 0.5 is not > 0.5... conf_threshold decides) -> empty annotations
+    low = dev(np.full((2, M + N + 4, H // 4, W // 4), -8.0, np.float32))
+    assert all(len(a.objects) == 0 for a in dec(head_views(low, M, N)))
