@@ -1299,6 +1299,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #ifdef SD_PP_TRACE
 // timing experiment (make SUFFIX=_pptrace EXTRA=-DSD_PP_TRACE): shader-clock time of the phases of every tap, summed per wave of block 0
 __device__ unsigned long long g_pp_trace[8][8];
+__device__ unsigned long long g_pp_tl[4096][4];      // per block (wave 0): 100 MHz times of start, loop begin, loop end, epilogue end
 #define PP_T(v) const unsigned long long v = __builtin_readcyclecounter();
 #define PP_ACC(k, a, b) tr[k] += (b) - (a);
 #else
@@ -1319,6 +1320,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     constexpr int BN = 128, EPS = 8, KC = 32, MT = 4, NTW = 2, NPP = 7;
     extern __shared__ __attribute__((aligned(16))) float pp_lds[];
     PP_T(tr_start)
+#ifdef SD_PP_TRACE
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const T* const px_ = reinterpret_cast<const T*>(p.x);
     const T* const pw_ = reinterpret_cast<const T*>(p.w);
     const T* const zero_ = reinterpret_cast<const T*>(g_zero_line);
@@ -1497,6 +1501,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     tr[5] = __builtin_readcyclecounter() - tr_end;
     tr[6] = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_pp_trace[wave][k] = tr[k]; }
+    if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
+        g_pp_tl[blockIdx.x][0] = tl_start; g_pp_tl[blockIdx.x][1] = tr_rbegin; g_pp_tl[blockIdx.x][2] = tr_rbegin + tr[7]; g_pp_tl[blockIdx.x][3] = tr[6];
+    }
 #endif
 }
 
@@ -4208,6 +4215,7 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
 
 #ifdef SD_PP_TRACE
 int sd_debug_pp_trace(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(sd::g_pp_trace), sizeof(unsigned long long) * 64); }
+int sd_debug_pp_timeline(unsigned long long* out, int blocks) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::g_pp_tl), sizeof(unsigned long long) * 4 * (blocks < 4096 ? blocks : 4096)); }
 #endif
 
 // Dispatch thresholds are THREAD-LOCAL (default-initialised in every host thread): two engines driven from two threads of one process

@@ -5,6 +5,7 @@
 // src/sdnet/model/network.py:6-57 and torchvision's resnet34 (BasicBlock), and
 // torch.optim.Adam in src/sdnet/model/trainer.py:53,124.
 #include "sd_common.h"
+#include "sd_mfma.h"
 #include <type_traits>
 
 namespace sd {
@@ -649,6 +650,76 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ x, c
     }
 }
 
+// Head forward on an fp32 NHWC input of 128 channels (the default FPN depth), Co <= 16: 537 MB in, 29 MB out at bs = 64 -- a pure HBM
+// stream.  k_head_fwd above stages 64 pixels per block and re-reads every staged row once per output-channel group plus the weights
+// per thread (13x the input bytes in LDS reads): 230 us, twice the stream's time.  Here, as in k_head_fwd_bf16_c128, every WAVE walks
+// its own tiles of 16 pixels with a private ring of NST stages (8 KB each) filled by LDS-DMA NST - 1 tiles ahead (no staging registers,
+// no block barrier, counted vmcnt), and multiplies on v_mfma_f32_16x16x4_f32: A = the tile (lane (row, kq) reads chunk 4 j + kq of its
+// pixel: one ds_read_b128 per four MFMA steps), B = the weights in registers (lane (n, kq): w[n][16 j + 4 kq + t]), D = 16 pixels x 16
+// output channels, lane (n, q) holding pixels 4 q .. 4 q + 3 of channel n: one 16-byte store into the NCHW plane.
+//   LDS image of a tile: row r x 32 slots of 16 bytes, chunk c of row r at physical slot c ^ (r & 15) (swizzle applied to the DMA's
+//   SOURCE address; the 16 lanes of a ds_read_b128 pass -- rows 0 .. 15, same chunk -- hit 16 different slots).
+constexpr int HF_NST = 4;
+__global__ __launch_bounds__(256) void k_head_fwd_f32_c128(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int HW, int Co, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float hf_lds[];             // 4 waves x HF_NST x 8 KB
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const T = hf_lds + wave * (HF_NST * 2048);
+    const uint32_t t_base = lds_addr(T);
+    const int row = lane & 15, kq = lane >> 4;
+    f32x4 bw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < Co) bw[j] = *reinterpret_cast<const f32x4*>(w + row * 128 + 16 * j + 4 * kq);
+    }
+    const float bv = row < Co ? bias[row] : 0.f;
+    const int nwaves = gridDim.x * 4;
+    const int dr = lane >> 5, dsl = lane & 31;                                 // DMA: lane -> (row within a 2-row piece, physical slot)
+    // tile t -> ring stage st: eight 1 KB pieces; tiles past the end re-read the last tile (the vmcnt accounting stays fixed; never consumed)
+#define HF_ISSUE(t_, st_)                                                                                          \
+    {                                                                                                              \
+        const int64_t m0_ = (int64_t)min((t_), ntiles - 1) * 16;                                                  \
+        _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                            \
+            const int r = 2 * d + dr;                                                                              \
+            lds_dma16(x + (m0_ + r) * 128 + ((dsl ^ (r & 15)) << 2), T + (st_) * 2048 + d * 256);                   \
+        }                                                                                                          \
+    }
+    int tile = blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int s = 0; s < HF_NST - 1; ++s) HF_ISSUE(tile + s * nwaves, s)
+    int stage = 0;
+    for (; tile < ntiles; tile += nwaves) {
+        const int nst = stage == 0 ? HF_NST - 1 : stage - 1;                   // the stage consumed in the previous trip (its reads were waited for)
+        HF_ISSUE(tile + (HF_NST - 1) * nwaves, nst)
+        // at most the pieces of the HF_NST - 1 younger tiles outstanding (this wave's interleaved output stores only make the wait stricter)
+        wait_vmcnt<8 * (HF_NST - 1)>();
+        const uint32_t a0 = t_base + (uint32_t)stage * 8192u + (uint32_t)row * 512u;
+        f32x4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = lds_read128_async<0>(a0 + (uint32_t)(((4 * j + kq) ^ row) << 4));
+        SD_LDS_WAIT4(0, a[0], a[1], a[2], a[3]);
+        SD_LDS_WAIT4(0, a[4], a[5], a[6], a[7]);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][t], bw[j][t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1][t], bw[j + 1][t], acc1, 0, 0, 0);
+            }
+        if (row < Co) {
+            const uint32_t m0 = (uint32_t)tile * 16u;                          // (M < 2^31)
+            const uint32_t b = m0 / (uint32_t)HW, pix = m0 - b * (uint32_t)HW; // (HW % 16 == 0: a tile stays inside one image)
+            const f32x4 o = {acc0[0] + acc1[0] + bv, acc0[1] + acc1[1] + bv, acc0[2] + acc1[2] + bv, acc0[3] + acc1[3] + bv};
+            *reinterpret_cast<f32x4*>(y + ((int64_t)b * Co + row) * HW + pix + 4 * kq) = o;
+        }
+        stage = stage + 1 == HF_NST ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();                                                           // (past-the-end DMAs still landing in this wave's LDS)
+#undef HF_ISSUE
+}
+
 // head data-gradient: dx[m][c] = sum_co dy[b][co][pix] * w[co][c]   (NCHW grad in, NHWC out)
 constexpr int HEAD_WG_PIX = 1024;   // pixels per block of the head weight-gradient kernels
 template <typename T>      // T = float, or uint16_t: dx is stored as bf16 (mixed-precision training)
@@ -826,6 +897,86 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ dy
         }
     }
     if (threadIdx.x < Co) dst[Co * C + threadIdx.x] = bsum;
+}
+
+// Head weight / bias gradient partials from an fp32 NHWC activation of 128 channels, Co <= 16, on v_mfma_f32_16x16x4_f32 (the reduction
+// index of the MFMA is the PIXEL).  Same wave-private LDS-DMA ring as k_head_fwd_f32_c128 (tiles of 16 pixels, HF_NST stages, eight 1 KB
+// pieces of x per tile, swizzled on the source side) plus one piece for dy: lane (co = n, kq) fetches dy[co][pixels 4 kq .. 4 kq + 3]
+// from the NCHW plane into its own 16-byte slot.  Per tile: A = dy (one ds_read_b128 per lane), B = x: lane (n, kq) reads chunks n and
+// 16 + n of pixels 4 kq + i (channels {4 n .. 4 n + 3, 64 + 4 n .. 64 + 4 n + 3}: 8 ds_read_b128, conflict-free), 32 MFMAs; x is read
+// exactly once (537 MB at bs = 64).  k_head_wgrad (scalar loads, LDS-broadcast dy, 7 FMAs per loaded float): 343 us, 3x the stream's time.
+// One partial row per WAVE, same layout as k_head_wgrad's (finished by k_head_wgrad_fin in a fixed order).
+constexpr int HWG_STAGE = 2048 + 256;                                          // floats: 8 KB of x + 1 KB of dy
+__global__ __launch_bounds__(256) void k_head_wgrad_f32_c128(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                              int HW, int Co, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float hw_lds[];             // 4 waves x HF_NST x 9 KB
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const T = hw_lds + wave * (HF_NST * HWG_STAGE);
+    const uint32_t t_base = lds_addr(T);
+    const int n = lane & 15, kq = lane >> 4;
+    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int dr = lane >> 5, dsl = lane & 31;
+    const int nco = min(n, Co - 1);                                            // (lanes n >= Co fetch a valid plane; their A operand is zeroed)
+#define HWG_ISSUE(t_, st_)                                                                                         \
+    {                                                                                                              \
+        const uint32_t m0_ = (uint32_t)min((t_), ntiles - 1) * 16u;                      /* (M < 2^31) */        \
+        const uint32_t b_ = m0_ / (uint32_t)HW, pix_ = m0_ - b_ * (uint32_t)HW;                                     \
+        _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                            \
+            const int r = 2 * d + dr;                                                                              \
+            lds_dma16(x + ((int64_t)m0_ + r) * 128 + ((dsl ^ (r & 15)) << 2), T + (st_) * HWG_STAGE + d * 256);     \
+        }                                                                                                          \
+        lds_dma16(dy + ((int64_t)b_ * Co + nco) * HW + pix_ + 4 * kq, T + (st_) * HWG_STAGE + 2048);               \
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    int tile = gw;
+#pragma unroll
+    for (int s = 0; s < HF_NST - 1; ++s) HWG_ISSUE(tile + s * nwaves, s)
+    int stage = 0;
+    for (; tile < ntiles; tile += nwaves) {
+        const int nst = stage == 0 ? HF_NST - 1 : stage - 1;
+        HWG_ISSUE(tile + (HF_NST - 1) * nwaves, nst)
+        wait_vmcnt<9 * (HF_NST - 1)>();
+        const uint32_t s0 = t_base + (uint32_t)stage * (HWG_STAGE * 4);
+        f32x4 a = lds_read128_async<0>(s0 + 8192u + (uint32_t)lane * 16u);
+        f32x4 xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t row = (uint32_t)(4 * kq + i);
+            xa[i] = lds_read128_async<0>(s0 + row * 512u + (((uint32_t)n ^ (row & 15u)) << 4));
+            xb[i] = lds_read128_async<0>(s0 + row * 512u + (((uint32_t)(16 + n) ^ (row & 15u)) << 4));
+        }
+        SD_LDS_WAIT4(0, xa[0], xa[1], xa[2], xa[3]);
+        SD_LDS_WAIT4(0, xb[0], xb[1], xb[2], xb[3]);
+        SD_LDS_WAIT2(0, a, xa[0]);
+        if (n >= Co) a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], xa[i][cb], acc[cb], 0, 0, 0);
+                acc[4 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], xb[i][cb], acc[4 + cb], 0, 0, 0);
+            }
+        bsum += (a[0] + a[1]) + (a[2] + a[3]);
+        stage = stage + 1 == HF_NST ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();
+#undef HWG_ISSUE
+    // D: lane (n' = n, q = kq) holds dW[co = 4 q + r][channel(n', cb)], channel = 4 n' + cb (cb < 4), 64 + 4 n' + cb - 4 (cb >= 4)
+    float* dst = partial + (int64_t)gw * (Co * 128 + Co);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kq + r;
+        if (co < Co) {                                                         // (row length Co * 129: no 16-byte alignment -> scalar stores)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) { dst[co * 128 + 4 * n + cb] = acc[cb][r]; dst[co * 128 + 64 + 4 * n + cb] = acc[4 + cb][r]; }
+        }
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (kq == 0 && n < Co) dst[Co * 128 + n] = bsum;
 }
 
 // 8 outputs x 32 lanes over the partial blocks per workgroup (deterministic order)
@@ -1628,14 +1779,27 @@ int sd_head_fwd(const float* x, const float* w, const float* bias, float* y, int
     SD_REQUIRE(x && w && bias && y && B > 0 && HW > 0, SD_ERR_INVALID, "sd_head_fwd: bad arguments");
     SD_REQUIRE(C % 4 == 0 && C <= 512 && Co > 0 && Co <= HEAD_MAX_CO, SD_ERR_INVALID, "sd_head_fwd: needs C %% 4 == 0, C <= 512, Co <= %d", HEAD_MAX_CO);
     const int64_t M = (int64_t)B * HW;
+    if (C == 128 && Co <= 16 && HW % 16 == 0 && M < (1ll << 31) && aligned16(x) && aligned16(w) && aligned16(y)) {
+        const int ntiles = (int)(M / 16);
+        const size_t lds_b = (size_t)4 * HF_NST * 2048 * sizeof(float);
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_fwd_f32_c128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        SD_HIP(attr_once);
+        hipLaunchKernelGGL(k_head_fwd_f32_c128, dim3(std::min(cdiv(ntiles, 4), 256)), dim3(256), lds_b, (hipStream_t)stream, x, w, bias, y, HW, Co, ntiles);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = ((size_t)64 * (C + 4) + (size_t)Co * C) * sizeof(float);
     hipLaunchKernelGGL(k_head_fwd, dim3(cdiv(M, 64)), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     return 0;
 }
 
+// partial rows of the head weight gradient: one per block of k_head_wgrad (1024 pixels), or one per WAVE of k_head_wgrad_f32_c128
+// (up to 1024 waves = one block of four waves per CU, each wave on tiles of 16 pixels)
+static int head_wgrad_wave_rows(int64_t M) { return (int)std::min<int64_t>(1024, (cdiv(M, 16) + 3) / 4 * 4); }
 size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co) {
-    return align_up((size_t)cdiv((int64_t)B * HW, HEAD_WG_PIX) * (Co * C + Co) * sizeof(float), 256);
+    const int64_t M = (int64_t)B * HW;
+    return align_up((size_t)std::max<int64_t>(cdiv(M, HEAD_WG_PIX), head_wgrad_wave_rows(M)) * (Co * C + Co) * sizeof(float), 256);
 }
 
 int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, int B, int HW, int C, int Co,
@@ -1646,13 +1810,24 @@ int sd_head_bwd(const float* dy, const float* x, const float* w, float* dx, floa
     SD_REQUIRE(workspace_bytes >= sd_head_bwd_workspace_bytes(B, HW, C, Co), SD_ERR_WORKSPACE, "sd_head_bwd: workspace too small");
     const int64_t M = (int64_t)B * HW;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_dgrad<float>, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, dx, M, HW, C, Co);
-    SD_LAUNCH_CHECK();
-    const int nb = cdiv(M, HEAD_WG_PIX);
-    hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dy, x, (float*)workspace, M, HW, C, Co);
+    // weight gradient first: it streams x while HBM is quiet; behind the data-gradient it shared the memory system with the write-back
+    // of that kernel's 537 MB (144 us instead of ~105)
+    int nb = cdiv(M, HEAD_WG_PIX);
+    if (C == 128 && Co <= 16 && HW % 16 == 0 && M < (1ll << 31) && aligned16(x) && aligned16(dy)) {
+        nb = head_wgrad_wave_rows(M);                                          // one partial row per wave
+        const int blocks = nb / 4;
+        const size_t lds_b = (size_t)4 * HF_NST * HWG_STAGE * sizeof(float);
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_wgrad_f32_c128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        SD_HIP(attr_once);
+        hipLaunchKernelGGL(k_head_wgrad_f32_c128, dim3(blocks), dim3(256), lds_b, st, dy, x, (float*)workspace, HW, Co, (int)(M / 16));
+    } else {
+        hipLaunchKernelGGL(k_head_wgrad, dim3(nb), dim3(256), 0, st, dy, x, (float*)workspace, M, HW, C, Co);
+    }
     SD_LAUNCH_CHECK();
     const int n = Co * C + Co;
     hipLaunchKernelGGL(k_head_wgrad_fin, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, nb, n, dw, dbias, Co * C, accumulate);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_head_dgrad<float>, dim3(cdiv(M, 64)), dim3(256), (size_t)Co * C * sizeof(float), st, dy, w, dx, M, HW, C, Co);
     SD_LAUNCH_CHECK();
     return 0;
 }

@@ -288,6 +288,40 @@ def test_bn_pool_head_adam():
     close(pd.cpu(), pr.detach(), 1e-6)
 
 
+@pytest.mark.parametrize("B,H,W,Co", [(2, 48, 48, 7), (3, 64, 80, 16), (1, 128, 128, 3)])
+def test_head_f32_c128_mfma_path(B, H, W, Co):
+    """sd_head_fwd / sd_head_bwd on the geometry of the default FPN depth (C = 128, Co <= 16, HW % 16 == 0): the wave-private LDS-DMA ring +
+    v_mfma_f32_16x16x4_f32 forward (k_head_fwd_f32_c128) and the MFMA weight-gradient partials (k_head_wgrad_f32_c128), against
+    F.conv2d and its autograd on the same operands (fp32; the sums run in another order: 1e-5 of the largest value)."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(B * 100 + Co)
+    xh = torch.randn(B, 128, H, W, generator=g).requires_grad_(True)
+    wh = (torch.randn(Co, 128, 1, 1, generator=g) / 11).requires_grad_(True); bh = torch.randn(Co, generator=g).requires_grad_(True)
+    yh = F.conv2d(xh, wh, bh)
+    dyh = torch.randn(yh.shape, generator=g)
+    yh.backward(dyh)
+    x_d = nhwc(xh.detach())
+    out = torch.empty(B, Co, H, W, device=DEV)
+    whd = wh.detach().reshape(Co, 128).to(DEV); bhd = bh.detach().to(DEV)
+    L.check(lib.sd_head_fwd(x_d.data_ptr(), whd.data_ptr(), bhd.data_ptr(), out.data_ptr(), B, H * W, 128, Co, L.stream()))
+    close(out.cpu(), yh.detach(), 1e-5)
+    dxh = torch.empty(B, H, W, 128, device=DEV); dwh = torch.empty(Co, 128, device=DEV); dbh = torch.empty(Co, device=DEV)
+    wsh = torch.empty(lib.sd_head_bwd_workspace_bytes(B, H * W, 128, Co), dtype=torch.uint8, device=DEV)
+    dy_d = dyh.to(DEV)
+    for acc in (0, 1):                      # overwrite, then accumulate on top: twice the gradient
+        L.check(lib.sd_head_bwd(dy_d.data_ptr(), x_d.data_ptr(), whd.data_ptr(), dxh.data_ptr(), dwh.data_ptr(), dbh.data_ptr(),
+                                B, H * W, 128, Co, acc, wsh.data_ptr(), wsh.numel(), L.stream()))
+        close(from_nhwc(dxh), xh.grad, 1e-5); close(dwh.cpu(), (1 + acc) * wh.grad.reshape(Co, 128), 1e-5); close(dbh.cpu(), (1 + acc) * bh.grad, 1e-5)
+    # same bits on every call (fixed partial order)
+    dw2 = torch.empty_like(dwh); db2 = torch.empty_like(dbh)
+    L.check(lib.sd_head_bwd(dy_d.data_ptr(), x_d.data_ptr(), whd.data_ptr(), dxh.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                            B, H * W, 128, Co, 0, wsh.data_ptr(), wsh.numel(), L.stream()))
+    L.check(lib.sd_head_bwd(dy_d.data_ptr(), x_d.data_ptr(), whd.data_ptr(), dxh.data_ptr(), dwh.data_ptr(), dbh.data_ptr(),
+                            B, H * W, 128, Co, 0, wsh.data_ptr(), wsh.numel(), L.stream()))
+    assert torch.equal(dw2, dwh) and torch.equal(db2, dbh)
+
+
 def _pair(M=2, N=1, seed=0):
     from structuredetector_amd.model import Network
     ref = O.build_reference_network(M, N, seed=seed)

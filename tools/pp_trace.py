@@ -40,3 +40,24 @@ for _ in range(10):
     lib.sd_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(d), 0, 0, 0, 0, 0, 0, 0, L.stream())
 e1.record(); torch.cuda.synchronize()
 print(f"launch to launch: {e0.elapsed_time(e1) * 100:.1f} us")
+
+# chip-level timeline of the last launch: every block's start / loop begin / loop end / epilogue end (100 MHz clock)
+import numpy as np
+nb = (64 * H * H // 512) * (ch // 128)
+nb = min(nb, 4096)
+tl = (C.c_ulonglong * (4 * nb))()
+assert raw.sd_debug_pp_timeline(tl, nb) == 0
+t = np.frombuffer(tl, dtype=np.uint64).astype(np.int64).reshape(nb, 4)
+t0 = t[:, 0].min()
+t = (t - t0) * 0.01
+order = np.argsort(t[:, 0])
+print(f"timeline of {nb} blocks (us since the first block started): kernel span {t[:, 3].max():.1f}")
+print("  start: first %.1f  median %.1f  last %.1f" % (t[:, 0].min(), np.median(t[:, 0]), t[:, 0].max()))
+pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+for name, v in (("prologue", pro), ("loop", loop), ("epilogue", epi)):
+    print(f"  {name:9s} min {v.min():6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f}")
+rounds = max(1, int(round(nb / 256)))
+for r in range(rounds):
+    sel = order[r * 256:(r + 1) * 256]
+    print(f"  round {r}: start {t[sel, 0].min():6.1f}..{t[sel, 0].max():6.1f}  loop begin med {np.median(t[sel, 1]):6.1f}  loop end med {np.median(t[sel, 2]):6.1f}  "
+          f"end med {np.median(t[sel, 3]):6.1f} max {t[sel, 3].max():6.1f}  | pro {np.median(pro[sel]):5.2f} loop {np.median(loop[sel]):5.2f} epi {np.median(epi[sel]):5.2f}")
