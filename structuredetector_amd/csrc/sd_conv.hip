@@ -2660,6 +2660,14 @@ __device__ __forceinline__ void stem_tile_coords(const StemArgs& p, int tile, in
 
 // BF16MM: the product runs on the bf16 MFMA (inference with the bf16 backbone): image patch and weights are rounded to bf16 on the
 // way into the MFMA operands (eight reduction indices per lane and step), accumulation stays fp32 -- 20 MFMAs per wave instead of 148.
+#ifdef SD_PP_TRACE
+__device__ unsigned long long g_stem_trace[8][8];
+#define ST_T(v) const unsigned long long v = __builtin_readcyclecounter();
+#define ST_ACC(k, a, b) str[k] += (b) - (a);
+#else
+#define ST_T(v)
+#define ST_ACC(k, a, b)
+#endif
 template <bool BF16MM>
 __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
     // Persistent blocks (two per CU): the 7x7 weights are staged ONCE per block, then the block walks its 128-pixel tiles --
@@ -2718,16 +2726,23 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
         stem_tile_coords(p, blockIdx.x, b, oy, ox0);
         stem_fetch_patch(p, pv, b, oy, ox0);
     }
+#ifdef SD_PP_TRACE
+    unsigned long long str[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        ST_T(t0_)
         int b, oy, ox0;
         stem_tile_coords(p, tile, b, oy, ox0);
         stem_commit_patch(p, patch, pv, oy, ox0);
+        ST_T(t1_)
         __syncthreads();                                 // patch (and, the first time, the weights) staged
+        ST_T(t2_)
         if (tile + (int)gridDim.x < p.ntiles) {
             int nb, noy, nox0;
             stem_tile_coords(p, tile + gridDim.x, nb, noy, nox0);
             stem_fetch_patch(p, pv, nb, noy, nox0);
         }
+        ST_T(t3_)
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -2767,6 +2782,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
             }
         }
         // 16-byte epilogue (see k_conv_igemm): the wave's 32 x 64 tile goes through its LDS region 16 rows at a time and comes back as rows
+        ST_T(t4_)
         const int64_t row0 = ((int64_t)b * p.Ho + oy) * p.Wo;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -2795,6 +2811,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
                 }
             }
         }
+        ST_T(t5_)
         if (p.stat) {
             // BatchNorm statistics of the raw conv output (tile pixels past the row end still see real image columns through the
             // 7-wide window, so they are masked): column sums per wave (32 pixels), the four waves combined through LDS in a fixed
@@ -2821,7 +2838,214 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd(StemArgs p) {
                 p.stat[(int64_t)tile * 128 + which * 64 + n] = v;
             }
         }
+        ST_T(t6_)
         __syncthreads();                                 // every wave is done with the patch (and `red`) before the next tile's load
+        ST_T(t7_)
+        ST_ACC(0, t0_, t1_) ST_ACC(1, t1_, t2_) ST_ACC(2, t2_, t3_) ST_ACC(3, t3_, t4_) ST_ACC(4, t4_, t5_) ST_ACC(5, t5_, t6_) ST_ACC(6, t6_, t7_)
+#ifdef SD_PP_TRACE
+        str[7] += 1;
+#endif
+    }
+#ifdef SD_PP_TRACE
+    if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_stem_trace[wave][k] = str[k]; }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 stem forward, second form (round 3).  In-kernel clocks (tools/stem_trace_f32.py; `sd_set_option("stem_fwd_blocks", 256)` for
+// one block per CU) of the two forms:
+//   k_stem_fwd<false>, two blocks per CU: a tile = 25.1 k cycles, 10.7 k of them the MFMA loop (148 MFMAs = 9.47 k), the rest staging
+//     the patch through registers (3.4 k + 3.1 k), epilogue 3.6 k, per-tile statistics 4.1 k;
+//   this kernel, ONE block per CU: MFMA loop 9.54 k, patch wait 2.3 k, epilogue 1.4 k, statistics + DMA issue 1.5 k = 14.9 k;
+//   this kernel, two blocks per CU: MFMA loop 9.54 k -- and the SAME epilogue 11.0 k: a wave streaming fp32 MFMAs leaves the other wave of
+//     its SIMD next to no issue slots, so two resident blocks take turns (2 x (9.5 + 2.8) k per pair of tiles) instead of overlapping;
+//     the second block only hides the patch round trip.  What counts is therefore the SOLO time of everything that is not an MFMA.
+// Hence:
+//   * the patch comes in by LDS-DMA: 22 pieces of 1 KB (patch column 0 = image column 2 ox0 - 4, so a group of four columns is 16-byte
+//     aligned in the image and lies inside the row or outside), issued at the end of the tile (every wave is done with the patch: barrier
+//     after the MFMA loop); per piece one compare pair and a select -- no staging registers, no LDS stores;
+//   * the reduction runs in row-pair order (see the weight staging): the A address of every MFMA step is an immediate offset from one of
+//     two per-lane bases.  In k = (r*7 + s)*3 + ci order hipcc hoisted the 74 per-lane offsets into registers, and what it spilled
+//     instead were the DMA source addresses: a scratch reload + `s_waitcnt vmcnt(0)` in front of every DMA, 2 k cycles each;
+//   * the BatchNorm column sums stay in registers for the whole block (fp32 sums of <= 64 tiles x 16 rows per lane, combined across
+//     lanes / waves once): one partial row per BLOCK instead of per tile -- no per-tile masks (full tiles), barrier or store;
+//   * patch, epilogue scratch and the weights are separate LDS objects: the compiler's wait insertion does not tie the epilogue's LDS
+//     accesses to the DMA in flight.
+// 840 -> 800 us per launch at bs = 64 (99 TFLOP/s).  Same 147 products per output as k_stem_fwd<false>, summed in another order
+// (fp32 rounding only; the statistics likewise).
+// ---------------------------------------------------------------------------------------------
+constexpr int SPD_PIECES = 22, SPD_FLOATS = SPD_PIECES * 256, SPD_GROUPS = 66;     // [21][264] floats inside 22 KB
+
+__device__ __forceinline__ int stem_koff1(int k) { return stem_koff(k) + 1; }      // (patch column 0 is one left of the 7-wide window)
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void k_stem_fwd_dma(StemArgs p) {
+    __shared__ __attribute__((aligned(16))) float patch[SPD_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Tall[4 * 1024];
+    __shared__ float red[4 * 2 * 64];
+    extern __shared__ __attribute__((aligned(16))) float sd_stem_wl[];     // [148][64] transposed weights, row 147 = 0
+    float* const wl = sd_stem_wl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        // weights in MFMA step order: reduction index k' = 2 step + h (h = lane half).  Steps 0 .. 69: patch rows (2 rp + h) of row pair
+        // rp = step / 7, column s = step % 7; steps 70 .. 73: the odd row 20, columns 2 j + h (column 7 is a phantom: zero weights).  The
+        // two halves' operands are then a CONSTANT distance apart (one patch row, or one column): the A address of every step is an
+        // immediate offset from one of two per-lane bases -- with k = (r*7 + s)*3 + ci order the distance changed from step to step, and
+        // hipcc kept the 74 per-lane offsets in registers (spilling the DMA addresses instead).
+        constexpr int NW = (STEM_KPAD * 64 / 4 + 255) / 256;      // 10 float4 per thread
+        float4 wv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + 256 * j, kp = i >> 4, n4 = (i & 15) * 4;
+            const int step = kp >> 1, h = kp & 1;
+            const int row = step < 70 ? 2 * (step / 7) + h : 20, sx = step < 70 ? step % 7 : 2 * (step - 70) + h;
+            const int ci = row / 7, r = row - ci * 7;
+            const float* src = (kp < STEM_KPAD && sx < 7) ? p.wt + ((r * 7 + sx) * 3 + ci) * 64 + n4 : g_zero_line;
+            wv[j] = *reinterpret_cast<const float4*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int i = tid + 256 * j;
+            if (i < STEM_KPAD * 64 / 4) reinterpret_cast<float4*>(wl)[i] = wv[j];
+        }
+    }
+    // DMA pieces of this wave: q = wave + 4 j (j < 6; q < 22).  Lane constants: image offset of its 4-column group relative to the
+    // patch origin, filter row and first column (a slot past row 20 never passes the row test).
+    int poff[6], pr[6], pc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g = (wave + 4 * j) * 64 + lane, row = g / SPD_GROUPS, c4 = g - row * SPD_GROUPS, ci = row / 7, r = row - ci * 7;
+        poff[j] = (ci * p.H + r) * p.W + 4 * c4;
+        pr[j] = row < SP_ROWS ? r : (1 << 20);
+        pc[j] = 4 * c4;
+    }
+#define SPD_ISSUE(tile_)                                                                                           \
+    {                                                                                                              \
+        int b_, oy_, ox0_;                                                                                         \
+        stem_tile_coords(p, (tile_), b_, oy_, ox0_);                                                               \
+        const int iy0_ = 2 * oy_ - 3, ix0_ = 2 * ox0_ - 4;                                                         \
+        const float* const base_ = p.x + (int64_t)b_ * 3 * p.H * p.W + (int64_t)iy0_ * p.W + ix0_;                 \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                            \
+            if (wave + 4 * j < SPD_PIECES) {                                                                       \
+                const bool ok_ = (unsigned)(iy0_ + pr[j]) < (unsigned)p.H && (unsigned)(ix0_ + pc[j]) < (unsigned)p.W; \
+                lds_dma16(ok_ ? base_ + poff[j] : g_zero_line, patch + (wave + 4 * j) * 256);                      \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    const int px = wave * 32 + fr;
+    const float* pa = patch + 2 * px;
+    const float* pb = wl + fh * 64 + fr;
+    const int c4 = (lane & 15) * 4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool affine = p.scale || p.shift || p.relu;
+    if (p.scale) sc4 = *reinterpret_cast<const float4*>(p.scale + c4);
+    if (p.shift) sh4 = *reinterpret_cast<const float4*>(p.shift + c4);
+    float* T = Tall + wave * 1024;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;            // BatchNorm column sums of this block's tiles (columns fr, 32 + fr)
+
+    if ((int)blockIdx.x < p.ntiles) SPD_ISSUE(blockIdx.x)
+#ifdef SD_PP_TRACE
+    unsigned long long str[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        ST_T(t0_)
+        int b, oy, ox0;
+        stem_tile_coords(p, tile, b, oy, ox0);
+        wait_vmcnt<0>();                                 // this wave's patch pieces (its youngest vector-memory operations) have landed
+        ST_T(t1_)
+        __syncthreads();                                 // every wave's pieces (and, the first time, the weights) are in LDS
+        ST_T(t2_)
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        {
+            // operands of step kk+1 are read while the MFMAs of step kk run (patch column 0 is one left of the 7-wide window: + 1)
+            const float* pah = pa + fh * SP_PITCH + 1, * pac = pa + fh + 1;
+            float na = pah[0], nb0 = pb[0], nb1 = pb[32];
+#pragma unroll
+            for (int kk = 0; kk < STEM_KPAD / 2; ++kk) {
+                const float a = na, b0 = nb0, b1 = nb1;
+                if (kk + 1 < STEM_KPAD / 2) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int k1 = kk + 1;
+                    na = k1 < 70 ? pah[2 * (k1 / 7) * SP_PITCH + k1 % 7] : pac[20 * SP_PITCH + 2 * (k1 - 70)];
+                    nb0 = pb[(2 * kk + 2) * 64];
+                    nb1 = pb[(2 * kk + 2) * 64 + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ST_T(t3_)
+        __syncthreads();                                 // every wave is done with the patch (the next tile's pieces are issued after the epilogue)
+        ST_T(t4_)
+        ST_T(t5_)
+        const bool full = ox0 + 128 <= p.Wo;
+        // 16-byte epilogue (see k_conv_igemm): the wave's 32 x 64 tile goes through its LDS region 16 rows at a time and comes back as rows
+        float* const ytile = p.y + ((((int64_t)b * p.Ho + oy) * p.Wo + ox0 + wave * 32 + (lane >> 4)) * 64 + c4);      // row (lane >> 4) of the wave's 32
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * h + e8;                         // (e >> 2) in {2h, 2h+1}: rows 16h .. 16h+15
+                const int rl = (e & 3) + 8 * ((e >> 2) - 2 * h) + 4 * fh;
+                T[rl * 64 + fr] = acc0[e];
+                T[rl * 64 + 32 + fr] = acc1[e];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 4 + (lane >> 4);
+                const int ox = ox0 + wave * 32 + 16 * h + rl;
+                if (!full && ox >= p.Wo) continue;
+                float4 v = *reinterpret_cast<const float4*>(T + rl * 64 + c4);
+                if (affine) {
+                    v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                *reinterpret_cast<float4*>(ytile + (16 * h + it * 4) * 64) = v;
+            }
+        }
+        ST_T(t6_)
+        if (STATS) {
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+            } else {                                     // tile pixels past the row end still see real image columns through the window: masked
+                const int lim = p.Wo - (ox0 + wave * 32 + 4 * fh);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) < lim) { s0 += acc0[e]; q0 += acc0[e] * acc0[e]; s1 += acc1[e]; q1 += acc1[e] * acc1[e]; }
+            }
+        }
+        // The next tile's pieces go out BEHIND this tile's output stores: issued in front of them (right after the barrier) they kept the
+        // stores waiting in the memory queue -- same tile time, measured both ways.  The round trip is covered by the other block's MFMAs.
+        if (tile + (int)gridDim.x < p.ntiles) SPD_ISSUE(tile + gridDim.x)
+        ST_T(t7_)
+        ST_ACC(0, t0_, t1_) ST_ACC(1, t1_, t2_) ST_ACC(2, t2_, t3_) ST_ACC(3, t3_, t4_) ST_ACC(4, t4_, t5_) ST_ACC(5, t5_, t6_) ST_ACC(6, t6_, t7_)
+#ifdef SD_PP_TRACE
+        str[7] += 1;
+#endif
+    }
+#ifdef SD_PP_TRACE
+    if (blockIdx.x == 8 && lane == 0) { for (int kk = 0; kk < 8; ++kk) g_stem_trace[wave][kk] = str[kk]; }
+#endif
+#undef SPD_ISSUE
+    if (STATS) {
+        // one partial row per block: lane halves, then the four waves through LDS in a fixed order
+        s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+        if (fh == 0) {
+            red[(wave * 2 + 0) * 64 + fr] = s0; red[(wave * 2 + 0) * 64 + 32 + fr] = s1;
+            red[(wave * 2 + 1) * 64 + fr] = q0; red[(wave * 2 + 1) * 64 + 32 + fr] = q1;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, n = tid & 63;
+            const float v = (red[(0 * 2 + which) * 64 + n] + red[(1 * 2 + which) * 64 + n]) + (red[(2 * 2 + which) * 64 + n] + red[(3 * 2 + which) * 64 + n]);
+            p.stat[(int64_t)blockIdx.x * 128 + which * 64 + n] = v;
+        }
     }
 }
 
@@ -3424,6 +3648,7 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
 // k_conv3x3_c64_rows_f32 applies: fp32, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
 // multiple of 64, plain or same-size residual, no fused BatchNorm-backward reduction, no split-K, and enough units to fill the chip.
 static thread_local int g_rowsf32_min_units = 192;   // sd_set_option("conv_rows_f32_min_units", n) (tests: 1; off: 1 << 30)
+static thread_local int g_stem_fwd_blocks = 512;      // persistent blocks of the fp32 stem forward (two per CU)
 static bool conv_rowsf32_geometry(const ConvArgs& a, int mode, RowsArgsF& r) {
     if (mode != 0 || a.Ck != 64 || a.Nn != 64 || a.R != 3 || a.S != 3 || a.mul != 1 || a.div != 1 || a.splits > 1) return false;
     if (!((a.rsign == 1 && a.off == -1) || (a.rsign == -1 && a.off == 1))) return false;
@@ -3806,7 +4031,7 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
         (void)attr_once; (void)attr_once_b;
         a.w = w;
         if (out_bf16) hipLaunchKernelGGL(k_stem_fwd<true>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);     // bf16 backbone: bf16 MFMA, bf16 output
-        else hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(k_stem_fwd_dma<false>, dim3(std::min(a.ntiles, 512)), dim3(256), (size_t)STEM_KPAD * 64 * sizeof(float), st, a);
         SD_LAUNCH_CHECK();
         return 0;
     }
@@ -3842,12 +4067,11 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
     StemArgs a{};
     a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
     stem_args(a, d);
-    const size_t lds = STEM_FWD_LDS_BYTES;
-    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr_once;
-    hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
+    // k_stem_fwd_dma: one partial statistics row per BLOCK (the workspace holds one per tile: more than enough)
+    const int blocks = std::min(a.ntiles, std::max(1, g_stem_fwd_blocks));
+    hipLaunchKernelGGL(k_stem_fwd_dma<true>, dim3(blocks), dim3(256), (size_t)STEM_KPAD * 64 * sizeof(float), st, a);
     SD_LAUNCH_CHECK();
-    return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+    return sd_bn_finalize_stats(partial, blocks, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
                                 partial + (size_t)a.ntiles * 128, stream);
 }
 
@@ -4215,6 +4439,7 @@ int sd_conv2d_dgrad_bn_reduce(const float* dy, const float* w_t, float* dx, cons
 
 #ifdef SD_PP_TRACE
 int sd_debug_pp_trace(unsigned long long* out32) { return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(sd::g_pp_trace), sizeof(unsigned long long) * 64); }
+int sd_debug_stem_trace(unsigned long long* out64) { return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(sd::g_stem_trace), sizeof(unsigned long long) * 64); }
 int sd_debug_pp_timeline(unsigned long long* out, int blocks) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sd::g_pp_tl), sizeof(unsigned long long) * 4 * (blocks < 4096 ? blocks : 4096)); }
 #endif
 
@@ -4229,6 +4454,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
     if (name && !strcmp(name, "conv_rows_f32_min_units")) { g_rowsf32_min_units = value; return 0; }
+    if (name && !strcmp(name, "stem_fwd_blocks")) { g_stem_fwd_blocks = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
