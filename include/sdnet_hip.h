@@ -312,7 +312,9 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * split K over blocks (default 1: small grids do), so that tests can put small problems on the single-pass kernels;
  * "conv_rows64_min_units": smallest number of (image, 128-pixel strip, row range) units for which the bf16 64 -> 64 channel 3x3 convs take
  * the row-stream kernel k_conv3x3_c64_rows_bf16 (default 192, and at least 16 rows per unit; 1 = always, for tests; 1 << 30 = never);
- * "conv_rows_f32_min_units": the same for the fp32 row-stream kernel k_conv3x3_c64_rows_f32 (units = image x 64-pixel strip x row range). */
+ * "conv_rows_f32_min_units": the same for the fp32 row-stream kernel k_conv3x3_c64_rows_f32 (units = image x 64-pixel strip x row range).
+ * "stem_fwd_blocks": persistent blocks of the fp32 training stem forward (default 512 = two per CU; 256 = one per CU, the setting the
+ *   in-kernel phase trace of tools/stem_trace_f32.py compares against). */
 int sd_set_option(const char* name, int value);
 
 /* Name of the device kernel the launchers pick for this geometry (pass 0 = sd_conv2d_fwd, 1 = sd_conv2d_dgrad,
@@ -453,7 +455,10 @@ int sd_maxpool_bn_relu_bwd(const float* dpool, const uint8_t* idx, const float* 
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream);
 
 /* Head (network.py:22-29): 1x1 conv C -> Co with bias; NHWC in, NCHW out (the layout the decoder
- * and the loss consume).  Co <= 32. */
+ * and the loss consume).  Co <= 32.  C = 128 (the default FPN depth), Co <= 16, HW % 16 == 0 and 16-byte aligned pointers take the
+ * MFMA kernels (forward: wave-private LDS-DMA ring + v_mfma_f32_16x16x4_f32; backward: weight-gradient partials likewise, one partial
+ * row per wave, before the data gradient); other shapes the generic kernels.  Same arithmetic either way (fp32 products and sums;
+ * the order of the sums differs). */
 int sd_head_fwd(const float* x_nhwc, const float* w, const float* bias, float* y_nchw, int B, int HW, int C, int Co,
                 sd_stream_t stream);
 size_t sd_head_bwd_workspace_bytes(int B, int HW, int C, int Co);
