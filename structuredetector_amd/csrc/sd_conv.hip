@@ -3932,6 +3932,8 @@ static void stem_args(StemArgs& a, const sd_conv_desc* d) {
     a.ntiles = d->B * d->Ho * a.tiles_x;
 }
 static bool stem_is_7x7s2(const sd_conv_desc* d) { return d->Cin == 3 && d->Cout == 64 && d->R == 7 && d->S == 7 && d->stride == 2 && d->pad == 3; }
+// k_stem_fwd_dma fetches the patch in aligned groups of four image columns: rows must be whole groups and 16-byte aligned
+static bool stem_dma_ok(const sd_conv_desc* d, const void* x, const void* y) { return d->Wi % 4 == 0 && aligned16(x) && aligned16(y); }
 
 size_t sd_conv2d_stem_fwd_workspace_bytes(const sd_conv_desc* d) { (void)d; return (size_t)STEM_K * 64 * sizeof(float); }
 
@@ -4035,7 +4037,8 @@ int sd_conv2d_stem_fwd(const float* x_nchw, const float* w, void* y, const sd_co
         (void)attr_once; (void)attr_once_b;
         a.w = w;
         if (out_bf16) hipLaunchKernelGGL(k_stem_fwd<true>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);     // bf16 backbone: bf16 MFMA, bf16 output
-        else hipLaunchKernelGGL(k_stem_fwd_dma<false>, dim3(std::min(a.ntiles, 512)), dim3(256), (size_t)STEM_KPAD * 64 * sizeof(float), st, a);
+        else if (stem_dma_ok(d, x_nchw, y)) hipLaunchKernelGGL(k_stem_fwd_dma<false>, dim3(std::min(a.ntiles, 512)), dim3(256), (size_t)STEM_KPAD * 64 * sizeof(float), st, a);
+        else hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
         SD_LAUNCH_CHECK();
         return 0;
     }
@@ -4071,6 +4074,15 @@ int sd_conv2d_stem_fwd_bn_stats(const float* x_nchw, const float* w, float* y, c
     StemArgs a{};
     a.x = x_nchw; a.wt = wt; a.y = y; a.stat = partial;
     stem_args(a, d);
+    if (!stem_dma_ok(d, x_nchw, y)) {                // odd widths / unaligned views: the register-staged kernel, one partial row per tile
+        const size_t lds = STEM_FWD_LDS_BYTES;
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr_once;
+        hipLaunchKernelGGL(k_stem_fwd<false>, dim3(std::min(a.ntiles, 512)), dim3(256), lds, st, a);
+        SD_LAUNCH_CHECK();
+        return sd_bn_finalize_stats(partial, a.ntiles, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+                                    partial + (size_t)a.ntiles * 128, stream);
+    }
     // k_stem_fwd_dma: one partial statistics row per BLOCK (the workspace holds one per tile: more than enough)
     const int blocks = std::min(a.ntiles, std::max(1, g_stem_fwd_blocks));
     hipLaunchKernelGGL(k_stem_fwd_dma<true>, dim3(blocks), dim3(256), (size_t)STEM_KPAD * 64 * sizeof(float), st, a);

@@ -763,10 +763,11 @@ def test_conv_dgrad_with_half_size_residual(case):
 
 def test_stem_conv_with_fused_bn_statistics():
     """sd_conv2d_stem_fwd_bn_stats: the 7x7/2 stem conv from the NCHW image and the batch statistics of its output (row widths that
-    are and are not multiples of the 128-pixel tile)."""
+    are and are not multiples of the 128-pixel tile; an image width that is not a multiple of 4 takes the register-staged kernel
+    instead of the LDS-DMA one, whose patch pieces are aligned groups of four columns)."""
     from structuredetector_amd import _lib as L
     lib = L.lib()
-    for (B, H, W) in ((2, 64, 96), (1, 32, 320)):
+    for (B, H, W) in ((2, 64, 96), (1, 32, 320), (3, 34, 90), (2, 512, 512)):
         g = torch.Generator().manual_seed(H + W)
         x = torch.randn(B, 3, H, W, generator=g)
         w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
