@@ -1296,6 +1296,114 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 //          LOAD(t) needs the weight piece issued last in LOAD(t-4): N(t) = 4 + p(t) + p(t-1) + p(t-2) + p(t-3).
 //   LDS: 4 x 25 KB patches + 7 x 8 KB weights = 156 KB (dynamic) + 1 KB statistics; epilogue scratch = the same array.
 // ---------------------------------------------------------------------------------------------
+// packed bf16 helpers (also used by the row-stream kernel below)
+typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+typedef short rs_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rs_pack2(float lo, float hi) {            // two fp32 -> one dword of two bf16 (round-to-nearest-even)
+    const rs_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rs_bf16x2));
+}
+__device__ __forceinline__ uint32_t rs_relu2(uint32_t two_bf16) {             // negative bf16 are negative int16: max(x, 0) per half
+    const rs_i16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(rs_i16x2, two_bf16), z));
+}
+// Lean epilogue of the two-group bf16 kernel for everything but a half-size residual map (those launches keep tile_epilogue).  The
+// generic epilogue costs a wave ~1100 vector instructions per tile (per-row validity branches, 64-bit index chains that also serve the
+// half-size residual, scalar fp32 math): 12-14 k cycles with the eight waves of the block in it at once, a fifth of a layer2 launch.
+// Here: the same trip of the accumulators through the wave's two 32-row LDS regions (64 rows per pass), then per 16-byte run
+// v_pk_fma_f32 for the affine, the residual added as shifted halves, one v_cvt_pk_bf16_f32 per pair and the ReLU as a signed 16-bit
+// integer max on the packed pairs (rounding is monotonic: max(round(x), 0) = round(max(x, 0))).  Bit-identical to tile_epilogue
+// (same fp32 operations per element in the same order).
+typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x16 (&acc)[4][2], int mbase, int TWl, int tid, int wave, int n0, int tile_m,
+                                                 float* T0, float* T1) {
+    constexpr int BN = 128;
+    const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wn0 = (wave & 1) * 64, wml = ((wave >> 1) & 1) * 128;           // column / row origin of the wave tile inside its group's sub-tile
+    const bool fwd_stat = p.stat && !p.bn_x;
+    float sv[2], qv[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        sv[ni] = qv[ni] = 0.f;
+        if (fwd_stat) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float a = bf2f(f2bf(acc[mi][ni][e])); sv[ni] += a; qv[ni] += a * a; }
+        }
+    }
+    __shared__ float pp_statred[2][BN];
+    const int c4 = (lane & 15) * 4, n = n0 + wn0 + c4;
+    const bool affine = p.scale || p.shift;
+    pp_f32x2 sc01 = {1.f, 1.f}, sc23 = {1.f, 1.f}, sh01 = {0.f, 0.f}, sh23 = {0.f, 0.f};
+    if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc01 = pp_f32x2{t.x, t.y}; sc23 = pp_f32x2{t.z, t.w}; }
+    if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh01 = pp_f32x2{t.x, t.y}; sh23 = pp_f32x2{t.z, t.w}; }
+    const int TWm = (1 << TWl) - 1, rsub = lane >> 4;
+    uint16_t* const yb = reinterpret_cast<uint16_t*>(p.y) + n;
+    const uint16_t* const rb = reinterpret_cast<const uint16_t*>(p.res) + n;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // the residual runs of the pass are requested before its trip through LDS
+        uint2 rr[16];
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int ml = wml + h * 64 + it * 4 + rsub;
+                const int m = mbase + (ml >> TWl) * p.Wo + (ml & TWm);
+                rr[it] = *reinterpret_cast<const uint2*>(rb + (int64_t)m * p.Nn);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                T0[r * 64 + ni * 32 + fr] = acc[2 * h][ni][e];
+                T1[r * 64 + ni * 32 + fr] = acc[2 * h + 1][ni][e];
+            }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int rl = it * 4 + rsub;                                     // row inside this pass: it < 8 -> T0, else T1
+            const int ml = wml + h * 64 + rl;
+            const int m = mbase + (ml >> TWl) * p.Wo + (ml & TWm);
+            const f32x4 v = *reinterpret_cast<const f32x4*>((it < 8 ? T0 : T1) + (rl & 31) * 64 + c4);
+            pp_f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+            if (affine) { v01 = v01 * sc01 + sh01; v23 = v23 * sc23 + sh23; }
+            if (p.res) {
+                v01 += pp_f32x2{__uint_as_float(rr[it].x << 16), __uint_as_float(rr[it].x & 0xffff0000u)};
+                v23 += pp_f32x2{__uint_as_float(rr[it].y << 16), __uint_as_float(rr[it].y & 0xffff0000u)};
+            }
+            uint2 pk;
+            pk.x = rs_pack2(v01[0], v01[1]); pk.y = rs_pack2(v23[0], v23[1]);
+            if (p.relu) { pk.x = rs_relu2(pk.x); pk.y = rs_relu2(pk.y); }
+            *reinterpret_cast<uint2*>(yb + (int64_t)m * p.Nn) = pk;
+        }
+    }
+    if (fwd_stat) {
+        // as tile_epilogue: lane halves, then wave rows 1 .. 3 into LDS one after the other (fixed order), wave row 0 finishes
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
+        if (tid < 2 * BN) pp_statred[tid / BN][tid % BN] = 0.f;
+        __syncthreads();
+        for (int wr = 1; wr < 4; ++wr) {
+            if (wave / 2 == wr && fh == 0) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) { pp_statred[0][wn0 + ni * 32 + fr] += sv[ni]; pp_statred[1][wn0 + ni * 32 + fr] += qv[ni]; }
+            }
+            __syncthreads();
+        }
+        if (wave / 2 == 0 && fh == 0) {
+            float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int c = wn0 + ni * 32 + fr;
+                dst[c] = sv[ni] + pp_statred[0][c]; dst[p.Nn + c] = qv[ni] + pp_statred[1][c];
+            }
+        }
+    }
+}
+
 #ifdef SD_PP_TRACE
 // timing experiment (make SUFFIX=_pptrace EXTRA=-DSD_PP_TRACE): shader-clock time of the phases of every tap, summed per wave of block 0
 __device__ unsigned long long g_pp_trace[8][8];
@@ -1490,7 +1598,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     // The 512-pixel tile is one statistics row: wave rows 0, 1 = group 0, rows 2, 3 = group 1.
     __syncthreads();
     float* T0 = pp_lds + wave * 4096;
-    tile_epilogue<BN, 4, 2, MT, NTW, true, true, true>(
+    if (p.res_up2 == 0) pp_epilogue_bf16(p, acc, mbase, TWl, tid, wave, n0, tile_m, T0, T0 + 2048);
+    else tile_epilogue<BN, 4, 2, MT, NTW, true, true, true>(
         p, acc, [&](int row) { const int ml = row & (BMB - 1); return mbase + (ml >> TWl) * p.Wo + (ml & (TW - 1)); },   // (rows of the wave's own group)
         [&](int, int m) {
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
@@ -1545,17 +1654,6 @@ struct RowsArgs {
 #define SD_RS_NOWAIT 0
 #endif
 constexpr int RS_B_AGPR = 56;
-typedef __bf16 rs_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
-typedef short rs_i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t rs_pack2(float lo, float hi) {            // two fp32 -> one dword of two bf16 (round-to-nearest-even)
-    const rs_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rs_bf16x2));
-}
-__device__ __forceinline__ uint32_t rs_relu2(uint32_t two_bf16) {             // negative bf16 are negative int16: max(x, 0) per half
-    const rs_i16x2 z = {0, 0};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(rs_i16x2, two_bf16), z));
-}
 template <bool B_IN_AGPR, bool ZERO>
 __device__ __forceinline__ void rs_mfma(f32x16& acc, const f32x4& a, const bf16x8& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
