@@ -1056,8 +1056,13 @@ constexpr int PT_FLOATS = 2 * PT_STAGE_FLOATS;     // 51.2 KB; the rolling mode 
 constexpr int PT_MAXP = 12;                        // patch pieces a wave can own (rolling: 4 rows x 3 slots)
 
 // BF16: elements are bf16, a chunk is 32 channels (the same 64-byte LDS rows, one 32x32x16 MFMA per tile and k-group), forward only
-template <int BN, bool BF16 = false>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
+// ROLL (the single rolling buffer of 128-pixel-wide maps, 12 pieces per wave) is a compile-time flag and its kernel a separate entry
+// point (k_conv3x3_patch_roll): with the mode decided at run time every launch carried the 12 source pointers of the rolling mode
+// (24 registers; the double-buffer mode owns at most 7 pieces per wave), the fp32 128-channel instantiation spilled four of them, and
+// the reload sat in the tap loop: `scratch_load` + `s_waitcnt vmcnt(0)` in front of wave 0's seventh piece -- a drain of the whole
+// prefetch stream once per chunk on maps with more than 24 pieces (layer2: 136 TFLOP/s against layer3's 140, same kernel).
+template <int BN, bool BF16, bool ROLL>
+__device__ __forceinline__ void conv3x3_patch_body(const ConvArgs& p) {
     using T = typename std::conditional<BF16, uint16_t, float>::type;
     constexpr int EPS = BF16 ? 8 : 4;                // elements per 16-byte slot
     constexpr int KC = BF16 ? 32 : BKB;              // channels per chunk
@@ -1079,17 +1084,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     const int n0 = (tile % n_tiles) * BN;
     const int m0 = tile_m * BMB;
     const int TWl = p.pt_tw_log2, TW = 1 << TWl, PW = p.pt_pw, TH = BMB >> TWl;
-    const bool rolling = p.pt_rolling != 0;
+    // (the rolling entry point keeps the flag a run-time value: with it folded, hipcc's schedule of that instantiation spills 60 registers)
+    const bool rolling = ROLL && p.pt_rolling != 0;
+    constexpr int NPC = ROLL ? PT_MAXP : 7;           // patch pieces a wave can own in this mode (double buffer: <= 25 pieces per stage)
     const int hw = p.Ho * p.Wo;
     const int bimg = m0 / hw, y0 = (m0 - bimg * hw) >> TWl;
     const int nchunks = p.Ck / KC;
 
     // ---- patch pieces of this wave.  double-buffer: piece j = wave + 4 i;  rolling: i = 3 r + u -> j = 9 r + wave + 4 u (u = 2: wave 0)
     const int prow = lane >> 2, pslot = lane & 3;
-    const T* pbase[PT_MAXP];
+    const T* pbase[NPC];
     unsigned okmask = 0, ownmask = 0;                 // okmask: the piece reads the image (else the zero line); ownmask: piece exists
 #pragma unroll
-    for (int i = 0; i < PT_MAXP; ++i) {
+    for (int i = 0; i < NPC; ++i) {
         const int j = rolling ? 9 * (i / 3) + wave + 4 * (i % 3) : wave + 4 * i;
         const bool own = rolling ? (wave + 4 * (i % 3) < 9) : (j < p.pt_pieces);
         const int pp = j * 16 + prow;
@@ -1109,7 +1116,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     for (int j = 0; j < PBW; ++j) bbase[j] = pw_ + (int64_t)(n0 + (wave * PBW + j) * 16 + prow) * wk + qeb;
     const T* const zsrc = zero_ + qeb;
 
-#define PT_PATCH(i, dst, c0) { lds_dma16(((okmask >> (i)) & 1u) ? pbase[i] + (c0) : pbase[i], (dst) + (rolling ? 9 * ((i) / 3) + wave + 4 * ((i) % 3) : wave + 4 * (i)) * 256); }
+#define PT_PB(i) pbase[(i) < NPC ? (i) : 0]          /* (the other mode's piece indices only occur in compiled-out branches) */
+#define PT_PATCH(i, dst, c0) { lds_dma16(((okmask >> (i)) & 1u) ? PT_PB(i) + (c0) : PT_PB(i), (dst) + (rolling ? 9 * ((i) / 3) + wave + 4 * ((i) % 3) : wave + 4 * (i)) * 256); }
 #define PT_OWN(i) ((ownmask >> (i)) & 1u)
     // weights of (chunk ccn, loop tap t2) -> ring stage st; past the end: the zero line (keeps the per-tap issue count fixed).
     // The data-gradient walks the patch in the same order (rows 0..2: the rolling refill depends on it) with the weight taps
@@ -1149,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
     PT_ISSUE_B(0, 0, 0)
     PT_ISSUE_B(0, 1, 1)
 #pragma unroll
-    for (int i = 0; i < PT_MAXP; ++i)
+    for (int i = 0; i < NPC; ++i)
         if (PT_OWN(i) && (!rolling || i < 6)) PT_PATCH(i, Pt, 0)
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -1262,6 +1270,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
 #undef PT_ISSUE_B
 #undef PT_OWN
 #undef PT_PATCH
+#undef PT_PB
     // 16-byte epilogue through the idle patch / weight buffers (BN = 128: 16 KB per wave); the barrier makes sure no other
     // wave's (past-the-end) DMA is still landing in them
     __syncthreads();
@@ -1274,6 +1283,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) {
         },
         tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, BN == 128 ? T0 + 2048 : nullptr);
 }
+
+template <int BN, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_patch(ConvArgs p) { conv3x3_patch_body<BN, BF16, false>(p); }
+template <int BN, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_patch_roll(ConvArgs p) { conv3x3_patch_body<BN, BF16, true>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // bf16 3x3 / stride 1 / pad 1 convolution, TWO-GROUP form of the patch-staging kernel (forward and flipped-tap data-gradient).
@@ -3864,10 +3878,16 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
         if (const int PBN = patch_tile_bn(pa, BN, mode, bf16)) {
             const int pt_tiles = (pa.M / BMB) * (pa.Nn / PBN);
             if (bf16) {
-                if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                if (pa.pt_rolling) {
+                    if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch_roll<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                    else hipLaunchKernelGGL((k_conv3x3_patch_roll<64, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                } else if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
                 else hipLaunchKernelGGL((k_conv3x3_patch<64, true>), dim3(pt_tiles), dim3(256), 0, st, pa);
             } else {
-                if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                if (pa.pt_rolling) {
+                    if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch_roll<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                    else hipLaunchKernelGGL((k_conv3x3_patch_roll<64, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
+                } else if (PBN == 128) hipLaunchKernelGGL((k_conv3x3_patch<128, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
                 else hipLaunchKernelGGL((k_conv3x3_patch<64, false>), dim3(pt_tiles), dim3(256), 0, st, pa);
             }
             SD_LAUNCH_CHECK();
@@ -4596,13 +4616,13 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         if (conv_rows64_geometry(a, mode, ra)) return "k_conv3x3_c64_rows_bf16";
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
         t = a;
-        if (const int PBN = patch_tile_bn(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, true>", PBN);
+        if (const int PBN = patch_tile_bn(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch%s<%d, true>", t.pt_rolling ? "_roll" : "", PBN);
         else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
         return name;
     }
     RowsArgsF rf;
     if (conv_rowsf32_geometry(a, mode, rf)) return "k_conv3x3_c64_rows_f32";
-    if (const int PBN = patch_tile_bn(t, BN, mode, false)) snprintf(name, sizeof(name), "k_conv3x3_patch<%d, false>", PBN);
+    if (const int PBN = patch_tile_bn(t, BN, mode, false)) snprintf(name, sizeof(name), "k_conv3x3_patch%s<%d, false>", t.pt_rolling ? "_roll" : "", PBN);
     else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
     return name;
