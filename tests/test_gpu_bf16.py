@@ -102,9 +102,11 @@ def _pair(M=2, N=1, seed=0):
     return ref, net.to(DEV)
 
 
-def test_network_bf16_inference_vs_oracle():
+@pytest.mark.parametrize("B,H,W", [(2, 128, 160), (3, 96, 160), (5, 64, 64), (1, 224, 96), (7, 128, 32)])
+def test_network_bf16_inference_vs_oracle(B, H, W):
+    """bf16 backbone, eval forward, at even and odd batch sizes and non-square inputs (down to a 1-pixel-high layer4 map)."""
     ref, net = _pair(seed=2)
-    x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(1))
+    x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1))
     ref.eval(); net.eval()
     with torch.no_grad():
         want32 = ref(x)
