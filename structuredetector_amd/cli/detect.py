@@ -24,7 +24,8 @@ def main(argv=None):
     out_dir = Path("predictions")
     out_dir.mkdir(exist_ok=True)
     written = []
-    for item, image_path in zip(dataset, dataset.images):
+    from ..data.feeder import prefetch_items
+    for item, image_path in zip(prefetch_items(dataset, getattr(args, "decode_workers", 0) or None), dataset.images):
         with torch.no_grad():
             output = net(item["img"][None].to(args.device))
         img_size = item["img_size"]

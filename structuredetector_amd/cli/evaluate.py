@@ -21,8 +21,9 @@ def main(argv=None):
         from ..data.synthetic import synthetic_samples
         samples = synthetic_samples(args, args.synthetic)
     else:
+        from ..data.feeder import prefetch_items
         ds = CropDataset(args, args.valid_dir)
-        samples = (ds[i] for i in range(len(ds)))
+        samples = prefetch_items(ds, getattr(args, "decode_workers", 0) or None)      # same items, same order; decode runs ahead on threads
     for image, annotation in samples:
         with torch.no_grad():
             output = net(image[None].to(args.device))

@@ -51,6 +51,32 @@ def default_decode_workers(world=1):
     return max(2, min(16, cpu_share() // max(world, 1) // 2))
 
 
+def prefetch_items(dataset, workers=None, depth=None):
+    """`dataset[0], dataset[1], ...` in order, read `depth` items ahead by a pool of `workers` threads.  For the host-only readers of the
+    batch-1 loops (`evaluate`: CropDataset(raw=False), `detect`: PredictionDataset -- PIL decode + resize + normalise, no GPU calls, the
+    decoders release the GIL): the reference walks them sequentially (src/sdnet/cli/evaluate.py:34-45), which at ~7 ms of PNG decode per
+    image leaves a 0.8 ms forward + decode waiting; items and their order are exactly those of the sequential walk."""
+    from collections import deque
+    n = len(dataset)
+    workers = int(workers or default_decode_workers())
+    depth = int(depth or 2 * workers)
+    if n == 0:
+        return
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="sd-read") as pool:
+        pending, nxt = deque(), 0
+        try:
+            while nxt < n and len(pending) < depth:
+                pending.append(pool.submit(dataset.__getitem__, nxt)); nxt += 1
+            while pending:
+                item = pending.popleft().result()
+                if nxt < n:
+                    pending.append(pool.submit(dataset.__getitem__, nxt)); nxt += 1
+                yield item
+        finally:
+            for f in pending:                                    # consumer stopped early (or a reader raised)
+                f.cancel()
+
+
 class GroupedBatch:
     """One batch as the GPU pipeline wants it: `groups` = {(height, width): (sample positions, (n, height, width, 3) uint8 DEVICE tensor)},
     `annotations` in sample order (ORIGINAL image pixels), `ready` = event after which the device tensors are complete."""

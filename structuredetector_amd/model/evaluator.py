@@ -187,20 +187,24 @@ class Evaluator:
 
     # ------------------------------------------------------------------ per-image accumulation (evaluator.py:226-242)
     def accumulate(self, prediction, annotation, part_heatmap=None, eval_csi=False, eval_classif=False):
-        self.anchor_eval += self.eval_anchor(prediction, annotation)
+        # both sides are mapped to image pixels ONCE per call (the four metrics only read them; each used to take its own resized copies:
+        # seven deep copies per image)
+        img_size = annotation.img_size
+        conv = (self._to_image(annotation, img_size), self._to_image(prediction, img_size))
+        self.anchor_eval += self.eval_anchor(prediction, annotation, _conv=conv)
         if part_heatmap is not None:
-            self.part_eval += self.eval_part(annotation, part_heatmap)
+            self.part_eval += self.eval_part(annotation, part_heatmap, _conv=conv)
         if eval_csi:
-            self.csi_eval += self.eval_csi(prediction, annotation)
+            self.csi_eval += self.eval_csi(prediction, annotation, _conv=conv)
         if eval_classif:
-            self.classification_eval += self.eval_classif(prediction, annotation)
+            self.classification_eval += self.eval_classif(prediction, annotation, _conv=conv)
 
     def _to_image(self, ann, img_size):
         return ann.resized((self.args.width, self.args.height), img_size)
 
-    def _match_objects(self, prediction, annotation, labels, key, inclusive):
+    def _match_objects(self, prediction, annotation, labels, key, inclusive, _conv=None):
         img_size = annotation.img_size
-        annotation, prediction = self._to_image(annotation, img_size), self._to_image(prediction, img_size)
+        annotation, prediction = _conv or (self._to_image(annotation, img_size), self._to_image(prediction, img_size))
         thr = min(img_size) * self.args.dist_threshold
         preds, gts = _by(prediction.objects, key), _by(annotation.objects, key)
         result = Evaluations(labels)
@@ -210,16 +214,16 @@ class Evaluator:
             result[label] = Evaluation(tp, len(gl), len(pl), [d / min(img_size) for d in dists])
         return result
 
-    def eval_anchor(self, prediction, annotation):                                     # evaluator.py:244-286
-        return self._match_objects(prediction, annotation, self.labels, lambda o: o.name, False)
+    def eval_anchor(self, prediction, annotation, _conv=None):                         # evaluator.py:244-286
+        return self._match_objects(prediction, annotation, self.labels, lambda o: o.name, False, _conv)
 
-    def eval_classif(self, prediction, annotation):                                    # evaluator.py:427-474 (<= threshold)
+    def eval_classif(self, prediction, annotation, _conv=None):                        # evaluator.py:427-474 (<= threshold)
         return self._match_objects(prediction, annotation, Evaluator.get_classification_labels(),
-                                   lambda o: f"{o.name}_{o.nb_parts}", True)
+                                   lambda o: f"{o.name}_{o.nb_parts}", True, _conv)
 
-    def eval_part(self, annotation, part_heatmap):                                     # evaluator.py:288-334
+    def eval_part(self, annotation, part_heatmap, _conv=None):                         # evaluator.py:288-334
         img_size = annotation.img_size
-        annotation = self._to_image(annotation, img_size)
+        annotation = _conv[0] if _conv else self._to_image(annotation, img_size)
         kps = [kp.resized((self.args.width, self.args.height), img_size) for kp in part_heatmap]
         thr = min(img_size) * self.args.dist_threshold
         preds = _by(kps, lambda kp: kp.kind)
@@ -245,9 +249,9 @@ class Evaluator:
             e.tp += tp
         return e.csi
 
-    def eval_csi(self, prediction, annotation):                                        # evaluator.py:380-419
+    def eval_csi(self, prediction, annotation, _conv=None):                            # evaluator.py:380-419
         img_size = annotation.img_size
-        annotation, prediction = self._to_image(annotation, img_size), self._to_image(prediction, img_size)
+        annotation, prediction = _conv or (self._to_image(annotation, img_size), self._to_image(prediction, img_size))
         thr = min(img_size) * self.args.dist_threshold
         preds, gts = _by(prediction.objects, lambda o: o.name), _by(annotation.objects, lambda o: o.name)
         result = Evaluations(self.labels)

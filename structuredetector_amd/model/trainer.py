@@ -307,7 +307,8 @@ class Trainer:
 
     def valid_samples(self):
         if self.valid_set is not None:
-            return (self.valid_set[i] for i in range(len(self.valid_set)))
+            from ..data.feeder import prefetch_items
+            return prefetch_items(self.valid_set, getattr(self.args, "decode_workers", 0) or None)
         from ..data.synthetic import synthetic_samples
         return synthetic_samples(self.args, min(max(self.args.synthetic, 1), 16), seed=20261003)
 

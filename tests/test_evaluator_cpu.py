@@ -3,6 +3,7 @@ Host-side code: CPU only."""
 from argparse import Namespace
 
 import numpy as np
+import pytest
 
 from tests.helpers import scene_from_flat
 
@@ -116,3 +117,43 @@ def test_evaluate16_directory_reader_and_evaluator_vs_reference(golden_dir, tmp_
         ev.accumulate(pred, ann, raw, True, True)
     assert_evaluator_equals_golden(ev, g)
     assert ev.anchor_eval.reduce().ndet == 125 and ev.csi_eval.reduce().tp == 88
+
+
+def test_prefetching_reader_yields_the_sequential_items_in_order(golden_dir, tmp_path):
+    """data/feeder.prefetch_items (the reader behind `evaluate`, the validation pass and `detect`): the items of the sequential walk,
+    bit for bit and in order, whatever the pool size / look-ahead; a reader error surfaces at its position; an early stop leaves no
+    thread behind."""
+    import threading
+
+    import torch
+    from structuredetector_amd.data import CropDataset
+    from structuredetector_amd.data.feeder import prefetch_items
+    from tests.helpers import EVAL16_LABELS, EVAL16_PARTS, write_evaluate16_dir
+    g = np.load(golden_dir / "evaluate16.npz")
+    write_evaluate16_dir(g, tmp_path / "valid")
+    W, H = (int(v) for v in g["cfg"][:2])
+    args = Namespace(labels=EVAL16_LABELS, parts=EVAL16_PARTS, width=W, height=H, anchor_name="stem")
+    ds = CropDataset(args, tmp_path / "valid")
+    want = [ds[i] for i in range(len(ds))]
+    for workers, depth in ((1, 1), (3, 2), (8, 32)):
+        got = list(prefetch_items(ds, workers, depth))
+        assert len(got) == len(want)
+        for (im, an), (im0, an0) in zip(got, want):
+            assert torch.equal(im, im0) and an.image_name == an0.image_name and tuple(an.img_size) == tuple(an0.img_size)
+            assert [(o.name, o.x, o.y, len(o.parts)) for o in an.objects] == [(o.name, o.x, o.y, len(o.parts)) for o in an0.objects]
+
+    class Broken:
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            if i == 3:
+                raise ValueError("unreadable sample 3")
+            return i
+    it = prefetch_items(Broken(), 2, 4)
+    assert [next(it), next(it), next(it)] == [0, 1, 2]
+    with pytest.raises(ValueError, match="unreadable sample 3"):
+        next(it)
+    it = prefetch_items(ds, 4, 8)
+    next(it); it.close()                                     # early stop: the pool is shut down by the generator's finally
+    assert not [t for t in threading.enumerate() if t.name.startswith("sd-read")]

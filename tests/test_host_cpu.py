@@ -235,14 +235,14 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
         assert name(64, 16, 512, 512, which=which) == "k_conv3x3_patch<64, true>"      # layer4: 128 two-group tiles, 256 patch tiles of 128 channels, 512 of 64
         assert name(64, 128, 128, 128, which=which) == "k_conv3x3_bf16_pp"          # up4.conv: 64-pixel column strips
         assert lib.sd_set_option(b"conv_pp_strips", 0) == 0
-        assert name(64, 128, 128, 128, which=which) == "k_conv3x3_patch<128, true>"
+        assert name(64, 128, 128, 128, which=which) == "k_conv3x3_patch_roll<128, true>"      # (128-wide map: the rolling-buffer entry point)
         assert lib.sd_set_option(b"conv_pp_strips", 1) == 0
     assert name(64, 64, 128, 256, stride=2) == "k_conv_igemm<128, 0, true>"
     assert name(64, 64, 128, 256, stride=2, which=17) == "k_conv_igemm<128, 2, true>"
     assert name(16, 64, 128, 128) == "k_conv3x3_patch<64, true>"          # 128 two-group tiles < 200, 256 one-group tiles < 512 <= 512 of 64 channels
     assert name(8, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # ... and 256 of 64 channels < 512
     assert name(32, 64, 128, 128) == "k_conv3x3_bf16_pp"                  # 256 two-group tiles
-    assert name(16, 128, 64, 64) == "k_conv3x3_patch<64, true>"           # 8 rows per unit < 16
+    assert name(16, 128, 64, 64) == "k_conv3x3_patch_roll<64, true>"      # 8 rows per unit < 16; 128-wide map: rolling-buffer entry point
     assert name(16, 256, 64, 64) == "k_conv3x3_c64_rows_bf16"             # stress config (1024 x 1024 inputs): two strips per row
     assert name(1, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # bs=1: split-K
 
