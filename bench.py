@@ -214,6 +214,13 @@ def main():
                          "describe the timed training steps only")
     a = ap.parse_args()
 
+    # A rank that hangs (a collective that never completes, a peer that died) would otherwise sit silently until the launcher's limit:
+    # after SDNET_BENCH_WATCHDOG seconds (default 20 minutes; 0 = off) every thread's Python stack goes to stderr and the process exits.
+    import faulthandler
+    watchdog = float(os.environ.get("SDNET_BENCH_WATCHDOG", "1200"))
+    if watchdog > 0:
+        faulthandler.dump_traceback_later(watchdog, exit=True)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
