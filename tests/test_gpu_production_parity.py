@@ -48,7 +48,7 @@ EXPECTED_KERNELS = {
     "down3.2.conv2": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3<32>"),
     "down4.1.conv1": ("k_conv3x3_patch<64, false>", "k_conv3x3_patch<64, false>", "k_wgrad3x3<16>"),
     "up2.conv.0": ("k_conv3x3_patch<64, false>", "k_conv3x3_patch<64, false>", "k_wgrad3x3<32>"),
-    "up4.conv.0": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3<32>"),
+    "up4.conv.0": ("k_conv3x3_patch_roll<128, false>", "k_conv3x3_patch_roll<128, false>", "k_wgrad3x3<32>"),    # 128-wide map: rolling-buffer entry point
 }
 
 
