@@ -27,7 +27,7 @@ def main(argv=None):
     for image, annotation in samples:
         with torch.no_grad():
             output = net(image[None].to(args.device))
-        data = decoder(output, return_metadata=True)
+        data = decoder(output, return_metadata=True, metadata_fields=("annotation", "raw_parts"))
         # CropDataset resized the annotation to the network input; the Evaluator maps both sides back to img_size
         evaluator.accumulate(data["annotation"][0], annotation, data["raw_parts"][0], True, True)
     evaluator.pretty_print()

@@ -322,7 +322,7 @@ class Trainer:
         for image, annotation in self.valid_samples():
             with torch.no_grad():
                 output = self.net(image[None].to(a.device))
-                data = self.decoder(output, return_metadata=True)
+                data = self.decoder(output, return_metadata=True, metadata_fields=("annotation", "raw_parts"))
                 self.evaluator.accumulate(data["annotation"][0], annotation, data["raw_parts"][0], eval_csi=True, eval_classif=True)
                 # the annotation is in network-input pixels (CropDataset / the synthetic generator): encode it as the target
                 target = self.encode.batch((a.width, a.height), [annotation], a.device)
