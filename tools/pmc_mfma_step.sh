@@ -1,12 +1,12 @@
 #!/bin/bash
 # MFMA utilisation of the kernels of the fp32 training step (bs=64, 512x512) from PMC counters, one pass, kernel-trace only:
 # per kernel: effective shader clock (GRBM_GUI_ACTIVE / 8 XCDs / duration), SQ_VALU_MFMA_BUSY_CYCLES against SQ_BUSY_CU_CYCLES.
-# usage: bash tools/pmc_mfma_step.sh [amp]
+# usage: bash tools/pmc_mfma_step.sh [script args...]   (default: tools/prof_train.py 2; e.g. tools/prof_train.py 2 amp, tools/prof_bf16_fwd.py 3)
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 tools/prof_train.py 2 "$@" > gpurun_out/pmc_mfma.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 ${@:-tools/prof_train.py 2} > gpurun_out/pmc_mfma.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 cc = glob.glob("gpurun_out/pmc_mfma/**/*counter_collection.csv", recursive=True)[0]
