@@ -3186,7 +3186,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd_dma(StemArgs p) {
 constexpr int SF_ROWS = 22, SF_PITCH = 320;        // bf16 patch rows of 640 bytes: the two lane halves (rows 2 step, 2 step + 1) hit disjoint banks
 constexpr int SF_K = 176, SF_WROW = 184;           // weight image [64][184] bf16 (368-byte rows: conflict-free 16-byte reads)
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
-static size_t stem_pool_lds_bytes(int Wp) { return (size_t)SF_ROWS * SF_PITCH * 2 + (size_t)64 * SF_WROW * 2 + 129 * 128 + (size_t)Wp * 128; }
+// LDS: [patch 22 x 320 bf16 = 14080 B][weights 64 x 184 bf16][rowbuf 129 x 64 bf16 = 16512 B][carry Wp x 64 bf16].  With the carry row of
+// a 1024-wide input (Wp = 256: 32 KB) that is 86.9 KB: one block per CU (294 us at bs=16 1024x1024 against 211 us for the same pixels at
+// 512x512).  alias = 1 puts the row tile ON the patch (dead once the tile's MFMAs have read it; one more barrier per tile, the left
+// neighbour pixel kept in a 128-byte side buffer): [max(patch, rowbuf)][weights][halo][carry] = 72.9 KB at Wp = 256 -- two blocks per CU.
+static size_t stem_pool_lds_bytes(int Wp, int alias = 0) {
+    const size_t patch = (size_t)SF_ROWS * SF_PITCH * 2, rowbuf = 129 * 128;
+    return (alias ? std::max(patch, rowbuf) + 128 : patch + rowbuf) + (size_t)64 * SF_WROW * 2 + (size_t)Wp * 128;
+}
 
 struct StemPoolArgs {
     const float* x;        // NCHW image
@@ -3195,14 +3202,17 @@ struct StemPoolArgs {
     const float* shift;
     uint16_t* y;           // [B][Hp][Wp][64] bf16
     int B, H, W, Ho, Wo, Hp, Wp, tiles_x, rows, units_per_img, nunits;
+    int alias_rowbuf;      // wide inputs: the activated row tile reuses the patch's LDS (see stem_pool_lds_bytes)
 };
 
 __global__ __launch_bounds__(256, 2) void k_stem_pool_bf16(StemPoolArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const bool alias = p.alias_rowbuf != 0;
     uint16_t* patch = reinterpret_cast<uint16_t*>(lds);                 // [22][320]
-    uint16_t* wl = patch + SF_ROWS * SF_PITCH;                          // [64][184]
-    uint16_t* rowbuf = wl + 64 * SF_WROW;                               // [129][64]
-    uint16_t* carry = rowbuf + 129 * 64;                                // [Wp][64]
+    uint16_t* wl = patch + (alias ? 129 * 64 : SF_ROWS * SF_PITCH);     // [64][184]   (alias: behind max(patch, rowbuf) = 129 x 64)
+    uint16_t* rowbuf = alias ? patch : wl + 64 * SF_WROW;               // [129][64]
+    uint16_t* halo = wl + 64 * SF_WROW;                                 // alias: [64] left neighbour pixel of the next tile
+    uint16_t* carry = alias ? halo + 64 : rowbuf + 129 * 64;            // [Wp][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < SF_ROWS * SF_PITCH / 2; i += 256) reinterpret_cast<uint32_t*>(patch)[i] = 0;   // pad columns / row 21 stay zero
     for (int i = tid; i < 64 * SF_WROW; i += 256) {
@@ -3267,7 +3277,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_pool_bf16(StemPoolArgs p) {
             pk.y = (uint32_t)f2bf(v[j].z) | ((uint32_t)f2bf(v[j].w) << 16);
             if (tid + 256 * j < TOTAL4) *reinterpret_cast<uint2*>(patch + g_lds[j]) = pk;
         }
-        if (tx == 0 && tid < 8) reinterpret_cast<uint4*>(rowbuf)[tid] = make_uint4(0, 0, 0, 0);                 // left padding pixel
+        if (tx == 0 && tid < 8) reinterpret_cast<uint4*>(alias ? halo : rowbuf)[tid] = make_uint4(0, 0, 0, 0);  // left padding pixel
         if (it.t == 0 && it.q0 == 0) {                      // above the image: the carry is the padding row
             for (int i = tid; i < p.Wp * 8; i += 256) reinterpret_cast<uint4*>(carry)[i] = make_uint4(0, 0, 0, 0);
         }
@@ -3305,6 +3315,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_pool_bf16(StemPoolArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (alias) {
+            __syncthreads();                         // (1b) every wave has read its operands: the row tile may overwrite the patch
+            if (tid < 8) reinterpret_cast<uint4*>(rowbuf)[tid] = reinterpret_cast<const uint4*>(halo)[tid];
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int pl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -3331,7 +3345,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_pool_bf16(StemPoolArgs p) {
         }
         PP_T(s6_)
         __syncthreads();                             // (3) rowbuf read: keep its last pixel as the next tile's left neighbour
-        if (tid < 8) reinterpret_cast<uint4*>(rowbuf)[tid] = reinterpret_cast<const uint4*>(rowbuf)[128 * 8 + tid];
+        if (tid < 8) reinterpret_cast<uint4*>(alias ? halo : rowbuf)[tid] = reinterpret_cast<const uint4*>(rowbuf)[128 * 8 + tid];
         it = nxt;
         PP_T(s7_)
         PP_ACC(0, s0_, s1_) PP_ACC(1, s1_, s2_) PP_ACC(2, s2_, s3_) PP_ACC(3, s3_, s4_) PP_ACC(4, s4_, s5_) PP_ACC(5, s5_, s6_) PP_ACC(6, s6_, s7_)
@@ -4461,7 +4475,8 @@ int sd_stem_bn_relu_maxpool_fwd_bf16(const float* x_nchw, const float* w, const 
     a.x = x_nchw; a.w = w; a.scale = scale; a.shift = shift; a.y = (uint16_t*)y;
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.Hp = d->Ho / 2; a.Wp = d->Wo / 2;
     a.tiles_x = cdiv(d->Wo, 128);
-    const size_t lds = stem_pool_lds_bytes(a.Wp);
+    a.alias_rowbuf = stem_pool_lds_bytes(a.Wp) > 80 * 1024 && stem_pool_lds_bytes(a.Wp, 1) <= 80 * 1024;
+    const size_t lds = stem_pool_lds_bytes(a.Wp, a.alias_rowbuf);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1, grid_max = 256 * per_cu;
     // pooled rows per work unit: enough units to fill the persistent grid, at most 16 rows (a unit recomputes one conv row)
     a.rows = std::max(1, std::min(16, (int)((int64_t)a.B * a.Hp / grid_max)));

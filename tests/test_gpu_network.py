@@ -830,7 +830,7 @@ def test_stem_conv_with_fused_bn_statistics():
         close(rv.cpu(), bn.running_var, 1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 1024, 1024), (1, 96, 1664), (1, 64, 2048)])
 def test_stem_bn_relu_maxpool_fused_bf16(shape):
     """sd_stem_bn_relu_maxpool_fwd_bf16 (network.py:59-63 `adpater` in one launch) against the two-kernel form of the bf16 backbone
     (sd_conv2d_stem_fwd with bf16 output, then sd_maxpool3x3s2_fwd_bf16: same values up to the summation order of the 147 products,
