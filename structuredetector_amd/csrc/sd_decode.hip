@@ -548,6 +548,13 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
     const int tid = threadIdx.x;
     const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
     const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
+    // The gathers of a thread's FIRST part go out before the anchors' pass and its barrier: they do not depend on the anchors, and behind
+    // the barrier they were one more dependent global round trip on the selector's critical path (same loads, same arithmetic).
+    float pf_ex = 0.f, pf_ey = 0.f, pf_ox = 0.f, pf_oy = 0.f;
+    if (tid < P) {
+        const int ind = pi_[tid];
+        pf_ex = emb_b[ind]; pf_ey = emb_b[rm.e_sc + ind]; pf_ox = off_b[ind]; pf_oy = off_b[rm.o_sc + ind];
+    }
     for (int a = tid; a < K; a += (int)blockDim.x) {
         const int ind = ai_[a];
         const int y = ind / w, x = ind - y * w;
@@ -567,9 +574,10 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         const int ind = pi_[p];
         const int y = ind / w, x = ind - y * w;
         const float score = ps_[p];
-        const float ex = emb_b[ind], ey = emb_b[rm.e_sc + ind]; // decoders.py:66
-        const float px = (float)x + off_b[ind];                 // decoders.py:67
-        const float py = (float)y + off_b[rm.o_sc + ind];       // decoders.py:68
+        const bool first = p == tid;
+        const float ex = first ? pf_ex : emb_b[ind], ey = first ? pf_ey : emb_b[rm.e_sc + ind];    // decoders.py:66
+        const float px = (float)x + (first ? pf_ox : off_b[ind]);                                   // decoders.py:67
+        const float py = (float)y + (first ? pf_oy : off_b[rm.o_sc + ind]);                         // decoders.py:68
         const float ox = px + ex, oy = py + ey;                 // decoders.py:69-70
         const bool m = score > conf;                            // decoders.py:78
         const float orx = m ? ox : -1e6f, ory = m ? oy : -1e6f; // decoders.py:80-81
