@@ -184,6 +184,22 @@ def pmc_traffic(kind):
     return round(row["hbm_bytes_per_launch"]), src
 
 
+def self_launch(n, argv):
+    """Spawn `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` (the driver's own launch line),
+    wait, and return the child's exit code.  No torch.cuda call happens in this (parent) process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    print(f"bench.py: --gpus {n} without a launcher: spawning {' '.join(cmd[1:7])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +230,12 @@ def main():
                          "describe the timed training steps only")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD `torch.distributed.run`, BEFORE
+        # this process makes any GPU call (a process that has initialised HIP must never be replaced by another program; a
+        # parent that has not touched the card may simply wait).  The child's rank 0 prints the one JSON line on our stdout.
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
+
     # A rank that hangs (a collective that never completes, a peer that died) would otherwise sit silently until the launcher's limit:
     # after SDNET_BENCH_WATCHDOG seconds (default 20 minutes; 0 = off) every thread's Python stack goes to stderr and the process exits.
     import faulthandler
@@ -224,6 +246,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:                                   # checked before the first GPU call
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -248,7 +272,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from structuredetector_amd.data import Decoder, Encode
     from structuredetector_amd.data.synthetic import synthetic_batch

@@ -109,18 +109,26 @@ def test_rccl_exchange_through_c_abi_single_rank():
     assert out["equal"] is True
 
 
-def test_bench_two_ranks_rehearsal_over_gloo():
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_rehearsal_over_gloo(launcher):
     """bench.py's multi-rank path as the driver launches it (torch.distributed.run, one process per rank, barrier + max-over-ranks
-    timing, rank 0 prints the one JSON line) with two ranks sharing the test GPU and gloo standing in for RCCL."""
+    timing, rank 0 prints the one JSON line) with two ranks sharing the test GPU and gloo standing in for RCCL -- and the same run
+    started as plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): bench.py then spawns its ranks itself before
+    any GPU call and relays rank 0's line and the child's exit code."""
     import json
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, SDNET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--size", "128"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    tail = [str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "128"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -426,3 +426,38 @@ def test_dispatch_options_are_thread_local():
         t.join(10)
     assert seen["other_default"] == default and seen["other_changed"] == changed
     assert name() == default                                             # the other thread's change never reached this one
+
+
+def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) must not die on a WORLD_SIZE assertion after touching the GPU:
+    it spawns `torch.distributed.run --nproc-per-node N bench.py ...` as a child and returns its exit code.  Checked on the command it
+    builds (no process started) and on the launcher-mismatch refusal, which comes before the first torch.cuda call."""
+    import importlib
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: pytest.fail("GPU touched before the ranks were spawned"))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                          # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    # a launcher whose WORLD_SIZE disagrees with --gpus is refused before the first GPU call
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.main()
