@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import warnings
 
 import torch
 import torch.nn as nn
@@ -85,6 +86,33 @@ class Head(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.conv = ConvParams(in_channels, out_channels, 1, bias=True)
+
+
+BACKBONE_FILE_GLOB = "resnet34-*.pth"          # torchvision ResNet34_Weights.DEFAULT = IMAGENET1K_V1 = resnet34-b627a593.pth
+
+
+def find_backbone_weights(args=None):
+    """Local lookup of the ImageNet ResNet-34 checkpoint `pretrained=True` asks for (network.py:41), in this order:
+    `args.backbone_weights`, $SDNET_BACKBONE_WEIGHTS (both must exist when given), then `resnet34-*.pth` in the directories
+    torchvision / torch.hub would have cached it in ($TORCH_HOME/hub/checkpoints, $XDG_CACHE_HOME/torch/hub/checkpoints,
+    ~/.cache/torch/hub/checkpoints).  Returns a Path or None; never downloads."""
+    import os
+    from pathlib import Path
+    for given in (getattr(args, "backbone_weights", None), os.environ.get("SDNET_BACKBONE_WEIGHTS")):
+        if given:
+            path = Path(given).expanduser()
+            if not path.is_file():
+                raise L.SdError(f"backbone weights file not found: {path}")
+            return path
+    homes = []
+    if os.environ.get("TORCH_HOME"):
+        homes.append(Path(os.environ["TORCH_HOME"]))
+    homes.append(Path(os.environ.get("XDG_CACHE_HOME", "~/.cache")).expanduser() / "torch")
+    for home in homes:
+        hits = sorted((home / "hub" / "checkpoints").glob(BACKBONE_FILE_GLOB))
+        if hits:
+            return hits[0]
+    return None
 
 
 def _layer(cin, cout, n, stride):
@@ -764,9 +792,23 @@ class Network(nn.Module):
         self.up3 = Fpn(128, self.fpn_depth)
         self.up4 = Fpn(64, self.fpn_depth)
         self.head = Head(self.fpn_depth, self.out_channels)
-        # The reference downloads ImageNet weights here (network.py:41); there is no network access and no
-        # torchvision in this environment, so `pretrained` selects nothing: load a checkpoint with --load_model.
         self.reset_parameters(seed=0)
+        # network.py:41: `resnet34(weights=ResNet34_Weights.DEFAULT if pretrained else None)` -- the ImageNet trunk.  torchvision would
+        # download `resnet34-b627a593.pth` into the hub cache; here the file is looked up locally (no download): `--backbone_weights`,
+        # $SDNET_BACKBONE_WEIGHTS, then torchvision's own cache locations.  Not finding it is announced loudly: the run then starts
+        # from a different model than the reference's.
+        self.backbone_weights = None
+        if pretrained:
+            path = find_backbone_weights(args)
+            if path is None:
+                warnings.warn(
+                    "Network(pretrained=True): no ImageNet ResNet-34 checkpoint found -- the trunk starts from RANDOM weights, unlike "
+                    "the reference (network.py:41).  Pass --backbone_weights /path/to/resnet34-b627a593.pth (torchvision's "
+                    "ResNet34_Weights.DEFAULT state_dict), set SDNET_BACKBONE_WEIGHTS, or place the file in "
+                    "$TORCH_HOME/hub/checkpoints/.", RuntimeWarning, stacklevel=2)
+            else:
+                self.load_backbone_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+                self.backbone_weights = str(path)
         self.flat_params = self.flat_grads = self.flat_params_bf16 = None
         self._flat_order, self._flat_off = [], {}
         self._folded = {}        # eval-mode (scale, shift) per BN, valid until the parameters can have changed
@@ -842,6 +884,37 @@ class Network(nn.Module):
     def load_state_dict(self, *a, **kw):
         self._folded = {}
         return super().load_state_dict(*a, **kw)
+
+    def load_backbone_state_dict(self, resnet_sd):
+        """Copy a torchvision ResNet-34 state_dict (keys `conv1.weight`, `bn1.*`, `layer{1..4}.{b}.*`, `fc.*`) onto the trunk, the way
+        network.py:41-50 picks the sub-modules: conv1 / bn1 -> `adpater.0` / `adpater.1`, layerL -> `downL`; `fc.*` is dropped (the
+        reference never registers it).  Strict on the trunk: every trunk tensor must be present with the right shape, and nothing
+        but `fc.*` may be left over.  FPN and head keep their initialisation, as in the reference."""
+        mapped, extra = {}, []
+        for k, v in resnet_sd.items():
+            if k.startswith("fc."):
+                continue
+            if k.startswith("conv1."):
+                mapped["adpater.0." + k[len("conv1."):]] = v
+            elif k.startswith("bn1."):
+                mapped["adpater.1." + k[len("bn1."):]] = v
+            elif k.startswith("layer") and k[5:6] in "1234" and k[6:7] == ".":
+                mapped["down" + k[5:]] = v
+            else:
+                extra.append(k)
+        own = self.state_dict()
+        trunk = [k for k in own if k.split(".")[0] in ("adpater", "down1", "down2", "down3", "down4")]
+        missing = [k for k in trunk if k not in mapped]
+        extra += [k for k in mapped if k not in own]
+        bad = [f"{k}: {tuple(mapped[k].shape)} != {tuple(own[k].shape)}" for k in trunk if k in mapped and mapped[k].shape != own[k].shape]
+        if missing or extra or bad:
+            raise L.SdError(f"not a torchvision ResNet-34 state_dict: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                            f"unexpected {extra[:4]}, shape mismatches {bad[:4]}")
+        self._folded = {}
+        with torch.no_grad():
+            for k in trunk:
+                own[k].copy_(mapped[k])
+        return len(trunk)
 
     # ---- reference API -------------------------------------------------------------------
     def forward(self, x):  # (B, 3, H, W)

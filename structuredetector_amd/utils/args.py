@@ -52,6 +52,10 @@ _FLAGS = [
     (("--resume",), dict(type=str, default=None, help="Continue a run from trainings/<stamp>/resume.pth (weights, Adam state, scheduler, epoch).")),
     (("--decode_workers",), dict(type=int, default=0, help="Image decode threads of the directory feed (0 = half of this rank's CPU share, 2 .. 16).")),
     (("--prefetch",), dict(type=int, default=3, help="Batches decoded and uploaded ahead of the training step.")),
+    (("--backbone_weights",), dict(type=str, default=None, help="torchvision ResNet-34 ImageNet state_dict (resnet34-b627a593.pth) for "
+                                   "the trunk: what the reference downloads for pretrained=True (default: $SDNET_BACKBONE_WEIGHTS, then the torch hub cache).")),
+    (("--log_dir",), dict(type=str, default=None, help="Directory for the training scalars (default: the run's save directory).")),
+    (("--eval_batch",), dict(type=int, default=16, help="Images per forward + decode launch in evaluate / validation / detect.")),
 ]
 
 _POSITIVE = ["in_channels", "fpn_depth", "batch_size", "epochs", "learning_rate", "down_ratio", "max_objects", "max_parts"]

@@ -461,3 +461,101 @@ def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
         bench.main()
+
+
+def _torchvision_resnet34_state_dict(seed=0):
+    """A state_dict in torchvision's resnet34 key schema (conv1 / bn1 / layer1..4 / fc; published BasicBlock [3, 4, 6, 3]), seeded values."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def bn(prefix, c):
+        sd[f"{prefix}.weight"] = torch.rand(c, generator=g) + 0.5
+        sd[f"{prefix}.bias"] = torch.randn(c, generator=g) * 0.1
+        sd[f"{prefix}.running_mean"] = torch.randn(c, generator=g) * 0.1
+        sd[f"{prefix}.running_var"] = torch.rand(c, generator=g) + 0.5
+        sd[f"{prefix}.num_batches_tracked"] = torch.tensor(1234, dtype=torch.long)
+
+    sd["conv1.weight"] = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    bn("bn1", 64)
+    cin = 64
+    for li, (n, c) in enumerate(((3, 64), (4, 128), (6, 256), (3, 512)), start=1):
+        for b in range(n):
+            p = f"layer{li}.{b}"
+            sd[f"{p}.conv1.weight"] = torch.randn(c, cin, 3, 3, generator=g) * 0.02
+            bn(f"{p}.bn1", c)
+            sd[f"{p}.conv2.weight"] = torch.randn(c, c, 3, 3, generator=g) * 0.02
+            bn(f"{p}.bn2", c)
+            if b == 0 and li > 1:
+                sd[f"{p}.downsample.0.weight"] = torch.randn(c, cin, 1, 1, generator=g) * 0.05
+                bn(f"{p}.downsample.1", c)
+            cin = c
+    sd["fc.weight"] = torch.randn(1000, 512, generator=g) * 0.01
+    sd["fc.bias"] = torch.zeros(1000)
+    return sd
+
+
+def test_pretrained_backbone_is_loaded_from_a_local_torchvision_checkpoint(tmp_path, monkeypatch):
+    """network.py:41-50: `pretrained=True` starts the trunk from torchvision's ImageNet ResNet-34 (conv1 / bn1 -> adpater.0 / .1,
+    layerL -> downL, fc dropped).  Here the checkpoint is looked up locally (flag, environment, torch hub cache); a missing file is
+    announced with a RuntimeWarning, a wrong one is refused."""
+    import warnings
+
+    import torch
+
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.model import network as PN
+    sd = _torchvision_resnet34_state_dict()
+    assert len(sd) == 216 + 2 and sum(v.numel() for k, v in sd.items() if v.dtype != torch.long and "running" not in k) == 21_797_672
+    path = tmp_path / "resnet34-b627a593.pth"
+    torch.save(sd, path)
+    monkeypatch.delenv("SDNET_BACKBONE_WEIGHTS", raising=False)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nothing_here"))
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "nothing_here_either"))
+    ns = lambda **kw: Namespace(labels={"a": 0, "b": 1}, parts={"p": 0}, fpn_depth=128, **kw)
+
+    def check(net):
+        own = net.state_dict()
+        assert torch.equal(own["adpater.0.weight"], sd["conv1.weight"]) and torch.equal(own["adpater.1.running_var"], sd["bn1.running_var"])
+        assert int(own["adpater.1.num_batches_tracked"]) == 1234
+        for k, v in sd.items():
+            if k.startswith("layer"):
+                assert torch.equal(own["down" + k[5:]], v), k
+        assert not any(k.startswith("fc.") for k in own)
+        assert net.backbone_weights is not None
+
+    # 1. explicit flag
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = PN.Network(ns(backbone_weights=str(path)), pretrained=True)
+    check(net)
+    base = PN.Network(ns(), pretrained=False)                              # FPN / head keep their own initialisation
+    for k in ("up1.weight", "up3.conv.0.weight", "head.conv.bias"):
+        assert torch.equal(net.state_dict()[k], base.state_dict()[k])
+    assert not torch.equal(net.state_dict()["down3.2.conv1.weight"], base.state_dict()["down3.2.conv1.weight"])
+    # 2. environment variable, 3. torch hub cache under $TORCH_HOME
+    monkeypatch.setenv("SDNET_BACKBONE_WEIGHTS", str(path))
+    check(PN.Network(ns(), pretrained=True))
+    monkeypatch.delenv("SDNET_BACKBONE_WEIGHTS")
+    hub = tmp_path / "home" / "hub" / "checkpoints"
+    hub.mkdir(parents=True)
+    (hub / path.name).write_bytes(path.read_bytes())
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "home"))
+    check(PN.Network(ns(), pretrained=True))
+    # nothing found: loud warning, random trunk; pretrained=False: silent
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nothing_here"))
+    with pytest.warns(RuntimeWarning, match="RANDOM weights"):
+        net = PN.Network(ns(), pretrained=True)
+    assert net.backbone_weights is None
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        PN.Network(ns(), pretrained=False)
+    # a named file that does not exist, and a checkpoint of the wrong architecture, are errors
+    with pytest.raises(L.SdError, match="not found"):
+        PN.Network(ns(backbone_weights=str(tmp_path / "missing.pth")), pretrained=True)
+    bad = dict(sd)
+    del bad["layer3.5.conv2.weight"]
+    bad["layer4.0.conv1.weight"] = torch.zeros(512, 256, 1, 1)
+    torch.save(bad, tmp_path / "bad.pth")
+    with pytest.raises(L.SdError, match="not a torchvision ResNet-34"):
+        PN.Network(ns(backbone_weights=str(tmp_path / "bad.pth")), pretrained=True)
