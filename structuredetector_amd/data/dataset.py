@@ -62,13 +62,16 @@ class CropDataset:
 
 
 class PredictionDataset:
-    """src/sdnet/data/dataset.py:166-181 + PredictionTransformation (transforms.py:265-280): every `.jpg` of a directory, resized to
-    the network input and ImageNet-normalised; items are {"img": (3,H,W) tensor, "img_size": (w, h) of the original}."""
+    """src/sdnet/data/dataset.py:166-181 + PredictionTransformation (transforms.py:265-280): every `.jpg` of a directory.
+    raw=False: items are {"img": (3,H,W) tensor resized to the network input and ImageNet-normalised on the host, "img_size": (w, h) of
+    the original}.  raw=True: items are ((H, W, 3) uint8 CPU tensor, empty ImageAnnotation carrying image_path and img_size): decode
+    only; Resize + Normalize then run for the whole batch on the GPU (model/predictor.py)."""
 
-    def __init__(self, directory, args):
+    def __init__(self, directory, args, raw=False):
         from pathlib import Path
         self.images = sorted(f for f in Path(directory).iterdir() if f.suffix == ".jpg")
         self.args = args
+        self.raw = raw
 
     def __len__(self):
         return len(self.images)
@@ -80,6 +83,9 @@ class PredictionDataset:
             raise IndexError(index)
         img = Image.open(self.images[index]).convert("RGB")
         size = img.size
+        if self.raw:
+            from ..utils.types import ImageAnnotation
+            return torch.from_numpy(np.asarray(img, np.uint8).copy()), ImageAnnotation(self.images[index], [], img_size=size)
         arr = np.asarray(img.resize((self.args.width, self.args.height), Image.BILINEAR), np.float32) / 255.0
         arr = (arr - np.asarray(_MEAN, np.float32)) / np.asarray(_STD, np.float32)
         return {"img": torch.from_numpy(arr).permute(2, 0, 1).contiguous(), "img_size": size}

@@ -161,6 +161,24 @@ class Decoder:
             annotations.append(ann)
         return annotations
 
+    def _redo_two_launch(self, outputs, conf_thresh, dist_thresh, exact_topk, device):
+        """A selector of sd_decode_fused gave up its bounded wait for a tile block (transient: another process or stream held the GPU).
+        The caller has synchronised this stream, so ITS state buffer -- and only its -- can be re-zeroed; the two-launch decoder has
+        no cross-block wait: retry once through it."""
+        self.selector_timeouts += 1
+        self._fused_state(device, 0).zero_()
+        packed, (B, K, P, _, _) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=exact_topk, fused=False)
+        host = self.split_packed(self._to_host(packed), B, K, P)
+        if host["status"].any():
+            raise L.SdError(f"sd_decode: non-zero status for image(s) {np.nonzero(host['status'])[0].tolist()}")
+        return packed, host
+
+    def _pinned(self, n, dtype):
+        """A pinned host buffer of n elements from this decoder's free list (returned by `PendingDecode.result`)."""
+        pool = self.__dict__.setdefault("_host_pool", {})
+        free = pool.setdefault((n, dtype), [])
+        return free.pop() if free else torch.empty(n, dtype=dtype, pin_memory=True)
+
     def _to_host(self, packed):
         """The packed result on the host: an asynchronous copy into a pinned buffer of this decoder + one stream wait.  (`tensor.cpu()`
         into pageable memory took 0.6 ms of a 0.72 ms call for these 1.4 KB per image; the values are consumed -- copied into Python
@@ -174,6 +192,45 @@ class Decoder:
         buf.copy_(packed, non_blocking=True)
         torch.cuda.current_stream(packed.device).synchronize()
         return buf.numpy()
+
+    def _assemble(self, host, B, out_h, out_w, conf_thresh, want_raw):
+        """decoders.py:103-159 on the host copy of the packed result: (annotations, raw_parts or None).  Values leave numpy ONCE
+        (`tolist()`: float(np.float32) == tensor.item()); the per-image loops run on plain Python lists."""
+        in_h, in_w = int(self.down_ratio * out_h), int(self.down_ratio * out_w)       # decoders.py:41
+        sx, sy = in_w / out_w, in_h / out_h                                            # utils.py:19-26
+        anchor_all, part_all, assign_all = host["anchor_out"].tolist(), host["part_out"].tolist(), host["assign"].tolist()
+        label_map, part_map, anchor_name = self.label_map, self.part_map, self.anchor_name
+        annotations, raw_parts = [], ([] if want_raw else None)
+        for b in range(B):                                                             # decoders.py:104-139
+            parts_b = part_all[b]
+            by_anchor = {}
+            for i, an in enumerate(assign_all[b]):
+                if an >= 0:
+                    by_anchor.setdefault(an, []).append(i)
+            ann = ImageAnnotation(f"batch_{b}")
+            objs = ann.objects
+            for an, (ax, ay, asc, alab) in enumerate(anchor_all[b]):
+                if asc > conf_thresh:                                                  # skip score <= conf (double compare)
+                    parts = [Keypoint(part_map[int(parts_b[i][3])], parts_b[i][0] * sx, parts_b[i][1] * sy, parts_b[i][2])
+                             for i in by_anchor.get(an, ())]
+                    objs.append(Object(name=label_map[int(alab)], anchor=Keypoint(anchor_name, ax * sx, ay * sy, asc), parts=parts))
+            annotations.append(ann)
+            if want_raw:                                                               # decoders.py:142-159: skip score < conf
+                raw_parts.append([Keypoint(part_map[int(pt[3])], pt[0] * sx, pt[1] * sy, pt[2]) for pt in parts_b if not pt[2] < conf_thresh])
+        return annotations, raw_parts
+
+    def submit(self, outputs, conf_thresh=None, dist_thresh=None, with_raw_parts=False):
+        """The device stage of `__call__` WITHOUT the host wait: launches the decoder, starts the copy of the packed result into a pinned
+        buffer and returns a `PendingDecode`; `.result()` waits for that copy and assembles `(annotations, raw_parts | None)`.  Lets a
+        batched caller (`evaluate`, validation, `detect`) queue the next batch's forward + decode before it assembles this one."""
+        conf_thresh = conf_thresh if conf_thresh is not None else self.args.conf_threshold
+        dist_thresh = dist_thresh if dist_thresh is not None else self.args.decoder_dist_thresh
+        packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=with_raw_parts)
+        buf = self._pinned(packed.numel(), packed.dtype)
+        buf.copy_(packed, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(packed.device))
+        return PendingDecode(self, outputs, packed, buf, done, (B, K, P, out_h, out_w), conf_thresh, dist_thresh, with_raw_parts)
 
     def __call__(self, outputs, conf_thresh=None, dist_thresh=None, return_metadata=False, metadata_fields=None):
         """decoders.py:29-179.  `metadata_fields` (extension, default None = the reference's full metadata dict): the keys a caller of
@@ -189,45 +246,12 @@ class Decoder:
 
         # the metadata exposes every top-k slot (also peaks below the threshold): exact selection only when it is asked for
         packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=return_metadata)
-        in_h, in_w = int(self.down_ratio * out_h), int(self.down_ratio * out_w)       # decoders.py:41
         host = self.split_packed(self._to_host(packed), B, K, P)                       # the one D2H (+ sync)
         if host["status"].any():
-            # transient (a tile block was delayed past the selector's bounded wait): the D2H above has synchronised this stream, so its
-            # state buffer -- and only its -- can be re-zeroed; the two-launch decoder has no cross-block wait, retry once through it
-            self.selector_timeouts += 1
-            self._fused_state(packed.device, 0).zero_()
-            packed, _ = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=return_metadata, fused=False)
-            host = self.split_packed(self._to_host(packed), B, K, P)
-            if host["status"].any():
-                raise L.SdError(f"sd_decode: non-zero status for image(s) {np.nonzero(host['status'])[0].tolist()}")
-        sx, sy = in_w / out_w, in_h / out_h                                            # utils.py:19-26
-
-        anchor_out = host["anchor_out"].astype(np.float64)        # float(np.float32) == tensor.item()
-        part_out = host["part_out"].astype(np.float64)
-        assign = host["assign"]
-        annotations = []
-        for b in range(B):                                                             # decoders.py:104-139
-            by_anchor = {}
-            for i in np.nonzero(assign[b] >= 0)[0]:
-                by_anchor.setdefault(int(assign[b, i]), []).append(i)
-            ann = ImageAnnotation(f"batch_{b}")
-            for a in np.nonzero(anchor_out[b, :, 2] > conf_thresh)[0]:                 # skip score <= conf
-                ax, ay, asc, alab = anchor_out[b, a].tolist()
-                parts = [Keypoint(self.part_map[int(part_out[b, i, 3])], part_out[b, i, 0].item() * sx,
-                                  part_out[b, i, 1].item() * sy, part_out[b, i, 2].item())
-                         for i in by_anchor.get(int(a), ())]
-                anchor = Keypoint(self.anchor_name, ax * sx, ay * sy, asc)
-                ann.objects.append(Object(name=self.label_map[int(alab)], anchor=anchor, parts=parts))
-            annotations.append(ann)
-
+            packed, host = self._redo_two_launch(outputs, conf_thresh, dist_thresh, return_metadata, packed.device)
+        annotations, raw_parts = self._assemble(host, B, out_h, out_w, conf_thresh, return_metadata)
         if not return_metadata:
             return annotations
-
-        raw_parts = []                                                                 # decoders.py:142-159
-        for b in range(B):
-            keep = np.nonzero(~(part_out[b, :, 2] < conf_thresh))[0]
-            raw_parts.append([Keypoint(self.part_map[int(part_out[b, i, 3])], part_out[b, i, 0].item() * sx,
-                                       part_out[b, i, 1].item() * sy, part_out[b, i, 2].item()) for i in keep])
 
         if metadata_fields is not None and set(metadata_fields) <= {"annotation", "raw_parts"}:
             return {"annotation": annotations, "raw_parts": raw_parts}
@@ -245,6 +269,27 @@ class Decoder:
             "raw_embeddings": outputs["embeddings"],
             "raw_offsets": outputs["offsets"],
         }
+
+
+class PendingDecode:
+    """A decode in flight (`Decoder.submit`): device buffer, pinned host copy, the event after which the copy is complete."""
+
+    def __init__(self, decoder, outputs, packed, host, done, dims, conf_thresh, dist_thresh, want_raw):
+        self.decoder, self.outputs, self.packed, self.host, self.done = decoder, outputs, packed, host, done
+        self.dims, self.conf_thresh, self.dist_thresh, self.want_raw = dims, conf_thresh, dist_thresh, want_raw
+
+    def result(self):
+        dec = self.decoder
+        B, K, P, out_h, out_w = self.dims
+        self.done.synchronize()
+        host = dec.split_packed(self.host.numpy(), B, K, P)
+        if host["status"].any():
+            torch.cuda.current_stream(self.packed.device).synchronize()
+            _, host = dec._redo_two_launch(self.outputs, self.conf_thresh, self.dist_thresh, self.want_raw, self.packed.device)
+        out = dec._assemble(host, B, out_h, out_w, self.conf_thresh, self.want_raw)
+        dec._host_pool[(self.host.numel(), self.host.dtype)].append(self.host)        # values were copied into Python objects
+        self.outputs = self.packed = self.host = None
+        return out
 
 
 class RawDecoder:

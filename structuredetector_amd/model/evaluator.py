@@ -35,6 +35,33 @@ def greedy_nearest(pred_xy, pred_score, gt_xy, threshold, inclusive=False):
     return len(winners), dmin[winners].tolist()
 
 
+def _dist_rows(px, py, gx, gy):
+    """Distance matrix (predictions x ground truths) as nested lists of Python floats; `np.hypot` like `Keypoint.distance` (utils.py:31-32)."""
+    if not px or not gx:
+        return []
+    return np.hypot(np.subtract.outer(np.asarray(px, np.float64), np.asarray(gx, np.float64)),
+                    np.subtract.outer(np.asarray(py, np.float64), np.asarray(gy, np.float64))).tolist()
+
+
+def _greedy_rows(rows, preds, gts, threshold, inclusive):
+    """`greedy_nearest` on rows of a precomputed distance matrix: `preds` = prediction indices in score-descending order, `gts` = ground-truth
+    indices; a prediction takes its NEAREST ground truth (first minimum: strict `<` scan) if that is within the threshold and still free."""
+    if not preds or not gts:
+        return 0, ()
+    taken, dists = set(), []
+    for p in preds:
+        row = rows[p]
+        jm, dm = None, None
+        for j in gts:
+            d = row[j]
+            if dm is None or d < dm:
+                dm, jm = d, j
+        if (dm <= threshold if inclusive else dm < threshold) and jm not in taken:
+            taken.add(jm)
+            dists.append(dm)
+    return len(dists), dists
+
+
 class Evaluation:
     def __init__(self, tp=0, npos=0, ndet=0, acc=None, counts=None):
         assert tp >= 0 and ndet >= 0 and npos >= 0, "tp, npos and ndet should be positive"
@@ -49,8 +76,10 @@ class Evaluation:
 
     def __iadd__(self, other):
         self.tp += other.tp; self.npos += other.npos; self.ndet += other.ndet
-        self.acc = self.acc + other.acc
-        self.count_errors = self.count_errors + other.count_errors
+        if other.acc:
+            self.acc.extend(other.acc)                      # in place: `self.acc + other.acc` re-copied the whole history for every image
+        if other.count_errors:
+            self.count_errors.extend(other.count_errors)
         return self
 
     def __add__(self, other):
@@ -187,6 +216,102 @@ class Evaluator:
 
     # ------------------------------------------------------------------ per-image accumulation (evaluator.py:226-242)
     def accumulate(self, prediction, annotation, part_heatmap=None, eval_csi=False, eval_classif=False):
+        """evaluator.py:226-242.  All four metrics of one image from THREE distance matrices (anchors x anchors, object parts x object
+        parts, raw parts x ground-truth parts; `np.hypot` like `Keypoint.distance`, utils.py:31-32) and plain-Python greedy scans over
+        their rows: the per-pair numpy calls of the public `eval_*` / `compute_csi` methods (kept below: the reference's API, and the
+        statement the fast path is tested against) cost ~10 us each on 1-3 element arrays, ~50 structure pairs per image."""
+        if type(self)._match_objects is Evaluator._match_objects and type(self).compute_csi is Evaluator.compute_csi:
+            return self._accumulate_fast(prediction, annotation, part_heatmap, eval_csi, eval_classif)
+        return self._accumulate_by_metric(prediction, annotation, part_heatmap, eval_csi, eval_classif)
+
+    def accumulate_batch(self, predictions, annotations, part_heatmaps=None, eval_csi=False, eval_classif=False):
+        """`accumulate` over the images of one decoded batch, in order (counters and accuracy lists are order-dependent only through the
+        list order, which is kept)."""
+        part_heatmaps = part_heatmaps if part_heatmaps is not None else [None] * len(predictions)
+        for pred, ann, raw in zip(predictions, annotations, part_heatmaps):
+            self.accumulate(pred, ann, raw, eval_csi, eval_classif)
+
+    def _accumulate_fast(self, prediction, annotation, part_heatmap, eval_csi, eval_classif):
+        a = self.args
+        img_size = annotation.img_size
+        fx, fy = img_size[0] / a.width, img_size[1] / a.height          # ann.resized((width, height), img_size): x *= ow / iw
+        side = min(img_size)
+        thr = side * a.dist_threshold
+
+        def flat(objects):
+            ax, ay, names, scores, nparts, owner, kx, ky, kinds, kscores = [], [], [], [], [], [], [], [], [], []
+            for i, o in enumerate(objects):
+                an = o.anchor
+                ax.append(an.x * fx); ay.append(an.y * fy); names.append(o.name); scores.append(an.score); nparts.append(len(o.parts))
+                for kp in o.parts:
+                    owner.append(i); kx.append(kp.x * fx); ky.append(kp.y * fy); kinds.append(kp.kind); kscores.append(kp.score)
+            return ax, ay, names, scores, nparts, owner, kx, ky, kinds, kscores
+
+        pax, pay, pname, pscore, pnp, pown, pkx, pky, pkind, pks = flat(prediction.objects)
+        gax, gay, gname, _, gnp, gown, gkx, gky, gkind, _ = flat(annotation.objects)
+        DA = _dist_rows(pax, pay, gax, gay)
+
+        def by_key(keys):
+            out = {}
+            for i, k in enumerate(keys):
+                out.setdefault(k, []).append(i)
+            return out
+
+        def ranked(idx, score):                                         # score-descending, stable (np.argsort(-s, kind="stable"))
+            return sorted(idx, key=lambda i: -score[i]) if len(idx) > 1 else idx
+
+        def matched(rows, pred_groups, gt_groups, labels, score, inclusive, into):
+            for label in labels:
+                pl, gl = pred_groups.get(label, ()), gt_groups.get(label, ())
+                tp, dists = _greedy_rows(rows, ranked(pl, score), gl, thr, inclusive)
+                e = into[label]
+                e.tp += tp; e.npos += len(gl); e.ndet += len(pl)
+                if dists:
+                    e.acc.extend(d / side for d in dists)
+
+        p_by_name, g_by_name = by_key(pname), by_key(gname)
+        matched(DA, p_by_name, g_by_name, self.labels, pscore, False, self.anchor_eval)            # evaluator.py:244-286
+        if part_heatmap is not None:                                                                # evaluator.py:288-334
+            rx, ry = [kp.x * fx for kp in part_heatmap], [kp.y * fy for kp in part_heatmap]
+            matched(_dist_rows(rx, ry, gkx, gky), by_key([kp.kind for kp in part_heatmap]), by_key(gkind), self.kp_labels,
+                    [kp.score for kp in part_heatmap], False, self.part_eval)
+        if eval_classif:                                                                            # evaluator.py:427-474 (<= threshold)
+            matched(DA, by_key([f"{n}_{k}" for n, k in zip(pname, pnp)]), by_key([f"{n}_{k}" for n, k in zip(gname, gnp)]),
+                    Evaluator.get_classification_labels(), pscore, True, self.classification_eval)
+        if eval_csi:                                                                                # evaluator.py:380-419, 538-581
+            DP = _dist_rows(pkx, pky, gkx, gky)
+            p_parts, g_parts = [{} for _ in pname], [{} for _ in gname]
+            for k, i in enumerate(pown):
+                p_parts[i].setdefault(pkind[k], []).append(k)
+            for k, j in enumerate(gown):
+                g_parts[j].setdefault(gkind[k], []).append(k)
+            p_parts = [{kind: ranked(idx, pks) for kind, idx in d.items()} for d in p_parts]
+            csi_thr = a.csi_threshold
+            for label in self.labels:
+                pl, gl = p_by_name.get(label, ()), g_by_name.get(label, ())
+                res = self.csi_eval[label]
+                res.ndet += len(pl); res.npos += len(gl)
+                visited = set()
+                for i in ranked(pl, pscore):
+                    best, idx = 0.0, None
+                    mine = p_parts[i]
+                    for j in gl:
+                        theirs = g_parts[j]
+                        tp, npos, ndet = int(DA[i][j] < thr), 1, 1
+                        for kind in theirs.keys() | mine.keys():
+                            pk, gk = mine.get(kind, ()), theirs.get(kind, ())
+                            npos += len(gk); ndet += len(pk)
+                            tp += _greedy_rows(DP, pk, gk, thr, False)[0]
+                        den = npos + ndet - tp
+                        c = tp / den if den != 0 else 1
+                        if c > best:
+                            best, idx = c, j
+                    if best >= csi_thr and idx not in visited:
+                        visited.add(idx)
+                        res.tp += 1
+                        res.acc.append(best)
+
+    def _accumulate_by_metric(self, prediction, annotation, part_heatmap=None, eval_csi=False, eval_classif=False):
         # both sides are mapped to image pixels ONCE per call (the four metrics only read them; each used to take its own resized copies:
         # seven deep copies per image)
         img_size = annotation.img_size

@@ -254,7 +254,7 @@ class Trainer:
         self.epoch = 0
         self.net = Network(args, pretrained=True)
         if args.pretrained_model:
-            self.net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu"))
+            self.net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu", weights_only=True))
         self.net.to(args.device).train()
         self.step = TrainStep(self.net, args, lr=args.learning_rate)
         self.step.sync_parameters()
@@ -272,8 +272,10 @@ class Trainer:
         from .evaluator import Evaluator
         from .loss import Loss
         self.decoder, self.evaluator, self.loss = Decoder(args), Evaluator(args), Loss(args)
-        self.valid_set = None if args.synthetic or not args.valid_dir else CropDataset(args, args.valid_dir)
+        self.valid_set = None if args.synthetic or not args.valid_dir else CropDataset(args, args.valid_dir, raw=True)
         self.start_epoch = 0
+        self.global_step = 0                      # trainer.py:35,129: images seen, the x axis of every scalar
+        self._writer = None
         if getattr(args, "resume", None):
             self.load_resume(args.resume)
 
@@ -306,29 +308,38 @@ class Trainer:
                 torch.set_num_threads(threads)
 
     def valid_samples(self):
-        if self.valid_set is not None:
-            from ..data.feeder import prefetch_items
-            return prefetch_items(self.valid_set, getattr(self.args, "decode_workers", 0) or None)
-        from ..data.synthetic import synthetic_samples
-        return synthetic_samples(self.args, min(max(self.args.synthetic, 1), 16), seed=20261003)
-
-    def valid(self):
-        """Validation pass of the reference (src/sdnet/model/trainer.py:137-237): eval-mode forward one image at a time,
-        Decoder + Evaluator + Loss, then the four `model_best_*.pth` checkpoints (rank 0 only)."""
+        """Per image, in order: (prediction, annotation in network-input pixels, raw_parts, this image's head views)."""
         a = self.args
-        self.net.eval()
-        self.evaluator.reset()
-        stats, n = LossStats(), 0
-        for image, annotation in self.valid_samples():
+        if self.valid_set is not None:
+            # decode threads -> GPU Resize + Normalize -> forward + decoder at --eval_batch images per launch (model/predictor.py)
+            from .predictor import batched_outputs
+            yield from batched_outputs(self.net, self.decoder, self.valid_set, a, keep_output=True)
+            return
+        from ..data.synthetic import synthetic_samples
+        for image, annotation in synthetic_samples(a, min(max(a.synthetic, 1), 16), seed=20261003):
             with torch.no_grad():
                 output = self.net(image[None].to(a.device))
                 data = self.decoder(output, return_metadata=True, metadata_fields=("annotation", "raw_parts"))
-                self.evaluator.accumulate(data["annotation"][0], annotation, data["raw_parts"][0], eval_csi=True, eval_classif=True)
-                # the annotation is in network-input pixels (CropDataset / the synthetic generator): encode it as the target
+            yield data["annotation"][0], annotation, data["raw_parts"][0], output
+
+    def valid(self):
+        """Validation pass of the reference (src/sdnet/model/trainer.py:137-237): eval-mode forward, Decoder + Evaluator + Loss PER IMAGE
+        (the loss statistics are means over images of per-image losses, :160-168), then the four `model_best_*.pth` checkpoints
+        (rank 0 only).  Forward and decoder run batched; the per-image loss is taken on that image's slice of the batch output."""
+        a = self.args
+        self.net.eval()
+        self.evaluator.reset()
+        stats, n, per_image = LossStats(), 0, []
+        for prediction, annotation, raw_parts, output in self.valid_samples():
+            with torch.no_grad():
+                self.evaluator.accumulate(prediction, annotation, raw_parts, eval_csi=True, eval_classif=True)
+                # the annotation is in network-input pixels (resized + clipped / the synthetic generator): encode it as the target
                 target = self.encode.batch((a.width, a.height), [annotation], a.device)
                 self.loss(output, target)
-            stats += LossStats(*(float(v) for v in (self.loss.stats.hm_loss, self.loss.stats.offset_loss, self.loss.stats.embedding_loss)))
+            per_image.append(torch.stack([self.loss.stats.hm_loss, self.loss.stats.offset_loss, self.loss.stats.embedding_loss]))
             n += 1
+        if n:                                                      # one host sync for the whole pass (it was three `.item()` per image)
+            stats = LossStats(*(torch.stack(per_image).double().sum(0).tolist()))
         self.net.train()
         if n:
             stats /= n
@@ -337,6 +348,13 @@ class Trainer:
         f1_kp = self.evaluator.kps_eval.reduce().f1_score
         if self.rank == 0:
             self.save_dir.mkdir(parents=True, exist_ok=True)
+            from ..utils.scalars import metric_dicts
+            writer = self.scalar_writer()
+            writer.add_scalars("Loss/Validation", dict(hm_loss=stats.hm_loss, offset_loss=stats.offset_loss,
+                                                        embedding_loss=stats.embedding_loss), self.global_step)      # trainer.py:240-242
+            for tag, values in metric_dicts(self.evaluator).items():                                                 # trainer.py:243-256
+                writer.add_scalars(tag, values, self.global_step)
+            writer.flush()
             print(f"validation ({n} images): loss {stats.total_loss:.5f} | kp F1 {f1_kp:.2%} | CSI F1 {f1_csi:.2%} | classification F1 {f1_classif:.2%}", flush=True)
             for value, attr, name, better in ((stats.total_loss, "best_loss", "loss", lambda v, b: v < b), (f1_csi, "best_csi", "csi", lambda v, b: v > b),
                                               (f1_classif, "best_classif", "classif", lambda v, b: v > b), (f1_kp, "best_kp_reg", "kp_reg", lambda v, b: v > b)):
@@ -355,7 +373,7 @@ class Trainer:
                     "optimizer": self.step.state_dict(), "scheduler": self.scheduler.state_dict(), "epoch": self.epoch,
                     "best": {k: getattr(self, k) for k in ("best_loss", "best_csi", "best_classif", "best_kp_reg")},
                     "augment_size": tuple(int(v) for v in self.augment.size), "torch_rng": torch.get_rng_state(),
-                    "numpy_rng": self.rng.bit_generator.state, "save_dir": str(self.save_dir)}, path)
+                    "numpy_rng": self.rng.bit_generator.state, "save_dir": str(self.save_dir), "global_step": int(self.global_step)}, path)
 
     def load_resume(self, path):
         from pathlib import Path
@@ -371,19 +389,37 @@ class Trainer:
             torch.set_rng_state(state["torch_rng"])
             self.rng.bit_generator.state = state["numpy_rng"]
             self.save_dir = Path(state["save_dir"])     # model_best_* and resume.pth of one run stay in one directory
+        self.global_step = int(state.get("global_step", 0))
+
+    def scalar_writer(self):
+        """The run's scalar log (rank 0), created on first use: TensorBoard when importable, always `<dir>/scalars.jsonl` (utils/scalars.py)."""
+        if self._writer is None:
+            from ..utils.scalars import ScalarWriter
+            self._writer = ScalarWriter(getattr(self.args, "log_dir", None) or self.save_dir) if self.rank == 0 else ScalarWriter(None)
+        return self._writer
 
     def train(self):
         steps = 0
         for epoch in range(self.start_epoch, self.args.epochs):
             self.epoch = epoch
-            running, n = torch.zeros(4, device=self.args.device), 0
+            per_step = []
             for images, targets in self.batches():
-                running += self.step(images, targets)
-                n += 1; steps += 1
+                per_step.append(self.step(images, targets).clone())    # (total, hm, offset, embedding) on the device: no host sync in the loop
+                steps += 1
                 if self.args.steps and steps >= self.args.steps:
                     break
-            mean = (running / max(n, 1)).tolist()                      # one host sync per epoch
+            n = len(per_step)
+            rows = torch.stack(per_step).tolist() if n else []         # one host sync per epoch
+            mean = [sum(r[k] for r in rows) / max(n, 1) for k in range(4)]
             if self.rank == 0:
+                # trainer.py:126-133: "Loss/Train" per optimizer step at global_step (+= batch_size per step), "Learning rate" per epoch;
+                # the reference's writer forces a device sync per step -- the same scalars are written here from the epoch's one copy
+                writer = self.scalar_writer()
+                for r in rows:
+                    writer.add_scalars("Loss/Train", dict(hm_loss=r[1], offset_loss=r[2], embedding_loss=r[3]), self.global_step)
+                    self.global_step += self.args.batch_size
+                writer.add_scalar("Learning rate", self.step.lr, self.global_step)
+                writer.flush()
                 print(f"epoch {epoch}: total {mean[0]:.5f} hm {mean[1]:.5f} offset {mean[2]:.5f} embedding {mean[3]:.5f} "
                       f"lr {self.step.lr:g} ({n} steps)", flush=True)
             if epoch % 2 == 0:                                         # trainer.py:98-99

@@ -55,7 +55,8 @@ class Keypoint(_Scalable):
         return Keypoint(self.kind, self.x, self.y, self.score) if type(self) is Keypoint and len(self.__dict__) == 4 else copy.deepcopy(self)
 
     def distance(self, other):
-        return math.hypot(self.x - other.x, self.y - other.y)
+        import numpy as np
+        return float(np.hypot(self.x - other.x, self.y - other.y))          # utils.py:31-32 (np.hypot, not math.hypot: they may differ by an ulp)
 
     def json_repr(self):
         return {"kind": self.kind, "location": {"x": self.x, "y": self.y}, "score": self.score}

@@ -157,3 +157,44 @@ def test_prefetching_reader_yields_the_sequential_items_in_order(golden_dir, tmp
     it = prefetch_items(ds, 4, 8)
     next(it); it.close()                                     # early stop: the pool is shut down by the generator's finally
     assert not [t for t in threading.enumerate() if t.name.startswith("sd-read")]
+
+
+def test_fast_accumulate_equals_the_per_metric_statement_on_adversarial_scenes():
+    """`Evaluator.accumulate` computes all four metrics of an image from three distance matrices; the public `eval_anchor / eval_part /
+    eval_csi / eval_classif / compute_csi` methods (the reference's API, evaluator.py:244-474,538-581) stay as the statement it must
+    equal: identical counters AND accuracy lists (same values, same order) on scenes with coincident keypoints, tied scores, tied
+    distances, empty sides, several part kinds, and predictions on / next to the threshold."""
+    from structuredetector_amd.model import Evaluator
+    from structuredetector_amd.utils import ImageAnnotation, Keypoint, Object
+    labels, parts = {"bean": 0, "maize": 1}, {"leaf": 0, "pod": 1}
+    args = Namespace(labels=labels, parts=parts, width=512, height=384, dist_threshold=0.05, csi_threshold=0.75)
+    rng = np.random.default_rng(7)
+    fast, slow = Evaluator(args), Evaluator(args)
+    grid = lambda n: rng.integers(0, 12, n) * 16.0                      # a coarse grid: coincident points and exactly tied distances
+    for n in range(300):
+        size = [(640, 480), (512, 384), (1000, 300)][n % 3]
+        n_gt, n_pr = int(rng.integers(0, 7)), int(rng.integers(0, 8))
+        gts = [Object(["bean", "maize"][int(rng.integers(2))], Keypoint("stem", float(x), float(y)),
+                      [Keypoint(["leaf", "pod"][int(rng.integers(2))], float(x + dx), float(y + dy)) for dx, dy in rng.integers(-2, 3, (int(rng.integers(0, 4)), 2)) * 8.0])
+               for x, y in zip(grid(n_gt), grid(n_gt))]
+        prs = [Object(["bean", "maize"][int(rng.integers(2))], Keypoint("stem", float(x), float(y), float(rng.integers(5, 10)) / 10),
+                      [Keypoint(["leaf", "pod"][int(rng.integers(2))], float(x + dx), float(y + dy), float(rng.integers(5, 10)) / 10)
+                       for dx, dy in rng.integers(-2, 3, (int(rng.integers(0, 4)), 2)) * 8.0])
+               for x, y in zip(grid(n_pr) + rng.choice([0.0, 0.0, 3.0, 19.2, 24.0], n_pr), grid(n_pr))]
+        raw = [Keypoint(kp.kind, kp.x, kp.y, kp.score) for o in prs for kp in o.parts] + \
+              [Keypoint("leaf", float(x), float(y), 0.5) for x, y in zip(grid(2), grid(2))]
+        gt, pred = ImageAnnotation(f"g{n}", gts, img_size=size), ImageAnnotation(f"p{n}", prs)
+        fast.accumulate(pred, gt, raw if n % 5 else None, eval_csi=bool(n % 2), eval_classif=bool(n % 3))
+        slow._accumulate_by_metric(pred, gt, raw if n % 5 else None, eval_csi=bool(n % 2), eval_classif=bool(n % 3))
+    for name in ("anchor_eval", "part_eval", "csi_eval", "classification_eval"):
+        for (label, a), (_, b) in zip(getattr(fast, name).items(), getattr(slow, name).items()):
+            assert (a.tp, a.npos, a.ndet) == (b.tp, b.npos, b.ndet), (name, label)
+            assert a.acc == b.acc, (name, label)
+    tot = fast.anchor_eval.reduce()
+    assert 0 < tot.tp < tot.ndet and 0 < fast.csi_eval.reduce().tp and 0 < fast.classification_eval.reduce().tp < tot.tp
+
+    class Custom(Evaluator):                                              # a subclass that overrides a metric keeps its override in charge
+        def compute_csi(prediction, target, dist_thresh):
+            return 1.0
+    c = Custom(args)
+    c.accumulate(pred, gt, None, eval_csi=True)

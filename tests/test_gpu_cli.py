@@ -66,13 +66,18 @@ def test_stress_config_shapes():
     assert len(anns) == 1
 
 
-def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monkeypatch, capsys):
+@pytest.mark.parametrize("eval_batch", [16, 5, 1])
+def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monkeypatch, capsys, eval_batch):
     """BASELINE configs[0]: `evaluate` over a directory of 16 PNG + JSON samples (2 labels / 1 part, anchor_name=stem), read
     by the product CropDataset, decoded by the HIP decoder, scored by the product Evaluator -- against the reference's own
     from_json / Resize / Encode-clip / Decoder / Evaluator on the same head tensors (tests/golden/evaluate16.npz).  The head
     tensors are planted (a stand-in Network returns them in file order: a random-init backbone has nothing to detect), so the
     counters, accuracy lists and the CSV must match the reference EXACTLY; the real backbone then runs over the same directory
-    for the plumbing, and its first head is checked against the oracle network on the image the reader produced."""
+    for the plumbing, and its first head is checked against the oracle network on the image the reader produced.
+    `evaluate` runs batched (decode threads -> GPU Resize + Normalize -> forward + decoder `--eval_batch` images per launch, next
+    batch queued before this one is assembled): whole batches, a ragged last batch (16 = 3 x 5 + 1) and the reference's batch of one
+    must all give the reference's numbers, and every image tensor the network is handed must equal, bit for bit, the host chain
+    PIL resize -> to_tensor -> Normalize of the reference's ValidationAugmentation (transforms.py:255-261)."""
     from oracle import sdnet_oracle as O
     from structuredetector_amd.cli import evaluate
     from structuredetector_amd.data import CropDataset
@@ -83,6 +88,7 @@ def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monk
     (tmp_path / "labels.json").write_text(json.dumps({"labels": ["bean", "maize"], "parts": ["leaf"]}))
     argv = ["--valid_dir", str(tmp_path / "valid"), "-s", "stem", "--labels", str(tmp_path / "labels.json"),
             "--save_csv_eval", str(tmp_path / "kps.csv")]
+    batch_flag = ["--eval_batch", str(eval_batch)]
     seen = []
 
     class PlantedNetwork(torch.nn.Module):
@@ -91,14 +97,18 @@ def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monk
             self.dummy = torch.nn.Parameter(torch.zeros(1))
 
         def forward(self, x):
-            assert tuple(x.shape) == (1, 3, 512, 512) and x.is_cuda
-            seen.append(x)
-            h = torch.from_numpy(heads[len(seen) - 1])[None].to(x.device)
+            assert tuple(x.shape[1:]) == (3, 512, 512) and x.shape[0] <= eval_batch and x.is_cuda
+            lo = len(seen)
+            seen.extend(x.cpu())
+            h = torch.from_numpy(np.stack(heads[lo:lo + x.shape[0]])).to(x.device)
             return {"anchor_hm": h[:, :2], "part_hm": h[:, 2:3], "offsets": h[:, 3:5], "embeddings": h[:, 5:7]}
 
     monkeypatch.setattr(evaluate, "Network", PlantedNetwork)
-    ev = evaluate.main(argv)
+    ev = evaluate.main(argv + batch_flag)
     assert len(seen) == 16
+    host_reader = CropDataset(evaluate.Arguments().parse(argv[:-2]), tmp_path / "valid")       # PIL resize + to_tensor + Normalize on the host
+    for i in range(16):
+        assert torch.equal(seen[i], host_reader[i][0]), f"image {i}: GPU Resize + Normalize differs from the PIL chain"
     assert_evaluator_equals_golden(ev, g)
     assert (tmp_path / "kps.csv").read_text() == str(g["csv"])
     out = capsys.readouterr().out
@@ -108,7 +118,7 @@ def test_evaluate_on_16_png_json_samples_vs_reference(golden_dir, tmp_path, monk
     # the real network over the same directory (seeded random checkpoint through --load_model)
     ref = O.build_reference_network(2, 1, seed=16)
     torch.save(ref.state_dict(), tmp_path / "seeded.pth")
-    ev2 = evaluate.main(argv[:-2] + ["-o", str(tmp_path / "seeded.pth")])
+    ev2 = evaluate.main(argv[:-2] + batch_flag + ["-o", str(tmp_path / "seeded.pth")])
     assert ev2.anchor_eval.reduce().npos == ev.anchor_eval.reduce().npos == 110
     args = evaluate.Arguments().parse(argv[:-2])
     image, _ = CropDataset(args, tmp_path / "valid")[1]                    # a 640x480 PNG resized to 512x512 and normalised

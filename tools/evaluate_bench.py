@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """`evaluate --valid_dir` wall time per image over N synthetic PNG + JSON samples (the reference's batch-1 loop, src/sdnet/cli/evaluate.py:34-45):
-the sequential reader (--decode_workers 1 = the reference's order of work) against the prefetching one (data/feeder.prefetch_items).
+one image per forward + decode on one decode thread (the reference's order of work) against the batched path (model/predictor.py).
 usage: evaluate_bench.py [--n 128] [--size 512] [--dir /tmp/sd_eval]"""
 import argparse
 import contextlib
@@ -23,13 +23,17 @@ def main():
     root = Path(a.dir)
     labels = write_samples(root / "valid", a.n, a.size)
     base = ["--valid_dir", str(root / "valid"), "--labels", str(labels), "-s", "stem", "-W", str(a.size), "-H", str(a.size)]
-    for label, extra in (("sequential reader (1 thread, no look-ahead)", ["--decode_workers", "1", "--prefetch", "1"]), ("prefetching reader (default pool)", [])):
+    rows = (("batch of one, one decode thread (the reference's order of work)", ["--eval_batch", "1", "--decode_workers", "1"]),
+            ("batch of one, decode pool", ["--eval_batch", "1"]),
+            ("--eval_batch 16 (default), decode pool", []),
+            ("--eval_batch 32, decode pool", ["--eval_batch", "32"]))
+    for label, extra in rows:
         for rep in range(2):                                    # second pass: page cache warm, kernels loaded
             torch.cuda.synchronize(); t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
                 evaluate.main(base + extra)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"{label:46s} {dt / a.n * 1e3:7.2f} ms per image  ({a.n / dt:7.1f} img/s)")
+        print(f"{label:66s} {dt / a.n * 1e3:7.2f} ms per image  ({a.n / dt:7.1f} img/s)", flush=True)
 
 
 if __name__ == "__main__":
