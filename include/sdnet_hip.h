@@ -130,7 +130,11 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
  * it, every thread starts from the default, so two engines in two threads of one process cannot disturb each other):
  * "tall_tiles_from" = number of 64x16-pixel tile blocks of a launch (B x (M+N) x tiles) from which the NMS runs on 64x32 tiles instead
  * (default 2688: batches of 56 and more at 128x128 maps; 1 = always, 1 << 30 = never).  The sizes returned by sd_decode_state_bytes /
- * _workspace_bytes cover both. */
+ * _workspace_bytes cover both.
+ * Knobs of sd_decode (same rules): "map_parallel_from" = number of 64x16-pixel tile blocks of a call from which sd_decode takes its
+ * map-parallel path -- tile pass without global atomics, one selector block per (image, map), one merge + association block per image;
+ * bit-identical results -- instead of the launch pair with one selector block per image (default 4096: batches of 4 and more at
+ * 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there. */
 int sd_decode_set_option(const char* name, int value);
 
 /* Explicit host wait for everything queued on `stream` (hipStreamSynchronize): the ONE blocking call of the decoder's host side,

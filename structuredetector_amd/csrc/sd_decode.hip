@@ -270,9 +270,9 @@ struct FlatSrc {
 constexpr int SPEC = 6;               // keys of a tile that travel INSIDE its 64-byte hand-off record (count word + 6 keys): one round trip
 constexpr int SPEC_TILES = 256;       // ... captured in LDS for the first SPEC_TILES tiles of the image (the others re-read them from the slots)
 
-template <int NT>
+template <int NT, bool COH = true>
 struct TiledSrc {
-    const uint64_t* base;   // slot 0 of the list's first tile (global; written by other workgroups of this launch -> sc1 loads)
+    const uint64_t* base;   // slot 0 of the list's first tile (global; COH: written by other workgroups of this launch -> sc1 loads)
     const int* cnt;         // LDS: candidates of each tile of the list
     const int* off;         // LDS: exclusive prefix of cnt within the list
     const uint64_t* spec;   // LDS: the first SPEC keys of the tiles that were loaded speculatively (image-wide tile index)
@@ -282,7 +282,7 @@ struct TiledSrc {
     __device__ __forceinline__ uint64_t key_at(int t, int j) const {
         const int ti = tile0 + t;
         if (j < SPEC && ti < SPEC_TILES) return spec[ti * SPEC + j];
-        return ldkey<true>(base + (int64_t)t * cap + j);
+        return ldkey<COH>(base + (int64_t)t * cap + j);
     }
     // candidate g of the list (0 <= g < n) -> (tile, slot): binary search in the exclusive prefix `off`
     __device__ __forceinline__ uint64_t key_of(int gidx) const {
@@ -328,6 +328,38 @@ struct LdsSrc {
     }
 };
 
+// Histogram increment with wave-level pre-aggregation.  NMS survivors are clamped sigmoids of a narrow score range: in the first radix
+// pass nearly all keys of a list share ONE digit (sign + exponent byte), and 64 lanes adding to one LDS word are 64 serialised atomics
+// per wave instruction (measured: ~20 us for a per-map selection of 1.4 k keys).  Two rounds of "the first active lane's digit: one
+// lane adds the population count of its group" take the dominant digits out; whatever is left (spread digits: distinct LDS words,
+// conflict-free) goes through plain atomics.  Called under divergent control flow: ballots see the active lanes only.
+__device__ __forceinline__ void hist_add(int* h, int digit) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(1);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (todo == 0ull) return;
+        const int leader = __ffsll((long long)todo) - 1;
+        const int d = __shfl(digit, leader);
+        const unsigned long long same = __ballot(digit == d) & todo;
+        if (lane == leader) atomicAdd(&h[d], __popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&h[digit], 1);
+}
+
+// Slot allocation from one LDS counter for the lanes with `take` set: one atomic per wave instead of one per lane.
+__device__ __forceinline__ int alloc_slot(int* counter, bool take) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return -1;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return take ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 // MSB-first 8-bit radix select of the k largest of the source's n unique keys into dst[0..np2k) (zero padded), then sorted
 // descending.  Two block barriers per pass (histograms double-buffered by pass parity, bucket scan by one wave); the passes stop
 // as soon as the boundary bucket is taken whole in EVERY team of the block (unique keys: usually after the score bytes) --
@@ -349,7 +381,7 @@ __device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64
         const int shift = pass * 8;
         if (!done)
             src.for_each(tid, [&](uint64_t key) {
-                if ((key & mask) == prefix) atomicAdd(&hcur[(int)((key >> shift) & 255ull)], 1);
+                if ((key & mask) == prefix) hist_add(hcur, (int)((key >> shift) & 255ull));
             });
         for (int i = tid; i < 256; i += NT) hnext[i] = 0;
         __syncthreads();
@@ -387,10 +419,8 @@ __device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64
     if (tid == 0) T.misc[2] = 0;
     __syncthreads();
     src.for_each(tid, [&](uint64_t key) {
-        if (key >= prefix) {
-            const int slot = atomicAdd(&T.misc[2], 1);
-            if (slot < np2k) dst[slot] = key;
-        }
+        const int slot = alloc_slot(&T.misc[2], key >= prefix);
+        if (slot >= 0 && slot < np2k) dst[slot] = key;
     });
     __syncthreads();
     if (np2k <= RANK_CAP) rank_sort_desc<NT>(T, dst, np2k);
@@ -555,10 +585,15 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         const int ind = pi_[tid];
         pf_ex = emb_b[ind]; pf_ey = emb_b[rm.e_sc + ind]; pf_ox = off_b[ind]; pf_oy = off_b[rm.o_sc + ind];
     }
+    __shared__ int n_live_s;                                    // 1 + the last anchor rank with score > conf
+    if (tid == 0) n_live_s = 0;
+    __syncthreads();
+    int last_live = 0;
     for (int a = tid; a < K; a += (int)blockDim.x) {
         const int ind = ai_[a];
         const int y = ind / w, x = ind - y * w;
         const float score = as_[a];
+        if (score > conf) last_live = a + 1;
         const float ax = (float)x + off_b[ind];                 // decoders.py:52
         const float ay = (float)y + off_b[rm.o_sc + ind];       // decoders.py:53
         const bool m = score > conf;                            // decoders.py:83
@@ -569,7 +604,9 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         L.anchor_smask[(int64_t)b * K + a] = m ? score : -1.0f; // decoders.py:84
         L.anchor_ind[(int64_t)b * K + a] = ind;
     }
+    if (last_live) atomicMax(&n_live_s, last_live);
     __syncthreads();
+    const int n_live = n_live_s;
     for (int p = tid; p < P; p += (int)blockDim.x) {
         const int ind = pi_[p];
         const int y = ind / w, x = ind - y * w;
@@ -581,13 +618,32 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         const float ox = px + ex, oy = py + ey;                 // decoders.py:69-70
         const bool m = score > conf;                            // decoders.py:78
         const float orx = m ? ox : -1e6f, ory = m ? oy : -1e6f; // decoders.py:80-81
-        float best = INFINITY;
+        // decoders.py:88-98, utils.py:433-435: d = sqrtf(fl(fl(dx*dx) + fl(dy*dy))), first minimum wins.  Anchors beyond rank n_live are all
+        // masked (they arrive sorted by score, so the live ones are a prefix); a masked anchor sits at (1e6, 1e6) (decoders.py:85-86) and a
+        // masked part starts from (-1e6, -1e6) (:80-81): neither comes within dist_px (<= the map side) of anything -- masked parts are
+        // unassigned without a scan, live parts scan the ranks below n_live only.  sqrtf is monotone: a sum that is not smaller than the best
+        // sum cannot give a smaller distance, so the square root is taken only for the few candidates that lower the running sum and the
+        // reference's strict `<` on the rounded distances decides there (equal rounded distances: the earlier anchor stays).
+        float best = INFINITY, best_s = INFINITY;
         int best_a = 0;
-        for (int a = 0; a < K; ++a) {                           // decoders.py:88-98, utils.py:433-435
-            const float dx = orx - posx[a], dy = ory - posy[a];
-            const float sx = dx * dx, sy = dy * dy;
-            const float d = sqrtf(sx + sy);
-            if (d < best) { best = d; best_a = a; }             // strict <: lowest anchor rank wins ties
+        if (m && dist_px < 1e5f) {
+            for (int a = 0; a < n_live; ++a) {
+                const float dx = orx - posx[a], dy = ory - posy[a];
+                const float sx = dx * dx, sy = dy * dy;
+                const float ss = sx + sy;
+                if (ss < best_s) {
+                    const float d = sqrtf(ss);
+                    best_s = ss;
+                    if (d < best) { best = d; best_a = a; }     // strict <: lowest anchor rank wins ties
+                }
+            }
+        } else {
+            for (int a = 0; a < K; ++a) {                       // (absurd thresholds: the reference's full scan)
+                const float dx = orx - posx[a], dy = ory - posy[a];
+                const float sx = dx * dx, sy = dy * dy;
+                const float d = sqrtf(sx + sy);
+                if (d < best) { best = d; best_a = a; }
+            }
         }
         float* po = L.part_out + ((int64_t)b * P + p) * 6;
         po[0] = px; po[1] = py; po[2] = score; po[3] = (float)pc_[p]; po[4] = ox; po[5] = oy;
@@ -622,6 +678,231 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t
     const int n = team ? n1 : n0, k = team ? P : K;
     const uint64_t* cand = team ? cand1 + (int64_t)b * N * hw : cand0 + (int64_t)b * M * hw;
     team_select_topk<SEL_THREADS>(T, FlatSrc<SEL_THREADS, false>{cand, n}, k, max(n0, n1), max(K, P), SORT_CAP);
+    fill_zero_slots<SEL_THREADS>(T, min(n, k), k);
+    float* os = team ? ps_ : as_;
+    int* oi = team ? pi_ : ai_;
+    int* oc = team ? pc_ : ac_;
+    for (int i = tid; i < k; i += SEL_THREADS) {
+        const uint64_t key = T.buf[i];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw;
+        os[i] = ord2f((uint32_t)(key >> 32)); oi[i] = flat - cls * hw; oc[i] = cls;
+    }
+    __syncthreads();
+    const PackedLayout L = packed_layout(packed, B, K, P);
+    block_group(b, K, P, w, conf, dist_px, rm, as_, ai_, ac_, ps_, pi_, pc_, posx, posy, L);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// MAP-PARALLEL decoder (sd_decode on large geometries: BASELINE configs[4], 1024x1024 inputs with 8 + 8 maps = 16 k tiles per batch
+// of 16).  What the two-launch pair above costs there (rocprofv3, profiles/r03_decode_variants.txt): k_nms_tile<1> 58 us -- its
+// 16 384 blocks append to 32 per-(image, group) counters, 512 same-address atomics each, serialised at the memory side -- and
+// k_select_group 55 us: ONE block per image radix-selects 11 k + 7 k candidates from global memory, ~10 us per pass of dependent
+// round trips, on 16 of 256 CUs.  Here:
+//   1. k_nms_slots<TH>: the tile pass without any global atomic: a tile owns TW x TH candidate slots and one count word (plain stores);
+//   2. k_select_map: one block per MAP (B x (M + N) blocks): the reference's own first stage -- per-class top-k (utils.py:451) -- on
+//      the map's tiles: counts -> prefix -> keys into LDS -> radix select; writes <= k keys per map;
+//   3. k_merge_group: one block per image: the reference's second stage (utils.py:459: top-k over the C x k stage-1 candidates,
+//      LDS-resident: M x K and N x P keys) + zero fill + association.
+// Two-stage top-k == global top-k as a set (any global top-k element is in its class's top-k), and the final order is the same
+// total order of the same keys: results are bit-identical to k_select_group's.
+// ---------------------------------------------------------------------------------------------
+template <int TH_>
+__global__ __launch_bounds__(256) void k_nms_slots(Group g0, Group g1, int h, int w, int tiles_x, int tiles, float min_score,
+                                                    uint64_t* __restrict__ cand, int* __restrict__ tile_cnt) {
+    constexpr int LH_ = TH_ + 2 * HALO, CAP_ = TW * TH_;
+    __shared__ float S[LH_][LW];
+    __shared__ float Hm[LH_][TW];
+    __shared__ int keep_n;
+    const int tid = threadIdx.x;
+    const int C = g0.C + g1.C;
+    const int64_t blk = blockIdx.x;                            // ((b * C) + m) * tiles + tile
+    const int tile = (int)(blk % tiles);
+    const int bm = (int)(blk / tiles);
+    const int b = bm / C, m = bm - b * C;
+    const int grp = (m >= g0.C) ? 1 : 0;
+    const Group g = grp ? g1 : g0;
+    const int c = grp ? m - g0.C : m;
+    const int tx0 = (tile % tiles_x) * TW;
+    const int ty0 = (tile / tiles_x) * TH_;
+    const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
+    uint64_t* mine = cand + blk * CAP_;
+    if (tid == 0) keep_n = 0;
+    constexpr int NLD = (LH_ * LW + 255) / 256;
+    float ld[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / LW, cc = i - r * LW;
+        const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
+        const bool ok = i < LH_ * LW && y >= 0 && y < h && x >= 0 && x < w;
+        ld[j] = plane[ok ? (int64_t)y * w + x : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / LW, cc = i - r * LW;
+        const int y = ty0 + r - HALO, x = tx0 + cc - HALO;
+        const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+        if (i < LH_ * LW) S[r][cc] = ok ? clamped_sigmoid(ld[j]) : -INFINITY;
+    }
+    __syncthreads();
+    for (int i = tid; i < LH_ * TW; i += 256) {
+        const int r = i / TW, cc = i - r * TW;
+        float mx = fmaxf(fmaxf(S[r][cc], S[r][cc + 1]), fmaxf(S[r][cc + 2], S[r][cc + 3]));
+        Hm[r][cc] = fmaxf(mx, S[r][cc + 4]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (TW * TH_) / 256; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / TW, cc = i - r * TW;
+        const int y = ty0 + r, x = tx0 + cc;
+        float mx = fmaxf(fmaxf(Hm[r][cc], Hm[r + 1][cc]), fmaxf(Hm[r + 2][cc], Hm[r + 3][cc]));
+        mx = fmaxf(mx, Hm[r + 4][cc]);
+        const float v = S[r + HALO][cc + HALO];
+        if ((y < h) && (x < w) && (v == mx) && (v >= min_score)) {            // `>=`: see k_nms_tile
+            const int slot = atomicAdd(&keep_n, 1);                            // LDS
+            mine[slot] = make_key(v, (uint32_t)(c * h * w + y * w + x));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) tile_cnt[blk] = keep_n;
+}
+
+constexpr int MAP_TILES_MAX = 1024;          // tiles of one map the per-map selector indexes in LDS (2048 x 2048 output maps at 64 x 32 tiles)
+
+// stage 1: one block per (image, map): top-k of the map's candidates (k = K for anchor maps, P for part maps), sorted, into
+// stage1[(b * C + m) * kmax ...] with the number of keys written in stage1_cnt[b * C + m]
+__global__ __launch_bounds__(SEL_THREADS) void k_select_map(const uint64_t* __restrict__ cand, const int* __restrict__ tile_cnt, int tiles,
+                                                             int cap, int M, int N, int K, int P, uint64_t* __restrict__ stage1,
+                                                             int* __restrict__ stage1_cnt) {
+    __shared__ uint64_t buf[SORT_CAP];
+    __shared__ uint64_t outb[SD_MAX_TOPK];
+    __shared__ int hist[2 * 256];
+    __shared__ int misc[4];
+    __shared__ int alive[2];
+    __shared__ int tcnt[MAP_TILES_MAX], toff[MAP_TILES_MAX + 1];
+    __shared__ int wave_tot[SEL_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int C = M + N;
+    const int bm = blockIdx.x, m = bm % C;
+    const int k = m < M ? K : P, kmax = max(K, P);
+    const int* cnt_g = tile_cnt + (int64_t)bm * tiles;
+    if (tid < 2) alive[tid] = 0;
+    {   // exclusive prefix of the map's tile counts: thread t owns a contiguous chunk (tiles <= MAP_TILES_MAX = 2 * SEL_THREADS)
+        const int chunk = (tiles + SEL_THREADS - 1) / SEL_THREADS;
+        const int lo = min(tid * chunk, tiles), hi = min(lo + chunk, tiles);
+        int sum = 0;
+        for (int t = lo; t < hi; ++t) { const int v = cnt_g[t]; tcnt[t] = v; sum += v; }
+        int incl = sum;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < wave; ++q) before += wave_tot[q];
+        int run = before + incl - sum;
+        for (int t = lo; t < hi; ++t) { toff[t] = run; run += tcnt[t]; }
+        if (tid == SEL_THREADS - 1) toff[tiles] = run;
+    }
+    __syncthreads();
+    const int n = toff[tiles];
+    const Team T{tid, buf, hist, misc, nullptr, outb, 0, alive};
+    // tile0 = SPEC_TILES: no tile of this source has speculative keys (that is the one-launch kernel's hand-off record)
+    const TiledSrc<SEL_THREADS, false> src{cand + (int64_t)bm * tiles * cap, tcnt, toff, nullptr, SPEC_TILES, tiles, n, cap};
+    team_select_topk<SEL_THREADS>(T, src, k, n, k, SORT_CAP);
+    const int take = min(n, k);
+    for (int i = tid; i < take; i += SEL_THREADS) stage1[(int64_t)bm * kmax + i] = buf[i];
+    if (tid == 0) stage1_cnt[bm] = take;
+}
+
+// stage-1 output of one group of maps as a key source: nseg segments of `stride` slots, cnt[s] of them valid
+template <int NT>
+struct SegSrc {
+    const uint64_t* p;      // global: stage1 + first map of the group
+    const int* cnt;         // LDS
+    const int* off;         // LDS: exclusive prefix of cnt
+    int nseg, stride, n;
+    template <class F>
+    __device__ __forceinline__ void for_each(int tid, F f) const {
+        const int total = nseg * stride;
+        for (int base = tid; base < total; base += 4 * NT) {
+            uint64_t key[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NT;
+                const int sgm = i / stride;
+                ok[u] = i < total && (i - sgm * stride) < cnt[min(sgm, nseg - 1)];
+                key[u] = ok[u] ? p[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) f(key[u]);
+        }
+    }
+    __device__ __forceinline__ void fill(int tid, uint64_t* buf, int np2) const {
+        for (int i = n + tid; i < np2; i += NT) buf[i] = 0ull;
+        const int total = nseg * stride;
+        for (int base = tid; base < total; base += 4 * NT) {
+            uint64_t key[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NT;
+                const int sgm = min(i / stride, nseg - 1);
+                const int j = i - sgm * stride;
+                at[u] = (i < total && j < cnt[sgm]) ? off[sgm] + j : -1;
+                key[u] = at[u] >= 0 ? p[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) buf[at[u]] = key[u];
+        }
+    }
+};
+
+// stage 2 + association: one block per image, anchors and parts side by side (two teams), like k_select_group
+__global__ __launch_bounds__(2 * SEL_THREADS) void k_merge_group(const uint64_t* __restrict__ stage1, const int* __restrict__ stage1_cnt,
+                                                                  int M, int N, int h, int w, int K, int P, float conf, float dist_px,
+                                                                  RegMaps rm, void* packed, int B) {
+    __shared__ uint64_t buf[2][SORT_CAP];
+    __shared__ int hist[2][2 * 256];
+    __shared__ int misc[2][4];
+    __shared__ int flags[2][SD_MAX_TOPK];
+    __shared__ int alive[2];
+    __shared__ float as_[SD_MAX_TOPK], ps_[SD_MAX_TOPK], posx[SD_MAX_TOPK], posy[SD_MAX_TOPK];
+    __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
+    __shared__ uint64_t outb[2][SD_MAX_TOPK];
+    __shared__ int scnt[64], soff[66];                         // M + N <= 64 maps (host-checked)
+    const int b = blockIdx.x, hw = h * w, C = M + N;
+    const int team = threadIdx.x >> 9, tid = threadIdx.x & (SEL_THREADS - 1);
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int m = 0; m < C; ++m) {
+            if (m == M) { soff[M] = run; run = 0; }            // soff[0..M): anchors, soff[M+1 .. C]: parts (slot M = anchor total)
+            const int v = stage1_cnt[b * C + m];
+            scnt[m] = v;
+            soff[m < M ? m : m + 1] = run;
+            run += v;
+        }
+        soff[C + 1] = run;
+        alive[0] = alive[1] = 0;
+    }
+    __syncthreads();
+    const int n0 = soff[M], n1 = soff[C + 1];
+    const int kmax = max(K, P);
+    const Team T{tid, buf[team], hist[team], misc[team], flags[team], outb[team], team, alive};
+    const int n = team ? n1 : n0, k = team ? P : K;
+    const SegSrc<SEL_THREADS> src{stage1 + ((int64_t)b * C + (team ? M : 0)) * kmax, scnt + (team ? M : 0), soff + (team ? M + 1 : 0),
+                                  team ? N : M, kmax, n};
+    team_select_topk<SEL_THREADS>(T, src, k, max(n0, n1), kmax, SORT_CAP);
     fill_zero_slots<SEL_THREADS>(T, min(n, k), k);
     float* os = team ? ps_ : as_;
     int* oi = team ? pi_ : ai_;
@@ -1086,9 +1367,43 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
     return 0;
 }
 
+// ---- map-parallel path of sd_decode (k_nms_slots -> k_select_map -> k_merge_group) ----
+struct MapWs {
+    uint64_t* cand;       // B * C * tiles * (TW * th) keys
+    int* tile_cnt;        // B * C * tiles
+    uint64_t* stage1;     // B * C * max(K, P) keys
+    int* stage1_cnt;      // B * C
+    size_t bytes;
+};
+static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int P) {
+    MapWs r;
+    char* p = reinterpret_cast<char*>(ws);
+    const size_t tiles = (size_t)cdiv(w, TW) * cdiv(h, th);
+    size_t off = 0;
+    r.cand = reinterpret_cast<uint64_t*>(p + off);     off += align_up((size_t)B * C * tiles * TW * th * 8, 256);
+    r.tile_cnt = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * C * tiles * sizeof(int), 256);
+    r.stage1 = reinterpret_cast<uint64_t*>(p + off);   off += align_up((size_t)B * C * std::max(K, P) * 8, 256);
+    r.stage1_cnt = reinterpret_cast<int*>(p + off);    off += align_up((size_t)B * C * sizeof(int), 256);
+    r.bytes = off;
+    return r;
+}
+// Tile blocks (at 64x16) from which sd_decode takes the map-parallel path, and its tile height (0 = by size); per host thread.
+// sd_decode_set_option("map_parallel_from" / "map_tile_height", n).
+static thread_local int g_map_parallel_from = 4096;
+static thread_local int g_map_tile_height = 0;
+static int map_tile_height(int64_t blocks16) {
+    if (g_map_tile_height == 16 || g_map_tile_height == 32) return g_map_tile_height;
+    return blocks16 >= 8192 ? 32 : 16;
+}
+static bool map_path_possible(int M, int N, int h, int w, int K, int P) {
+    return M + N <= 64 && (int64_t)cdiv(w, TW) * cdiv(h, 16) <= MAP_TILES_MAX && K <= SD_MAX_TOPK && P <= SD_MAX_TOPK;
+}
+
 size_t sd_decode_workspace_bytes(int B, int M, int N, int h, int w, int K, int P) {
-    (void)K; (void)P;
-    return carve(nullptr, B, M, N, h, w).bytes;
+    size_t need = carve(nullptr, B, M, N, h, w).bytes;
+    if (map_path_possible(M, N, h, w, K, P))           // either tile height (the option may change between sizing and launch)
+        need = std::max({need, carve_map(nullptr, B, M + N, h, w, 16, K, P).bytes, carve_map(nullptr, B, M + N, h, w, 32, K, P).bytes});
+    return need;
 }
 
 size_t sd_decode_packed_words(int B, int K, int P) { return (size_t)B * (6 * (size_t)K + 11 * (size_t)P + 1); }
@@ -1104,12 +1419,31 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     SD_REQUIRE(K > 0 && K <= SD_MAX_TOPK && (int64_t)K <= (int64_t)M * h * w, SD_ERR_INVALID, "sd_decode: max_objects=%d out of range", K);
     SD_REQUIRE(P > 0 && P <= SD_MAX_TOPK && (int64_t)P <= (int64_t)N * h * w, SD_ERR_INVALID, "sd_decode: max_parts=%d out of range", P);
     SD_REQUIRE(packed && workspace, SD_ERR_INVALID, "sd_decode: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
+    const int64_t blocks16 = (int64_t)B * (M + N) * cdiv(w, TW) * cdiv(h, 16);
+    if (map_path_possible(M, N, h, w, K, P) && blocks16 >= g_map_parallel_from && blocks16 < (1ll << 30)) {
+        const int th = map_tile_height(blocks16);
+        const MapWs mw = carve_map(workspace, B, M + N, h, w, th, K, P);
+        SD_REQUIRE(workspace_bytes >= mw.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, mw.bytes);
+        const int tiles_x = cdiv(w, TW), tiles = tiles_x * cdiv(h, th), C = M + N;
+        const float min_score = exact_topk ? 0.f : conf;
+        if (th == 32)
+            hipLaunchKernelGGL(k_nms_slots<32>, dim3((unsigned)((int64_t)B * C * tiles)), dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        else
+            hipLaunchKernelGGL(k_nms_slots<16>, dim3((unsigned)((int64_t)B * C * tiles)), dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        SD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_select_map, dim3(B * C), dim3(SEL_THREADS), 0, st, mw.cand, mw.tile_cnt, tiles, TW * th, M, N, K, P, mw.stage1, mw.stage1_cnt);
+        SD_LAUNCH_CHECK();
+        RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
+        hipLaunchKernelGGL(k_merge_group, dim3(B), dim3(2 * SEL_THREADS), 0, st, mw.stage1, mw.stage1_cnt, M, N, h, w, K, P, conf, dist_px, rm, packed, B);
+        SD_LAUNCH_CHECK();
+        return 0;
+    }
     const PeaksWs ws = carve(workspace, B, M, N, h, w);
     SD_REQUIRE(workspace_bytes >= ws.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, ws.bytes);
-    hipStream_t st = (hipStream_t)stream;
     SD_HIP(hipMemsetAsync(ws.counters, 0, (size_t)B * 2 * CNT_STRIDE * sizeof(int), st));
     const int tiles_x = cdiv(w, TW), tiles_y = cdiv(h, TH);
-    Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
     hipLaunchKernelGGL(k_nms_tile<1>, dim3(tiles_x * tiles_y, M + N, B), dim3(256), 0, st, g0, g1, h, w, tiles_x, 1, exact_topk ? 0.f : conf, (float*)nullptr,
                        ws.cand0, ws.cand1, ws.counters);
     SD_LAUNCH_CHECK();
@@ -1130,6 +1464,8 @@ static int next_pow2_host(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static thread_local int g_tall_tiles_from = 2688;      // per host thread, like the conv dispatch thresholds
 int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from = value; return 0; }
+    if (name && !strcmp(name, "map_parallel_from")) { g_map_parallel_from = value; return 0; }
+    if (name && !strcmp(name, "map_tile_height")) { g_map_tile_height = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }

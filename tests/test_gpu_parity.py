@@ -438,6 +438,54 @@ def test_decoder_thresholds_vs_golden(golden_dir):
     assert (r[:, 3] == float(c32)).sum() == 1
 
 
+# ------------------------------------------------------------------------------------------ map-parallel decoder
+@pytest.mark.parametrize("B,img,M,N,K,P,kind", [(4, 1024, 8, 8, 128, 512, "scene"), (2, 1024, 8, 8, 128, 512, "noise"), (64, 512, 2, 1, 20, 40, "scene"),
+                                                (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise")])
+def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, kind):
+    """sd_decode's map-parallel path (tile pass without global atomics -> one selector block per MAP = the reference's per-class top-k,
+    utils.py:451 -> one merge + association block per image = its second top-k, utils.py:459) against the launch pair with one selector
+    block per image: identical packed buffers bit for bit, both selection modes, both tile heights; lists that fit the ranking sort,
+    the LDS radix select, the global radix select (one plateau: 64 k candidates in one map) and K / P close to the 1024 limit."""
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.data import Decoder
+    rng = np.random.default_rng(B * 131 + img + K)
+    h = img // 4
+    if kind == "noise":
+        head = (2 * rng.standard_normal((B, M + N + 4, h, h))).astype(np.float32)
+    elif kind == "flat":
+        head = np.full((B, M + N + 4, h, h), -20.0, np.float32)
+        head[:, :, 5, 7] = 3.0
+    else:
+        n_max = 96 if K > 20 else 12
+        head = np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N, n_max // 2, n_max), M, N, K, P, 4.0, 0.1),
+                                             M, N, noise=0.3) for _ in range(B)])
+    if kind == "noise" and K == 128:
+        head[0, 1] = -20.0                                                                       # one whole map a plateau: 65 536 tied candidates
+    views = head_views(dev(head), M, N)
+    dec = Decoder(make_args(M, N, K, P))
+    lib = L.lib()
+    try:
+        for exact in (True, False):
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 1 << 30))
+            want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
+            for th in (16, 32, 0):
+                L.check(lib.sd_decode_set_option(b"map_tile_height", th))
+                got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+                assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th}"
+    finally:
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
+        L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
+    if kind == "scene":
+        t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
+        try:
+            got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=True, fused=False)
+        finally:
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
+        assert_decode_matches_oracle(dec.split_packed(got.cpu().numpy(), B, K, P), t, 0.5, SIG_TOL)
+
+
 # ------------------------------------------------------------------------------------------ one-launch decoder
 @pytest.mark.parametrize("B,img,M,N,K,P,kind", [(1, 512, 2, 1, 20, 40, "scene"), (64, 512, 2, 1, 20, 40, "scene"), (5, 256, 3, 2, 12, 24, "noise"),
                                                 (3, 1024, 8, 8, 128, 512, "scene"), (2, 512, 8, 8, 128, 512, "noise"), (2, 132, 1, 1, 3, 2, "flat")])

@@ -23,6 +23,12 @@ hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
 head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
                   0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
 outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
+import os  # noqa: E402
+from structuredetector_amd import _lib as L  # noqa: E402
+if os.environ.get("SD_MAP_FROM"):
+    L.check(L.lib().sd_decode_set_option(b"map_parallel_from", int(os.environ["SD_MAP_FROM"])))
+if os.environ.get("SD_MAP_TH"):
+    L.check(L.lib().sd_decode_set_option(b"map_tile_height", int(os.environ["SD_MAP_TH"])))
 for _ in range(100):
     dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact, fused=fused)
     torch.cuda.synchronize()
