@@ -134,8 +134,15 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
  * Knobs of sd_decode (same rules): "map_parallel_from" = number of 64x16-pixel tile blocks of a call from which sd_decode takes its
  * map-parallel path -- tile pass without global atomics, one selector block per (image, map), one merge + association block per image;
  * bit-identical results -- instead of the launch pair with one selector block per image (default 4096: batches of 4 and more at
- * 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there. */
+ * 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there;
+ * "map_scalar_nms" = 1 keeps the per-pixel-sigmoid tile kernel where the logit-domain one (w % 4 == 0, aligned planes) applies. */
 int sd_decode_set_option(const char* name, int value);
+
+/* Device self-check of the two properties the logit-domain NMS tile pass of sd_decode rests on, over ALL 2^32 fp32 bit patterns:
+ * out3[0] = violations of "clamped sigmoid is monotone non-decreasing", out3[1] = violations of the near-tie margin table
+ * (a logit further below the window maximum than the margin has a strictly smaller sigmoid), out3[2] = values visited
+ * (2^32 - NaNs = 4 278 190 082).  out3: three 64-bit words of device memory.  ~10 ms. */
+int sd_selfcheck_sigmoid(unsigned long long* out3, sd_stream_t stream);
 
 /* Explicit host wait for everything queued on `stream` (hipStreamSynchronize): the ONE blocking call of the decoder's host side,
  * after which a `packed` buffer that lives in pinned, device-mapped host memory may be read (decoders.py:103-139 reads its

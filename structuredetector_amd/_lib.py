@@ -67,6 +67,7 @@ _SIGNATURES = {
     "sd_decode_fused_supported": (c_int, [c_int] * 7),
     "sd_decode_fused_recommended": (c_int, [c_int] * 8),
     "sd_stream_synchronize": (c_int, [c_vp]),
+    "sd_selfcheck_sigmoid": (c_int, [c_vp, c_vp]),
     "sd_decode_fused_workspace_bytes": (c_size, [c_int] * 7),
     "sd_decode_fused": (c_int, _MAP * 4 + [c_int] * 7 + [c_float, c_float, c_int, c_vp, c_vp, c_size, c_vp, c_size, c_vp]),
     "sd_decode_group": (c_int, [c_vp] * 6 + _MAP * 2 + [c_int] * 5 + [c_float, c_float, c_vp, c_vp]),

@@ -27,6 +27,13 @@ __device__ __forceinline__ uint64_t make_key(float v, uint32_t flat) {
     return ((uint64_t)f2ord(v) << 32) | (uint64_t)(~flat);
 }
 
+#ifdef SD_DECODE_TRACE
+// timing experiment (not in product builds; reported by sd_build_flags bit 3): 100 MHz timestamps of the stages of k_decode_fused
+__device__ unsigned long long sd_trace[8192];
+#define SD_TRACE(slot) do { if (threadIdx.x == 0 && (slot) >= 0 && (slot) < 8192) sd_trace[(slot)] = wall_clock64(); } while (0)
+#else
+#define SD_TRACE(slot) do { } while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // Kernel 1: tile NMS.  One 256-thread block per 64x16 output tile of one map; the (64+4)x(16+4)
 // neighbourhood is staged once in LDS as clamped-sigmoid values, 5-max is separable
@@ -235,6 +242,39 @@ __device__ void rank_sort_desc(const Team& T, uint64_t* buf, int np2) {
     __syncthreads();
 }
 
+// Descending bitonic sort of buf[0..np2), np2 <= NT, ONE key per thread held in a register: the 64-lane stages exchange through
+// cross-lane shuffles, only compare distances >= 64 go through LDS (two block barriers each).  The LDS network above needs a dependent
+// LDS round trip + wait per stage (45 stages for 512 keys: 9.9 us measured in the per-image merge); here 512 keys take 39 shuffle
+// stages + 6 LDS stages.  Same compare-exchange network, same result.  Every thread of the block runs the same barrier sequence
+// (np2 must be block-uniform: teams pass the common size).
+template <int NT>
+__device__ void reg_bitonic_desc(const Team& T, uint64_t* buf, int np2) {
+    const int i = T.tid;
+    const bool in = i < np2;
+    uint64_t key = in ? buf[i] : 0ull;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            uint64_t other;
+            if (j < 64) {
+                other = __shfl_xor((unsigned long long)key, j);
+            } else {
+                __syncthreads();                          // everybody has read the previous exchange
+                if (in) buf[i] = key;
+                __syncthreads();
+                other = in ? buf[i ^ j] : 0ull;
+            }
+            const bool lower = (i & j) == 0;              // this thread holds the lower index of the pair (i, i ^ j)
+            const uint64_t lo = lower ? key : other, hi = lower ? other : key;
+            const int li = lower ? i : (i ^ j);
+            const bool swap = (lo < hi) == ((li & k) == 0);
+            key = (lower == swap) ? hi : lo;              // lower index takes hi when swapped, upper takes lo
+        }
+    }
+    __syncthreads();
+    if (in) buf[i] = key;
+    __syncthreads();
+}
+
 // keys the `out` buffer of a team must hold for selections of up to k_max keys
 __host__ __device__ constexpr int out_keys(int np2k) { return np2k <= RANK_CAP ? 2 * np2k : np2k; }
 
@@ -375,6 +415,8 @@ __device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64
     for (int i = tid; i < 512; i += NT) T.hist[i] = 0;          // double-buffered histogram
     if (tid == 0) T.alive[T.team] = done ? 0 : 1;
     __syncthreads();
+    [[maybe_unused]] const int rtrace = (blockIdx.x == 0 && T.team == 0) ? 6300 : -100;       // (trace builds: radix select of block 0, team 0)
+    SD_TRACE(rtrace + 0);
     for (int pass = 7; pass >= 0; --pass) {
         int* hcur = T.hist + (pass & 1) * 256;
         int* hnext = T.hist + ((pass & 1) ^ 1) * 256;
@@ -412,8 +454,10 @@ __device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64
             remaining = T.misc[1];
             done = T.alive[T.team] == 0;
         }
+        SD_TRACE(rtrace + 8 - pass);
         if ((T.alive[0] | T.alive[1]) == 0) break;
     }
+    SD_TRACE(rtrace + 10);
     // keys are unique, so exactly min(k, n) keys are >= prefix
     for (int i = tid; i < np2k; i += NT) dst[i] = 0ull;
     if (tid == 0) T.misc[2] = 0;
@@ -423,8 +467,11 @@ __device__ void radix_select_sorted(const Team& T, const Src& src, int k, uint64
         if (slot >= 0 && slot < np2k) dst[slot] = key;
     });
     __syncthreads();
+    SD_TRACE(rtrace + 11);
     if (np2k <= RANK_CAP) rank_sort_desc<NT>(T, dst, np2k);
+    else if (np2k <= NT) reg_bitonic_desc<NT>(T, dst, np2k);
     else bitonic_desc<NT>(T, dst, np2k);
+    SD_TRACE(rtrace + 12);
 }
 
 // Exact top-k of the source's n unique keys (descending) into T.buf[0..k).  The path depends only on (n_max, k_max, cap), the
@@ -703,8 +750,11 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_select_group(const uint64_t
 //   1. k_nms_slots<TH>: the tile pass without any global atomic: a tile owns TW x TH candidate slots and one count word (plain stores);
 //   2. k_select_map: one block per MAP (B x (M + N) blocks): the reference's own first stage -- per-class top-k (utils.py:451) -- on
 //      the map's tiles: counts -> prefix -> keys into LDS -> radix select; writes <= k keys per map;
-//   3. k_merge_group: one block per image: the reference's second stage (utils.py:459: top-k over the C x k stage-1 candidates,
-//      LDS-resident: M x K and N x P keys) + zero fill + association.
+//   3. k_rank_maps: the reference's second stage (utils.py:459: top-k over the C x k stage-1 candidates) WITHOUT a second selection:
+//      the stage-1 lists are sorted, a key's final rank is a sum of binary searches -- one block per map again;
+//   4. k_group_wide: zero slots + association, 64 parts per block.
+// (A first version merged and associated in ONE block per image: 41 us for 16 images -- in-kernel timestamps: 22 us of radix select +
+// bitonic sort of 512 keys, 18-25 us for the K x P distance scan on one CU.)
 // Two-stage top-k == global top-k as a set (any global top-k element is in its class's top-k), and the final order is the same
 // total order of the same keys: results are bit-identical to k_select_group's.
 // ---------------------------------------------------------------------------------------------
@@ -771,6 +821,144 @@ __global__ __launch_bounds__(256) void k_nms_slots(Group g0, Group g1, int h, in
     if (tid == 0) tile_cnt[blk] = keep_n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tile pass in the LOGIT domain (k_nms_slots_v): k_nms_slots is VALU-bound -- ~80 instructions per pixel, a third of them the exact
+// sigmoid (expf + IEEE division) of every staged pixel, the rest scalar index arithmetic -- at 48 us for 67 MB (1.4 TB/s).  The clamped
+// sigmoid is monotone non-decreasing in fp32 (checked over ALL 2^32 bit patterns on the device: sd_selfcheck_sigmoid), so
+//     max over the window of sigma(x_j) == sigma(max over the window of x_j)        and
+//     pixel c survives  <=>  sigma(x_c) == sigma(m),   m = the window's maximum logit:
+//   * x_c == m: survives, no sigmoid needed for the decision;
+//   * x_c <  m - margin(m): sigma(x_c) < sigma(m) strictly (the margin table is part of the same exhaustive check): suppressed;
+//   * in between (a near-tie, or a saturated window: sigma clamps at both ends, whole plateaus survive): the two sigmoids decide.
+// Sigmoids are evaluated only for the compacted survivors (~4 % of the pixels), whose score the key needs anyway.  Staging, row maxima
+// and column maxima work on float4 (16-byte global loads, ds_read / ds_write_b128): one index computation per four pixels.
+// Needs w % 4 == 0 and 16-byte aligned planes (map_view gives them); k_nms_slots stays as the general kernel.  Same survivors, same
+// keys as k_nms_slots.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nms_margin(float m) {
+    return m < 4.0f ? (m > -13.7f ? 1e-4f : INFINITY) : (m < 8.0f ? 4e-3f : (m < 11.0f ? 0.1f : (m < 13.0f ? 1.0f : INFINITY)));
+}
+__device__ __forceinline__ float max5(float a, float b, float c, float d, float e) { return fmaxf(fmaxf(fmaxf(a, b), c), fmaxf(d, e)); }
+
+template <int TH_>
+__global__ __launch_bounds__(256) void k_nms_slots_v(Group g0, Group g1, int h, int w, int tiles_x, int tiles, float min_score,
+                                                      uint64_t* __restrict__ cand, int* __restrict__ tile_cnt) {
+    constexpr int LH_ = TH_ + 2 * HALO, CAP_ = TW * TH_;
+    constexpr int SV = (TW + 8) / 4, OV = TW / 4;              // float4 per staged row (columns tx0 - 4 .. tx0 + TW + 3) / per output row
+    __shared__ float4 S[LH_][SV];
+    __shared__ float4 Hm[LH_][OV];
+    __shared__ unsigned short list[CAP_];                       // survivors / near-ties: local pixel index | near << 15
+    __shared__ int keep_n, out_n;
+    const int tid = threadIdx.x;
+    const int C = g0.C + g1.C;
+    const int64_t blk = blockIdx.x;                            // ((b * C) + m) * tiles + tile
+    const int tile = (int)(blk % tiles);
+    const int bm = (int)(blk / tiles);
+    const int b = bm / C, m = bm - b * C;
+    const int grp = (m >= g0.C) ? 1 : 0;
+    const Group g = grp ? g1 : g0;
+    const int c = grp ? m - g0.C : m;
+    const int tx0 = (tile % tiles_x) * TW;
+    const int ty0 = (tile / tiles_x) * TH_;
+    const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
+    uint64_t* mine = cand + blk * CAP_;
+    if (tid == 0) { keep_n = 0; out_n = 0; }
+    constexpr int NLD = (LH_ * SV + 255) / 256;
+    float4 ld[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int u = tid + j * 256;
+        const int r = u / SV, q = u - r * SV;
+        const int y = ty0 + r - HALO, x0 = tx0 - 4 + 4 * q;
+        const bool ok = u < LH_ * SV && y >= 0 && y < h && x0 >= 0 && x0 < w;
+        ld[j] = *reinterpret_cast<const float4*>(plane + (ok ? (int64_t)y * w + x0 : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int u = tid + j * 256;
+        const int r = u / SV, q = u - r * SV;
+        const int y = ty0 + r - HALO, x0 = tx0 - 4 + 4 * q;
+        const bool ok = y >= 0 && y < h && x0 >= 0 && x0 < w;
+        if (u < LH_ * SV) S[r][q] = ok ? ld[j] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    __syncthreads();
+    for (int v = tid; v < LH_ * OV; v += 256) {                 // horizontal 5-maxima of output columns 4q .. 4q + 3
+        const int r = v / OV, q = v - r * OV;
+        const float4 a = S[r][q], bq = S[r][q + 1], cq = S[r][q + 2];       // staged columns 4q .. 4q + 11 = output columns 4q - 4 .. 4q + 7
+        Hm[r][q] = make_float4(max5(a.z, a.w, bq.x, bq.y, bq.z), max5(a.w, bq.x, bq.y, bq.z, bq.w), max5(bq.x, bq.y, bq.z, bq.w, cq.x),
+                               max5(bq.y, bq.z, bq.w, cq.x, cq.y));
+    }
+    __syncthreads();
+    for (int v = tid; v < TH_ * OV; v += 256) {
+        const int r = v / OV, q = v - r * OV;
+        const float4 h0 = Hm[r][q], h1 = Hm[r + 1][q], h2 = Hm[r + 2][q], h3 = Hm[r + 3][q], h4 = Hm[r + 4][q];
+        const float4 xc = S[r + HALO][q + 1];
+        const float mx[4] = {max5(h0.x, h1.x, h2.x, h3.x, h4.x), max5(h0.y, h1.y, h2.y, h3.y, h4.y), max5(h0.z, h1.z, h2.z, h3.z, h4.z),
+                             max5(h0.w, h1.w, h2.w, h3.w, h4.w)};
+        const float xv[4] = {xc.x, xc.y, xc.z, xc.w};
+        const bool row_in = ty0 + r < h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mg = nms_margin(mx[e]);
+            const bool top = xv[e] == mx[e];
+            const bool near = !top && (mg == INFINITY || xv[e] >= mx[e] - mg);
+            if (row_in && tx0 + 4 * q + e < w && (top || near)) {
+                const int slot = atomicAdd(&keep_n, 1);                        // LDS
+                list[slot] = (unsigned short)((r * TW + 4 * q + e) | (near ? 0x8000 : 0));
+            }
+        }
+    }
+    __syncthreads();
+    const int n = keep_n;
+    const float* Sf = reinterpret_cast<const float*>(&S[0][0]);
+    const float* Hf = reinterpret_cast<const float*>(&Hm[0][0]);
+    for (int i = tid; i < n; i += 256) {
+        const int ent = list[i];
+        const int li = ent & 0x7fff, r = li / TW, cx = li - r * TW;
+        const float x = Sf[(r + HALO) * (SV * 4) + cx + 4];
+        const float v = clamped_sigmoid(x);
+        bool ok = v >= min_score;                                              // `>=`: see k_nms_tile
+        if (ok && (ent & 0x8000)) {                                            // near-tie / saturated window: the reference's own compare
+            const float mxl = max5(Hf[r * TW + cx], Hf[(r + 1) * TW + cx], Hf[(r + 2) * TW + cx], Hf[(r + 3) * TW + cx], Hf[(r + 4) * TW + cx]);
+            ok = clamped_sigmoid(mxl) == v;
+        }
+        if (ok) {
+            const int slot = atomicAdd(&out_n, 1);
+            mine[slot] = make_key(v, (uint32_t)(c * h * w + (ty0 + r) * w + tx0 + cx));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) tile_cnt[blk] = out_n;
+}
+
+// Exhaustive check of the two properties k_nms_slots_v rests on, over every fp32 bit pattern in numeric order o -> ord2f(o):
+//   out[0] += 1 for every consecutive pair with clamped_sigmoid(next) < clamped_sigmoid(this)             (monotonicity)
+//   out[1] += 1 for every m with a finite margin where the largest x < m - margin(m) has sigma(x) >= sigma(m) (margin table)
+//   out[2] += number of values visited
+__global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* out) {
+    unsigned long long bad_mono = 0, bad_margin = 0, seen = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x; o < (1ull << 32); o += stride) {
+        const float x = ord2f((uint32_t)o);
+        if (x != x) continue;
+        ++seen;
+        const float sx = clamped_sigmoid(x);
+        if (o + 1 < (1ull << 32)) {
+            const float y = ord2f((uint32_t)(o + 1));
+            if (y == y && clamped_sigmoid(y) < sx) ++bad_mono;
+        }
+        const float mg = nms_margin(x);
+        if (mg != INFINITY) {
+            const float t = x - mg;
+            const float below = ord2f(f2ord(t) - 1u);
+            if (!(clamped_sigmoid(below) < sx)) ++bad_margin;
+        }
+    }
+    if (bad_mono) atomicAdd(&out[0], bad_mono);
+    if (bad_margin) atomicAdd(&out[1], bad_margin);
+    atomicAdd(&out[2], seen);
+}
+
 constexpr int MAP_TILES_MAX = 1024;          // tiles of one map the per-map selector indexes in LDS (2048 x 2048 output maps at 64 x 32 tiles)
 
 // stage 1: one block per (image, map): top-k of the map's candidates (k = K for anchor maps, P for part maps), sorted, into
@@ -790,6 +978,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_map(const uint64_t* __re
     const int bm = blockIdx.x, m = bm % C;
     const int k = m < M ? K : P, kmax = max(K, P);
     const int* cnt_g = tile_cnt + (int64_t)bm * tiles;
+    [[maybe_unused]] const int trace0 = bm == 0 ? 6100 : (bm == M ? 6200 : -100);
+    SD_TRACE(trace0 + 0);
     if (tid < 2) alive[tid] = 0;
     {   // exclusive prefix of the map's tile counts: thread t owns a contiguous chunk (tiles <= MAP_TILES_MAX = 2 * SEL_THREADS)
         const int chunk = (tiles + SEL_THREADS - 1) / SEL_THREADS;
@@ -816,108 +1006,195 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_map(const uint64_t* __re
     const Team T{tid, buf, hist, misc, nullptr, outb, 0, alive};
     // tile0 = SPEC_TILES: no tile of this source has speculative keys (that is the one-launch kernel's hand-off record)
     const TiledSrc<SEL_THREADS, false> src{cand + (int64_t)bm * tiles * cap, tcnt, toff, nullptr, SPEC_TILES, tiles, n, cap};
+    SD_TRACE(trace0 + 1);
     team_select_topk<SEL_THREADS>(T, src, k, n, k, SORT_CAP);
+    SD_TRACE(trace0 + 2);
     const int take = min(n, k);
     for (int i = tid; i < take; i += SEL_THREADS) stage1[(int64_t)bm * kmax + i] = buf[i];
     if (tid == 0) stage1_cnt[bm] = take;
+    SD_TRACE(trace0 + 3);
 }
 
-// stage-1 output of one group of maps as a key source: nseg segments of `stride` slots, cnt[s] of them valid
-template <int NT>
-struct SegSrc {
-    const uint64_t* p;      // global: stage1 + first map of the group
-    const int* cnt;         // LDS
-    const int* off;         // LDS: exclusive prefix of cnt
-    int nseg, stride, n;
-    template <class F>
-    __device__ __forceinline__ void for_each(int tid, F f) const {
-        const int total = nseg * stride;
-        for (int base = tid; base < total; base += 4 * NT) {
-            uint64_t key[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * NT;
-                const int sgm = i / stride;
-                ok[u] = i < total && (i - sgm * stride) < cnt[min(sgm, nseg - 1)];
-                key[u] = ok[u] ? p[i] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (ok[u]) f(key[u]);
-        }
-    }
-    __device__ __forceinline__ void fill(int tid, uint64_t* buf, int np2) const {
-        for (int i = n + tid; i < np2; i += NT) buf[i] = 0ull;
-        const int total = nseg * stride;
-        for (int base = tid; base < total; base += 4 * NT) {
-            uint64_t key[4];
-            int at[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * NT;
-                const int sgm = min(i / stride, nseg - 1);
-                const int j = i - sgm * stride;
-                at[u] = (i < total && j < cnt[sgm]) ? off[sgm] + j : -1;
-                key[u] = at[u] >= 0 ? p[i] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (at[u] >= 0) buf[at[u]] = key[u];
-        }
-    }
-};
-
-// stage 2 + association: one block per image, anchors and parts side by side (two teams), like k_select_group
-__global__ __launch_bounds__(2 * SEL_THREADS) void k_merge_group(const uint64_t* __restrict__ stage1, const int* __restrict__ stage1_cnt,
-                                                                  int M, int N, int h, int w, int K, int P, float conf, float dist_px,
-                                                                  RegMaps rm, void* packed, int B) {
-    __shared__ uint64_t buf[2][SORT_CAP];
-    __shared__ int hist[2][2 * 256];
-    __shared__ int misc[2][4];
-    __shared__ int flags[2][SD_MAX_TOPK];
-    __shared__ int alive[2];
-    __shared__ float as_[SD_MAX_TOPK], ps_[SD_MAX_TOPK], posx[SD_MAX_TOPK], posy[SD_MAX_TOPK];
-    __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
-    __shared__ uint64_t outb[2][SD_MAX_TOPK];
-    __shared__ int scnt[64], soff[66];                         // M + N <= 64 maps (host-checked)
-    const int b = blockIdx.x, hw = h * w, C = M + N;
-    const int team = threadIdx.x >> 9, tid = threadIdx.x & (SEL_THREADS - 1);
-    if (threadIdx.x == 0) {
+// stage 2: one block per (image, map) again.  The stage-1 lists are sorted, so the final rank of a key is its position in its own
+// list plus, for every other list of its group, the number of keys there that beat it (binary search; keys are unique): no radix
+// select, no sort, and B x (M + N) blocks instead of one block per image.  Keys with rank < k land at final[(b * 2 + group) * kmax + rank]
+// -- the group's top-k in the reference's order (utils.py:459) -- and final_cnt[b * 2 + group] = min(candidates of the group, k).
+constexpr int RANK_KEYS_MAX = 8192;         // keys of one group (maps x k) held in LDS by k_rank_maps: 64 KB
+__global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __restrict__ stage1, const int* __restrict__ stage1_cnt,
+                                                            int M, int N, int K, int P, uint64_t* __restrict__ final_keys,
+                                                            int* __restrict__ final_cnt) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int scnt[64], soff[65];
+    const int tid = threadIdx.x;
+    const int C = M + N, kmax = max(K, P);
+    const int bm = blockIdx.x, b = bm / C, m = bm - b * C;
+    const int grp = m >= M ? 1 : 0;
+    const int nl = grp ? N : M, first = grp ? M : 0, own = m - first, k = grp ? P : K;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);        // the group's lists back to back (list l at soff[l])
+    if (tid == 0) {
         int run = 0;
-        for (int m = 0; m < C; ++m) {
-            if (m == M) { soff[M] = run; run = 0; }            // soff[0..M): anchors, soff[M+1 .. C]: parts (slot M = anchor total)
-            const int v = stage1_cnt[b * C + m];
-            scnt[m] = v;
-            soff[m < M ? m : m + 1] = run;
-            run += v;
+        for (int l = 0; l < nl; ++l) { const int v = stage1_cnt[b * C + first + l]; scnt[l] = v; soff[l] = run; run += v; }
+        soff[nl] = run;
+    }
+    __syncthreads();
+    const uint64_t* src = stage1 + ((int64_t)b * C + first) * kmax;
+    for (int l = 0; l < nl; ++l)
+        for (int i = tid; i < scnt[l]; i += SEL_THREADS) keys[soff[l] + i] = src[(int64_t)l * kmax + i];
+    __syncthreads();
+    const int mine = scnt[own];
+    for (int i = tid; i < mine; i += SEL_THREADS) {
+        const uint64_t key = keys[soff[own] + i];
+        int rank = i;
+        for (int l = 0; l < nl; ++l) {
+            if (l == own) continue;
+            const uint64_t* lst = keys + soff[l];
+            int lo = 0, hi = scnt[l];                           // first position whose key is smaller than `key` (descending list)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (lst[mid] > key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
         }
-        soff[C + 1] = run;
-        alive[0] = alive[1] = 0;
+        if (rank < k) final_keys[((int64_t)b * 2 + grp) * kmax + rank] = key;
     }
-    __syncthreads();
-    const int n0 = soff[M], n1 = soff[C + 1];
-    const int kmax = max(K, P);
-    const Team T{tid, buf[team], hist[team], misc[team], flags[team], outb[team], team, alive};
-    const int n = team ? n1 : n0, k = team ? P : K;
-    const SegSrc<SEL_THREADS> src{stage1 + ((int64_t)b * C + (team ? M : 0)) * kmax, scnt + (team ? M : 0), soff + (team ? M + 1 : 0),
-                                  team ? N : M, kmax, n};
-    team_select_topk<SEL_THREADS>(T, src, k, max(n0, n1), kmax, SORT_CAP);
-    fill_zero_slots<SEL_THREADS>(T, min(n, k), k);
-    float* os = team ? ps_ : as_;
-    int* oi = team ? pi_ : ai_;
-    int* oc = team ? pc_ : ac_;
-    for (int i = tid; i < k; i += SEL_THREADS) {
-        const uint64_t key = T.buf[i];
-        const uint32_t flat = ~(uint32_t)key;
-        const int cls = flat / hw;
-        os[i] = ord2f((uint32_t)(key >> 32)); oi[i] = flat - cls * hw; oc[i] = cls;
-    }
-    __syncthreads();
-    const PackedLayout L = packed_layout(packed, B, K, P);
-    block_group(b, K, P, w, conf, dist_px, rm, as_, ai_, ac_, ps_, pi_, pc_, posx, posy, L);
+    if (own == 0 && tid == 0) final_cnt[b * 2 + grp] = min(soff[nl], k);
 }
 
+// stage 3: association, GROUP_PARTS parts per block (grid: B x ceil(P / GROUP_PARTS)), four lanes per part.  Every block decodes the
+// image's K anchors (zero slots filled as fill_zero_slots does) and refines them (K gathers); block 0 of an image also writes the
+// anchor outputs.  A part's four lanes scan interleaved quarters of the anchors with score > conf (a prefix: the list is sorted) and
+// combine by (distance, anchor rank): the reference's first minimum over the rounded distances (decoders.py:88-100).
+constexpr int GROUP_PARTS = 64, GROUP_THREADS = 256;
+// keys[npos..k) := the zero slots of the reference's top-k on a map whose suppressed pixels are exactly 0 (utils.py:451): the lowest
+// class-major flat indices that are not peaks, ascending (same rule as fill_zero_slots).  Block-wide, GROUP_THREADS threads; `flags` has
+// k ints.  Only runs when the list has fewer than k peaks; always executes the same three barriers.
+__device__ void fill_zero_keys(uint64_t* keys, int npos, int k, int* flags, int* wave_tot) {
+    const int tid = threadIdx.x;
+    const bool need = npos < k;
+    if (need)
+        for (int f = tid; f < k; f += GROUP_THREADS) {
+            int used = 0;
+            for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~keys[j]) == (uint32_t)f);
+            flags[f] = used ? 0 : 1;
+        }
+    __syncthreads();
+    const int per = (k + GROUP_THREADS - 1) / GROUP_THREADS;     // thread t owns flat indices [t * per, t * per + per)
+    const int lo = min(tid * per, k), hi = min(lo + per, k);
+    int sum = 0;
+    if (need)
+        for (int f = lo; f < hi; ++f) sum += flags[f];
+    int incl = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (need) {
+        int run = incl - sum;
+        for (int q = 0; q < wave; ++q) run += wave_tot[q];
+        for (int f = lo; f < hi; ++f)
+            if (flags[f]) {
+                if (npos + run < k) keys[npos + run] = make_key(0.0f, (uint32_t)f);
+                ++run;
+            }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __restrict__ final_keys, const int* __restrict__ final_cnt,
+                                                               int h, int w, int K, int P, float conf, float dist_px, RegMaps rm,
+                                                               void* packed, int B) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* akeys = reinterpret_cast<uint64_t*>(smem);                 // [K]
+    uint64_t* pkeys = akeys + K;                                          // [P]
+    float* posx = reinterpret_cast<float*>(pkeys + P);                    // [K]
+    float* posy = posx + K;                                               // [K]
+    int* flags = reinterpret_cast<int*>(posy + K);                        // [max(K, P)]
+    __shared__ int n_live_s;
+    __shared__ int wave_tot[GROUP_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int hw = h * w, kmax = max(K, P);
+    const int na = final_cnt[b * 2 + 0], np = final_cnt[b * 2 + 1];
+    const uint64_t* fa = final_keys + ((int64_t)b * 2 + 0) * kmax;
+    const uint64_t* fp = final_keys + ((int64_t)b * 2 + 1) * kmax;
+    if (tid == 0) n_live_s = 0;
+    for (int i = tid; i < na; i += GROUP_THREADS) akeys[i] = fa[i];
+    for (int i = tid; i < np; i += GROUP_THREADS) pkeys[i] = fp[i];
+    __syncthreads();
+    fill_zero_keys(akeys, na, K, flags, wave_tot);
+    fill_zero_keys(pkeys, np, P, flags, wave_tot);
+    const PackedLayout L = packed_layout(packed, B, K, P);
+    const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
+    const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
+    int last_live = 0;
+    for (int a = tid; a < K; a += GROUP_THREADS) {
+        const uint64_t key = akeys[a];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw, ind = flat - cls * hw;
+        const int y = ind / w, x = ind - y * w;
+        const float score = ord2f((uint32_t)(key >> 32));
+        const float ax = (float)x + off_b[ind];                 // decoders.py:52
+        const float ay = (float)y + off_b[rm.o_sc + ind];       // decoders.py:53
+        const bool mk = score > conf;                           // decoders.py:83
+        if (mk) last_live = a + 1;
+        posx[a] = mk ? ax : 1e6f;                               // decoders.py:85-86
+        posy[a] = mk ? ay : 1e6f;
+        if (chunk == 0) {
+            float* ao = L.anchor_out + ((int64_t)b * K + a) * 4;
+            ao[0] = ax; ao[1] = ay; ao[2] = score; ao[3] = (float)cls;
+            L.anchor_smask[(int64_t)b * K + a] = mk ? score : -1.0f; // decoders.py:84
+            L.anchor_ind[(int64_t)b * K + a] = ind;
+        }
+    }
+    if (last_live) atomicMax(&n_live_s, last_live);
+    __syncthreads();
+    // anchors beyond the last live rank are all masked: at (1e6, 1e6) they are never within dist_px of a live part (see block_group)
+    const int n_scan = dist_px < 1e5f ? n_live_s : K;
+    const int p = chunk * GROUP_PARTS + (tid >> 2), q = tid & 3;
+    if (p < P) {
+        const uint64_t key = pkeys[p];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw, ind = flat - cls * hw;
+        const int y = ind / w, x = ind - y * w;
+        const float score = ord2f((uint32_t)(key >> 32));
+        const float ex = emb_b[ind], ey = emb_b[rm.e_sc + ind];                          // decoders.py:66
+        const float px = (float)x + off_b[ind];                                         // decoders.py:67
+        const float py = (float)y + off_b[rm.o_sc + ind];                               // decoders.py:68
+        const float ox = px + ex, oy = py + ey;                 // decoders.py:69-70
+        const bool mk = score > conf;                           // decoders.py:78
+        const float orx = mk ? ox : -1e6f, ory = mk ? oy : -1e6f; // decoders.py:80-81
+        float best = INFINITY;
+        int best_a = 0x7fffffff;
+        if (mk || dist_px >= 1e5f) {
+            for (int a = q; a < n_scan; a += 4) {               // decoders.py:88-98, utils.py:433-435
+                const float dx = orx - posx[a], dy = ory - posy[a];
+                const float sx = dx * dx, sy = dy * dy;
+                const float d = sqrtf(sx + sy);
+                if (d < best) { best = d; best_a = a; }         // ascending a within the lane: first minimum
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {                       // the part's four lanes: minimum by (distance, anchor rank)
+            const float od = __shfl_xor(best, o);
+            const int oa = __shfl_xor(best_a, o);
+            if (od < best || (od == best && oa < best_a)) { best = od; best_a = oa; }
+        }
+        if (q == 0) {
+            float* po = L.part_out + ((int64_t)b * P + p) * 6;
+            po[0] = px; po[1] = py; po[2] = score; po[3] = (float)cls; po[4] = ox; po[5] = oy;
+            L.part_emb[((int64_t)b * P + p) * 2 + 0] = ex;
+            L.part_emb[((int64_t)b * P + p) * 2 + 1] = ey;
+            L.part_smask[(int64_t)b * P + p] = mk ? score : -1.0f;   // decoders.py:79
+            L.part_ind[(int64_t)b * P + p] = ind;
+            L.assign[(int64_t)b * P + p] = (best < dist_px) ? best_a : -1;   // decoders.py:100
+        }
+    }
+    if (chunk == 0 && tid == 0) L.status[b] = 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // ONE-launch decoder (sd_decode_fused): NMS tile blocks + one SELECTOR block per image in the same grid.  bs = 1 inference is
@@ -939,13 +1216,6 @@ __global__ __launch_bounds__(2 * SEL_THREADS) void k_merge_group(const uint64_t*
 // 256 threads; dynamic LDS sized by the host from K, P and the tile count (cfg: ~22 KB).
 // Results are bit-identical to sd_decode (same keys, same total order, same block_group arithmetic).
 // ---------------------------------------------------------------------------------------------
-#ifdef SD_DECODE_TRACE
-// timing experiment (not in product builds; reported by sd_build_flags bit 3): 100 MHz timestamps of the stages of k_decode_fused
-__device__ unsigned long long sd_trace[8192];
-#define SD_TRACE(slot) do { if (threadIdx.x == 0 && (slot) >= 0 && (slot) < 8192) sd_trace[(slot)] = wall_clock64(); } while (0)
-#else
-#define SD_TRACE(slot) do { } while (0)
-#endif
 constexpr int FUSED_THREADS = 256;
 constexpr int FUSED_TEAM = 128;               // the selector works on the anchor list and the part list side by side: 2 teams x 2 waves
 // keys per team sorted in LDS (longer lists take the radix select), chosen by the launcher: the LDS of the selector is paid by
@@ -1367,12 +1637,14 @@ int sd_decode_peaks(const float* logits, int64_t sb, int64_t sc, int B, int C, i
     return 0;
 }
 
-// ---- map-parallel path of sd_decode (k_nms_slots -> k_select_map -> k_merge_group) ----
+// ---- map-parallel path of sd_decode (k_nms_slots -> k_select_map -> k_rank_maps -> k_group_wide) ----
 struct MapWs {
     uint64_t* cand;       // B * C * tiles * (TW * th) keys
     int* tile_cnt;        // B * C * tiles
     uint64_t* stage1;     // B * C * max(K, P) keys
     int* stage1_cnt;      // B * C
+    uint64_t* final_keys; // B * 2 * max(K, P) keys
+    int* final_cnt;       // B * 2
     size_t bytes;
 };
 static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int P) {
@@ -1384,6 +1656,8 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
     r.tile_cnt = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * C * tiles * sizeof(int), 256);
     r.stage1 = reinterpret_cast<uint64_t*>(p + off);   off += align_up((size_t)B * C * std::max(K, P) * 8, 256);
     r.stage1_cnt = reinterpret_cast<int*>(p + off);    off += align_up((size_t)B * C * sizeof(int), 256);
+    r.final_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up((size_t)B * 2 * std::max(K, P) * 8, 256);
+    r.final_cnt = reinterpret_cast<int*>(p + off);     off += align_up((size_t)B * 2 * sizeof(int), 256);
     r.bytes = off;
     return r;
 }
@@ -1391,12 +1665,14 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
 // sd_decode_set_option("map_parallel_from" / "map_tile_height", n).
 static thread_local int g_map_parallel_from = 4096;
 static thread_local int g_map_tile_height = 0;
+static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
 static int map_tile_height(int64_t blocks16) {
     if (g_map_tile_height == 16 || g_map_tile_height == 32) return g_map_tile_height;
     return blocks16 >= 8192 ? 32 : 16;
 }
 static bool map_path_possible(int M, int N, int h, int w, int K, int P) {
-    return M + N <= 64 && (int64_t)cdiv(w, TW) * cdiv(h, 16) <= MAP_TILES_MAX && K <= SD_MAX_TOPK && P <= SD_MAX_TOPK;
+    return M <= 64 && N <= 64 && (int64_t)cdiv(w, TW) * cdiv(h, 16) <= MAP_TILES_MAX && K <= SD_MAX_TOPK && P <= SD_MAX_TOPK &&
+           (int64_t)M * K <= RANK_KEYS_MAX && (int64_t)N * P <= RANK_KEYS_MAX;
 }
 
 size_t sd_decode_workspace_bytes(int B, int M, int N, int h, int w, int K, int P) {
@@ -1428,15 +1704,30 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
         SD_REQUIRE(workspace_bytes >= mw.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, mw.bytes);
         const int tiles_x = cdiv(w, TW), tiles = tiles_x * cdiv(h, th), C = M + N;
         const float min_score = exact_topk ? 0.f : conf;
-        if (th == 32)
-            hipLaunchKernelGGL(k_nms_slots<32>, dim3((unsigned)((int64_t)B * C * tiles)), dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
-        else
-            hipLaunchKernelGGL(k_nms_slots<16>, dim3((unsigned)((int64_t)B * C * tiles)), dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
+        const bool vec = g_map_scalar_nms == 0 && w % 4 == 0 && aligned16(anchor_hm) && aligned16(part_hm) && a_sb % 4 == 0 && a_sc % 4 == 0 &&
+                         p_sb % 4 == 0 && p_sc % 4 == 0;
+        if (vec && th == 32) hipLaunchKernelGGL(k_nms_slots_v<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        else if (vec)        hipLaunchKernelGGL(k_nms_slots_v<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        else if (th == 32)   hipLaunchKernelGGL(k_nms_slots<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+        else                 hipLaunchKernelGGL(k_nms_slots<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
         SD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_select_map, dim3(B * C), dim3(SEL_THREADS), 0, st, mw.cand, mw.tile_cnt, tiles, TW * th, M, N, K, P, mw.stage1, mw.stage1_cnt);
         SD_LAUNCH_CHECK();
+        const size_t rank_lds = (size_t)std::max((int64_t)M * K, (int64_t)N * P) * 8;
+        if (rank_lds > 48 * 1024) {
+            static thread_local bool raised = false;               // per host thread: cheap, idempotent
+            if (!raised) {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_maps), hipFuncAttributeMaxDynamicSharedMemorySize, RANK_KEYS_MAX * 8));
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL(k_rank_maps, dim3(B * C), dim3(SEL_THREADS), rank_lds, st, mw.stage1, mw.stage1_cnt, M, N, K, P, mw.final_keys, mw.final_cnt);
+        SD_LAUNCH_CHECK();
         RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
-        hipLaunchKernelGGL(k_merge_group, dim3(B), dim3(2 * SEL_THREADS), 0, st, mw.stage1, mw.stage1_cnt, M, N, h, w, K, P, conf, dist_px, rm, packed, B);
+        const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)K * 8 + (size_t)std::max(K, P) * 4;
+        hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, mw.final_cnt, h, w, K, P,
+                           conf, dist_px, rm, packed, B);
         SD_LAUNCH_CHECK();
         return 0;
     }
@@ -1466,6 +1757,7 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from = value; return 0; }
     if (name && !strcmp(name, "map_parallel_from")) { g_map_parallel_from = value; return 0; }
     if (name && !strcmp(name, "map_tile_height")) { g_map_tile_height = value; return 0; }
+    if (name && !strcmp(name, "map_scalar_nms")) { g_map_scalar_nms = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }
@@ -1493,6 +1785,14 @@ int sd_debug_read_trace(unsigned long long* out, int n) {
     return 0;
 }
 #endif
+
+int sd_selfcheck_sigmoid(unsigned long long* out3, sd_stream_t stream) {
+    SD_REQUIRE(out3 != nullptr, SD_ERR_INVALID, "sd_selfcheck_sigmoid: null pointer");
+    SD_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_selfcheck_sigmoid, dim3(4096), dim3(256), 0, (hipStream_t)stream, out3);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
 
 int sd_stream_synchronize(sd_stream_t stream) {
     SD_HIP(hipStreamSynchronize((hipStream_t)stream));

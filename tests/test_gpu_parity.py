@@ -439,8 +439,23 @@ def test_decoder_thresholds_vs_golden(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------ map-parallel decoder
+def test_sigmoid_properties_behind_the_logit_domain_nms_hold_for_every_fp32_value():
+    """k_nms_slots_v decides the 5x5 NMS on LOGITS (survivor <=> sigma(x) == sigma(window maximum)), which equals the reference's compare
+    of clamped sigmoids (utils.py:441-443 after :355-361) iff the device's clamped sigmoid is monotone non-decreasing, and its near-tie
+    margin table is valid iff a logit further below the maximum than the margin always has a strictly smaller sigmoid.  Both are
+    checked here for ALL 2^32 bit patterns on the device."""
+    from structuredetector_amd import _lib as L
+    out = torch.zeros(3, dtype=torch.int64, device=DEV)
+    L.check(L.lib().sd_selfcheck_sigmoid(out.data_ptr(), L.stream()))
+    mono, margin, seen = out.cpu().tolist()
+    assert seen == 2 ** 32 - 2 * (2 ** 23 - 1)                       # every non-NaN value
+    assert mono == 0, f"{mono} consecutive fp32 pairs where the clamped sigmoid decreases"
+    assert margin == 0, f"{margin} window maxima whose margin admits a tie"
+
+
 @pytest.mark.parametrize("B,img,M,N,K,P,kind", [(4, 1024, 8, 8, 128, 512, "scene"), (2, 1024, 8, 8, 128, 512, "noise"), (64, 512, 2, 1, 20, 40, "scene"),
-                                                (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise")])
+                                                (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise"),
+                                                (3, 512, 2, 2, 64, 200, "ties"), (2, 528, 2, 1, 20, 40, "ties"), (2, 266, 2, 1, 20, 40, "noise")])
 def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, kind):
     """sd_decode's map-parallel path (tile pass without global atomics -> one selector block per MAP = the reference's per-class top-k,
     utils.py:451 -> one merge + association block per image = its second top-k, utils.py:459) against the launch pair with one selector
@@ -459,6 +474,18 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
         n_max = 96 if K > 20 else 12
         head = np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N, n_max // 2, n_max), M, N, K, P, 4.0, 0.1),
                                              M, N, noise=0.3) for _ in range(B)])
+    elif kind == "ties":
+        # what the logit-domain tile pass must get right: exact ties (coarse grid), near-ties one ulp apart, both saturated ends of the
+        # clamp (|x| > 13.8: plateaus where every tied pixel survives), windows whose maximum sits in each band of the margin table
+        q = np.round(3 * rng.standard_normal((B, M + N + 4, h, h))) * np.float32(2.5)             # grid of 2.5: many equal neighbours, |x| up to ~30
+        head = q.astype(np.float32)
+        bump = rng.random(head.shape) < 0.3
+        head[bump] = np.nextafter(head[bump], np.float32(np.inf))                                # one ulp above a neighbour's value
+        head[:, 0, :8, :] = 14.5; head[:, 0, 8:16, :] = np.float32(13.9); head[:, 0, 16:20, :] = np.float32(-13.9)
+        for i, v in enumerate((3.9, 4.0, 7.99, 8.0, 10.99, 11.0, 12.99, 13.0, 13.7, -13.69, -13.71)):
+            head[:, 1, 30 + 2 * (i // 4), 10 + 8 * (i % 4)] = np.float32(v)
+            head[:, 1, 30 + 2 * (i // 4), 11 + 8 * (i % 4)] = np.nextafter(np.float32(v), np.float32(-np.inf))
+            head[:, 1, 30 + 2 * (i // 4), 12 + 8 * (i % 4)] = np.float32(v) - np.float32(0.003)
     if kind == "noise" and K == 128:
         head[0, 1] = -20.0                                                                       # one whole map a plateau: 65 536 tied candidates
     views = head_views(dev(head), M, N)
@@ -469,13 +496,15 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
             L.check(lib.sd_decode_set_option(b"map_parallel_from", 1 << 30))
             want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
             L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
-            for th in (16, 32, 0):
+            for th, scalar in ((16, 0), (32, 0), (0, 0), (16, 1), (32, 1)):                        # logit-domain / per-pixel-sigmoid tile kernels
                 L.check(lib.sd_decode_set_option(b"map_tile_height", th))
+                L.check(lib.sd_decode_set_option(b"map_scalar_nms", scalar))
                 got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-                assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th}"
+                assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar}"
     finally:
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
+        L.check(lib.sd_decode_set_option(b"map_scalar_nms", 0))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))

@@ -17,14 +17,14 @@ for V in "1073741824 0 1" "1 16 1" "1 32 1" "1 32 0" "1073741824 0 0"; do
   python3 - "$F" "$T" >> $OUT <<'PY'
 import csv, sys
 import numpy as np
-names = ("k_nms_tile", "k_select_group", "fillBuffer", "k_nms_slots", "k_select_map", "k_merge_group")
+names = ("k_nms_tile", "k_select_group", "fillBuffer", "k_nms_slots", "k_select_map", "k_rank_maps", "k_group_wide")
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].replace("void ", "").split("(")[0]
     if any(k in n for k in names):
         print(f"   {n[:44]:44s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f}")
 rows = [r for r in csv.DictReader(open(sys.argv[2])) if any(k in r["Kernel_Name"] for k in names)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-per = 3
+per = len({r["Kernel_Name"].split("(")[0] for r in rows})
 spans = [(int(rows[i + per - 1]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3 for i in range(0, len(rows) - per + 1, per)][10:]
 print(f"   device span per call (incl. launch gaps): median {np.median(spans):.2f} us = {np.median(spans) / 16:.2f} us per image, min {min(spans):.2f} us")
 PY

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Stage timestamps inside the map-parallel decoder kernels (k_select_map, k_merge_group) on the stress geometry.
+Library built with `make -C structuredetector_amd/csrc SUFFIX=_trace EXTRA=-DSD_DECODE_TRACE`; run with
+SDNET_HIP_LIB=structuredetector_amd/csrc/libsdnet_hip_trace.so SDNET_ALLOW_ABLATION=1."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import make_args  # noqa: E402
+from structuredetector_amd import _lib as L  # noqa: E402
+from structuredetector_amd.data import Decoder, Encode  # noqa: E402
+from structuredetector_amd.data.synthetic import synthetic_batch  # noqa: E402
+
+exact = bool(int(sys.argv[1])) if len(sys.argv) > 1 else True
+dev = torch.device("cuda")
+M, N, K, P, img, B = 8, 8, 128, 512, 1024, 16
+args = make_args(dev, M, N, K, P)
+enc, dec = Encode(args), Decoder(args)
+gen = torch.Generator(device=dev).manual_seed(0)
+tgt = enc.render(enc.plan(img, img, *synthetic_batch(np.random.default_rng(B), B, img, img, M, N, 64, 96)), dev)
+hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
+head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
+                  0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
+outs = {"anchor_hm": head[:, :M], "part_hm": head[:, M:M + N], "offsets": head[:, M + N:M + N + 2], "embeddings": head[:, M + N + 2:]}
+lib = L.lib()
+L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
+lib.sd_debug_read_trace.restype = C.c_int
+lib.sd_debug_read_trace.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 8192)()
+rows = []
+for it in range(30):
+    dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact, fused=False)
+    torch.cuda.synchronize()
+    lib.sd_debug_read_trace(buf, 8192)
+    t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+    if it >= 10:
+        rows.append(np.concatenate([t[6100:6104] - t[6100], t[6200:6204] - t[6200], t[6000:6006] - t[6000], t[6300:6313] - t[6300]]))
+r = np.median(np.array(rows, np.float64), axis=0) * 0.01
+print(f"stress decode, exact={exact}: us since the block started (medians over 20 runs)")
+print("  k_select_map (anchor map 0):  prefix %.2f, selected %.2f, written %.2f" % tuple(r[1:4]))
+print("  k_select_map (part map 0):    prefix %.2f, selected %.2f, written %.2f" % tuple(r[5:8]))
+print("  k_merge_group (image 0):      counts %.2f, selected %.2f, zero fill %.2f, keys decoded %.2f, grouped %.2f" % tuple(r[9:14]))
+print("  radix select of k_merge_group (anchor team; both teams share the barriers): start 0, after pass 7..0: "
+      + " ".join(f"{v:.2f}" for v in r[15:23]) + f"; passes done {r[24]:.2f}, collected {r[25]:.2f}, sorted {r[26]:.2f}")
