@@ -470,10 +470,6 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
     elif kind == "flat":
         head = np.full((B, M + N + 4, h, h), -20.0, np.float32)
         head[:, :, 5, 7] = 3.0
-    else:
-        n_max = 96 if K > 20 else 12
-        head = np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N, n_max // 2, n_max), M, N, K, P, 4.0, 0.1),
-                                             M, N, noise=0.3) for _ in range(B)])
     elif kind == "ties":
         # what the logit-domain tile pass must get right: exact ties (coarse grid), near-ties one ulp apart, both saturated ends of the
         # clamp (|x| > 13.8: plateaus where every tied pixel survives), windows whose maximum sits in each band of the margin table
@@ -486,6 +482,10 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
             head[:, 1, 30 + 2 * (i // 4), 10 + 8 * (i % 4)] = np.float32(v)
             head[:, 1, 30 + 2 * (i // 4), 11 + 8 * (i % 4)] = np.nextafter(np.float32(v), np.float32(-np.inf))
             head[:, 1, 30 + 2 * (i // 4), 12 + 8 * (i % 4)] = np.float32(v) - np.float32(0.003)
+    else:
+        n_max = 96 if K > 20 else 12
+        head = np.stack([O.head_from_targets(rng, O.encode(img, img, O.synthetic_scene(rng, img, img, M, N, n_max // 2, n_max), M, N, K, P, 4.0, 0.1),
+                                             M, N, noise=0.3) for _ in range(B)])
     if kind == "noise" and K == 128:
         head[0, 1] = -20.0                                                                       # one whole map a plateau: 65 536 tied candidates
     views = head_views(dev(head), M, N)
