@@ -835,8 +835,11 @@ __global__ __launch_bounds__(256) void k_nms_slots(Group g0, Group g1, int h, in
 // Needs w % 4 == 0 and 16-byte aligned planes (map_view gives them); k_nms_slots stays as the general kernel.  Same survivors, same
 // keys as k_nms_slots.
 // ---------------------------------------------------------------------------------------------
+// margin(m): INFINITY where the clamp may be active (|m| >= 13: sigma(+-13.8) are the clamp values), 1e-4 below m = 4 (there one ulp of
+// sigma is < 2e-5 of a logit step), 1.0 up to 13 (sigma(13) - sigma(12) = 65 ulp).  Three instructions; the table is deliberately
+// coarse: a wider margin only sends a few more pixels around strong peaks through the exact compare.
 __device__ __forceinline__ float nms_margin(float m) {
-    return m < 4.0f ? (m > -13.7f ? 1e-4f : INFINITY) : (m < 8.0f ? 4e-3f : (m < 11.0f ? 0.1f : (m < 13.0f ? 1.0f : INFINITY)));
+    return fabsf(m) >= 13.0f ? INFINITY : (m < 4.0f ? 1e-4f : 1.0f);
 }
 __device__ __forceinline__ float max5(float a, float b, float c, float d, float e) { return fmaxf(fmaxf(fmaxf(a, b), c), fmaxf(d, e)); }
 
@@ -899,12 +902,11 @@ __global__ __launch_bounds__(256) void k_nms_slots_v(Group g0, Group g1, int h, 
         const bool row_in = ty0 + r < h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float mg = nms_margin(mx[e]);
             const bool top = xv[e] == mx[e];
-            const bool near = !top && (mg == INFINITY || xv[e] >= mx[e] - mg);
-            if (row_in && tx0 + 4 * q + e < w && (top || near)) {
+            const bool near = !(mx[e] - xv[e] > nms_margin(mx[e]));             // (also true for top; NaN-safe: inf - inf fails `>`)
+            if (row_in && tx0 + 4 * q + e < w && near) {
                 const int slot = atomicAdd(&keep_n, 1);                        // LDS
-                list[slot] = (unsigned short)((r * TW + 4 * q + e) | (near ? 0x8000 : 0));
+                list[slot] = (unsigned short)((r * TW + 4 * q + e) | (top ? 0 : 0x8000));
             }
         }
     }
@@ -1031,29 +1033,59 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
     const int grp = m >= M ? 1 : 0;
     const int nl = grp ? N : M, first = grp ? M : 0, own = m - first, k = grp ? P : K;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);        // the group's lists back to back (list l at soff[l])
+    if (tid < nl) scnt[tid] = stage1_cnt[b * C + first + tid];
+    __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int l = 0; l < nl; ++l) { const int v = stage1_cnt[b * C + first + l]; scnt[l] = v; soff[l] = run; run += v; }
+        for (int l = 0; l < nl; ++l) { soff[l] = run; run += scnt[l]; }
         soff[nl] = run;
     }
     __syncthreads();
     const uint64_t* src = stage1 + ((int64_t)b * C + first) * kmax;
-    for (int l = 0; l < nl; ++l)
-        for (int i = tid; i < scnt[l]; i += SEL_THREADS) keys[soff[l] + i] = src[(int64_t)l * kmax + i];
+    // one flat loop over the (list, slot) space of the group: every thread's loads are in flight together (a loop per list was eight
+    // dependent global round trips: 10 us for this kernel)
+    const int span = nl * k;
+    for (int base = tid; base < span; base += 4 * SEL_THREADS) {
+        uint64_t kv[4];
+        int at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * SEL_THREADS;
+            const int l = min(i / k, nl - 1), j = i - l * k;
+            at[u] = (i < span && j < scnt[l]) ? soff[l] + j : -1;
+            kv[u] = at[u] >= 0 ? src[(int64_t)l * kmax + j] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (at[u] >= 0) keys[at[u]] = kv[u];
+    }
     __syncthreads();
     const int mine = scnt[own];
     for (int i = tid; i < mine; i += SEL_THREADS) {
         const uint64_t key = keys[soff[own] + i];
         int rank = i;
-        for (int l = 0; l < nl; ++l) {
-            if (l == own) continue;
-            const uint64_t* lst = keys + soff[l];
-            int lo = 0, hi = scnt[l];                           // first position whose key is smaller than `key` (descending list)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (lst[mid] > key) lo = mid + 1; else hi = mid;
+        for (int l0 = 0; l0 < nl; l0 += 8) {                    // eight lists at a time: their binary searches advance together
+            int lo[8], hi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int l = l0 + u;
+                lo[u] = 0;
+                hi[u] = (l < nl && l != own) ? scnt[l] : 0;
             }
-            rank += lo;
+            bool any = true;
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (lo[u] < hi[u]) {                        // first position whose key is smaller than `key` (descending list)
+                        const int mid = (lo[u] + hi[u]) >> 1;
+                        if (keys[soff[min(l0 + u, nl - 1)] + mid] > key) lo[u] = mid + 1; else hi[u] = mid;
+                        any = any || lo[u] < hi[u];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += lo[u];
         }
         if (rank < k) final_keys[((int64_t)b * 2 + grp) * kmax + rank] = key;
     }
@@ -1067,15 +1099,17 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
 constexpr int GROUP_PARTS = 64, GROUP_THREADS = 256;
 // keys[npos..k) := the zero slots of the reference's top-k on a map whose suppressed pixels are exactly 0 (utils.py:451): the lowest
 // class-major flat indices that are not peaks, ascending (same rule as fill_zero_slots).  Block-wide, GROUP_THREADS threads; `flags` has
-// k ints.  Only runs when the list has fewer than k peaks; always executes the same three barriers.
+// k ints.  Only works when the list has fewer than k peaks; always executes the same four barriers.
 __device__ void fill_zero_keys(uint64_t* keys, int npos, int k, int* flags, int* wave_tot) {
     const int tid = threadIdx.x;
     const bool need = npos < k;
     if (need)
-        for (int f = tid; f < k; f += GROUP_THREADS) {
-            int used = 0;
-            for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~keys[j]) == (uint32_t)f);
-            flags[f] = used ? 0 : 1;
+        for (int f = tid; f < k; f += GROUP_THREADS) flags[f] = 1;
+    __syncthreads();
+    if (need)
+        for (int j = tid; j < npos; j += GROUP_THREADS) {          // a peak whose flat index is below k takes that index out
+            const uint32_t flat = (uint32_t)(~keys[j]);
+            if (flat < (uint32_t)k) flags[flat] = 0;
         }
     __syncthreads();
     const int per = (k + GROUP_THREADS - 1) / GROUP_THREADS;     // thread t owns flat indices [t * per, t * per + per)
@@ -1122,17 +1156,45 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     const uint64_t* fa = final_keys + ((int64_t)b * 2 + 0) * kmax;
     const uint64_t* fp = final_keys + ((int64_t)b * 2 + 1) * kmax;
     if (tid == 0) n_live_s = 0;
-    for (int i = tid; i < na; i += GROUP_THREADS) akeys[i] = fa[i];
-    for (int i = tid; i < np; i += GROUP_THREADS) pkeys[i] = fp[i];
-    __syncthreads();
-    fill_zero_keys(akeys, na, K, flags, wave_tot);
-    fill_zero_keys(pkeys, np, P, flags, wave_tot);
+    // every load that does not depend on another goes out first: the counts, this thread's anchor keys, its part key (slots beyond
+    // the counts hold stale keys: ignored below); the chain is then counts / keys -> gathers -> scan instead of five round trips
+    const int p = chunk * GROUP_PARTS + (tid >> 2), q = tid & 3;
+    uint64_t pkey = (p < P) ? fp[p] : 0ull;
+    constexpr int APT = SD_MAX_TOPK / GROUP_THREADS;            // anchor keys per thread
+    uint64_t ak[APT];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) ak[u] = (tid + u * GROUP_THREADS < K) ? fa[tid + u * GROUP_THREADS] : 0ull;
     const PackedLayout L = packed_layout(packed, B, K, P);
     const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
     const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
+    if (na < K || np < P) {                                     // (block-uniform) fewer peaks than slots: the lists go through LDS for the zero slots
+#pragma unroll
+        for (int u = 0; u < APT; ++u)
+            if (tid + u * GROUP_THREADS < na) akeys[tid + u * GROUP_THREADS] = ak[u];
+        for (int i = tid; i < np; i += GROUP_THREADS) pkeys[i] = fp[i];
+        __syncthreads();
+        fill_zero_keys(akeys, na, K, flags, wave_tot);
+        fill_zero_keys(pkeys, np, P, flags, wave_tot);
+#pragma unroll
+        for (int u = 0; u < APT; ++u)
+            if (tid + u * GROUP_THREADS < K) ak[u] = akeys[tid + u * GROUP_THREADS];
+        if (p < P) pkey = pkeys[p];
+    }
+    // this thread's part: its gathers are issued before the anchors' pass (they do not depend on it)
+    float ex = 0.f, ey = 0.f, pox = 0.f, poy = 0.f;
+    int p_ind = 0, p_cls = 0;
+    if (p < P) {
+        const uint32_t flat = ~(uint32_t)pkey;
+        p_cls = flat / hw; p_ind = flat - p_cls * hw;
+        ex = emb_b[p_ind]; ey = emb_b[rm.e_sc + p_ind];                                // decoders.py:66
+        pox = off_b[p_ind]; poy = off_b[rm.o_sc + p_ind];
+    }
     int last_live = 0;
-    for (int a = tid; a < K; a += GROUP_THREADS) {
-        const uint64_t key = akeys[a];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        const int a = tid + u * GROUP_THREADS;
+        if (a >= K) break;
+        const uint64_t key = ak[u];
         const uint32_t flat = ~(uint32_t)key;
         const int cls = flat / hw, ind = flat - cls * hw;
         const int y = ind / w, x = ind - y * w;
@@ -1154,16 +1216,12 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     __syncthreads();
     // anchors beyond the last live rank are all masked: at (1e6, 1e6) they are never within dist_px of a live part (see block_group)
     const int n_scan = dist_px < 1e5f ? n_live_s : K;
-    const int p = chunk * GROUP_PARTS + (tid >> 2), q = tid & 3;
     if (p < P) {
-        const uint64_t key = pkeys[p];
-        const uint32_t flat = ~(uint32_t)key;
-        const int cls = flat / hw, ind = flat - cls * hw;
+        const int cls = p_cls, ind = p_ind;
         const int y = ind / w, x = ind - y * w;
-        const float score = ord2f((uint32_t)(key >> 32));
-        const float ex = emb_b[ind], ey = emb_b[rm.e_sc + ind];                          // decoders.py:66
-        const float px = (float)x + off_b[ind];                                         // decoders.py:67
-        const float py = (float)y + off_b[rm.o_sc + ind];                               // decoders.py:68
+        const float score = ord2f((uint32_t)(pkey >> 32));
+        const float px = (float)x + pox;                                                // decoders.py:67
+        const float py = (float)y + poy;                                                // decoders.py:68
         const float ox = px + ex, oy = py + ey;                 // decoders.py:69-70
         const bool mk = score > conf;                           // decoders.py:78
         const float orx = mk ? ox : -1e6f, ory = mk ? oy : -1e6f; // decoders.py:80-81
