@@ -961,13 +961,178 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
     atomicAdd(&out[2], seen);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_map_stream_select: tile pass AND the per-map selection in one kernel, one 512-thread block per (image, map).  At BASELINE
+// configs[4] a batch is 16 x 16 = 256 maps of 256 KB: one map per CU, each CU streaming at its share of the HBM rate (~20 GB/s), no
+// candidate list in global memory, no tile counts, no second launch for the first selection stage.
+//   * streaming: a wave owns a strip of up to 256 columns (one float4 per lane) and walks 16 output rows (+ 4 halo rows); the horizontal
+//     neighbours come from the adjacent lanes (cross-lane moves; the two edge lanes load their halo), the vertical window is five rows of
+//     horizontal maxima in registers: no LDS, no barrier, no index arithmetic per pixel; rows are requested eight ahead of their use;
+//   * the logit-domain survivor rule of k_nms_slots_v; candidates are appended (one LDS atomic per wave and row) as raw entries
+//     {logit, near flag, pixel} to a 4096-entry LDS stage, and the sigmoids are taken afterwards over the compacted entries;
+//   * selection from LDS (radix select, ranking / register bitonic sort) and one store of the map's sorted top-k, zero padded to k:
+//     the later stages need no counts.
+// A map with more than 4096 candidates (plateaus; > 6 % of all pixels) is walked a second time with the keys going to the global
+// candidate list and selected from there.  Needs w % 4 == 0 and 16-byte aligned planes.
+// ---------------------------------------------------------------------------------------------
+constexpr int STREAM_THREADS = 512, STREAM_WAVES = STREAM_THREADS / 64, STREAM_ROWS = 16, STREAM_CAP = 4096, STREAM_AHEAD = 8;
+
+template <bool INLINE_KEYS>
+__device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
+                                           float* mxs, int* count, uint64_t* __restrict__ gkeys) {
+    constexpr int R = STREAM_ROWS, NR = R + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strips = (w + 255) >> 8, chunks = (h + R - 1) / R;
+    const float NEG = -INFINITY;
+    for (int unit = wave; unit < strips * chunks; unit += STREAM_WAVES) {
+        const int sy = unit / strips, sx = unit - sy * strips;
+        const int x0 = sx * 256 + lane * 4;
+        const bool col_in = x0 < w;
+        const int y0 = sy * R;
+        // the edge lanes' halo: lane 0 needs the two columns left of the strip, lane 63 the two right of it (8-byte aligned pairs)
+        const int hx = lane == 0 ? x0 - 2 : x0 + 4;
+        const bool halo_in = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+        float4 v[NR];
+        float2 hl[NR];
+        auto request = [&](int j) {
+            const int y = y0 + j - 2;
+            const bool row_in = y >= 0 && y < h;
+            v[j] = *reinterpret_cast<const float4*>(plane + ((col_in && row_in) ? (int64_t)y * w + x0 : 0));
+            hl[j] = *reinterpret_cast<const float2*>(plane + ((halo_in && row_in) ? (int64_t)y * w + hx : 0));
+        };
+#pragma unroll
+        for (int j = 0; j < STREAM_AHEAD; ++j) request(j);
+        float4 hm[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (j + STREAM_AHEAD < NR) request(j + STREAM_AHEAD);
+            {
+                const int y = y0 + j - 2;
+                const bool row_in = y >= 0 && y < h;
+                if (!(col_in && row_in)) v[j] = make_float4(NEG, NEG, NEG, NEG);
+                if (!(halo_in && row_in)) hl[j] = make_float2(NEG, NEG);
+                float lz = __shfl_up(v[j].z, 1), lw = __shfl_up(v[j].w, 1), rx = __shfl_down(v[j].x, 1), ry = __shfl_down(v[j].y, 1);
+                if (lane == 0) { lz = hl[j].x; lw = hl[j].y; }
+                if (lane == 63) { rx = hl[j].x; ry = hl[j].y; }
+                hm[j] = make_float4(max5(lz, lw, v[j].x, v[j].y, v[j].z), max5(lw, v[j].x, v[j].y, v[j].z, v[j].w),
+                                    max5(v[j].x, v[j].y, v[j].z, v[j].w, rx), max5(v[j].y, v[j].z, v[j].w, rx, ry));
+            }
+            if (j < 4) continue;
+            const int yo = y0 + j - 4;                                 // output row: window rows j - 4 .. j, centre j - 2
+            if (yo >= h) continue;                                      // (wave-uniform)
+            const float4 a0 = hm[j - 4], a1 = hm[j - 3], a2 = hm[j - 2], a3 = hm[j - 1], a4 = hm[j];
+            const float mx[4] = {max5(a0.x, a1.x, a2.x, a3.x, a4.x), max5(a0.y, a1.y, a2.y, a3.y, a4.y), max5(a0.z, a1.z, a2.z, a3.z, a4.z),
+                                 max5(a0.w, a1.w, a2.w, a3.w, a4.w)};
+            const float xv[4] = {v[j - 2].x, v[j - 2].y, v[j - 2].z, v[j - 2].w};
+            bool cand[4];
+            float sc[4];
+            unsigned long long msk[4];
+            int tot = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cand[e] = col_in && !(mx[e] - xv[e] > nms_margin(mx[e]));
+                sc[e] = 0.f;
+                if (INLINE_KEYS && cand[e]) {                            // (second walk of an overflowing map: keys with their sigmoids at once)
+                    sc[e] = clamped_sigmoid(xv[e]);
+                    cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
+                }
+                msk[e] = __ballot(cand[e]);
+                tot += __popcll(msk[e]);
+            }
+            if (tot == 0) continue;                                     // (wave-uniform)
+            int base = 0;
+            if (lane == 0) base = atomicAdd(count, tot);                // LDS: one atomic per wave and row
+            base = __shfl(base, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int slot = base + __popcll(msk[e] & below);
+                base += __popcll(msk[e]);
+                if (!cand[e]) continue;
+                const uint32_t pix = (uint32_t)(yo * w + x0 + e);
+                if (INLINE_KEYS) {
+                    gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix);
+                } else if (slot < STREAM_CAP) {
+                    const bool top = xv[e] == mx[e];
+                    stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | pix;
+                    if (!top) mxs[slot] = mx[e];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
+                                                                       uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1) {
+    __shared__ uint64_t stage[STREAM_CAP];                              // raw entries, then scratch of the selection (T.out)
+    __shared__ uint64_t buf[STREAM_CAP];                                // keys
+    __shared__ float mxs[STREAM_CAP];
+    __shared__ int hist[2 * 256];
+    __shared__ int misc[4];
+    __shared__ int alive[2];
+    __shared__ int counts[2];                                           // [0] raw entries / global keys, [1] keys
+    const int tid = threadIdx.x;
+    const int C = g0.C + g1.C;
+    const int bm = blockIdx.x, b = bm / C, m = bm - b * C;
+    const int grp = (m >= g0.C) ? 1 : 0;
+    const Group g = grp ? g1 : g0;
+    const int c = grp ? m - g0.C : m;
+    const int k = grp ? P : K, kmax = max(K, P);
+    const int hw = h * w;
+    const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
+    if (tid < 2) { counts[tid] = 0; alive[tid] = 0; }
+    __syncthreads();
+    stream_map<false>(plane, h, w, c, min_score, stage, mxs, &counts[0], nullptr);
+    __syncthreads();
+    const int nraw = counts[0];
+    const Team T{tid, buf, hist, misc, nullptr, stage, 0, alive};
+    const int np2k = max(next_pow2(k), 2);
+    uint64_t* out = stage1 + (int64_t)bm * kmax;
+    if (nraw <= STREAM_CAP) {                                           // (block-uniform)
+        for (int i = tid; i < nraw; i += STREAM_THREADS) {              // sigmoids of the compacted entries only
+            const uint64_t ent = stage[i];
+            const float x = __uint_as_float((uint32_t)(ent >> 32));
+            const float v = clamped_sigmoid(x);
+            bool ok = v >= min_score;                                   // `>=`: see k_nms_tile
+            if (ok && ((uint32_t)ent & 0x80000000u)) ok = clamped_sigmoid(mxs[i]) == v;    // near-tie / saturated window
+            const int slot = alloc_slot(&counts[1], ok);
+            if (slot >= 0) buf[slot] = make_key(v, (uint32_t)(c * hw) + ((uint32_t)ent & 0x7fffffffu));
+        }
+        __syncthreads();
+        const int n = counts[1];
+        if (n <= k) {                                                   // every candidate is selected: sort them all
+            const int np2 = max(next_pow2(n), 2);
+            for (int i = n + tid; i < np2; i += STREAM_THREADS) buf[i] = 0ull;
+            __syncthreads();
+            if (np2 <= RANK_CAP) rank_sort_desc<STREAM_THREADS>(T, buf, np2);
+            else if (np2 <= STREAM_THREADS) reg_bitonic_desc<STREAM_THREADS>(T, buf, np2);
+            else bitonic_desc<STREAM_THREADS>(T, buf, np2);
+            for (int i = tid; i < k; i += STREAM_THREADS) out[i] = i < n ? buf[i] : 0ull;
+        } else {
+            radix_select_sorted<STREAM_THREADS>(T, LdsSrc<STREAM_THREADS>{buf, n}, k, stage, np2k);
+            for (int i = tid; i < k; i += STREAM_THREADS) out[i] = stage[i];
+        }
+        return;
+    }
+    // more candidates than the stage holds: second walk, keys straight to the map's global list, selection from there
+    __syncthreads();
+    if (tid == 0) counts[0] = 0;
+    __syncthreads();
+    uint64_t* glist = cand + (int64_t)bm * hw;
+    stream_map<true>(plane, h, w, c, min_score, nullptr, nullptr, &counts[0], glist);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n = counts[0];
+    radix_select_sorted<STREAM_THREADS>(T, FlatSrc<STREAM_THREADS, true>{glist, n}, k, buf, np2k);
+    for (int i = tid; i < k; i += STREAM_THREADS) out[i] = i < min(n, k) ? buf[i] : 0ull;
+}
+
 constexpr int MAP_TILES_MAX = 1024;          // tiles of one map the per-map selector indexes in LDS (2048 x 2048 output maps at 64 x 32 tiles)
 
-// stage 1: one block per (image, map): top-k of the map's candidates (k = K for anchor maps, P for part maps), sorted, into
-// stage1[(b * C + m) * kmax ...] with the number of keys written in stage1_cnt[b * C + m]
+// stage 1 (after k_nms_slots; k_map_stream_select does both at once): one block per (image, map): top-k of the map's candidates
+// (k = K for anchor maps, P for part maps), sorted, zero padded to k, into stage1[(b * C + m) * kmax ...]
 __global__ __launch_bounds__(SEL_THREADS) void k_select_map(const uint64_t* __restrict__ cand, const int* __restrict__ tile_cnt, int tiles,
-                                                             int cap, int M, int N, int K, int P, uint64_t* __restrict__ stage1,
-                                                             int* __restrict__ stage1_cnt) {
+                                                             int cap, int M, int N, int K, int P, uint64_t* __restrict__ stage1) {
     __shared__ uint64_t buf[SORT_CAP];
     __shared__ uint64_t outb[SD_MAX_TOPK];
     __shared__ int hist[2 * 256];
@@ -1012,84 +1177,65 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_map(const uint64_t* __re
     team_select_topk<SEL_THREADS>(T, src, k, n, k, SORT_CAP);
     SD_TRACE(trace0 + 2);
     const int take = min(n, k);
-    for (int i = tid; i < take; i += SEL_THREADS) stage1[(int64_t)bm * kmax + i] = buf[i];
-    if (tid == 0) stage1_cnt[bm] = take;
+    for (int i = tid; i < k; i += SEL_THREADS) stage1[(int64_t)bm * kmax + i] = i < take ? buf[i] : 0ull;      // zero padded: no counts downstream
     SD_TRACE(trace0 + 3);
 }
 
-// stage 2: one block per (image, map) again.  The stage-1 lists are sorted, so the final rank of a key is its position in its own
-// list plus, for every other list of its group, the number of keys there that beat it (binary search; keys are unique): no radix
-// select, no sort, and B x (M + N) blocks instead of one block per image.  Keys with rank < k land at final[(b * 2 + group) * kmax + rank]
-// -- the group's top-k in the reference's order (utils.py:459) -- and final_cnt[b * 2 + group] = min(candidates of the group, k).
+// stage 2: one block per (image, map) again.  The stage-1 lists are sorted (and zero padded to k: a zero key is smaller than every
+// candidate's), so the final rank of a key is its position in its own list plus, for every other list of its group, the number of keys
+// there that beat it (binary search; keys are unique): no radix select, no sort, and B x (M + N) blocks instead of one block per
+// image.  Keys with rank < k land at final[(b * 2 + group) * kmax + rank] -- the group's top-k in the reference's order (utils.py:459);
+// the block of the group's first map zeroes the slots beyond the group's candidates (the ranks are dense: 0 .. candidates - 1).
 constexpr int RANK_KEYS_MAX = 8192;         // keys of one group (maps x k) held in LDS by k_rank_maps: 64 KB
-__global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __restrict__ stage1, const int* __restrict__ stage1_cnt,
-                                                            int M, int N, int K, int P, uint64_t* __restrict__ final_keys,
-                                                            int* __restrict__ final_cnt) {
+__global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __restrict__ stage1, int M, int N, int K, int P,
+                                                            uint64_t* __restrict__ final_keys) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int scnt[64], soff[65];
+    __shared__ int total;
     const int tid = threadIdx.x;
     const int C = M + N, kmax = max(K, P);
     const int bm = blockIdx.x, b = bm / C, m = bm - b * C;
     const int grp = m >= M ? 1 : 0;
     const int nl = grp ? N : M, first = grp ? M : 0, own = m - first, k = grp ? P : K;
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);        // the group's lists back to back (list l at soff[l])
-    if (tid < nl) scnt[tid] = stage1_cnt[b * C + first + tid];
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int l = 0; l < nl; ++l) { soff[l] = run; run += scnt[l]; }
-        soff[nl] = run;
-    }
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);        // [nl][k]
+    if (tid == 0) total = 0;
     __syncthreads();
     const uint64_t* src = stage1 + ((int64_t)b * C + first) * kmax;
-    // one flat loop over the (list, slot) space of the group: every thread's loads are in flight together (a loop per list was eight
-    // dependent global round trips: 10 us for this kernel)
     const int span = nl * k;
-    for (int base = tid; base < span; base += 4 * SEL_THREADS) {
+    int nonzero = 0;
+    for (int base = tid; base < span; base += 4 * SEL_THREADS) {            // every load of the thread in flight together
         uint64_t kv[4];
-        int at[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * SEL_THREADS;
-            const int l = min(i / k, nl - 1), j = i - l * k;
-            at[u] = (i < span && j < scnt[l]) ? soff[l] + j : -1;
-            kv[u] = at[u] >= 0 ? src[(int64_t)l * kmax + j] : 0ull;
+            const int l = i / k;
+            kv[u] = i < span ? src[(int64_t)l * kmax + (i - l * k)] : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (at[u] >= 0) keys[at[u]] = kv[u];
+            if (base + u * SEL_THREADS < span) { keys[base + u * SEL_THREADS] = kv[u]; nonzero += kv[u] != 0ull; }
     }
+    if (own == 0 && nonzero) atomicAdd(&total, nonzero);
     __syncthreads();
-    const int mine = scnt[own];
-    for (int i = tid; i < mine; i += SEL_THREADS) {
-        const uint64_t key = keys[soff[own] + i];
+    int top = 1;                                                // largest power of two <= k: first probe of the branch-free search
+    while (top * 2 <= k) top *= 2;
+    uint64_t* out = final_keys + ((int64_t)b * 2 + grp) * kmax;
+    for (int i = tid; i < k; i += SEL_THREADS) {
+        const uint64_t key = keys[own * k + i];
+        if (key == 0ull) continue;
         int rank = i;
-        for (int l0 = 0; l0 < nl; l0 += 8) {                    // eight lists at a time: their binary searches advance together
-            int lo[8], hi[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int l = l0 + u;
-                lo[u] = 0;
-                hi[u] = (l < nl && l != own) ? scnt[l] : 0;
-            }
-            bool any = true;
-            while (any) {
-                any = false;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (lo[u] < hi[u]) {                        // first position whose key is smaller than `key` (descending list)
-                        const int mid = (lo[u] + hi[u]) >> 1;
-                        if (keys[soff[min(l0 + u, nl - 1)] + mid] > key) lo[u] = mid + 1; else hi[u] = mid;
-                        any = any || lo[u] < hi[u];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rank += lo[u];
+#pragma unroll 4
+        for (int l = 0; l < nl; ++l) {
+            if (l == own) continue;
+            const uint64_t* lst = keys + l * k;                 // descending; count of keys greater than `key`
+            int pos = 0;
+            for (int step = top; step > 0; step >>= 1)
+                if (pos + step <= k && lst[pos + step - 1] > key) pos += step;
+            rank += pos;
         }
-        if (rank < k) final_keys[((int64_t)b * 2 + grp) * kmax + rank] = key;
+        if (rank < k) out[rank] = key;
     }
-    if (own == 0 && tid == 0) final_cnt[b * 2 + grp] = min(soff[nl], k);
+    if (own == 0)
+        for (int i = min(total, k) + tid; i < k; i += SEL_THREADS) out[i] = 0ull;
 }
 
 // stage 3: association, GROUP_PARTS parts per block (grid: B x ceil(P / GROUP_PARTS)), four lanes per part.  Every block decodes the
@@ -1138,41 +1284,45 @@ __device__ void fill_zero_keys(uint64_t* keys, int npos, int k, int* flags, int*
     __syncthreads();
 }
 
-__global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __restrict__ final_keys, const int* __restrict__ final_cnt,
-                                                               int h, int w, int K, int P, float conf, float dist_px, RegMaps rm,
-                                                               void* packed, int B) {
+__global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __restrict__ final_keys, int h, int w, int K, int P, float conf,
+                                                               float dist_px, RegMaps rm, void* packed, int B) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* akeys = reinterpret_cast<uint64_t*>(smem);                 // [K]
     uint64_t* pkeys = akeys + K;                                          // [P]
     float* posx = reinterpret_cast<float*>(pkeys + P);                    // [K]
     float* posy = posx + K;                                               // [K]
     int* flags = reinterpret_cast<int*>(posy + K);                        // [max(K, P)]
-    __shared__ int n_live_s;
+    __shared__ int n_live_s, cnt_s[2];
     __shared__ int wave_tot[GROUP_THREADS / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int hw = h * w, kmax = max(K, P);
-    const int na = final_cnt[b * 2 + 0], np = final_cnt[b * 2 + 1];
     const uint64_t* fa = final_keys + ((int64_t)b * 2 + 0) * kmax;
     const uint64_t* fp = final_keys + ((int64_t)b * 2 + 1) * kmax;
-    if (tid == 0) n_live_s = 0;
-    // every load that does not depend on another goes out first: the counts, this thread's anchor keys, its part key (slots beyond
-    // the counts hold stale keys: ignored below); the chain is then counts / keys -> gathers -> scan instead of five round trips
+    if (tid == 0) { n_live_s = 0; cnt_s[0] = 0; cnt_s[1] = 0; }
+    // every load that does not depend on another goes out first: this thread's anchor keys, its part key, and the LAST key of both
+    // lists (zero <=> the list has fewer candidates than slots; the zeros are a suffix); the chain is keys -> gathers -> scan
     const int p = chunk * GROUP_PARTS + (tid >> 2), q = tid & 3;
     uint64_t pkey = (p < P) ? fp[p] : 0ull;
     constexpr int APT = SD_MAX_TOPK / GROUP_THREADS;            // anchor keys per thread
     uint64_t ak[APT];
 #pragma unroll
     for (int u = 0; u < APT; ++u) ak[u] = (tid + u * GROUP_THREADS < K) ? fa[tid + u * GROUP_THREADS] : 0ull;
+    const uint64_t a_last = fa[K - 1], p_last = fp[P - 1];
     const PackedLayout L = packed_layout(packed, B, K, P);
     const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
     const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
-    if (na < K || np < P) {                                     // (block-uniform) fewer peaks than slots: the lists go through LDS for the zero slots
+    if (a_last == 0ull || p_last == 0ull) {                     // (block-uniform) fewer peaks than slots: the lists go through LDS for the zero slots
+        __syncthreads();
+        int na_t = 0, np_t = 0;
 #pragma unroll
         for (int u = 0; u < APT; ++u)
-            if (tid + u * GROUP_THREADS < na) akeys[tid + u * GROUP_THREADS] = ak[u];
-        for (int i = tid; i < np; i += GROUP_THREADS) pkeys[i] = fp[i];
+            if (tid + u * GROUP_THREADS < K) { akeys[tid + u * GROUP_THREADS] = ak[u]; na_t += ak[u] != 0ull; }
+        for (int i = tid; i < P; i += GROUP_THREADS) { const uint64_t kv = fp[i]; pkeys[i] = kv; np_t += kv != 0ull; }
+        if (na_t) atomicAdd(&cnt_s[0], na_t);
+        if (np_t) atomicAdd(&cnt_s[1], np_t);
         __syncthreads();
+        const int na = cnt_s[0], np = cnt_s[1];
         fill_zero_keys(akeys, na, K, flags, wave_tot);
         fill_zero_keys(pkeys, np, P, flags, wave_tot);
 #pragma unroll
@@ -1723,6 +1873,7 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
 // sd_decode_set_option("map_parallel_from" / "map_tile_height", n).
 static thread_local int g_map_parallel_from = 4096;
 static thread_local int g_map_tile_height = 0;
+static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
 static int map_tile_height(int64_t blocks16) {
     if (g_map_tile_height == 16 || g_map_tile_height == 32) return g_map_tile_height;
@@ -1762,16 +1913,22 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
         SD_REQUIRE(workspace_bytes >= mw.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, mw.bytes);
         const int tiles_x = cdiv(w, TW), tiles = tiles_x * cdiv(h, th), C = M + N;
         const float min_score = exact_topk ? 0.f : conf;
-        const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
         const bool vec = g_map_scalar_nms == 0 && w % 4 == 0 && aligned16(anchor_hm) && aligned16(part_hm) && a_sb % 4 == 0 && a_sc % 4 == 0 &&
                          p_sb % 4 == 0 && p_sc % 4 == 0;
-        if (vec && th == 32) hipLaunchKernelGGL(k_nms_slots_v<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
-        else if (vec)        hipLaunchKernelGGL(k_nms_slots_v<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
-        else if (th == 32)   hipLaunchKernelGGL(k_nms_slots<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
-        else                 hipLaunchKernelGGL(k_nms_slots<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
-        SD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_select_map, dim3(B * C), dim3(SEL_THREADS), 0, st, mw.cand, mw.tile_cnt, tiles, TW * th, M, N, K, P, mw.stage1, mw.stage1_cnt);
-        SD_LAUNCH_CHECK();
+        if (vec && g_map_scalar_nms == 0 && g_map_stream) {
+            // tile pass + per-map selection in one kernel (candidate list `cand`: h * w slots per map, only touched by overflowing maps)
+            hipLaunchKernelGGL(k_map_stream_select, dim3(B * C), dim3(STREAM_THREADS), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            SD_LAUNCH_CHECK();
+        } else {
+            const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
+            if (vec && th == 32) hipLaunchKernelGGL(k_nms_slots_v<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+            else if (vec)        hipLaunchKernelGGL(k_nms_slots_v<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+            else if (th == 32)   hipLaunchKernelGGL(k_nms_slots<32>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+            else                 hipLaunchKernelGGL(k_nms_slots<16>, tgrid, dim3(256), 0, st, g0, g1, h, w, tiles_x, tiles, min_score, mw.cand, mw.tile_cnt);
+            SD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_select_map, dim3(B * C), dim3(SEL_THREADS), 0, st, mw.cand, mw.tile_cnt, tiles, TW * th, M, N, K, P, mw.stage1);
+            SD_LAUNCH_CHECK();
+        }
         const size_t rank_lds = (size_t)std::max((int64_t)M * K, (int64_t)N * P) * 8;
         if (rank_lds > 48 * 1024) {
             static thread_local bool raised = false;               // per host thread: cheap, idempotent
@@ -1780,11 +1937,11 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
                 raised = true;
             }
         }
-        hipLaunchKernelGGL(k_rank_maps, dim3(B * C), dim3(SEL_THREADS), rank_lds, st, mw.stage1, mw.stage1_cnt, M, N, K, P, mw.final_keys, mw.final_cnt);
+        hipLaunchKernelGGL(k_rank_maps, dim3(B * C), dim3(SEL_THREADS), rank_lds, st, mw.stage1, M, N, K, P, mw.final_keys);
         SD_LAUNCH_CHECK();
         RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
         const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)K * 8 + (size_t)std::max(K, P) * 4;
-        hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, mw.final_cnt, h, w, K, P,
+        hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, h, w, K, P,
                            conf, dist_px, rm, packed, B);
         SD_LAUNCH_CHECK();
         return 0;
@@ -1816,6 +1973,7 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "map_parallel_from")) { g_map_parallel_from = value; return 0; }
     if (name && !strcmp(name, "map_tile_height")) { g_map_tile_height = value; return 0; }
     if (name && !strcmp(name, "map_scalar_nms")) { g_map_scalar_nms = value; return 0; }
+    if (name && !strcmp(name, "map_stream")) { g_map_stream = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }

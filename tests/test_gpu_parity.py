@@ -496,15 +496,19 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
             L.check(lib.sd_decode_set_option(b"map_parallel_from", 1 << 30))
             want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
             L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
-            for th, scalar in ((16, 0), (32, 0), (0, 0), (16, 1), (32, 1)):                        # logit-domain / per-pixel-sigmoid tile kernels
+            # streaming kernel (tile pass + per-map selection in one) / logit-domain tile kernel / per-pixel-sigmoid tile kernel + k_select_map
+            for th, scalar, stream in ((0, 0, 1), (16, 0, 0), (32, 0, 0), (16, 1, 0), (32, 1, 0)):
                 L.check(lib.sd_decode_set_option(b"map_tile_height", th))
                 L.check(lib.sd_decode_set_option(b"map_scalar_nms", scalar))
-                got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-                assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar}"
+                L.check(lib.sd_decode_set_option(b"map_stream", stream))
+                for _ in range(2):                                                                # (back to back: no state left behind)
+                    got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+                    assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream}"
     finally:
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
         L.check(lib.sd_decode_set_option(b"map_scalar_nms", 0))
+        L.check(lib.sd_decode_set_option(b"map_stream", 1))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))

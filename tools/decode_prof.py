@@ -27,6 +27,8 @@ import os  # noqa: E402
 from structuredetector_amd import _lib as L  # noqa: E402
 if os.environ.get("SD_MAP_FROM"):
     L.check(L.lib().sd_decode_set_option(b"map_parallel_from", int(os.environ["SD_MAP_FROM"])))
+if os.environ.get("SD_MAP_STREAM"):
+    L.check(L.lib().sd_decode_set_option(b"map_stream", int(os.environ["SD_MAP_STREAM"])))
 if os.environ.get("SD_MAP_TH"):
     L.check(L.lib().sd_decode_set_option(b"map_tile_height", int(os.environ["SD_MAP_TH"])))
 for _ in range(100):

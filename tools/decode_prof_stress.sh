@@ -6,18 +6,18 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 OUT=gpurun_out/decode_prof_stress_${1:-r04}.txt
 : > $OUT
-for V in "1073741824 0 1" "1 16 1" "1 32 1" "1 32 0" "1073741824 0 0"; do
+for V in "1073741824 0 1 0" "1 32 1 0" "1 0 1 1" "1 0 0 1" "1073741824 0 0 0"; do
   set -- $V
-  TAG=from$1_th$2_exact$3
+  TAG=from$1_th$2_exact$3_stream$4
   rm -rf gpurun_out/dps_$TAG
-  SD_MAP_FROM=$1 SD_MAP_TH=$2 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/dps_$TAG -- python3 tools/decode_prof.py 16 0 $3 stress > gpurun_out/dps_$TAG.log 2>&1
+  SD_MAP_FROM=$1 SD_MAP_TH=$2 SD_MAP_STREAM=$4 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/dps_$TAG -- python3 tools/decode_prof.py 16 0 $3 stress > gpurun_out/dps_$TAG.log 2>&1
   F=$(find gpurun_out/dps_$TAG -name '*kernel_stats.csv' | head -1)
   T=$(find gpurun_out/dps_$TAG -name '*kernel_trace.csv' | head -1)
-  echo "== map_parallel_from $1, map_tile_height $2, exact_topk $3 (bs 16, 1024x1024, 8 + 8 maps, K 128, P 512)" >> $OUT
+  echo "== map_parallel_from $1, map_tile_height $2, exact_topk $3, map_stream $4 (bs 16, 1024x1024, 8 + 8 maps, K 128, P 512)" >> $OUT
   python3 - "$F" "$T" >> $OUT <<'PY'
 import csv, sys
 import numpy as np
-names = ("k_nms_tile", "k_select_group", "fillBuffer", "k_nms_slots", "k_select_map", "k_rank_maps", "k_group_wide")
+names = ("k_nms_tile", "k_select_group", "fillBuffer", "k_nms_slots", "k_select_map", "k_rank_maps", "k_group_wide", "k_map_stream_select")
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].replace("void ", "").split("(")[0]
     if any(k in n for k in names):
