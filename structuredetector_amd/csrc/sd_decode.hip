@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // candidate list in global memory, no tile counts, no second launch for the first selection stage.
 //   * streaming: a wave owns a strip of up to 256 columns (one float4 per lane) and walks 16 output rows (+ 4 halo rows); the horizontal
 //     neighbours come from the adjacent lanes (cross-lane moves; the two edge lanes load their halo), the vertical window is five rows of
-//     horizontal maxima in registers: no LDS, no barrier, no index arithmetic per pixel; rows are requested eight ahead of their use;
+//     horizontal maxima in registers: no LDS, no barrier, no index arithmetic per pixel; rows are requested five ahead of their use;
 //   * the logit-domain survivor rule of k_nms_slots_v; candidates are appended (one LDS atomic per wave and row) as raw entries
 //     {logit, near flag, pixel} to a 4096-entry LDS stage, and the sigmoids are taken afterwards over the compacted entries;
 //   * selection from LDS (radix select, ranking / register bitonic sort) and one store of the map's sorted top-k, zero padded to k:
@@ -975,12 +975,21 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // A map with more than 4096 candidates (plateaus; > 6 % of all pixels) is walked a second time with the keys going to the global
 // candidate list and selected from there.  Needs w % 4 == 0 and 16-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
-constexpr int STREAM_THREADS = 512, STREAM_WAVES = STREAM_THREADS / 64, STREAM_ROWS = 16, STREAM_CAP = 4096, STREAM_AHEAD = 8;
+constexpr int STREAM_THREADS = 512, STREAM_WAVES = STREAM_THREADS / 64, STREAM_ROWS = 16, STREAM_CAP = 4096;
+
+// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1: one VALU move, no trip through the LDS crossbar)
+__device__ __forceinline__ float lane_from_left(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_from_right(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
 
 template <bool INLINE_KEYS>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys) {
-    constexpr int R = STREAM_ROWS, NR = R + 4;
+    constexpr int R = STREAM_ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
+    static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strips = (w + 255) >> 8, chunks = (h + R - 1) / R;
     const float NEG = -INFINITY;
@@ -992,70 +1001,73 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
         // the edge lanes' halo: lane 0 needs the two columns left of the strip, lane 63 the two right of it (8-byte aligned pairs)
         const int hx = lane == 0 ? x0 - 2 : x0 + 4;
         const bool halo_in = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
-        float4 v[NR];
-        float2 hl[NR];
-        auto request = [&](int j) {
+        float4 v[RING], hm[RING];
+        float2 hl[RING];
+        float4 c1 = make_float4(NEG, NEG, NEG, NEG), c2 = c1;   // the rows one and two above the row being staged
+        auto request = [&](int j, int slot) {
             const int y = y0 + j - 2;
             const bool row_in = y >= 0 && y < h;
-            v[j] = *reinterpret_cast<const float4*>(plane + ((col_in && row_in) ? (int64_t)y * w + x0 : 0));
-            hl[j] = *reinterpret_cast<const float2*>(plane + ((halo_in && row_in) ? (int64_t)y * w + hx : 0));
+            v[slot] = *reinterpret_cast<const float4*>(plane + ((col_in && row_in) ? (int64_t)y * w + x0 : 0));
+            hl[slot] = *reinterpret_cast<const float2*>(plane + ((halo_in && row_in) ? (int64_t)y * w + hx : 0));
         };
 #pragma unroll
-        for (int j = 0; j < STREAM_AHEAD; ++j) request(j);
-        float4 hm[NR];
+        for (int u = 0; u < RING; ++u) request(u, u);
+        for (int jb = 0; jb < NR; jb += RING) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            if (j + STREAM_AHEAD < NR) request(j + STREAM_AHEAD);
-            {
+            for (int u = 0; u < RING; ++u) {
+                const int j = jb + u;
                 const int y = y0 + j - 2;
                 const bool row_in = y >= 0 && y < h;
-                if (!(col_in && row_in)) v[j] = make_float4(NEG, NEG, NEG, NEG);
-                if (!(halo_in && row_in)) hl[j] = make_float2(NEG, NEG);
-                float lz = __shfl_up(v[j].z, 1), lw = __shfl_up(v[j].w, 1), rx = __shfl_down(v[j].x, 1), ry = __shfl_down(v[j].y, 1);
-                if (lane == 0) { lz = hl[j].x; lw = hl[j].y; }
-                if (lane == 63) { rx = hl[j].x; ry = hl[j].y; }
-                hm[j] = make_float4(max5(lz, lw, v[j].x, v[j].y, v[j].z), max5(lw, v[j].x, v[j].y, v[j].z, v[j].w),
-                                    max5(v[j].x, v[j].y, v[j].z, v[j].w, rx), max5(v[j].y, v[j].z, v[j].w, rx, ry));
-            }
-            if (j < 4) continue;
-            const int yo = y0 + j - 4;                                 // output row: window rows j - 4 .. j, centre j - 2
-            if (yo >= h) continue;                                      // (wave-uniform)
-            const float4 a0 = hm[j - 4], a1 = hm[j - 3], a2 = hm[j - 2], a3 = hm[j - 1], a4 = hm[j];
-            const float mx[4] = {max5(a0.x, a1.x, a2.x, a3.x, a4.x), max5(a0.y, a1.y, a2.y, a3.y, a4.y), max5(a0.z, a1.z, a2.z, a3.z, a4.z),
-                                 max5(a0.w, a1.w, a2.w, a3.w, a4.w)};
-            const float xv[4] = {v[j - 2].x, v[j - 2].y, v[j - 2].z, v[j - 2].w};
-            bool cand[4];
-            float sc[4];
-            unsigned long long msk[4];
-            int tot = 0;
+                float4 cur = v[u];
+                float2 hh = hl[u];
+                if (j + RING < NR) request(j + RING, u);               // the slot is free again: row j + RING goes out
+                if (!(col_in && row_in)) cur = make_float4(NEG, NEG, NEG, NEG);
+                if (!(halo_in && row_in)) hh = make_float2(NEG, NEG);
+                float lz = lane_from_left(cur.z), lw = lane_from_left(cur.w), rx = lane_from_right(cur.x), ry = lane_from_right(cur.y);
+                if (lane == 0) { lz = hh.x; lw = hh.y; }
+                if (lane == 63) { rx = hh.x; ry = hh.y; }
+                hm[u] = make_float4(max5(lz, lw, cur.x, cur.y, cur.z), max5(lw, cur.x, cur.y, cur.z, cur.w), max5(cur.x, cur.y, cur.z, cur.w, rx),
+                                    max5(cur.y, cur.z, cur.w, rx, ry));
+                const float4 centre = c2;                               // row j - 2
+                c2 = c1; c1 = cur;
+                const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all RING slots), centre j - 2
+                if (j < 4 || yo >= h) continue;                         // (wave-uniform)
+                const float mx[4] = {max5(hm[0].x, hm[1].x, hm[2].x, hm[3].x, hm[4].x), max5(hm[0].y, hm[1].y, hm[2].y, hm[3].y, hm[4].y),
+                                     max5(hm[0].z, hm[1].z, hm[2].z, hm[3].z, hm[4].z), max5(hm[0].w, hm[1].w, hm[2].w, hm[3].w, hm[4].w)};
+                const float xv[4] = {centre.x, centre.y, centre.z, centre.w};
+                bool cand[4];
+                float sc[4];
+                unsigned long long msk[4];
+                int tot = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cand[e] = col_in && !(mx[e] - xv[e] > nms_margin(mx[e]));
-                sc[e] = 0.f;
-                if (INLINE_KEYS && cand[e]) {                            // (second walk of an overflowing map: keys with their sigmoids at once)
-                    sc[e] = clamped_sigmoid(xv[e]);
-                    cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
+                for (int e = 0; e < 4; ++e) {
+                    cand[e] = col_in && !(mx[e] - xv[e] > nms_margin(mx[e]));
+                    sc[e] = 0.f;
+                    if (INLINE_KEYS && cand[e]) {                        // (second walk of an overflowing map: keys with their sigmoids at once)
+                        sc[e] = clamped_sigmoid(xv[e]);
+                        cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
+                    }
+                    msk[e] = __ballot(cand[e]);
+                    tot += __popcll(msk[e]);
                 }
-                msk[e] = __ballot(cand[e]);
-                tot += __popcll(msk[e]);
-            }
-            if (tot == 0) continue;                                     // (wave-uniform)
-            int base = 0;
-            if (lane == 0) base = atomicAdd(count, tot);                // LDS: one atomic per wave and row
-            base = __shfl(base, 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
+                if (tot == 0) continue;                                 // (wave-uniform)
+                int base = 0;
+                if (lane == 0) base = atomicAdd(count, tot);            // LDS: one atomic per wave and row
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int slot = base + __popcll(msk[e] & below);
-                base += __popcll(msk[e]);
-                if (!cand[e]) continue;
-                const uint32_t pix = (uint32_t)(yo * w + x0 + e);
-                if (INLINE_KEYS) {
-                    gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix);
-                } else if (slot < STREAM_CAP) {
-                    const bool top = xv[e] == mx[e];
-                    stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | pix;
-                    if (!top) mxs[slot] = mx[e];
+                for (int e = 0; e < 4; ++e) {
+                    const int slot = base + __popcll(msk[e] & below);
+                    base += __popcll(msk[e]);
+                    if (!cand[e]) continue;
+                    const uint32_t pix = (uint32_t)(yo * w + x0 + e);
+                    if (INLINE_KEYS) {
+                        gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix);
+                    } else if (slot < STREAM_CAP) {
+                        const bool top = xv[e] == mx[e];
+                        stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | pix;
+                        if (!top) mxs[slot] = mx[e];
+                    }
                 }
             }
         }
