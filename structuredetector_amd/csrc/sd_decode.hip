@@ -985,6 +985,14 @@ __device__ __forceinline__ float lane_from_right(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
 }
 
+// max of three in ONE instruction (fmaxf chains compile to v_max_f32 pairs plus NaN canonicalisation moves: 47 instructions for the
+// 14 three-way maxima of a row)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <bool INLINE_KEYS>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys) {
@@ -997,18 +1005,22 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
         const int sy = unit / strips, sx = unit - sy * strips;
         const int x0 = sx * 256 + lane * 4;
         const bool col_in = x0 < w;
+        const bool narrow = sx * 256 + 256 > w;                 // (wave-uniform) the strip has lanes beyond the map's right edge
         const int y0 = sy * R;
         // the edge lanes' halo: lane 0 needs the two columns left of the strip, lane 63 the two right of it (8-byte aligned pairs)
         const int hx = lane == 0 ? x0 - 2 : x0 + 4;
         const bool halo_in = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+        // row pointers advance by w per request; lanes outside the map (and the 62 inner lanes' halo) re-read the plane's first words
+        const float* pv = plane + (col_in ? x0 : 0);
+        const float* ph = plane + (halo_in ? hx : 0);
+        const int64_t vstep = col_in ? w : 0, hstep = halo_in ? w : 0;
         float4 v[RING], hm[RING];
         float2 hl[RING];
         float4 c1 = make_float4(NEG, NEG, NEG, NEG), c2 = c1;   // the rows one and two above the row being staged
         auto request = [&](int j, int slot) {
-            const int y = y0 + j - 2;
-            const bool row_in = y >= 0 && y < h;
-            v[slot] = *reinterpret_cast<const float4*>(plane + ((col_in && row_in) ? (int64_t)y * w + x0 : 0));
-            hl[slot] = *reinterpret_cast<const float2*>(plane + ((halo_in && row_in) ? (int64_t)y * w + hx : 0));
+            const int y = min(max(y0 + j - 2, 0), h - 1);       // rows outside the map: a valid row is read and discarded below
+            v[slot] = *reinterpret_cast<const float4*>(pv + y * vstep);
+            hl[slot] = *reinterpret_cast<const float2*>(ph + y * hstep);
         };
 #pragma unroll
         for (int u = 0; u < RING; ++u) request(u, u);
@@ -1017,57 +1029,55 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
             for (int u = 0; u < RING; ++u) {
                 const int j = jb + u;
                 const int y = y0 + j - 2;
-                const bool row_in = y >= 0 && y < h;
                 float4 cur = v[u];
                 float2 hh = hl[u];
                 if (j + RING < NR) request(j + RING, u);               // the slot is free again: row j + RING goes out
-                if (!(col_in && row_in)) cur = make_float4(NEG, NEG, NEG, NEG);
-                if (!(halo_in && row_in)) hh = make_float2(NEG, NEG);
+                if (y < 0 || y >= h) {                                  // (wave-uniform)
+                    cur = make_float4(NEG, NEG, NEG, NEG); hh = make_float2(NEG, NEG);
+                } else {
+                    if (narrow && !col_in) cur = make_float4(NEG, NEG, NEG, NEG);
+                    if (!halo_in) hh = make_float2(NEG, NEG);
+                }
                 float lz = lane_from_left(cur.z), lw = lane_from_left(cur.w), rx = lane_from_right(cur.x), ry = lane_from_right(cur.y);
                 if (lane == 0) { lz = hh.x; lw = hh.y; }
                 if (lane == 63) { rx = hh.x; ry = hh.y; }
-                hm[u] = make_float4(max5(lz, lw, cur.x, cur.y, cur.z), max5(lw, cur.x, cur.y, cur.z, cur.w), max5(cur.x, cur.y, cur.z, cur.w, rx),
-                                    max5(cur.y, cur.z, cur.w, rx, ry));
+                const float ma = max3f(cur.x, cur.y, cur.z), mb = max3f(cur.y, cur.z, cur.w);
+                hm[u] = make_float4(max3f(ma, lz, lw), max3f(ma, lw, cur.w), max3f(mb, cur.x, rx), max3f(mb, rx, ry));
                 const float4 centre = c2;                               // row j - 2
                 c2 = c1; c1 = cur;
                 const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all RING slots), centre j - 2
                 if (j < 4 || yo >= h) continue;                         // (wave-uniform)
-                const float mx[4] = {max5(hm[0].x, hm[1].x, hm[2].x, hm[3].x, hm[4].x), max5(hm[0].y, hm[1].y, hm[2].y, hm[3].y, hm[4].y),
-                                     max5(hm[0].z, hm[1].z, hm[2].z, hm[3].z, hm[4].z), max5(hm[0].w, hm[1].w, hm[2].w, hm[3].w, hm[4].w)};
+                const float mx[4] = {max3f(max3f(hm[0].x, hm[1].x, hm[2].x), hm[3].x, hm[4].x), max3f(max3f(hm[0].y, hm[1].y, hm[2].y), hm[3].y, hm[4].y),
+                                     max3f(max3f(hm[0].z, hm[1].z, hm[2].z), hm[3].z, hm[4].z), max3f(max3f(hm[0].w, hm[1].w, hm[2].w), hm[3].w, hm[4].w)};
                 const float xv[4] = {centre.x, centre.y, centre.z, centre.w};
                 bool cand[4];
                 float sc[4];
-                unsigned long long msk[4];
-                int tot = 0;
+                int cnt = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    cand[e] = col_in && !(mx[e] - xv[e] > nms_margin(mx[e]));
+                    cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e]));     // (lanes beyond the map hold -inf: inf - inf fails `>` ...)
                     sc[e] = 0.f;
                     if (INLINE_KEYS && cand[e]) {                        // (second walk of an overflowing map: keys with their sigmoids at once)
                         sc[e] = clamped_sigmoid(xv[e]);
                         cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
                     }
-                    msk[e] = __ballot(cand[e]);
-                    tot += __popcll(msk[e]);
+                    cnt += cand[e] ? 1 : 0;
                 }
-                if (tot == 0) continue;                                 // (wave-uniform)
-                int base = 0;
-                if (lane == 0) base = atomicAdd(count, tot);            // LDS: one atomic per wave and row
-                base = __builtin_amdgcn_readfirstlane(base);
-                const unsigned long long below = (1ull << lane) - 1ull;
+                if (narrow && !col_in) cnt = 0;                         // (... so they are dropped here)
+                if (cnt == 0) continue;
+                int slot = atomicAdd(count, cnt);                       // LDS; the few lanes of a row that hold candidates
+                const uint32_t pix = (uint32_t)(yo * w + x0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int slot = base + __popcll(msk[e] & below);
-                    base += __popcll(msk[e]);
                     if (!cand[e]) continue;
-                    const uint32_t pix = (uint32_t)(yo * w + x0 + e);
                     if (INLINE_KEYS) {
-                        gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix);
+                        gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix + e);
                     } else if (slot < STREAM_CAP) {
                         const bool top = xv[e] == mx[e];
-                        stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | pix;
+                        stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | (pix + e);
                         if (!top) mxs[slot] = mx[e];
                     }
+                    ++slot;
                 }
             }
         }
@@ -1093,9 +1103,13 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     const int hw = h * w;
     const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
     if (tid < 2) { counts[tid] = 0; alive[tid] = 0; }
+    [[maybe_unused]] const int trace0 = bm == 0 ? 6400 : (bm == g0.C ? 6420 : (bm == 255 ? 6440 : -100));
+    SD_TRACE(trace0 + 0);
     __syncthreads();
     stream_map<false>(plane, h, w, c, min_score, stage, mxs, &counts[0], nullptr);
+    SD_TRACE(trace0 + 1);
     __syncthreads();
+    SD_TRACE(trace0 + 2);
     const int nraw = counts[0];
     const Team T{tid, buf, hist, misc, nullptr, stage, 0, alive};
     const int np2k = max(next_pow2(k), 2);
@@ -1111,6 +1125,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
             if (slot >= 0) buf[slot] = make_key(v, (uint32_t)(c * hw) + ((uint32_t)ent & 0x7fffffffu));
         }
         __syncthreads();
+        SD_TRACE(trace0 + 3);
         const int n = counts[1];
         if (n <= k) {                                                   // every candidate is selected: sort them all
             const int np2 = max(next_pow2(n), 2);
@@ -1122,8 +1137,10 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
             for (int i = tid; i < k; i += STREAM_THREADS) out[i] = i < n ? buf[i] : 0ull;
         } else {
             radix_select_sorted<STREAM_THREADS>(T, LdsSrc<STREAM_THREADS>{buf, n}, k, stage, np2k);
+            SD_TRACE(trace0 + 4);
             for (int i = tid; i < k; i += STREAM_THREADS) out[i] = stage[i];
         }
+        SD_TRACE(trace0 + 5);
         return;
     }
     // more candidates than the stage holds: second walk, keys straight to the map's global list, selection from there

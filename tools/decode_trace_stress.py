@@ -38,11 +38,11 @@ for it in range(30):
     lib.sd_debug_read_trace(buf, 8192)
     t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
     if it >= 10:
-        rows.append(np.concatenate([t[6100:6104] - t[6100], t[6200:6204] - t[6200], t[6000:6006] - t[6000], t[6300:6313] - t[6300]]))
+        rows.append(np.concatenate([t[6400:6406] - t[6400], t[6420:6426] - t[6420], t[6440:6446] - t[6440], t[6300:6313] - t[6300], [t[6440] - t[6400]]]))
 r = np.median(np.array(rows, np.float64), axis=0) * 0.01
-print(f"stress decode, exact={exact}: us since the block started (medians over 20 runs)")
-print("  k_select_map (anchor map 0):  prefix %.2f, selected %.2f, written %.2f" % tuple(r[1:4]))
-print("  k_select_map (part map 0):    prefix %.2f, selected %.2f, written %.2f" % tuple(r[5:8]))
-print("  k_merge_group (image 0):      counts %.2f, selected %.2f, zero fill %.2f, keys decoded %.2f, grouped %.2f" % tuple(r[9:14]))
-print("  radix select of k_merge_group (anchor team; both teams share the barriers): start 0, after pass 7..0: "
-      + " ".join(f"{v:.2f}" for v in r[15:23]) + f"; passes done {r[24]:.2f}, collected {r[25]:.2f}, sorted {r[26]:.2f}")
+print(f"stress decode, exact={exact}: k_map_stream_select, us since the block started (wave 0's view; medians over 20 runs)")
+for name, o in (("anchor map 0 (block 0)", 0), ("part map 0 (block 8)", 6), ("last block (255)", 12)):
+    print(f"  {name:24s} wave 0 streamed {r[o + 1]:.2f}, all waves {r[o + 2]:.2f}, keys {r[o + 3]:.2f}, selected {r[o + 4]:.2f}, stored {r[o + 5]:.2f}")
+print(f"  block 255 started {r[-1]:.2f} us after block 0")
+print("  radix select of block 0: start 0, after passes: " + " ".join(f"{v:.2f}" for v in r[19:27] if abs(v) < 1e6)
+      + f"; passes done {r[28]:.2f}, collected {r[29]:.2f}, sorted {r[30]:.2f}")
