@@ -993,14 +993,24 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return r;
 }
 
+// Candidates of a wave go to the wave's OWN segment of the stage (STREAM_SEG entries), the fill level lives in a scalar register: one
+// ballot per row ("this lane has a candidate") ranks the lanes, no atomic -- per-lane LDS atomics on one block-wide counter serialise
+// (~20 cycles each, 80 per row over the block's waves: the append then cost as much as the whole rest of the walk), per-element ballots
+// cost ~100 instructions per row.  A lane with a SECOND candidate among its four pixels (ties only: 5x5 maxima are >= 3 apart) puts it
+// on the small block-wide `extra` list through an LDS atomic.  count[0] = largest fill level of a segment seen (block-wide maximum:
+// the overflow test), count[1] = entries on the extra list; the wave's fill level goes to seg_fill[wave].
+constexpr int STREAM_SEG = STREAM_CAP / STREAM_WAVES, STREAM_EXTRA = 256;
 template <bool INLINE_KEYS>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
-                                           float* mxs, int* count, uint64_t* __restrict__ gkeys) {
+                                           float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx) {
     constexpr int R = STREAM_ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
     static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strips = (w + 255) >> 8, chunks = (h + R - 1) / R;
     const float NEG = -INFINITY;
+    int fill = 0;                                               // (wave-uniform) entries in this wave's segment
+    uint64_t* seg = stage + wave * STREAM_SEG;
+    float* seg_mx = mxs + wave * STREAM_SEG;
     for (int unit = wave; unit < strips * chunks; unit += STREAM_WAVES) {
         const int sy = unit / strips, sx = unit - sy * strips;
         const int x0 = sx * 256 + lane * 4;
@@ -1047,52 +1057,91 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                 c2 = c1; c1 = cur;
                 const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all RING slots), centre j - 2
                 if (j < 4 || yo >= h) continue;                         // (wave-uniform)
+#if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 2                         // timing experiment: loads + horizontal maxima only
+                if (hm[u].x != 12345.f) continue;
+#endif
                 const float mx[4] = {max3f(max3f(hm[0].x, hm[1].x, hm[2].x), hm[3].x, hm[4].x), max3f(max3f(hm[0].y, hm[1].y, hm[2].y), hm[3].y, hm[4].y),
                                      max3f(max3f(hm[0].z, hm[1].z, hm[2].z), hm[3].z, hm[4].z), max3f(max3f(hm[0].w, hm[1].w, hm[2].w), hm[3].w, hm[4].w)};
                 const float xv[4] = {centre.x, centre.y, centre.z, centre.w};
-                bool cand[4];
-                float sc[4];
-                int cnt = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e]));     // (lanes beyond the map hold -inf: inf - inf fails `>` ...)
-                    sc[e] = 0.f;
-                    if (INLINE_KEYS && cand[e]) {                        // (second walk of an overflowing map: keys with their sigmoids at once)
-                        sc[e] = clamped_sigmoid(xv[e]);
-                        cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
-                    }
-                    cnt += cand[e] ? 1 : 0;
-                }
-                if (narrow && !col_in) cnt = 0;                         // (... so they are dropped here)
-                if (cnt == 0) continue;
-                int slot = atomicAdd(count, cnt);                       // LDS; the few lanes of a row that hold candidates
                 const uint32_t pix = (uint32_t)(yo * w + x0);
+                if (INLINE_KEYS) {                                       // (second walk of an overflowing map: keys with their sigmoids at once)
+                    int cnt = 0;
+                    bool cand[4];
+                    float sc[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!cand[e]) continue;
-                    if (INLINE_KEYS) {
-                        gkeys[slot] = make_key(sc[e], (uint32_t)(c * h * w) + pix + e);
-                    } else if (slot < STREAM_CAP) {
-                        const bool top = xv[e] == mx[e];
-                        stage[slot] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (top ? 0u : 0x80000000u) | (pix + e);
-                        if (!top) mxs[slot] = mx[e];
+                    for (int e = 0; e < 4; ++e) {
+                        cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e])) && !(narrow && !col_in);
+                        sc[e] = 0.f;
+                        if (cand[e]) {
+                            sc[e] = clamped_sigmoid(xv[e]);
+                            cand[e] = sc[e] >= min_score && (xv[e] == mx[e] || clamped_sigmoid(mx[e]) == sc[e]);
+                        }
+                        cnt += cand[e] ? 1 : 0;
                     }
-                    ++slot;
+                    if (cnt == 0) continue;
+                    int slot = atomicAdd(count, cnt);                   // LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cand[e]) gkeys[slot++] = make_key(sc[e], (uint32_t)(c * h * w) + pix + e);
+                    continue;
                 }
+                // (lanes beyond the map hold -inf: inf - inf fails `>`, they are dropped by the `narrow` term)
+                const bool c0 = !(mx[0] - xv[0] > nms_margin(mx[0])), c1e = !(mx[1] - xv[1] > nms_margin(mx[1]));
+                const bool c2e = !(mx[2] - xv[2] > nms_margin(mx[2])), c3 = !(mx[3] - xv[3] > nms_margin(mx[3]));
+                const bool any = (c0 || c1e || c2e || c3) && !(narrow && !col_in);
+#if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 1                         // timing experiment: no append (results wrong by design)
+                if (mx[0] != 12345.f) continue;
+#endif
+                const unsigned long long has = __ballot(any);
+                if (has == 0ull) continue;                              // (wave-uniform)
+                if (any) {
+                    // the lane's FIRST candidate goes to the wave's segment at fill + (lanes below with a candidate)
+                    const int e0 = c0 ? 0 : (c1e ? 1 : (c2e ? 2 : 3));
+                    const float x0v = c0 ? xv[0] : (c1e ? xv[1] : (c2e ? xv[2] : xv[3]));
+                    const float m0v = c0 ? mx[0] : (c1e ? mx[1] : (c2e ? mx[2] : mx[3]));
+                    const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                    if (slot < STREAM_SEG) {
+                        const bool top = x0v == m0v;
+                        seg[slot] = ((uint64_t)__float_as_uint(x0v) << 32) | (top ? 0u : 0x80000000u) | (pix + e0);
+                        if (!top) seg_mx[slot] = m0v;
+                    }
+                    const int more = (c0 ? 1 : 0) + (c1e ? 1 : 0) + (c2e ? 1 : 0) + (c3 ? 1 : 0) - 1;
+                    if (more > 0) {                                     // further candidates of the same four pixels: ties / near-ties only
+                        int xs = atomicAdd(&count[1], more);            // LDS
+                        const bool ce[4] = {c0, c1e, c2e, c3};
+#pragma unroll
+                        for (int e = 1; e < 4; ++e) {
+                            if (!ce[e] || e == e0) continue;
+                            if (xs < STREAM_EXTRA) {
+                                extra[xs] = ((uint64_t)__float_as_uint(xv[e]) << 32) | (xv[e] == mx[e] ? 0u : 0x80000000u) | (pix + e);
+                                extra_mx[xs] = mx[e];
+                            }
+                            ++xs;
+                        }
+                    }
+                }
+                fill += __popcll(has);
             }
         }
+    }
+    if (!INLINE_KEYS && lane == 0) {
+        seg_fill[wave] = min(fill, STREAM_SEG);
+        atomicMax(&count[0], fill);
     }
 }
 
 __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
                                                                        uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1) {
     __shared__ uint64_t stage[STREAM_CAP];                              // raw entries, then scratch of the selection (T.out)
-    __shared__ uint64_t buf[STREAM_CAP];                                // keys
+    __shared__ uint64_t buf[STREAM_CAP + STREAM_EXTRA];                 // keys (segments + extra list)
     __shared__ float mxs[STREAM_CAP];
     __shared__ int hist[2 * 256];
     __shared__ int misc[4];
     __shared__ int alive[2];
-    __shared__ int counts[2];                                           // [0] raw entries / global keys, [1] keys
+    __shared__ int counts[3];                                           // [0] fullest segment / global keys, [1] extra entries, [2] keys
+    __shared__ int seg_fill[STREAM_WAVES];
+    __shared__ uint64_t extra[STREAM_EXTRA];
+    __shared__ float extra_mx[STREAM_EXTRA];
     const int tid = threadIdx.x;
     const int C = g0.C + g1.C;
     const int bm = blockIdx.x, b = bm / C, m = bm - b * C;
@@ -1102,31 +1151,37 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     const int k = grp ? P : K, kmax = max(K, P);
     const int hw = h * w;
     const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
-    if (tid < 2) { counts[tid] = 0; alive[tid] = 0; }
+    if (tid < 3) counts[tid] = 0;
+    if (tid < 2) alive[tid] = 0;
     [[maybe_unused]] const int trace0 = bm == 0 ? 6400 : (bm == g0.C ? 6420 : (bm == 255 ? 6440 : -100));
     SD_TRACE(trace0 + 0);
     __syncthreads();
-    stream_map<false>(plane, h, w, c, min_score, stage, mxs, &counts[0], nullptr);
+    stream_map<false>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
     SD_TRACE(trace0 + 1);
+    // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
+    auto convert = [&](uint64_t ent, float mxv) {
+        const float x = __uint_as_float((uint32_t)(ent >> 32));
+        const float v = clamped_sigmoid(x);
+        bool ok = v >= min_score;                                       // `>=`: see k_nms_tile
+        if (ok && ((uint32_t)ent & 0x80000000u)) ok = clamped_sigmoid(mxv) == v;       // near-tie / saturated window
+        const int slot = alloc_slot(&counts[2], ok);
+        if (slot >= 0) buf[slot] = make_key(v, (uint32_t)(c * hw) + ((uint32_t)ent & 0x7fffffffu));
+    };
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nseg = min(__builtin_amdgcn_readfirstlane(seg_fill[wave]), STREAM_SEG);   // (written by this wave's lane 0: LDS is in order per wave)
+        for (int i = lane; i < nseg; i += 64) convert(stage[wave * STREAM_SEG + i], mxs[wave * STREAM_SEG + i]);
+    }
     __syncthreads();
     SD_TRACE(trace0 + 2);
-    const int nraw = counts[0];
     const Team T{tid, buf, hist, misc, nullptr, stage, 0, alive};
     const int np2k = max(next_pow2(k), 2);
     uint64_t* out = stage1 + (int64_t)bm * kmax;
-    if (nraw <= STREAM_CAP) {                                           // (block-uniform)
-        for (int i = tid; i < nraw; i += STREAM_THREADS) {              // sigmoids of the compacted entries only
-            const uint64_t ent = stage[i];
-            const float x = __uint_as_float((uint32_t)(ent >> 32));
-            const float v = clamped_sigmoid(x);
-            bool ok = v >= min_score;                                   // `>=`: see k_nms_tile
-            if (ok && ((uint32_t)ent & 0x80000000u)) ok = clamped_sigmoid(mxs[i]) == v;    // near-tie / saturated window
-            const int slot = alloc_slot(&counts[1], ok);
-            if (slot >= 0) buf[slot] = make_key(v, (uint32_t)(c * hw) + ((uint32_t)ent & 0x7fffffffu));
-        }
+    if (counts[0] <= STREAM_SEG && counts[1] <= STREAM_EXTRA) {         // (block-uniform) nothing overflowed
+        for (int i = tid; i < counts[1]; i += STREAM_THREADS) convert(extra[i], extra_mx[i]);
         __syncthreads();
         SD_TRACE(trace0 + 3);
-        const int n = counts[1];
+        const int n = counts[2];
         if (n <= k) {                                                   // every candidate is selected: sort them all
             const int np2 = max(next_pow2(n), 2);
             for (int i = n + tid; i < np2; i += STREAM_THREADS) buf[i] = 0ull;
@@ -1148,7 +1203,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     if (tid == 0) counts[0] = 0;
     __syncthreads();
     uint64_t* glist = cand + (int64_t)bm * hw;
-    stream_map<true>(plane, h, w, c, min_score, nullptr, nullptr, &counts[0], glist);
+    stream_map<true>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
