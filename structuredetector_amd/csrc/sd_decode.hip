@@ -226,6 +226,27 @@ __device__ void bitonic_desc(const Team& T, uint64_t* buf, int np2) {
 constexpr int RANK_CAP = 256;
 template <int NT>
 __device__ void rank_sort_desc(const Team& T, uint64_t* buf, int np2) {
+    if (np2 * 4 <= NT && np2 >= 16) {                        // four lanes per key, each counting over a quarter of the list (np2 is team-uniform)
+        const int i = T.tid >> 2, q = T.tid & 3;
+        const bool in = i < np2;
+        const uint64_t key = in ? buf[i] : 0ull;
+        int rank = 0;
+        if (in) {
+#pragma unroll 4
+            for (int j = q * 2; j < np2; j += 8) {
+                const uint64_t a = buf[j], bb = buf[j + 1];
+                rank += (a > key || (a == key && j < i)) ? 1 : 0;
+                rank += (bb > key || (bb == key && j + 1 < i)) ? 1 : 0;
+            }
+        }
+        rank += __shfl_xor(rank, 1);
+        rank += __shfl_xor(rank, 2);
+        if (in && q == 0) buf[np2 + rank] = key;
+        __syncthreads();
+        for (int t = T.tid; t < np2; t += NT) buf[t] = buf[np2 + t];
+        __syncthreads();
+        return;
+    }
     for (int i = T.tid; i < np2; i += NT) {
         const uint64_t key = buf[i];
         int rank = 0;
@@ -380,7 +401,7 @@ __device__ __forceinline__ void hist_add(int* h, int digit) {
     for (int round = 0; round < 2; ++round) {
         if (todo == 0ull) return;
         const int leader = __ffsll((long long)todo) - 1;
-        const int d = __shfl(digit, leader);
+        const int d = __builtin_amdgcn_readlane(digit, leader);       // (leader is wave-uniform: v_readlane, not a trip through the LDS crossbar)
         const unsigned long long same = __ballot(digit == d) & todo;
         if (lane == leader) atomicAdd(&h[d], __popcll(same));
         todo &= ~same;
@@ -396,8 +417,8 @@ __device__ __forceinline__ int alloc_slot(int* counter, bool take) {
     const int leader = __ffsll((long long)m) - 1;
     int base = 0;
     if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader);
-    return take ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    base = __builtin_amdgcn_readlane(base, leader);
+    return take ? base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) : -1;
 }
 
 // MSB-first 8-bit radix select of the k largest of the source's n unique keys into dst[0..np2k) (zero padded), then sorted
@@ -1286,16 +1307,16 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
     const uint64_t* src = stage1 + ((int64_t)b * C + first) * kmax;
     const int span = nl * k;
     int nonzero = 0;
-    for (int base = tid; base < span; base += 4 * SEL_THREADS) {            // every load of the thread in flight together
-        uint64_t kv[4];
+    for (int base = tid; base < span; base += 8 * SEL_THREADS) {            // every load of the thread in flight together
+        uint64_t kv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int i = base + u * SEL_THREADS;
             const int l = i / k;
             kv[u] = i < span ? src[(int64_t)l * kmax + (i - l * k)] : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
             if (base + u * SEL_THREADS < span) { keys[base + u * SEL_THREADS] = kv[u]; nonzero += kv[u] != 0ull; }
     }
     if (own == 0 && nonzero) atomicAdd(&total, nonzero);
@@ -1307,14 +1328,22 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
         const uint64_t key = keys[own * k + i];
         if (key == 0ull) continue;
         int rank = i;
-#pragma unroll 4
-        for (int l = 0; l < nl; ++l) {
-            if (l == own) continue;
-            const uint64_t* lst = keys + l * k;                 // descending; count of keys greater than `key`
-            int pos = 0;
-            for (int step = top; step > 0; step >>= 1)
-                if (pos + step <= k && lst[pos + step - 1] > key) pos += step;
-            rank += pos;
+        for (int l0 = 0; l0 < nl; l0 += 4) {                    // four lists at a time: their (dependent) probes overlap
+            int pos[4] = {0, 0, 0, 0};
+            const uint64_t* lst[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                on[u] = l0 + u < nl && l0 + u != own;
+                lst[u] = keys + (on[u] ? l0 + u : own) * k;     // descending; count of keys greater than `key`
+            }
+            for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (pos[u] + step <= k && lst[u][pos[u] + step - 1] > key) pos[u] += step;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank += on[u] ? pos[u] : 0;
         }
         if (rank < k) out[rank] = key;
     }
