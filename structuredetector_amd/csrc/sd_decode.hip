@@ -1302,6 +1302,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
     const int grp = m >= M ? 1 : 0;
     const int nl = grp ? N : M, first = grp ? M : 0, own = m - first, k = grp ? P : K;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);        // [nl][k]
+    [[maybe_unused]] const int trace0 = bm == 0 ? 6500 : (bm == M ? 6510 : (bm == (int)gridDim.x - 1 ? 6520 : -100));
+    SD_TRACE(trace0 + 0);
     if (tid == 0) total = 0;
     __syncthreads();
     const uint64_t* src = stage1 + ((int64_t)b * C + first) * kmax;
@@ -1321,6 +1323,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
     }
     if (own == 0 && nonzero) atomicAdd(&total, nonzero);
     __syncthreads();
+    SD_TRACE(trace0 + 1);
     int top = 1;                                                // largest power of two <= k: first probe of the branch-free search
     while (top * 2 <= k) top *= 2;
     uint64_t* out = final_keys + ((int64_t)b * 2 + grp) * kmax;
@@ -1337,16 +1340,19 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
                 on[u] = l0 + u < nl && l0 + u != own;
                 lst[u] = keys + (on[u] ? l0 + u : own) * k;     // descending; count of keys greater than `key`
             }
-            for (int step = top; step > 0; step >>= 1) {
+            for (int step = top; step > 0; step >>= 1) {        // branch-free: four probes in flight, then four updates
+                uint64_t probe[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (pos[u] + step <= k && lst[u][pos[u] + step - 1] > key) pos[u] += step;
+                for (int u = 0; u < 4; ++u) probe[u] = lst[u][min(pos[u] + step, k) - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos[u] += (pos[u] + step <= k && probe[u] > key) ? step : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) rank += on[u] ? pos[u] : 0;
         }
         if (rank < k) out[rank] = key;
     }
+    SD_TRACE(trace0 + 2);
     if (own == 0)
         for (int i = min(total, k) + tid; i < k; i += SEL_THREADS) out[i] = 0ull;
 }
@@ -1402,9 +1408,10 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* akeys = reinterpret_cast<uint64_t*>(smem);                 // [K]
     uint64_t* pkeys = akeys + K;                                          // [P]
-    float* posx = reinterpret_cast<float*>(pkeys + P);                    // [K]
-    float* posy = posx + K;                                               // [K]
-    int* flags = reinterpret_cast<int*>(posy + K);                        // [max(K, P)]
+    const int Kp = (K + 3) & ~3;                                          // (float4 reads of the anchor positions)
+    float* posx = reinterpret_cast<float*>(pkeys + P);                    // [Kp]
+    float* posy = posx + Kp;                                              // [Kp]
+    int* flags = reinterpret_cast<int*>(posy + Kp);                       // [max(K, P)]
     __shared__ int n_live_s, cnt_s[2];
     __shared__ int wave_tot[GROUP_THREADS / 64];
     const int tid = threadIdx.x;
@@ -1412,6 +1419,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     const int hw = h * w, kmax = max(K, P);
     const uint64_t* fa = final_keys + ((int64_t)b * 2 + 0) * kmax;
     const uint64_t* fp = final_keys + ((int64_t)b * 2 + 1) * kmax;
+    [[maybe_unused]] const int trace0 = (b == 0 && chunk == 0) ? 6600 : ((b == (int)gridDim.x - 1 && chunk == (int)gridDim.y - 1) ? 6610 : -100);
+    SD_TRACE(trace0 + 0);
     if (tid == 0) { n_live_s = 0; cnt_s[0] = 0; cnt_s[1] = 0; }
     // every load that does not depend on another goes out first: this thread's anchor keys, its part key, and the LAST key of both
     // lists (zero <=> the list has fewer candidates than slots; the zeros are a suffix); the chain is keys -> gathers -> scan
@@ -1476,7 +1485,9 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
         }
     }
     if (last_live) atomicMax(&n_live_s, last_live);
+    SD_TRACE(trace0 + 1);
     __syncthreads();
+    SD_TRACE(trace0 + 2);
     // anchors beyond the last live rank are all masked: at (1e6, 1e6) they are never within dist_px of a live part (see block_group)
     const int n_scan = dist_px < 1e5f ? n_live_s : K;
     if (p < P) {
@@ -1491,11 +1502,20 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
         float best = INFINITY;
         int best_a = 0x7fffffff;
         if (mk || dist_px >= 1e5f) {
-            for (int a = q; a < n_scan; a += 4) {               // decoders.py:88-98, utils.py:433-435
-                const float dx = orx - posx[a], dy = ory - posy[a];
-                const float sx = dx * dx, sy = dy * dy;
-                const float d = sqrtf(sx + sy);
-                if (d < best) { best = d; best_a = a; }         // ascending a within the lane: first minimum
+            // decoders.py:88-98, utils.py:433-435.  Lane q scans the anchors of its quarter (whole groups of four: one ds_read_b128
+            // of x and of y per four anchors), ascending: first minimum within the lane
+            const int groups = (n_scan + 3) >> 2, per = (groups + 3) >> 2;
+            const int g_lo = q * per, g_hi = min(g_lo + per, groups);
+            for (int gi = g_lo; gi < g_hi; ++gi) {
+                const float4 ax4 = reinterpret_cast<const float4*>(posx)[gi], ay4 = reinterpret_cast<const float4*>(posy)[gi];
+                const float axs[4] = {ax4.x, ax4.y, ax4.z, ax4.w}, ays[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dx = orx - axs[e], dy = ory - ays[e];
+                    const float sx = dx * dx, sy = dy * dy;
+                    const float d = sqrtf(sx + sy);
+                    if (d < best && gi * 4 + e < n_scan) { best = d; best_a = gi * 4 + e; }
+                }
             }
         }
 #pragma unroll
@@ -1514,6 +1534,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
             L.assign[(int64_t)b * P + p] = (best < dist_px) ? best_a : -1;   // decoders.py:100
         }
     }
+    SD_TRACE(trace0 + 3);
     if (chunk == 0 && tid == 0) L.status[b] = 0;
 }
 
@@ -2053,7 +2074,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
         hipLaunchKernelGGL(k_rank_maps, dim3(B * C), dim3(SEL_THREADS), rank_lds, st, mw.stage1, M, N, K, P, mw.final_keys);
         SD_LAUNCH_CHECK();
         RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
-        const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)K * 8 + (size_t)std::max(K, P) * 4;
+        const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)((K + 3) & ~3) * 8 + (size_t)std::max(K, P) * 4;
         hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, h, w, K, P,
                            conf, dist_px, rm, packed, B);
         SD_LAUNCH_CHECK();

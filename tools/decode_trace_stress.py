@@ -31,13 +31,15 @@ L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
 lib.sd_debug_read_trace.restype = C.c_int
 lib.sd_debug_read_trace.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * 8192)()
-rows = []
+rows, more = [], []
 for it in range(30):
     dec.decode_packed(outs, 0.5, 0.1, exact_topk=exact, fused=False)
     torch.cuda.synchronize()
     lib.sd_debug_read_trace(buf, 8192)
     t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
     if it >= 10:
+        more.append(np.concatenate([t[6500:6503] - t[6500], t[6520:6523] - t[6520], [t[6520] - t[6500]], t[6600:6604] - t[6600], t[6610:6614] - t[6610],
+                                    [t[6610] - t[6600], t[6500] - t[6400], t[6600] - t[6500]]]))
         rows.append(np.concatenate([t[6400:6406] - t[6400], t[6420:6426] - t[6420], t[6440:6446] - t[6440], t[6300:6313] - t[6300], [t[6440] - t[6400]]]))
 r = np.median(np.array(rows, np.float64), axis=0) * 0.01
 print(f"stress decode, exact={exact}: k_map_stream_select, us since the block started (wave 0's view; medians over 20 runs)")
@@ -46,3 +48,7 @@ for name, o in (("anchor map 0 (block 0)", 0), ("part map 0 (block 8)", 6), ("la
 print(f"  block 255 started {r[-1]:.2f} us after block 0")
 print("  radix select of block 0: start 0, after passes: " + " ".join(f"{v:.2f}" for v in r[19:27] if abs(v) < 1e6)
       + f"; passes done {r[28]:.2f}, collected {r[29]:.2f}, sorted {r[30]:.2f}")
+q = np.median(np.array(more, np.float64), axis=0) * 0.01
+print(f"k_rank_maps block 0: lists in LDS {q[1]:.2f}, ranked {q[2]:.2f}; last block: {q[4]:.2f}, {q[5]:.2f} (started {q[6]:.2f} after block 0)")
+print(f"k_group_wide block (0, 0): anchors posted {q[8]:.2f}, barrier {q[9]:.2f}, parts done {q[10]:.2f}; last block: {q[12]:.2f}, {q[13]:.2f}, {q[14]:.2f} (started {q[15]:.2f} after block 0)")
+print(f"block 0 of k_rank_maps starts {q[16]:.2f} us after block 0 of k_map_stream_select, block 0 of k_group_wide {q[17]:.2f} us after block 0 of k_rank_maps")
