@@ -499,10 +499,13 @@ def main():
             with torch.no_grad():
                 sf = timed(lambda: snet(simg), 5)
                 sd_ = timed(lambda: sdec.decode_packed(souts, 0.5, 0.1, exact_topk=True), 10)
+                sd_fast = timed(lambda: sdec.decode_packed(souts, 0.5, 0.1, exact_topk=False), 10)   # what Decoder.__call__ runs without metadata
                 sboth = timed(lambda: (snet(simg), sdec.decode_packed(souts, 0.5, 0.1, exact_topk=True)), 5)
             return {"batch": Bs, "fwd_ms": round(sf * 1e3, 3), "fwd_tflops": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3, 1),
                     "fwd_frac_of_bf16_mfma_peak": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "decode_us_per_img": round(sd_ / Bs * 1e6, 2), "decode_GBps": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9, 1),
+                    "decode_frac_of_hbm_peak": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9 / PEAK_HBM_GBPS, 4),
+                    "decode_annotations_only_us_per_img": round(sd_fast / Bs * 1e6, 2),
                     "fwd_plus_decode_ms": round(sboth * 1e3, 3), "objects_per_img": "64-96", "K": Ks, "P": Ps}
 
         net.eval()
