@@ -133,8 +133,8 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
  * _workspace_bytes cover both.
  * Knobs of sd_decode (same rules): "map_parallel_from" = number of 64x16-pixel tile blocks of a call from which sd_decode takes its
  * map-parallel path -- tile pass without global atomics, one selector block per (image, map), one merge + association block per image;
- * bit-identical results -- instead of the launch pair with one selector block per image (default 4096: batches of 4 and more at
- * 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there;
+ * bit-identical results -- instead of the launch pair with one selector block per image (default 2560, and always for images of 1024+
+ * tile blocks such as 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there;
  * "map_scalar_nms" = 1 keeps the per-pixel-sigmoid tile kernel where the logit-domain one (w % 4 == 0, aligned planes) applies. */
 int sd_decode_set_option(const char* name, int value);
 

@@ -2005,7 +2005,7 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
 }
 // Tile blocks (at 64x16) from which sd_decode takes the map-parallel path, and its tile height (0 = by size); per host thread.
 // sd_decode_set_option("map_parallel_from" / "map_tile_height", n).
-static thread_local int g_map_parallel_from = 4096;
+static thread_local int g_map_parallel_from = 2560;
 static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
@@ -2041,7 +2041,12 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     hipStream_t st = (hipStream_t)stream;
     Group g0{anchor_hm, a_sb, a_sc, M}, g1{part_hm, p_sb, p_sc, N};
     const int64_t blocks16 = (int64_t)B * (M + N) * cdiv(w, TW) * cdiv(h, 16);
-    if (map_path_possible(M, N, h, w, K, P) && blocks16 >= g_map_parallel_from && blocks16 < (1ll << 30)) {
+    // measured (tools/decode_path_sweep.py): the launch pair costs ~20 us + what ONE block per image needs for its lists (1024x1024, 8 + 8
+    // maps: 64 us at bs = 1), the map-parallel chain 25-35 us + the tile pass; they cross at ~2500 tile blocks, and images of 1024 and
+    // more tile blocks are better off on the map-parallel path at any batch size
+    const int64_t tiles_img16 = (int64_t)(M + N) * cdiv(w, TW) * cdiv(h, 16);
+    const bool want_map = blocks16 >= g_map_parallel_from || (g_map_parallel_from < (1 << 30) && tiles_img16 >= 1024);
+    if (map_path_possible(M, N, h, w, K, P) && want_map && blocks16 < (1ll << 30)) {
         const int th = map_tile_height(blocks16);
         const MapWs mw = carve_map(workspace, B, M + N, h, w, th, K, P);
         SD_REQUIRE(workspace_bytes >= mw.bytes, SD_ERR_WORKSPACE, "sd_decode: workspace %zu < %zu", workspace_bytes, mw.bytes);

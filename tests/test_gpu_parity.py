@@ -505,7 +505,7 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
                     got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
                     assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream}"
     finally:
-        L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
         L.check(lib.sd_decode_set_option(b"map_scalar_nms", 0))
         L.check(lib.sd_decode_set_option(b"map_stream", 1))
@@ -515,7 +515,7 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
         try:
             got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=True, fused=False)
         finally:
-            L.check(lib.sd_decode_set_option(b"map_parallel_from", 4096))
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
         assert_decode_matches_oracle(dec.split_packed(got.cpu().numpy(), B, K, P), t, 0.5, SIG_TOL)
 
 
