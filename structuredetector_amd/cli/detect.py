@@ -18,7 +18,7 @@ def main(argv=None):
     assert args.valid_dir, "Path to a directory with the images to process must be specified (--valid_dir)."
     dataset = PredictionDataset(args.valid_dir, args, raw=True)
     decoder = Decoder(args)
-    net = Network(args, pretrained=not args.pretrained_model)             # detect.py:24-25: every tensor comes from the checkpoint
+    net = Network(args, pretrained=not args.pretrained_model, init_weights=not args.pretrained_model)             # detect.py:24-25: every tensor comes from the checkpoint
     if args.pretrained_model:
         net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu", weights_only=True))
     net = net.eval().to(args.device)

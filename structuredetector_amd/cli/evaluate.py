@@ -17,7 +17,7 @@ def main(argv=None):
     decoder = Decoder(args)
     # evaluate.py:30-31 builds Network(args) (ImageNet trunk) and then overwrites every tensor from the checkpoint: the ImageNet file is
     # only looked up when there is no checkpoint to load
-    net = Network(args, pretrained=not args.pretrained_model)
+    net = Network(args, pretrained=not args.pretrained_model, init_weights=not args.pretrained_model)
     if args.pretrained_model:
         net.load_state_dict(torch.load(args.pretrained_model, map_location="cpu", weights_only=True))
     net = net.eval().to(args.device)

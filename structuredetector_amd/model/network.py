@@ -37,7 +37,7 @@ class ConvParams(nn.Module):
     def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
-        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        w = torch.empty((cout, cin, k, k), memory_format=torch.channels_last)
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
@@ -766,7 +766,9 @@ class _NetFn(torch.autograd.Function):
 
 
 class Network(nn.Module):
-    def __init__(self, args, pretrained=True, raw_output: bool = False):
+    def __init__(self, args, pretrained=True, raw_output: bool = False, init_weights: bool = True):
+        """network.py:33.  `init_weights=False` (extension): leave the parameters uninitialised -- for callers that load a complete
+        state_dict right away (`evaluate`, `detect`, `Predictor`: the seeded random init of 21.8 M values is 0.1-0.6 s of their start-up)."""
         super().__init__()
         self.raw_output = raw_output
         # bf16 backbone for the eval-mode forward (BASELINE stress config: "bf16 backbone + fp32 decode"): `--bf16_inference`, or
@@ -792,7 +794,8 @@ class Network(nn.Module):
         self.up3 = Fpn(128, self.fpn_depth)
         self.up4 = Fpn(64, self.fpn_depth)
         self.head = Head(self.fpn_depth, self.out_channels)
-        self.reset_parameters(seed=0)
+        if init_weights:
+            self.reset_parameters(seed=0)
         # network.py:41: `resnet34(weights=ResNet34_Weights.DEFAULT if pretrained else None)` -- the ImageNet trunk.  torchvision would
         # download `resnet34-b627a593.pth` into the hub cache; here the file is looked up locally (no download): `--backbone_weights`,
         # $SDNET_BACKBONE_WEIGHTS, then torchvision's own cache locations.  Not finding it is announced loudly: the run then starts

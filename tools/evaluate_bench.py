@@ -22,7 +22,13 @@ def main():
     from structuredetector_amd.cli import evaluate
     root = Path(a.dir)
     labels = write_samples(root / "valid", a.n, a.size)
-    base = ["--valid_dir", str(root / "valid"), "--labels", str(labels), "-s", "stem", "-W", str(a.size), "-H", str(a.size)]
+    # the reference's evaluate REQUIRES a checkpoint (cli/evaluate.py:14-16): a seeded one is written once and loaded by every run
+    ckpt = root / "seeded.pth"
+    if not ckpt.exists():
+        from argparse import Namespace
+        from structuredetector_amd.model import Network
+        Network(Namespace(labels={"bean": 0, "maize": 1}, parts={"leaf": 0}, fpn_depth=128), pretrained=False).save(ckpt)
+    base = ["--valid_dir", str(root / "valid"), "--labels", str(labels), "-s", "stem", "-W", str(a.size), "-H", str(a.size), "-o", str(ckpt)]
     rows = (("batch of one, one decode thread (the reference's order of work)", ["--eval_batch", "1", "--decode_workers", "1"]),
             ("batch of one, decode pool", ["--eval_batch", "1"]),
             ("--eval_batch 16 (default), decode pool", []),
