@@ -174,11 +174,20 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, T* __
                                                    const T* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
+    // The grid stride is a multiple of the column count for every power-of-two channel count (256 % cols == 0): a thread then stays on
+    // ONE column and its four parameter vectors are loaded once -- inside the loop they were four 16-byte L1 requests next to one or two
+    // requests of data per element (`fixed`); other channel counts take the per-element lookup.
+    const bool fixed = stride % cols == 0;
+    const int col0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cols);
+    float4 mu = reinterpret_cast<const float4*>(mean)[col0], is = reinterpret_cast<const float4*>(invstd)[col0];
+    float4 g = reinterpret_cast<const float4*>(gamma)[col0], b = reinterpret_cast<const float4*>(beta)[col0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const int col = (int)(i % cols);
         const float4 v = ld4(x, i);
-        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
-        const float4 g = reinterpret_cast<const float4*>(gamma)[col], b = reinterpret_cast<const float4*>(beta)[col];
+        if (!fixed) {
+            const int col = (int)(i % cols);
+            mu = reinterpret_cast<const float4*>(mean)[col]; is = reinterpret_cast<const float4*>(invstd)[col];
+            g = reinterpret_cast<const float4*>(gamma)[col]; b = reinterpret_cast<const float4*>(beta)[col];
+        }
         float4 o;
         o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
         o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
@@ -212,12 +221,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ dy, 
                                                        const float* __restrict__ mgx, T* __restrict__ dx, T* __restrict__ g_out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 2;
+    const bool fixed = stride % cols == 0;                      // (see k_bn_apply: one column per thread, parameters loaded once)
+    const int col0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cols);
+    float4 mu = reinterpret_cast<const float4*>(mean)[col0], is = reinterpret_cast<const float4*>(invstd)[col0];
+    float4 ga = reinterpret_cast<const float4*>(gamma)[col0];
+    float4 be = relu == 2 ? reinterpret_cast<const float4*>(beta)[col0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = reinterpret_cast<const float4*>(mg)[col0], b = reinterpret_cast<const float4*>(mgx)[col0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const int col = (int)(i % cols);
         float4 g = ld4(dy, i);
         const float4 xv = ld4(x, i);
-        const float4 mu = reinterpret_cast<const float4*>(mean)[col], is = reinterpret_cast<const float4*>(invstd)[col];
-        const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
+        if (!fixed) {
+            const int col = (int)(i % cols);
+            mu = reinterpret_cast<const float4*>(mean)[col]; is = reinterpret_cast<const float4*>(invstd)[col];
+            ga = reinterpret_cast<const float4*>(gamma)[col];
+            if (relu == 2) be = reinterpret_cast<const float4*>(beta)[col];
+            a = reinterpret_cast<const float4*>(mg)[col]; b = reinterpret_cast<const float4*>(mgx)[col];
+        }
         if (relu == 1) {
             const float4 yy = ld4(y, i);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
@@ -225,11 +244,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ dy, 
             const uint8_t mb = reinterpret_cast<const uint8_t*>(y)[i];
             g.x = (mb & 1) ? g.x : 0.f; g.y = (mb & 2) ? g.y : 0.f; g.z = (mb & 4) ? g.z : 0.f; g.w = (mb & 8) ? g.w : 0.f;
         } else if (relu == 2) {
-            const float4 be = reinterpret_cast<const float4*>(beta)[col];
             g.x = ((xv.x - mu.x) * is.x * ga.x + be.x) > 0.f ? g.x : 0.f; g.y = ((xv.y - mu.y) * is.y * ga.y + be.y) > 0.f ? g.y : 0.f;
             g.z = ((xv.z - mu.z) * is.z * ga.z + be.z) > 0.f ? g.z : 0.f; g.w = ((xv.w - mu.w) * is.w * ga.w + be.w) > 0.f ? g.w : 0.f;
         }
-        const float4 a = reinterpret_cast<const float4*>(mg)[col], b = reinterpret_cast<const float4*>(mgx)[col];
         float4 o;
         o.x = ga.x * is.x * (g.x - a.x - (xv.x - mu.x) * is.x * b.x);
         o.y = ga.y * is.y * (g.y - a.y - (xv.y - mu.y) * is.y * b.y);
@@ -1242,18 +1259,31 @@ __global__ __launch_bounds__(256) void k_bn_apply_bf16x8(const uint16_t* __restr
                                                           const uint16_t* __restrict__ res, int relu, uint8_t* __restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 3;
+    const bool fixed = stride % cols == 0;                      // (see k_bn_apply: one column per thread; here EIGHT parameter vectors per element)
+    const int col0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cols);
+    float4 mu[2], is[2], g[2], b[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        mu[h] = reinterpret_cast<const float4*>(mean)[2 * col0 + h]; is[h] = reinterpret_cast<const float4*>(invstd)[2 * col0 + h];
+        g[h] = reinterpret_cast<const float4*>(gamma)[2 * col0 + h]; b[h] = reinterpret_cast<const float4*>(beta)[2 * col0 + h];
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-        const int col = (int)(i % cols);
         const F8 v = ld8(x, i);
+        if (!fixed) {
+            const int col = (int)(i % cols);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                mu[h] = reinterpret_cast<const float4*>(mean)[2 * col + h]; is[h] = reinterpret_cast<const float4*>(invstd)[2 * col + h];
+                g[h] = reinterpret_cast<const float4*>(gamma)[2 * col + h]; b[h] = reinterpret_cast<const float4*>(beta)[2 * col + h];
+            }
+        }
         F8 o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 mu = reinterpret_cast<const float4*>(mean)[2 * col + h], is = reinterpret_cast<const float4*>(invstd)[2 * col + h];
-            const float4 g = reinterpret_cast<const float4*>(gamma)[2 * col + h], b = reinterpret_cast<const float4*>(beta)[2 * col + h];
             const float4 vv = h ? v.b : v.a;
             float4 oo;
-            oo.x = (vv.x - mu.x) * is.x * g.x + b.x; oo.y = (vv.y - mu.y) * is.y * g.y + b.y;
-            oo.z = (vv.z - mu.z) * is.z * g.z + b.z; oo.w = (vv.w - mu.w) * is.w * g.w + b.w;
+            oo.x = (vv.x - mu[h].x) * is[h].x * g[h].x + b[h].x; oo.y = (vv.y - mu[h].y) * is[h].y * g[h].y + b[h].y;
+            oo.z = (vv.z - mu[h].z) * is[h].z * g[h].z + b[h].z; oo.w = (vv.w - mu[h].w) * is[h].w * g[h].w + b[h].w;
             if (h) o.b = oo; else o.a = oo;
         }
         if (res) {
@@ -1291,26 +1321,34 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_bf16x8(const uint16_t* __r
                                                               const float* __restrict__ mgx, uint16_t* __restrict__ dx, uint16_t* __restrict__ g_out) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int cols = C >> 3;
+    const bool fixed = stride % cols == 0;                      // (see k_bn_apply: one column per thread; here up to TWELVE parameter vectors per element)
+    const int col0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % cols);
+    float4 mu[2], is[2], ga[2], be[2], a[2], b[2];
+    auto params = [&](int col) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            mu[h] = reinterpret_cast<const float4*>(mean)[2 * col + h]; is[h] = reinterpret_cast<const float4*>(invstd)[2 * col + h];
+            ga[h] = reinterpret_cast<const float4*>(gamma)[2 * col + h];
+            be[h] = relu == 2 ? reinterpret_cast<const float4*>(beta)[2 * col + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[h] = reinterpret_cast<const float4*>(mg)[2 * col + h]; b[h] = reinterpret_cast<const float4*>(mgx)[2 * col + h];
+        }
+    };
+    params(col0);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
-        const int col = (int)(i % cols);
         const F8 gy = ld8(dy, i), xv = ld8(x, i);
+        if (!fixed) params((int)(i % cols));
         uchar2 mb = make_uchar2(0, 0);
         if (relu == 3) mb = reinterpret_cast<const uchar2*>(maskb)[i];
         F8 o, gm;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 mu = reinterpret_cast<const float4*>(mean)[2 * col + h], is = reinterpret_cast<const float4*>(invstd)[2 * col + h];
-            const float4 ga = reinterpret_cast<const float4*>(gamma)[2 * col + h];
-            float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (relu == 2) be = reinterpret_cast<const float4*>(beta)[2 * col + h];
             const float4 xx = h ? xv.b : xv.a;
-            const float4 g = bn_mask4(h ? gy.b : gy.a, xx, mu, is, ga, be, relu, h ? mb.y : mb.x);
-            const float4 a = reinterpret_cast<const float4*>(mg)[2 * col + h], b = reinterpret_cast<const float4*>(mgx)[2 * col + h];
+            const float4 g = bn_mask4(h ? gy.b : gy.a, xx, mu[h], is[h], ga[h], be[h], relu, h ? mb.y : mb.x);
             float4 oo;
-            oo.x = ga.x * is.x * (g.x - a.x - (xx.x - mu.x) * is.x * b.x);
-            oo.y = ga.y * is.y * (g.y - a.y - (xx.y - mu.y) * is.y * b.y);
-            oo.z = ga.z * is.z * (g.z - a.z - (xx.z - mu.z) * is.z * b.z);
-            oo.w = ga.w * is.w * (g.w - a.w - (xx.w - mu.w) * is.w * b.w);
+            oo.x = ga[h].x * is[h].x * (g.x - a[h].x - (xx.x - mu[h].x) * is[h].x * b[h].x);
+            oo.y = ga[h].y * is[h].y * (g.y - a[h].y - (xx.y - mu[h].y) * is[h].y * b[h].y);
+            oo.z = ga[h].z * is[h].z * (g.z - a[h].z - (xx.z - mu[h].z) * is[h].z * b[h].z);
+            oo.w = ga[h].w * is[h].w * (g.w - a[h].w - (xx.w - mu[h].w) * is[h].w * b[h].w);
             if (h) { o.b = oo; gm.b = g; } else { o.a = oo; gm.a = g; }
         }
         st8(dx, i, o);
