@@ -2,7 +2,7 @@
 # Regenerates every profile artefact of a round in ONE gpurun call; results land in gpurun_out/profiles_<tag>/ (copy to profiles/).
 # usage: bash tools/make_profiles.sh r02
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
