@@ -21,11 +21,14 @@ for r in csv.DictReader(open(sys.argv[1])):
     if (n.startswith("sd::") and "render" not in n) or "fill" in n:
         print(f"   {n[:40]:40s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f}")
 # device span of one decode call (first kernel start -> last kernel end, i.e. including the gaps between dependent launches)
-rows = [r for r in csv.DictReader(open(sys.argv[2])) if any(k in r["Kernel_Name"] for k in ("k_nms_tile", "k_select_group", "fillBuffer", "k_decode_fused"))]
+NAMES = ("k_nms_tile", "k_nms_slots", "k_select_group", "k_select_map", "k_select_peaks", "fillBuffer", "k_decode_fused", "k_map_stream_select", "k_rank_maps", "k_group_wide")
+rows = [r for r in csv.DictReader(open(sys.argv[2])) if any(k in r["Kernel_Name"] for k in NAMES)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-per = 1 if any("k_decode_fused" in r["Kernel_Name"] for r in rows) else 3
+# launches per decode call: the kernel sequence repeats, so the period is the distance between two launches of the first kernel's name
+first = rows[0]["Kernel_Name"]
+per = next((i for i in range(1, len(rows)) if rows[i]["Kernel_Name"] == first), len(rows))
 spans = [(int(rows[i + per - 1]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3 for i in range(0, len(rows) - per + 1, per)][10:]
-print(f"   device span per call (incl. launch gaps): median {np.median(spans):.2f} us, min {min(spans):.2f} us")
+print(f"   launches per call {per}; device span per call (incl. launch gaps): median {np.median(spans):.2f} us, min {min(spans):.2f} us")
 PY
 done
 cat $OUT
