@@ -1294,11 +1294,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch_roll(ConvArgs p) { con
 // Why: a bf16 tap is 16 MFMAs of 32 cycles per wave -- 8x shorter than the fp32 tap -- so in k_conv3x3_patch<128, true> the
 // per-tap barrier, the fragment reads and above all the 2-tap prefetch distance of the weight ring (shorter than one L2 round trip)
 // are exposed: 31 % of the MFMA peak.  Here ONE 512-thread block per CU holds two 256-pixel sub-tiles that share the weights:
-//   group g = wave / 4 owns sub-tile g (its own double-buffered patch) and runs exactly k_conv3x3_patch's 2 x 2 wave grid on it;
+//   group g = wave / 4 owns sub-tile g (its own double-buffered patch); its four waves take 64 pixels x all 128 channels each;
 //   the weight ring has 7 stages of one tap (8 KB), tap t + 5 is issued during tap t (all 8 waves, one 1 KB piece each):
 //     staged weight bytes per MFMA are half of the 256-pixel tile's and a piece has > 5 tap times to land;
 //   the groups run half a tap apart (group 1 does one extra s_barrier first, group 0 one last): every tap is
-//     LOAD [12 ds_read_b128, then the tap's LDS-DMA, counted vmcnt] - s_barrier - MFMA [16 x 32x32x16, raised priority] - s_barrier
+//     LOAD [12 ds_read_b128, then the tap's LDS-DMA, counted vmcnt] - s_barrier - MFMA [32 x 16x16x32 (round 4; 16 x 32x32x16 before), raised priority] - s_barrier
 //     so that one group's LOAD always runs under the other group's MFMAs on the same SIMDs (2 waves per SIMD).
 //   Hazards (t = tap, interval = time between two barriers; group 0 LOADs tap t in interval 2t, group 1 in 2t + 1):
 //     RAW  a piece of tap t+1 is covered by its issuer's vmcnt wait in LOAD(t), which ends with a barrier every reader passes
@@ -1330,56 +1330,63 @@ __device__ __forceinline__ uint32_t rs_relu2(uint32_t two_bf16) {             //
 // integer max on the packed pairs (rounding is monotonic: max(round(x), 0) = round(max(x, 0))).  Bit-identical to tile_epilogue
 // (same fp32 operations per element in the same order).
 typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x16 (&acc)[4][2], int mbase, int TWl, int tid, int wave, int n0, int tile_m,
+// acc[mi][ni] = 16 x 16 tile (mi: 16 pixels, ni: 16 channels) of v_mfma_f32_16x16x32_bf16: lane (r16 = lane & 15, kq = lane >> 4) holds
+// channel column r16, pixel rows kq * 4 + e.  Wave tile: 64 pixels x all 128 channels; a pass = one 64-channel half of it.
+__device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x4 (&acc)[4][8], int mbase, int TWl, int tid, int wave, int n0, int tile_m,
                                                  float* T0, float* T1) {
     constexpr int BN = 128;
-    const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
-    const int wn0 = (wave & 1) * 64, wml = ((wave >> 1) & 1) * 128;           // column / row origin of the wave tile inside its group's sub-tile
+    const int lane = tid & 63, r16 = lane & 15, kq = lane >> 4;
+    const int wml = (wave & 3) * 64;                                          // row origin of the wave tile inside its group's sub-tile
     const bool fwd_stat = p.stat && !p.bn_x;
-    float sv[2], qv[2];
+    float sv[8], qv[8];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < 8; ++ni) {
         sv[ni] = qv[ni] = 0.f;
         if (fwd_stat) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { const float a = bf2f(f2bf(acc[mi][ni][e])); sv[ni] += a; qv[ni] += a * a; }
+                for (int e = 0; e < 4; ++e) { const float a = bf2f(f2bf(acc[mi][ni][e])); sv[ni] += a; qv[ni] += a * a; }
         }
     }
     __shared__ float pp_statred[2][BN];
-    const int c4 = (lane & 15) * 4, n = n0 + wn0 + c4;
+    const int c4 = (lane & 15) * 4;
     const bool affine = p.scale || p.shift;
-    pp_f32x2 sc01 = {1.f, 1.f}, sc23 = {1.f, 1.f}, sh01 = {0.f, 0.f}, sh23 = {0.f, 0.f};
-    if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc01 = pp_f32x2{t.x, t.y}; sc23 = pp_f32x2{t.z, t.w}; }
-    if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh01 = pp_f32x2{t.x, t.y}; sh23 = pp_f32x2{t.z, t.w}; }
     const int TWm = (1 << TWl) - 1, rsub = lane >> 4;
-    uint16_t* const yb = reinterpret_cast<uint16_t*>(p.y) + n;
-    const uint16_t* const rb = reinterpret_cast<const uint16_t*>(p.res) + n;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        const int n = n0 + h * 64 + c4;
+        pp_f32x2 sc01 = {1.f, 1.f}, sc23 = {1.f, 1.f}, sh01 = {0.f, 0.f}, sh23 = {0.f, 0.f};
+        if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc01 = pp_f32x2{t.x, t.y}; sc23 = pp_f32x2{t.z, t.w}; }
+        if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh01 = pp_f32x2{t.x, t.y}; sh23 = pp_f32x2{t.z, t.w}; }
+        uint16_t* const yb = reinterpret_cast<uint16_t*>(p.y) + n;
+        const uint16_t* const rb = reinterpret_cast<const uint16_t*>(p.res) + n;
         // the residual runs of the pass are requested before its trip through LDS
         uint2 rr[16];
         if (p.res) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int ml = wml + h * 64 + it * 4 + rsub;
+                const int ml = wml + it * 4 + rsub;
                 const int m = mbase + (ml >> TWl) * p.Wo + (ml & TWm);
                 rr[it] = *reinterpret_cast<const uint2*>(rb + (int64_t)m * p.Nn);
             }
         }
+        // 64 pixel rows x 64 channels of the pass -> the wave's two 32-row x 64-float regions (two lane groups share a bank set: free
+        // on ds_write_b32)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                T0[r * 64 + ni * 32 + fr] = acc[2 * h][ni][e];
-                T1[r * 64 + ni * 32 + fr] = acc[2 * h + 1][ni][e];
+            for (int e = 0; e < 4; ++e) {
+                const int r = kq * 4 + e;
+                T0[r * 64 + nj * 16 + r16] = acc[0][4 * h + nj][e];
+                T0[(r + 16) * 64 + nj * 16 + r16] = acc[1][4 * h + nj][e];
+                T1[r * 64 + nj * 16 + r16] = acc[2][4 * h + nj][e];
+                T1[(r + 16) * 64 + nj * 16 + r16] = acc[3][4 * h + nj][e];
             }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int rl = it * 4 + rsub;                                     // row inside this pass: it < 8 -> T0, else T1
-            const int ml = wml + h * 64 + rl;
+            const int rl = it * 4 + rsub;                                     // row of the wave tile: it < 8 -> T0, else T1
+            const int ml = wml + rl;
             const int m = mbase + (ml >> TWl) * p.Wo + (ml & TWm);
             const f32x4 v = *reinterpret_cast<const f32x4*>((it < 8 ? T0 : T1) + (rl & 31) * 64 + c4);
             pp_f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
@@ -1395,23 +1402,27 @@ __device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x16 (&acc
         }
     }
     if (fwd_stat) {
-        // as tile_epilogue: lane halves, then wave rows 1 .. 3 into LDS one after the other (fixed order), wave row 0 finishes
+        // lane groups (fixed order), then waves 1 .. 7 into LDS one after the other (fixed order), wave 0 finishes: the 512-pixel tile is
+        // one statistics row
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) { sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32); }
+        for (int ni = 0; ni < 8; ++ni) {
+            sv[ni] += __shfl_xor(sv[ni], 16); qv[ni] += __shfl_xor(qv[ni], 16);
+            sv[ni] += __shfl_xor(sv[ni], 32); qv[ni] += __shfl_xor(qv[ni], 32);
+        }
         if (tid < 2 * BN) pp_statred[tid / BN][tid % BN] = 0.f;
         __syncthreads();
-        for (int wr = 1; wr < 4; ++wr) {
-            if (wave / 2 == wr && fh == 0) {
+        for (int wr = 1; wr < 8; ++wr) {
+            if (wave == wr && kq == 0) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) { pp_statred[0][wn0 + ni * 32 + fr] += sv[ni]; pp_statred[1][wn0 + ni * 32 + fr] += qv[ni]; }
+                for (int ni = 0; ni < 8; ++ni) { pp_statred[0][ni * 16 + r16] += sv[ni]; pp_statred[1][ni * 16 + r16] += qv[ni]; }
             }
             __syncthreads();
         }
-        if (wave / 2 == 0 && fh == 0) {
+        if (wave == 0 && kq == 0) {
             float* dst = p.stat + (int64_t)tile_m * 2 * p.Nn + n0;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int c = wn0 + ni * 32 + fr;
+            for (int ni = 0; ni < 8; ++ni) {
+                const int c = ni * 16 + r16;
                 dst[c] = sv[ni] + pp_statred[0][c]; dst[p.Nn + c] = qv[ni] + pp_statred[1][c];
             }
         }
@@ -1439,7 +1450,7 @@ constexpr int PP_BM = 512;
 __device__ __forceinline__ f32x4 pp_fake_read(uint32_t addr) { f32x4 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(addr)); v[1] = v[2] = v[3] = v[0]; return v; }
 __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     using T = uint16_t;
-    constexpr int BN = 128, EPS = 8, KC = 32, MT = 4, NTW = 2, NPP = 7;
+    constexpr int BN = 128, EPS = 8, KC = 32, MT = 4, NTW = 8, NPP = 7;     // wave tile: 4 (pixels) x 8 (channels) MFMA tiles of 16 x 16
     extern __shared__ __attribute__((aligned(16))) float pp_lds[];
     PP_T(tr_start)
 #ifdef SD_PP_TRACE
@@ -1478,13 +1489,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
         const int py = pp / PW, pxx = pp - py * PW;
         const int iy = y0 - 1 + py, ix = x0 + pxx - 1;
         const bool ok = py < TH + 2 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const int qe = (pslot ^ ((pp >> 2) & 3)) * EPS;
+        const int qe = (pslot ^ ((pp >> 1) & 2)) * EPS;                  // slot swizzle of the 16 x 16 x 32 operand layout (see below)
         pbase[i] = ok ? px_ + (((int64_t)bimg * p.Hi + iy) * p.Wi + ix) * p.Ck + qe : zero_ + qe;
         okmask |= (ok ? 1u : 0u) << i;
         pdst[i] = j * 256;
     }
     const int wk = 9 * p.Ck;
-    const int qeb = (pslot ^ ((prow >> 2) & 3)) * EPS;
+    const int qeb = (pslot ^ ((prow >> 1) & 2)) * EPS;
     const T* const bbase = pw_ + (int64_t)(n0 + wave * 16 + prow) * wk + qeb;
     const T* const zsrc = zero_ + qeb;
 
@@ -1500,25 +1511,28 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
         else lds_dma16(zsrc, bd);                                                                  \
     }
 
-    // ---- MFMA side (inside the group: k_conv3x3_patch's 2 x 2 wave grid, wave tile 128 x 64)
-    const int wm0 = (wl >> 1) * 128, wn0 = (wl & 1) * 64;
-    const int fr = lane & 31, fh = lane >> 5;
-    int bpp[MT];
+    // ---- MFMA side: inside the group the four waves take 64 pixels x all 128 channels each = 4 x 8 tiles of v_mfma_f32_16x16x32_bf16.
+    // Shape: the chip holds a higher clock on the 16x16x32 form than on 32x32x16 at the same flops and LDS traffic (random operands;
+    // tools/micro/mfma_bf16_shape.hip, and this kernel with every 32x32x16 replaced by two 16x16x32 on the same registers: forward -4.7 %).
+    // Operand layout: lane = (r16 = lane & 15: pixel row / channel column of the tile, kq = lane >> 4: 8-wide k group) -- ONE ds_read_b128
+    // per operand tile covers the chunk's K = 32.  Conflict-free slot swizzle for that lane map at every tap offset: slot ^ ((row >> 1) & 2)
+    // (brute-forced over all patch origins against the four ds_read_b128 lane groups).  The pixel side has the expensive addresses (tap
+    // offset + swizzle per tile and tap), the weight side one base + immediates: hence 4 pixel tiles x 8 channel tiles per wave.
+    const int wm0 = wl * 64;
+    const int r16 = lane & 15, kq = lane >> 4;
+    uint32_t bppk[MT];                                                      // byte offset of (tile pixel, k group) in an unswizzled patch
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int ml = wm0 + mi * 32 + fr;
-        bpp[mi] = (ml >> TWl) * PW + (ml & (TW - 1));
+        const int ml = wm0 + mi * 16 + r16;
+        bppk[mi] = (uint32_t)((ml >> TWl) * PW + (ml & (TW - 1))) * 64u + (uint32_t)(kq << 4);
     }
-    const int rd_swz_b = (fr >> 2) & 3;
-    const uint32_t b_k0 = ((wn0 + fr) * BKB + ((fh ^ rd_swz_b) << 2)) * 4;
-    constexpr int TSTR = 32 * BKB * 4;
-    f32x16 acc[MT][NTW];
+    const uint32_t b_k0 = (uint32_t)(r16 * BKB * 4) + (uint32_t)((kq ^ ((r16 >> 1) & 2)) << 4);
+    constexpr int TSTR = 16 * BKB * 4;                                      // 16 weight rows = one channel tile
+    f32x4 acc[MT][NTW];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NTW; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: the patch of chunk 0 and the weights of taps 0 .. PP_D-1
     bool pp_in_loop = false; (void)pp_in_loop;
@@ -1541,25 +1555,25 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
 #if SD_PP_ABL == 3 || SD_PP_ABL == 7
 #define PP_MFMA(A, B, mi, ni) asm volatile("" :: "v"(A), "v"(B));
 #else
-#define PP_MFMA(A, B, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni], 0, 0, 0);
+#define PP_MFMA(A, B, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni], 0, 0, 0);
 #endif
 #define PP_TAP(t, NW)                                                                              \
     {                                                                                              \
         /* LOAD */                                                                                 \
         PP_T(t0_)                                                                                  \
         const int tapoff = ((t) / 3) * PW + ((t) % 3);                                             \
+        /* four VALU per address, recomputed every tap: hoisted out of the chunk loop the 36 (tile, tap) addresses do not fit the    \
+           register file beside 128 accumulators + 48 fragment registers (the empty asm keeps the compiler from hoisting them) */    \
         uint32_t aa[MT];                                                                           \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                        \
-            const int pp = bpp[mi] + tapoff;                                                       \
-            aa[mi] = pt_cur + (uint32_t)pp * 64u + (uint32_t)((fh ^ ((pp >> 2) & 3)) << 4);        \
+            asm volatile("" : "+v"(bppk[mi]));                                                     \
+            const uint32_t x0 = bppk[mi] + (uint32_t)tapoff * 64u;      /* = pixel * 64 + kq * 16: bit 8 = bit 2 of the patch pixel */ \
+            aa[mi] = (x0 ^ ((x0 >> 3) & 32u)) + pt_cur;                                            \
         }                                                                                          \
         const uint32_t bb = bs_base + (uint32_t)rp * (PP_B_FLOATS * 4) + b_k0;                     \
-        f32x4 a00 = PP_RD(0, aa[0]), a01 = PP_RD(0, aa[1]);                                        \
-        f32x4 a02 = PP_RD(0, aa[2]), a03 = PP_RD(0, aa[3]);                                        \
-        f32x4 b00 = PP_RD(0, bb), b01 = PP_RD(TSTR, bb);                                           \
-        f32x4 a10 = PP_RD(0, aa[0] ^ 32u), a11 = PP_RD(0, aa[1] ^ 32u);                            \
-        f32x4 a12 = PP_RD(0, aa[2] ^ 32u), a13 = PP_RD(0, aa[3] ^ 32u);                            \
-        f32x4 b10 = PP_RD(0, bb ^ 32u), b11 = PP_RD(TSTR, bb ^ 32u);                               \
+        f32x4 a0 = PP_RD(0, aa[0]), a1 = PP_RD(0, aa[1]), a2 = PP_RD(0, aa[2]), a3 = PP_RD(0, aa[3]); \
+        f32x4 b0 = PP_RD(0, bb), b1 = PP_RD(TSTR, bb), b2 = PP_RD(2 * TSTR, bb), b3 = PP_RD(3 * TSTR, bb); \
+        f32x4 b4 = PP_RD(4 * TSTR, bb), b5 = PP_RD(5 * TSTR, bb), b6 = PP_RD(6 * TSTR, bb), b7 = PP_RD(7 * TSTR, bb); \
         /* the DMA goes out AFTER the fragment reads: the CU takes one 1 KB LDS-DMA instruction per ~32 cycles and a wave waits at \
            its DMA instruction until the queue takes it -- in front of the reads that wait was on the interval's critical path */ \
         if ((t) == 0) { PP_PATCH(0, pt_nxt, cc + 1) PP_PATCH(1, pt_nxt, cc + 1) }                  \
@@ -1572,14 +1586,18 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
         if (SD_PP_ABL != 5) wait_vmcnt<NW>();                                                      \
         __builtin_amdgcn_s_barrier();                                                              \
         /* MFMA */                                                                                 \
-        SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01);                                             \
+        SD_LDS_WAIT8(4, a0, a1, a2, a3, b0, b1, b2, b3);                                           \
         PP_T(t1_)                                                                                  \
         if (SD_PP_ABL != 4) __builtin_amdgcn_s_setprio(1);                                         \
-        PP_MFMA(a00, b00, 0, 0) PP_MFMA(a01, b00, 1, 0) PP_MFMA(a02, b00, 2, 0) PP_MFMA(a03, b00, 3, 0) \
-        PP_MFMA(a00, b01, 0, 1) PP_MFMA(a01, b01, 1, 1) PP_MFMA(a02, b01, 2, 1) PP_MFMA(a03, b01, 3, 1) \
-        SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11);                                             \
-        PP_MFMA(a10, b10, 0, 0) PP_MFMA(a11, b10, 1, 0) PP_MFMA(a12, b10, 2, 0) PP_MFMA(a13, b10, 3, 0) \
-        PP_MFMA(a10, b11, 0, 1) PP_MFMA(a11, b11, 1, 1) PP_MFMA(a12, b11, 2, 1) PP_MFMA(a13, b11, 3, 1) \
+        PP_MFMA(a0, b0, 0, 0) PP_MFMA(a1, b0, 1, 0) PP_MFMA(a2, b0, 2, 0) PP_MFMA(a3, b0, 3, 0)    \
+        PP_MFMA(a0, b1, 0, 1) PP_MFMA(a1, b1, 1, 1) PP_MFMA(a2, b1, 2, 1) PP_MFMA(a3, b1, 3, 1)    \
+        PP_MFMA(a0, b2, 0, 2) PP_MFMA(a1, b2, 1, 2) PP_MFMA(a2, b2, 2, 2) PP_MFMA(a3, b2, 3, 2)    \
+        PP_MFMA(a0, b3, 0, 3) PP_MFMA(a1, b3, 1, 3) PP_MFMA(a2, b3, 2, 3) PP_MFMA(a3, b3, 3, 3)    \
+        SD_LDS_WAIT4(0, b4, b5, b6, b7);                                                           \
+        PP_MFMA(a0, b4, 0, 4) PP_MFMA(a1, b4, 1, 4) PP_MFMA(a2, b4, 2, 4) PP_MFMA(a3, b4, 3, 4)    \
+        PP_MFMA(a0, b5, 0, 5) PP_MFMA(a1, b5, 1, 5) PP_MFMA(a2, b5, 2, 5) PP_MFMA(a3, b5, 3, 5)    \
+        PP_MFMA(a0, b6, 0, 6) PP_MFMA(a1, b6, 1, 6) PP_MFMA(a2, b6, 2, 6) PP_MFMA(a3, b6, 3, 6)    \
+        PP_MFMA(a0, b7, 0, 7) PP_MFMA(a1, b7, 1, 7) PP_MFMA(a2, b7, 2, 7) PP_MFMA(a3, b7, 3, 7)    \
         __builtin_amdgcn_s_setprio(0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         PP_T(t2_)                                                                                  \
@@ -1612,14 +1630,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     // The 512-pixel tile is one statistics row: wave rows 0, 1 = group 0, rows 2, 3 = group 1.
     __syncthreads();
     float* T0 = pp_lds + wave * 4096;
-    if (p.res_up2 == 0) pp_epilogue_bf16(p, acc, mbase, TWl, tid, wave, n0, tile_m, T0, T0 + 2048);
-    else tile_epilogue<BN, 4, 2, MT, NTW, true, true, true>(
-        p, acc, [&](int row) { const int ml = row & (BMB - 1); return mbase + (ml >> TWl) * p.Wo + (ml & (TW - 1)); },   // (rows of the wave's own group)
-        [&](int, int m) {
-            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-            return (p.res_up2 == 2 && ((ox | oy) & 1)) ? -1 : (b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1);
-        },
-        tid, wave, fr, fh, (wave >> 1) * 128, wn0, n0, tile_m, T0, T0 + 2048);
+    pp_epilogue_bf16(p, acc, mbase, TWl, tid, wave, n0, tile_m, T0, T0 + 2048);        // (no half-size residual here: conv_pp_geometry)
 #ifdef SD_PP_TRACE
     tr[5] = __builtin_readcyclecounter() - tr_end;
     tr[6] = __builtin_amdgcn_s_memrealtime();
@@ -3801,7 +3812,7 @@ static bool conv_rowsf32_geometry(const ConvArgs& a, int mode, RowsArgsF& r) {
 static thread_local int g_pp_min_tiles = 200;        // sd_set_option("conv_pp_min_tiles", n) (tests: 1; off: 1 << 30)
 static thread_local int g_pp_strips = 1;             // sd_set_option("conv_pp_strips", 0): maps of 128 pixels and wider stay on k_conv3x3_patch (A/B)
 static bool conv_pp_geometry(ConvArgs& a, int mode) {
-    if (a.Nn % 128 || a.M % PP_BM || (a.M / PP_BM) * (a.Nn / 128) < g_pp_min_tiles) return false;
+    if (a.Nn % 128 || a.M % PP_BM || (a.M / PP_BM) * (a.Nn / 128) < g_pp_min_tiles || a.res_up2) return false;   // (a half-size residual map: k_conv3x3_patch)
     a.pt_strip_log2 = 0;
     int l2 = 0;
     while ((1 << l2) < a.Wo) ++l2;

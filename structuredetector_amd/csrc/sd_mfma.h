@@ -63,6 +63,7 @@ __device__ __forceinline__ f32x4 lds_read128_async(uint32_t addr) {
 }
 // s_waitcnt lgkmcnt(N) that the fragments are threaded through, so that no consumer can be scheduled above it
 #define SD_LDS_WAIT6(N, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) :: "memory")
+#define SD_LDS_WAIT8(N, a, b, c, d, e, f, g, h) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory")
 #define SD_LDS_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
 #define SD_LDS_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b) :: "memory")
 

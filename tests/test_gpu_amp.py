@@ -328,14 +328,17 @@ def test_conv_bf16_two_group_kernel(case):
             L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
                                            r16.data_ptr() if r16 is not None else 0, up2, relu, 0, 0, L.stream()))
             close(back(y), ref, 8e-3)
-        # against the one-group kernel on the same operands: same accumulation order -> identical bits
+        # against the one-group kernel on the same operands: the two-group kernel multiplies on v_mfma_f32_16x16x32_bf16, the one-group
+        # kernel on 32x32x16 -- the same fp32 products summed in another order inside the instruction: equal up to the last bf16 bit
         L.check(lib.sd_set_option(b"conv_pp_min_tiles", 1 << 30))
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 1))
         y1 = torch.empty_like(y)
         L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y1.data_ptr(), C.byref(d), scale_d.data_ptr(), shift_d.data_ptr(),
                                        0, 0, 0, 0, 0, L.stream()))
         if lib.sd_conv2d_kernel_name(C.byref(d), 16).decode().startswith("k_conv3x3_patch"):
-            assert torch.equal(y, y1)
+            ya, yb = y.float(), y1.float()
+            assert (ya - yb).abs().max() <= 2.0 ** -7 * yb.abs().max()                 # one bf16 ulp of the largest value
+            assert (ya != yb).float().mean() < 0.05                                  # and only where a sum sits on a rounding boundary
     finally:
         L.check(lib.sd_set_option(b"conv_pp_min_tiles", 200))
         L.check(lib.sd_set_option(b"conv_patch_min_tiles", 512))
