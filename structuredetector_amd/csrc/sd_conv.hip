@@ -56,12 +56,29 @@ namespace sd {
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL)
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP)
 #define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
 #else
 #define SD_EXPERIMENT_FLAG 0
 #endif
 extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG | SD_EXPERIMENT_FLAG; }
+
+// Timing experiment (WRONG RESULTS; make SUFFIX=_shape EXTRA=-DSD_SHAPE_EXP=<mask>): the 32x32x16 bf16 MFMAs of the selected kernels are replaced
+// by two 16x16x32 on the same operand registers (same flops, same LDS traffic) -- decides whether a kernel is worth converting to the shape the
+// chip clocks higher on.  mask: 1 k_conv_igemm<bf16>, 2 k_conv3x3_patch<bf16>, 4 k_wgrad3x3_bf16, 8 k_wgrad_tap_bf16
+#ifndef SD_SHAPE_EXP
+#define SD_SHAPE_EXP 0
+#else
+#define SD_SHAPE_EXP_BUILD 1
+#endif
+__device__ __forceinline__ f32x16 mfma_shape_exp(bf16x8 a, bf16x8 b, f32x16 c) {
+    f32x4 c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+}
+#define SD_MFMA_BF16(BIT, a, b, c) (((SD_SHAPE_EXP) & (BIT)) ? mfma_shape_exp(a, b, c) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0))
 
 #ifndef SD_IGEMM_LATE_DMA
 #define SD_IGEMM_LATE_DMA 0   // 1 = issue the next stage's DMA after the first MFMA group of the chunk (experiment)
@@ -419,11 +436,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(ConvArgs p) {
             if (BF16) {   /* one 16-byte slot = 8 bf16 = this lane's k-half of a 32x32x16 MFMA step */            \
                 const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);          \
                 const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);          \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);                \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);                \
+                acc[0][0] = SD_MFMA_BF16(1, xa0, xb0, acc[0][0]);                                              \
+                acc[1][0] = SD_MFMA_BF16(1, xa1, xb0, acc[1][0]);                                              \
                 if (NT == 2) {                                                                                    \
-                    acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][NT - 1], 0, 0, 0);  \
-                    acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][NT - 1], 0, 0, 0);  \
+                    acc[0][NT - 1] = SD_MFMA_BF16(1, xa0, xb1, acc[0][NT - 1]);                                \
+                    acc[1][NT - 1] = SD_MFMA_BF16(1, xa1, xb1, acc[1][NT - 1]);                                \
                 }                                                                                                 \
             } else {      /* k-step outermost: consecutive MFMAs hit different accumulators */                    \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
@@ -1165,7 +1182,7 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvArgs& p) {
     const uint32_t pt_base = lds_addr(Pt), bs_base = lds_addr(Bs);
     // the MFMAs of one k-group: fp32 = four 32x32x2 steps over the slot's four k values, bf16 = one 32x32x16 step over its eight
 #define PT_MFMA1(A, B, mi, ni)                                                                     \
-    if (BF16) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni], 0, 0, 0); \
+    if (BF16) acc[mi][ni] = SD_MFMA_BF16(2, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[mi][ni]); \
     else { _Pragma("unroll") for (int k = 0; k < 4; ++k) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k], B[k], acc[mi][ni], 0, 0, 0); }
 #define PT_MFMA_GROUP(A0, A1, A2, A3, B0, B1)                                                      \
     if (BF16) {                                                                                    \
@@ -1639,6 +1656,123 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
         g_pp_tl[blockIdx.x][0] = tl_start; g_pp_tl[blockIdx.x][1] = tr_rbegin; g_pp_tl[blockIdx.x][2] = tr_rbegin + tr[7]; g_pp_tl[blockIdx.x][3] = tr[6];
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 1x1 / stride 1 convolution onto 128 output channels (the FPN laterals: 64 -> 128 on the 128 x 128 map moves 470 MB for 17 GFLOP)
+// as a STREAM: k_conv_igemm's 128 x 128 tile has a two-chunk loop there, all prologue and epilogue (172 us = 2.7 TB/s at bs = 64).
+// Here every wave is its own pipeline with no LDS and no barrier:
+//   weights : all 128 x CIN in registers as the A operands of v_mfma_f32_16x16x32_bf16 (8 channel tiles x CIN / 32 k-steps, loaded once)
+//   pixels  : the B operand straight from global memory, 16 bytes per lane = 8 consecutive channels of the lane's pixel (the operand
+//             is streamed once and shared with no other wave: no LDS round trip); the next tile's loads are issued before this tile's
+//             epilogue, the residual's before the MFMAs
+//   output  : D rows = channels, columns = pixels.  Tile t holds the channels 32 (t / 2) + 8 (row / 4) + 4 (t % 2) + row % 4, so that a
+//             lane ends up with 8 CONSECUTIVE channels of one pixel per tile pair: bias + (upsampled) residual + ReLU in registers and
+//             one 16-byte store, no transpose through LDS.
+// Tiles of 16 P pixels, waves walk them with a grid stride.  Host side: launch_igemm (bf16, R = S = 1, unit stride, Nn = 128, Ck = 64 / 128,
+// no scale, no statistics, res_up2 <= 1).
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int P>
+__global__ __launch_bounds__(256, 2) void k_conv1x1_stream_bf16(ConvArgs p, int ntiles) {
+    constexpr int KS = CIN / 32;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const uint16_t* const x = reinterpret_cast<const uint16_t*>(p.x);
+    const uint16_t* const w = reinterpret_cast<const uint16_t*>(p.w);
+    const uint16_t* const res = reinterpret_cast<const uint16_t*>(p.res);
+    uint16_t* const y = reinterpret_cast<uint16_t*>(p.y);
+    // A operands: tile t, row i = j -> channel 32 (t >> 1) + 8 (i >> 2) + 4 (t & 1) + (i & 3); this lane holds its k group g of every step
+    bf16x8 wf[8][KS];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int c = 32 * (t >> 1) + 8 * (j >> 2) + 4 * (t & 1) + (j & 3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[t][ks] = *reinterpret_cast<const bf16x8*>(w + c * CIN + ks * 32 + g * 8);
+    }
+    const int nwaves = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HWo = p.Ho * p.Wo, Wh = p.Wo >> 1, HWh = (p.Ho >> 1) * Wh;
+    bf16x8 xb[P][KS];
+    if (tile < ntiles) {
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xb[pt][ks] = *reinterpret_cast<const bf16x8*>(x + (int64_t)(tile * (16 * P) + pt * 16 + j) * CIN + ks * 32 + g * 8);
+    }
+    for (; tile < ntiles; tile += nwaves) {
+        const int m0 = tile * (16 * P);
+        // residual runs of this tile: 8 channels (32 u + 8 g ..) of the lane's pixel, or of its parent in the half-size map
+        uint4 rr[P][4];
+        if (res) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                const int m = m0 + pt * 16 + j;
+                int64_t rm = m;
+                if (p.res_up2) {
+                    const int b = m / HWo, r = m - b * HWo, oy = r / p.Wo, ox = r - oy * p.Wo;
+                    rm = (int64_t)b * HWh + (oy >> 1) * Wh + (ox >> 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rr[pt][u] = *reinterpret_cast<const uint4*>(res + rm * 128 + u * 32 + g * 8);
+            }
+        }
+        f32x4 acc[P][8];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) acc[pt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][ks], xb[pt][ks], acc[pt][t], 0, 0, 0);
+        // the next tile's pixels are requested before this tile's epilogue
+        const int nxt = tile + nwaves;
+        if (nxt < ntiles) {
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xb[pt][ks] = *reinterpret_cast<const bf16x8*>(x + (int64_t)(nxt * (16 * P) + pt * 16 + j) * CIN + ks * 32 + g * 8);
+        }
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const int64_t m = m0 + pt * 16 + j;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cb = u * 32 + g * 8;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[pt][2 * u][e]; v[4 + e] = acc[pt][2 * u + 1][e]; }
+                if (p.shift) {
+                    const float4 s0 = *reinterpret_cast<const float4*>(p.shift + cb), s1 = *reinterpret_cast<const float4*>(p.shift + cb + 4);
+                    v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+                }
+                if (res) {
+                    const uint4 r = rr[pt][u];
+                    v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+                    v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xffff0000u);
+                    v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xffff0000u);
+                }
+                uint4 pk;
+                pk.x = rs_pack2(v[0], v[1]); pk.y = rs_pack2(v[2], v[3]); pk.z = rs_pack2(v[4], v[5]); pk.w = rs_pack2(v[6], v[7]);
+                if (p.relu) { pk.x = rs_relu2(pk.x); pk.y = rs_relu2(pk.y); pk.z = rs_relu2(pk.z); pk.w = rs_relu2(pk.w); }
+                *reinterpret_cast<uint4*>(y + m * 128 + cb) = pk;
+            }
+        }
+    }
+}
+// geometry / argument conditions of k_conv1x1_stream_bf16; `mode` as in launch_igemm.  sd_set_option("conv1x1_stream_min_pixels", n): output
+// pixels from which the stream kernel replaces the tile kernel (tests: 32; off: 1 << 30).
+static thread_local int g_conv1x1_stream_min_px = 32 * 2048;
+static bool conv1x1_stream_geometry(const ConvArgs& a, int mode) {
+    if (mode != 0 || a.R != 1 || a.S != 1 || a.mul != 1 || a.div != 1 || a.off != 0) return false;
+    if (a.Nn != 128 || (a.Ck != 64 && a.Ck != 128) || a.Ho != a.Hi || a.Wo != a.Wi) return false;
+    if (a.M % 32 || a.M < g_conv1x1_stream_min_px) return false;          // small maps: the tile kernel (split-K) fills the chip better
+    return true;
+}
+static bool conv1x1_stream_args(const ConvArgs& a) {
+    return !a.scale && !a.stat && !a.bn_x && a.splits <= 1 && a.res_up2 <= 1 && (!a.res_up2 || (a.Ho % 2 == 0 && a.Wo % 2 == 0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2538,7 +2672,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
                     TrPair bp;                                                                                    \
                     bp.lo = rd((X), row0, b_slot);                                                                \
                     bp.hi = rd((X), row0 + 4, b_slot);                                                            \
-                    acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bp), acc[r * 3 + s2], 0, 0, 0); \
+                    acc[r * 3 + s2] = SD_MFMA_BF16(4, av, __builtin_bit_cast(bf16x8, bp), acc[r * 3 + s2]); \
                 }                                                                                                 \
         }                                                                                                         \
     }
@@ -2668,7 +2802,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_tap_bf16(WgradArgs16t p) {
             }                                                                                                     \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
                 _Pragma("unroll") for (int j = 0; j < NTC; ++j)                                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);        \
+                    acc[i][j] = SD_MFMA_BF16(8, av[i], bv[j], acc[i][j]);                                       \
         }                                                                                                         \
     }
 #define WT_ITER(CUR)                                                                                              \
@@ -3861,6 +3995,12 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
     const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
     const int mode = stem ? 1 : (a.par ? 2 : (a.div > 1 ? 3 : 0));
     if (!stem && bf16) {
+        if (conv1x1_stream_geometry(a, mode) && conv1x1_stream_args(a)) {
+            if (a.Ck == 64) { const int nt = a.M / 32; hipLaunchKernelGGL((k_conv1x1_stream_bf16<64, 2>), dim3(std::min(512, cdiv(nt, 4))), dim3(256), 0, st, a, nt); }
+            else { const int nt = a.M / 16; hipLaunchKernelGGL((k_conv1x1_stream_bf16<128, 1>), dim3(std::min(512, cdiv(nt, 4))), dim3(256), 0, st, a, nt); }
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
         RowsArgs ra;
         if (conv_rows64_geometry(a, mode, ra)) {
             static thread_local bool raised64 = false;
@@ -4609,6 +4749,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_min_tiles")) { g_patch_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
+    if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
     if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
@@ -4638,6 +4779,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         a.kchunks = a.Ck / 64; a.nk = a.R * a.S * a.kchunks;
         a.splits = pass == 0 ? fwd_splits(d, 64) : 1;
         t = a;
+        if (conv1x1_stream_geometry(a, mode)) return a.Ck == 64 ? "k_conv1x1_stream_bf16<64, 2>" : "k_conv1x1_stream_bf16<128, 1>";   // (launches with a scale or statistics: k_conv_igemm)
         RowsArgs ra;
         if (conv_rows64_geometry(a, mode, ra)) return "k_conv3x3_c64_rows_bf16";
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";

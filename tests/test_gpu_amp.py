@@ -345,6 +345,58 @@ def test_conv_bf16_two_group_kernel(case):
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64), (1, 8, 20, 64), (3, 12, 8, 128), (2, 32, 32, 128), (64, 128, 128, 64)])
+def test_conv1x1_stream_kernel(case):
+    """k_conv1x1_stream_bf16 (the FPN laterals: 1x1 / stride 1 onto 128 channels, weights in registers, pixels streamed from global memory
+    as MFMA operands, 16-byte epilogue without LDS): bias, residual, half-size residual upsampled (network.py:13-18), ReLU; identical
+    maths to the tile kernel (bf16 products, fp32 sums) -> equal to one bf16 ulp; the 1x1 data-gradient reaches it too."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W, cin = case
+    cout = 128
+    d = make_desc(L, B, H, W, cin, cout, 1, 1, 0)
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).bfloat16().float()
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g).bfloat16().float()
+    half = torch.randn(B, cout, H // 2, W // 2, generator=g).bfloat16().float()
+    xd, wd, bias_d = nhwc16(x), nhwc16(w), bias.to(DEV)
+    conv = F.conv2d(x, w, bias)
+    L.check(lib.sd_set_option(b"conv1x1_stream_min_pixels", 32))
+    try:
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode().startswith("k_conv1x1_stream_bf16")
+        outs = []
+        for r16, up2, relu, ref in ((None, 0, 0, conv), (nhwc16(res), 0, 1, torch.relu(conv + res)),
+                                    (nhwc16(half), 1, 0, conv + F.interpolate(half, scale_factor=2, mode="nearest"))):
+            y = torch.full((B, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, bias_d.data_ptr(),
+                                           r16.data_ptr() if r16 is not None else 0, up2, relu, 0, 0, L.stream()))
+            close(back(y), ref, 8e-3)
+            outs.append(y)
+        # the tile kernel on the same operands
+        L.check(lib.sd_set_option(b"conv1x1_stream_min_pixels", 1 << 30))
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode().startswith("k_conv_igemm")
+        y1 = torch.empty_like(outs[0])
+        L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y1.data_ptr(), C.byref(d), 0, bias_d.data_ptr(), 0, 0, 0, 0, 0, L.stream()))
+        ya, yb = outs[0].float(), y1.float()
+        assert (ya - yb).abs().max() <= 2.0 ** -7 * yb.abs().max() and (ya != yb).float().mean() < 0.05
+        # data gradient of a 128 -> 128 1x1 conv = the same stream with the transposed weights (+ an accumulated gradient)
+        if cin == 128:
+            L.check(lib.sd_set_option(b"conv1x1_stream_min_pixels", 32))
+            assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode().startswith("k_conv1x1_stream_bf16")
+            dy = torch.randn(B, cout, H, W, generator=g).bfloat16().float()
+            wt = w.permute(1, 2, 3, 0).contiguous().to(DEV).to(torch.bfloat16)
+            dx = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+            prev = nhwc16(res)
+            L.check(lib.sd_conv2d_dgrad_bf16(nhwc16(dy).data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), prev.data_ptr(), 1, L.stream()))
+            xg = x.clone().requires_grad_(True)
+            F.conv2d(xg, w).backward(dy)
+            close(back(dx), xg.grad + res, 8e-3)
+    finally:
+        L.check(lib.sd_set_option(b"conv1x1_stream_min_pixels", 32 * 2048))
+
+
 def test_conv_bf16_narrow_patch_tiles_for_wide_layers():
     """bf16 layers whose 128-channel patch tiles do not fill the chip (layer4 at bs=64) take 64-channel patch tiles (`conv_patch_narrow` = 2):
     the checks of the other bf16 conv kernels on a 256 -> 256 channel layer cut into four channel tiles."""

@@ -2,7 +2,7 @@
 """Same-box A/B of two builds of libsdnet_hip.so on the bf16 eval forward (bs = 64, 512x512) and the stress forward (bs = 16, 1024x1024,
 8 + 8 maps): each build in its own child process, alternating, best of the repetitions.  Timing-only experiment builds are allowed
 (SDNET_ALLOW_ABLATION=1): the outputs are not compared.
-usage: ab_fwd_bf16.py <libA.so> <libB.so> [reps=3]"""
+usage: ab_fwd_bf16.py <libA.so> <libB.so> [<libC.so> ...] [reps=3]"""
 import os
 import subprocess
 import sys
@@ -32,8 +32,8 @@ for (B, S, M, N, K, P) in ((64, 512, 2, 1, 20, 40), (16, 1024, 8, 8, 128, 512)):
     del net, x
 print("RESULT", *out)
 '''
-libs = [str(Path(p).resolve()) for p in sys.argv[1:3]]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [str(Path(p).resolve()) for p in sys.argv[1:] if p.endswith(".so")]          # two or more builds
+reps = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 res = {lib: [] for lib in libs}
 for _ in range(reps):
     for lib in libs:

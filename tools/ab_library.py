@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of two builds of libsdnet_hip.so (a code change, not an option): the fp32 and the mixed-precision training step,
 bs = 64, 512x512, each build in its own child process, alternating, best of the repetitions.
-usage: ab_library.py <libA.so> <libB.so> [reps=3]"""
+usage: ab_library.py <libA.so> <libB.so> [<libC.so> ...] [reps=3]"""
 import os
 import subprocess
 import sys
@@ -37,8 +37,8 @@ for amp in (False, True):
     del net, step, x
 print("RESULT", *out)
 '''
-libs = [str(Path(p).resolve()) for p in sys.argv[1:3]]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [str(Path(p).resolve()) for p in sys.argv[1:] if p.endswith(".so")]          # two or more builds
+reps = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 res = {lib: [] for lib in libs}
 for _ in range(reps):
     for lib in libs:
