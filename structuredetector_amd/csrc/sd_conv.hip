@@ -56,7 +56,7 @@ namespace sd {
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP)
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP) || defined(SD_W16_ABL)
 #define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
 #else
 #define SD_EXPERIMENT_FLAG 0
@@ -2604,15 +2604,46 @@ struct WgradArgs16 {
     int M, splits, m_per_split;
 };
 
+// Round 4: THREE LDS stages and explicit waits.  The first form (two stages, a __syncthreads() per 32-pixel chunk) spent two thirds of
+// its time waiting: the barrier's fence drains the LDS-DMA issued one chunk earlier (a ~1-2 us round trip for 0.27 us of MFMAs per wave).
+// Now chunk ch + 2 is issued while chunk ch is multiplied; per chunk one counted vmcnt wait + a bare s_barrier; the transposed reads are
+// inline asm (the compiler's wait insertion would drain the DMAs in flight in front of them) with the stage and the tap's row offset as
+// immediates: address registers = one for dY and four for X (the slot swizzle depends on (row & 3), i.e. on the tap's row constant mod 4).
+#ifndef SD_W16_ABL
+#define SD_W16_ABL 0          // timing experiments (WRONG RESULTS): 1 no DMA in the loop, 2 no transposed reads, 3 no MFMA, 4 no partial stores, 5 no barrier
+#else
+#define SD_W16_ABL_BUILD 1
+#endif
+template <int OFF>
+__device__ __forceinline__ v4i16 lds_tr16_async(uint32_t addr) {
+    v4i16 v;
+    if (SD_W16_ABL == 2) { v = __builtin_bit_cast(v4i16, uint2{addr, addr ^ 0x3f803f80u}); asm volatile("" : "+v"(v)); return v; }
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// patch row constant of (k-block kb, tap t): the lane adds its own pixel `khalf`
+template <int ROWW>
+constexpr int w16_row(int kb, int t) { return ROWW == 32 ? (t / 3) * 34 + kb * 16 + t % 3 : (kb + t / 3) * 18 + t % 3; }
+template <int ROWW, int XB, int KB, int T>
+__device__ __forceinline__ void w16_read_tap(const uint32_t (&xo)[4], TrPair& bp) {
+    constexpr int C = w16_row<ROWW>(KB, T);
+    bp.lo = lds_tr16_async<XB + C * 128>(xo[C & 3]);
+    bp.hi = lds_tr16_async<XB + (C + 4) * 128>(xo[C & 3]);
+}
+#define SD_W16_WAIT10(N, a, b0, b1, b2, b3, b4, b5, b6, b7, b8)                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a.lo), "+v"(a.hi), "+v"(b0.lo), "+v"(b0.hi), "+v"(b1.lo), "+v"(b1.hi), "+v"(b2.lo), "+v"(b2.hi), \
+                 "+v"(b3.lo), "+v"(b3.hi), "+v"(b4.lo), "+v"(b4.hi), "+v"(b5.lo), "+v"(b5.hi), "+v"(b6.lo), "+v"(b6.hi), "+v"(b7.lo), "+v"(b7.hi),    \
+                 "+v"(b8.lo), "+v"(b8.hi) :: "memory")
+
 template <int ROWW>
 __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
     constexpr int PX = ROWW + 2, ROWS = 32 / ROWW + 2;
     constexpr int XPIX = ROWS * PX;                                  // patch pixels: 102 / 72
     constexpr int XPIECES = ((XPIX + 7) / 8 + 3) / 4 * 4;            // 1 KB pieces of 8 pixel rows, a multiple of 4: 16 / 12
-    __shared__ __attribute__((aligned(16))) uint16_t Ds0[32 * 64];
-    __shared__ __attribute__((aligned(16))) uint16_t Ds1[32 * 64];
-    __shared__ __attribute__((aligned(16))) uint16_t Xs0[XPIECES * 512];
-    __shared__ __attribute__((aligned(16))) uint16_t Xs1[XPIECES * 512];
+    constexpr int NP = 1 + XPIECES / 4;                              // LDS-DMA instructions per wave and stage
+    constexpr int STG = 2048 + XPIECES * 512;                        // elements per stage: dY chunk (32 x 64) + patch
+    constexpr int STGB = STG * 2;                                    // bytes: 20480 / 16384
+    __shared__ __attribute__((aligned(16))) uint16_t W3[3 * STG];    // ONE object: the stage is an immediate offset of the reads
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x;
     const int c_tiles = p.Ck >> 6;
@@ -2631,67 +2662,84 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
     // DMA source of this lane inside an 8-row piece: row lane / 8, logical 16-byte chunk (lane % 8) ^ ((row & 3) << 1)
     const int srow = lane >> 3;
     const int schunk = ((lane & 7) ^ ((srow & 3) << 1)) * 8;          // element offset inside the 64-channel row
-#define W16_STAGE(ch, D, X)                                                                                       \
+    // chunk ch -> stage ST (always NP instructions per wave: past-the-end chunks re-load the zero line, the vmcnt counts stay fixed)
+#define W16_STAGE(ch, ST)                                                                                         \
     {                                                                                                             \
+        uint16_t* const D_ = W3 + (ST) * STG;                                                                     \
+        uint16_t* const X_ = D_ + 2048;                                                                           \
         const int m0 = m_beg + (ch) * 32;                                                                         \
+        const bool live = m0 < m_end;                                                                             \
         const int ox0 = m0 % p.Wo, t_ = m0 / p.Wo, oy = t_ % p.Ho, b = t_ / p.Ho;                                 \
         {                                                                                                         \
             const int row = wave * 8 + srow;                    /* pixel of the chunk: 4 pieces, one per wave */   \
-            const uint16_t* src = (m0 < m_end) ? p.dy + (int64_t)(m0 + row) * p.Nn + tn0 + schunk : zero16;       \
-            lds_dma16(src, reinterpret_cast<float*>((D) + wave * 512));                                           \
+            const uint16_t* src = live ? p.dy + (int64_t)(m0 + row) * p.Nn + tn0 + schunk : zero16;               \
+            lds_dma16(src, reinterpret_cast<float*>(D_ + wave * 512));                                            \
         }                                                                                                         \
         _Pragma("unroll") for (int j = 0; j < XPIECES / 4; ++j) {                                                 \
             const int q = wave + 4 * j;                                                                           \
             const int idx = q * 8 + srow;                       /* patch pixel: row idx / PX, column idx % PX */   \
             const int r = idx / PX, px = idx - r * PX;                                                            \
             const int iy = oy - 1 + r, ix = ox0 - 1 + px;                                                         \
-            const bool ok = m0 < m_end && idx < XPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
+            const bool ok = live && idx < XPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi; \
             const uint16_t* src = ok ? p.x + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Ck + tc0 + schunk : zero16; \
-            lds_dma16(src, reinterpret_cast<float*>((X) + q * 512));                                              \
+            lds_dma16(src, reinterpret_cast<float*>(X_ + q * 512));                                               \
         }                                                                                                         \
     }
     // transposed-read geometry of this lane: 16-lane group g = lane / 16 -> column half g & 1, 8-pixel half g >> 1 of the 16-pixel
-    // step; lane 4q + pp of the group addresses row q, columns 4 pp .. 4 pp + 3 of the group's 4 x 16 block
+    // step; lane 4q + pp of the group addresses row q, columns 4 pp .. 4 pp + 3 of the group's 4 x 16 block.  Byte address of (row, slot):
+    // row * 128 + ((slot ^ (row & 3)) << 5) + pp * 8 with row = constant + khalf: the constant * 128 is an immediate, the rest per lane
     const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
     const int a_slot = (wn0 >> 4) + (g & 1), b_slot = (wc0 >> 4) + (g & 1);
     const int khalf = (g >> 1) * 8 + q4;                             // pixel of the 16-pixel step this lane addresses (first read; +4 second)
-    auto rd = [&](const uint16_t* base, int row, int slot) -> v4i16 {
-        return lds_tr16(base + row * 64 + ((slot ^ (row & 3)) << 4) + pp * 4);
-    };
-#define W16_COMPUTE(D, X)                                                                                         \
+    const uint32_t w3 = lds_addr(W3);
+    const uint32_t ao0 = w3 + (uint32_t)(khalf * 128 + ((a_slot ^ (khalf & 3)) << 5) + pp * 8);       // dY rows: constants 0, 4, 16, 20
+    uint32_t xo0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xo0[k] = w3 + (uint32_t)(khalf * 128 + ((b_slot ^ ((k + khalf) & 3)) << 5) + pp * 8);
+#define W16_MFMA(A, BP, T) if (SD_W16_ABL == 3) { asm volatile("" :: "v"(A.lo), "v"(A.hi), "v"(BP.lo), "v"(BP.hi)); } else { acc[T] = SD_MFMA_BF16(4, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, BP), acc[T]); }
+#define W16_COMPUTE(st)                                                                                           \
     {                                                                                                             \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                        \
-            const int prow = ROWW == 32 ? 0 : kb, pcol = ROWW == 32 ? kb * 16 : 0;                                \
-            TrPair ap;                                                                                            \
-            ap.lo = rd((D), kb * 16 + khalf, a_slot);                                                             \
-            ap.hi = rd((D), kb * 16 + khalf + 4, a_slot);                                                         \
-            const bf16x8 av = __builtin_bit_cast(bf16x8, ap);                                                     \
-            _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                         \
-                _Pragma("unroll") for (int s2 = 0; s2 < 3; ++s2) {                                                \
-                    const int row0 = (prow + r) * PX + pcol + s2 + khalf;                                         \
-                    TrPair bp;                                                                                    \
-                    bp.lo = rd((X), row0, b_slot);                                                                \
-                    bp.hi = rd((X), row0 + 4, b_slot);                                                            \
-                    acc[r * 3 + s2] = SD_MFMA_BF16(4, av, __builtin_bit_cast(bf16x8, bp), acc[r * 3 + s2]); \
-                }                                                                                                 \
-        }                                                                                                         \
+        constexpr int DB = 0, XB = 4096;                                                                          \
+        const uint32_t so_ = (uint32_t)(st) * STGB;             /* the stage: five adds per chunk */               \
+        const uint32_t ao = ao0 + so_;                                                                            \
+        const uint32_t xo[4] = {xo0[0] + so_, xo0[1] + so_, xo0[2] + so_, xo0[3] + so_};                          \
+        TrPair a0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8;                                                        \
+        a0.lo = lds_tr16_async<DB>(ao); a0.hi = lds_tr16_async<DB + 4 * 128>(ao);                                 \
+        w16_read_tap<ROWW, XB, 0, 0>(xo, b0); w16_read_tap<ROWW, XB, 0, 1>(xo, b1); w16_read_tap<ROWW, XB, 0, 2>(xo, b2); \
+        w16_read_tap<ROWW, XB, 0, 3>(xo, b3); w16_read_tap<ROWW, XB, 0, 4>(xo, b4); w16_read_tap<ROWW, XB, 0, 5>(xo, b5); \
+        w16_read_tap<ROWW, XB, 0, 6>(xo, b6); w16_read_tap<ROWW, XB, 0, 7>(xo, b7); w16_read_tap<ROWW, XB, 0, 8>(xo, b8); \
+        SD_W16_WAIT10(0, a0, b0, b1, b2, b3, b4, b5, b6, b7, b8);                                                 \
+        a1.lo = lds_tr16_async<DB + 16 * 128>(ao); a1.hi = lds_tr16_async<DB + 20 * 128>(ao);                     \
+        /* second k-block: a tap's operand registers are re-read as soon as its MFMA has been issued */            \
+        W16_MFMA(a0, b0, 0) w16_read_tap<ROWW, XB, 1, 0>(xo, b0);                                                 \
+        W16_MFMA(a0, b1, 1) w16_read_tap<ROWW, XB, 1, 1>(xo, b1);                                                 \
+        W16_MFMA(a0, b2, 2) w16_read_tap<ROWW, XB, 1, 2>(xo, b2);                                                 \
+        W16_MFMA(a0, b3, 3) w16_read_tap<ROWW, XB, 1, 3>(xo, b3);                                                 \
+        W16_MFMA(a0, b4, 4) w16_read_tap<ROWW, XB, 1, 4>(xo, b4);                                                 \
+        W16_MFMA(a0, b5, 5) w16_read_tap<ROWW, XB, 1, 5>(xo, b5);                                                 \
+        W16_MFMA(a0, b6, 6) w16_read_tap<ROWW, XB, 1, 6>(xo, b6);                                                 \
+        W16_MFMA(a0, b7, 7) w16_read_tap<ROWW, XB, 1, 7>(xo, b7);                                                 \
+        W16_MFMA(a0, b8, 8) w16_read_tap<ROWW, XB, 1, 8>(xo, b8);                                                 \
+        SD_W16_WAIT10(0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8);                                                 \
+        W16_MFMA(a1, b0, 0) W16_MFMA(a1, b1, 1) W16_MFMA(a1, b2, 2) W16_MFMA(a1, b3, 3) W16_MFMA(a1, b4, 4)       \
+        W16_MFMA(a1, b5, 5) W16_MFMA(a1, b6, 6) W16_MFMA(a1, b7, 7) W16_MFMA(a1, b8, 8)                           \
     }
-#define W16_ITER(CUR)                                                                                             \
-    {                                                                                                             \
-        if (ch + 1 < nchunks) { W16_STAGE(ch + 1, (CUR) ? Ds0 : Ds1, (CUR) ? Xs0 : Xs1) }                         \
-        W16_COMPUTE((CUR) ? Ds1 : Ds0, (CUR) ? Xs1 : Xs0)                                                         \
-        __syncthreads();                                                                                          \
-        ++ch;                                                                                                     \
+    // iteration: chunk ch's pieces of this wave have landed (NP younger ones may be in flight), barrier (every wave's pieces are in, and
+    // every wave is done reading chunk ch - 1: its stage takes chunk ch + 2), multiply
+    W16_STAGE(0, 0)
+    W16_STAGE(1, 1)
+    int st = 0;                                                   // stage of chunk ch; chunk ch + 2 goes to stage (st + 2) % 3
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (SD_W16_ABL != 1) wait_vmcnt<NP>();
+        if (SD_W16_ABL != 5) __builtin_amdgcn_s_barrier();
+        const int st2 = st == 0 ? 2 : st - 1;
+        if (SD_W16_ABL != 1) { W16_STAGE(ch + 2, st2) }
+        W16_COMPUTE(st)
+        st = st == 2 ? 0 : st + 1;
     }
-    if (nchunks > 0) { W16_STAGE(0, Ds0, Xs0) }
-    __syncthreads();
-    int ch = 0;
-    while (ch < nchunks) {
-        W16_ITER(0)
-        if (ch < nchunks) W16_ITER(1)
-    }
-#undef W16_ITER
+    wait_vmcnt<0>();
 #undef W16_COMPUTE
+#undef W16_MFMA
 #undef W16_STAGE
     float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
 #pragma unroll
@@ -2699,7 +2747,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
-            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+            if (SD_W16_ABL != 4 || acc[t][e] == 123.456f) out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
         }
 }
 
