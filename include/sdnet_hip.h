@@ -324,6 +324,9 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * "conv_rows64_min_units": smallest number of (image, 128-pixel strip, row range) units for which the bf16 64 -> 64 channel 3x3 convs take
  * the row-stream kernel k_conv3x3_c64_rows_bf16 (default 192, and at least 16 rows per unit; 1 = always, for tests; 1 << 30 = never);
  * "conv_rows_f32_min_units": the same for the fp32 row-stream kernel k_conv3x3_c64_rows_f32 (units = image x 64-pixel strip x row range).
+ * "conv1x1_stream_min_pixels": smallest number of output pixels for which a bf16 1x1 / stride 1 conv onto 128 channels (Cin 64 or 128, no
+ *   scale, no statistics: the FPN laterals and the 128 -> 128 1x1 data-gradient) takes the stream kernel k_conv1x1_stream_bf16 (default
+ *   65536; 32 = always, for tests; 1 << 30 = never).
  * "stem_fwd_blocks": persistent blocks of the fp32 training stem forward (default 512 = two per CU; 256 = one per CU, the setting the
  *   in-kernel phase trace of tools/stem_trace_f32.py compares against). */
 int sd_set_option(const char* name, int value);

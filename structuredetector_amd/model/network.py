@@ -940,8 +940,10 @@ class Network(nn.Module):
     # ---- hipGraph replay of the eval forward (launch-bound small batches) --------------------
     def graphed(self, example: torch.Tensor):
         """Capture the eval-mode forward for `example`'s shape into a hipGraph and return `run(x) -> head tensor`.
-        The ~90 launches of a bs=1 forward then cost one graph launch; input and output buffers are static
-        (the returned tensor is overwritten by the next call)."""
+        Input and output buffers are static (the returned tensor is overwritten by the next call; write into `run.static_in` to skip the
+        input copy).  Measured (tools/graph_vs_eager.sh, round 4): at bs=1 the eager stream is already gap-free -- the host enqueues ahead and
+        the 44 kernels run back to back (sum of kernel durations = wall time) -- so a replay has no launch gaps to remove and adds its own
+        fixed cost (the copy launch + ~9 us between replays): use it when the HOST is the bottleneck (a busy Python thread), not for speed."""
         if self.training:
             raise L.SdError("graphed() captures the inference forward: call net.eval() first")
         static_in = example.detach().clone().contiguous().float()
@@ -957,7 +959,8 @@ class Network(nn.Module):
                 static_out = self._engine.forward(static_in, False)
 
         def run(x):
-            static_in.copy_(x, non_blocking=True)
+            if x.data_ptr() != static_in.data_ptr():      # a caller that fills `run.static_in` itself saves the copy launch
+                static_in.copy_(x, non_blocking=True)
             graph.replay()
             return static_out
 
