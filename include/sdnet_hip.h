@@ -377,6 +377,19 @@ int sd_maxpool_bn_relu_bwd_bf16(const void* dpool_bf16, const uint8_t* idx, cons
                                 void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* [Cout][taps][Cin] fp32 -> [Cin][taps][Cout] bf16 in one pass (the data-gradient's weights under --amp). */
 int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, int taps, int Cin, sd_stream_t stream);
+
+/* Inference: the last FPN convolution (network.py:17-18: conv3x3 + folded BatchNorm + ReLU onto fpn_depth = 128 channels) with the network's
+ * 1x1 head (network.py:22-29) applied to every output tile in the kernel's epilogue -- the FPN output tensor (268 MB in bf16 at bs = 64,
+ * 512x512) is neither written nor read back, and the head launch disappears.  head_y = fp32 NCHW (B, head_co, Ho, Wo), the tensor
+ * Network.forward slices into its four views (network.py:77-84).  `head_prepared` = sd_head_split_bf16_bytes() bytes written by
+ * sd_head_split_bf16 from the fp32 head weights [head_co][128] and bias (hi / lo bf16 halves, zero padded to 32 rows: once per set of
+ * weights).  sd_conv2d_fwd_bf16_head_supported = 1 where the convolution takes k_conv3x3_bf16_pp (bs = 64 at 512x512, bs = 16 at
+ * 1024x1024, ...); elsewhere call sd_conv2d_fwd_bf16 + sd_head_fwd_bf16. */
+int sd_conv2d_fwd_bf16_head_supported(const sd_conv_desc* d, int head_co);
+size_t sd_head_split_bf16_bytes(void);
+int sd_head_split_bf16(const float* head_w, const float* head_bias, int head_co, void* prepared, sd_stream_t stream);
+int sd_conv2d_fwd_bf16_head(const void* x_bf16, const void* w_bf16, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
+                            const void* head_prepared, int head_co, float* head_y, sd_stream_t stream);
 /* dx = dgrad(dy) [+ residual]: bf16 dy / transposed weights [Cin][R][S][Cout] / dx; res_mode 0 none, 1 bf16 tensor of dx's shape,
  * 2 bf16 half-size map added at the even pixels (the 1x1 / stride-2 downsample branch). */
 int sd_conv2d_dgrad_bf16(const void* dy_bf16, const void* w_t_bf16, void* dx_bf16, const sd_conv_desc* d, const void* residual_bf16,

@@ -92,6 +92,10 @@ _SIGNATURES = {
     "sd_cast_f32_to_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sd_conv2d_fwd_bf16_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_fwd_bf16_head_supported": (c_int, [C.POINTER(ConvDesc), c_int]),
+    "sd_head_split_bf16_bytes": (c_size, []),
+    "sd_head_split_bf16": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
+    "sd_conv2d_fwd_bf16_head": (c_int, [c_vp, c_vp, C.POINTER(ConvDesc), c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "sd_cast_bf16_to_f32": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sd_conv2d_fwd_bf16_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_fwd_bf16_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),

@@ -115,6 +115,12 @@ struct ConvArgs {
     int pt_strip_log2;       // k_conv3x3_bf16_pp: log2 of the column strips a map row is cut into (0: a sub-tile's rows span the map)
     int par;              // stride-2 data-gradient: output pixels are grouped by (y&1, x&1) so that a tile only
                           // walks the filter taps that can reach its parity class (9/4 instead of 9 taps for 3x3)
+    // k_conv3x3_bf16_pp with the 1x1 head fused into its epilogue (inference: sd_conv2d_fwd_bf16_head).  head_y != nullptr: the conv output
+    // (all Nn = 128 channels of a pixel sit in one wave) is NOT stored; the head's head_co <= 32 channels go to head_y as NCHW fp32 planes
+    const uint16_t* head_w;   // [2][32][128] bf16: hi and lo halves of the fp32 head weights (rows >= head_co zero): w = hi + lo to 2^-17
+    const float* head_b;      // [32] bias (zero padded)
+    float* head_y;            // [B][head_co][Ho * Wo]
+    int head_co;
 };
 
 __device__ __attribute__((aligned(128))) float g_zero_line[64];   // zero-initialised: source of padded (out-of-image) rows
@@ -1349,6 +1355,12 @@ __device__ __forceinline__ uint32_t rs_relu2(uint32_t two_bf16) {             //
 typedef float pp_f32x2 __attribute__((ext_vector_type(2)));
 // acc[mi][ni] = 16 x 16 tile (mi: 16 pixels, ni: 16 channels) of v_mfma_f32_16x16x32_bf16: lane (r16 = lane & 15, kq = lane >> 4) holds
 // channel column r16, pixel rows kq * 4 + e.  Wave tile: 64 pixels x all 128 channels; a pass = one 64-channel half of it.
+// HEAD (inference, network.py:22-29 fused behind network.py:17-18): the rounded bf16 rows of a pass are written back IN PLACE over the
+// fp32 scratch rows they were read from (a wave's LDS operations execute in order: every lane of a row has read its 16 bytes before the
+// row's 8-byte pieces land) at a position that makes the 16 x 16 x 32 operand reads conflict-free -- logical 16-byte slot s of row r at
+// physical slot (s & 1) * 8 + ((r + 2 (s >> 1)) & 7) of the row's 256 bytes -- and multiplied by the head weights (hi + lo bf16 halves of
+// the fp32 weights, fp32 accumulation: x * hi + x * lo equals the fp32 product to fp32 rounding because x is bf16 already).
+template <bool HEAD>
 __device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x4 (&acc)[4][8], int mbase, int TWl, int tid, int wave, int n0, int tile_m,
                                                  float* T0, float* T1) {
     constexpr int BN = 128;
@@ -1370,9 +1382,26 @@ __device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x4 (&acc)
     const int c4 = (lane & 15) * 4;
     const bool affine = p.scale || p.shift;
     const int TWm = (1 << TWl) - 1, rsub = lane >> 4;
+    f32x4 hacc[4][2];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { hacc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const bool head2 = HEAD && p.head_co > 16;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int n = n0 + h * 64 + c4;
+        // head weights of this pass's two k-steps (channels 64 h + 32 ks + 8 kq ..): lane = (output channel r16 (+ 16), k group kq)
+        bf16x8 hw[2][2][2];                                     // [k-step][output tile][hi / lo]
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int no = 0; no < 2; ++no)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl)
+                        hw[ks][no][hl] = *reinterpret_cast<const bf16x8*>(p.head_w + ((hl * 32 + (head2 ? no : 0) * 16 + r16) * 128 + h * 64 + ks * 32 + kq * 8));
+        }
         pp_f32x2 sc01 = {1.f, 1.f}, sc23 = {1.f, 1.f}, sh01 = {0.f, 0.f}, sh23 = {0.f, 0.f};
         if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc01 = pp_f32x2{t.x, t.y}; sc23 = pp_f32x2{t.z, t.w}; }
         if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh01 = pp_f32x2{t.x, t.y}; sh23 = pp_f32x2{t.z, t.w}; }
@@ -1415,7 +1444,53 @@ __device__ __forceinline__ void pp_epilogue_bf16(const ConvArgs& p, f32x4 (&acc)
             uint2 pk;
             pk.x = rs_pack2(v01[0], v01[1]); pk.y = rs_pack2(v23[0], v23[1]);
             if (p.relu) { pk.x = rs_relu2(pk.x); pk.y = rs_relu2(pk.y); }
-            *reinterpret_cast<uint2*>(yb + (int64_t)m * p.Nn) = pk;
+            if constexpr (HEAD) {
+                const int rr = rl & 31, i = lane & 15, sl = i >> 1;            // piece i = channels 4 i .. 4 i + 3 of the pass: logical slot i / 2
+                const int ps = (sl & 1) * 8 + ((rr + 2 * (sl >> 1)) & 7);
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(it < 8 ? T0 : T1) + rr * 256 + ps * 16 + (i & 1) * 8) = pk;
+            } else {
+                *reinterpret_cast<uint2*>(yb + (int64_t)m * p.Nn) = pk;
+            }
+        }
+        if constexpr (HEAD) {
+            // 64 pixels x 64 channels of bf16 rows -> A operands (pixel r16 of tile mi, k group kq), two k-steps
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int rr = (mi & 1) * 16 + r16;
+                const char* const tb = reinterpret_cast<const char*>(mi < 2 ? T0 : T1) + rr * 256;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int sl = ks * 4 + kq;
+                    const int ps = (sl & 1) * 8 + ((rr + 2 * (sl >> 1)) & 7);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(tb + ps * 16);
+                    hacc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hw[ks][0][0], hacc[mi][0], 0, 0, 0);
+                    hacc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hw[ks][0][1], hacc[mi][0], 0, 0, 0);
+                    if (head2) {
+                        hacc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hw[ks][1][0], hacc[mi][1], 0, 0, 0);
+                        hacc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hw[ks][1][1], hacc[mi][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HEAD) {
+        // D: column = output channel r16 (+ 16), rows = pixels 4 kq + e of tile mi: four consecutive pixels of one map row -> one 16-byte
+        // store into the channel's NCHW plane
+        const int HW = p.Ho * p.Wo;
+#pragma unroll
+        for (int no = 0; no < 2; ++no) {
+            const int co = no * 16 + r16;
+            if (co >= p.head_co) continue;
+            const float bv = p.head_b[co];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int ml = wml + mi * 16 + kq * 4;
+                const int m = mbase + (ml >> TWl) * p.Wo + (ml & TWm);
+                const int b = m / HW, pix = m - b * HW;
+                f32x4 o = hacc[mi][no];
+                o[0] += bv; o[1] += bv; o[2] += bv; o[3] += bv;
+                *reinterpret_cast<f32x4*>(p.head_y + ((int64_t)b * p.head_co + co) * HW + pix) = o;
+            }
         }
     }
     if (fwd_stat) {
@@ -1465,7 +1540,8 @@ constexpr int PP_LDS_FLOATS = 4 * PT_STAGE_FLOATS + PP_NST * PP_B_FLOATS;       
 constexpr int PP_BM = 512;
 
 __device__ __forceinline__ f32x4 pp_fake_read(uint32_t addr) { f32x4 v; asm volatile("v_mov_b32 %0, %1" : "=v"(v[0]) : "v"(addr)); v[1] = v[2] = v[3] = v[0]; return v; }
-__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
+template <bool HEAD>
+__device__ __forceinline__ void conv3x3_bf16_pp_body(const ConvArgs& p) {
     using T = uint16_t;
     constexpr int BN = 128, EPS = 8, KC = 32, MT = 4, NTW = 8, NPP = 7;     // wave tile: 4 (pixels) x 8 (channels) MFMA tiles of 16 x 16
     extern __shared__ __attribute__((aligned(16))) float pp_lds[];
@@ -1647,7 +1723,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     // The 512-pixel tile is one statistics row: wave rows 0, 1 = group 0, rows 2, 3 = group 1.
     __syncthreads();
     float* T0 = pp_lds + wave * 4096;
-    pp_epilogue_bf16(p, acc, mbase, TWl, tid, wave, n0, tile_m, T0, T0 + 2048);        // (no half-size residual here: conv_pp_geometry)
+    pp_epilogue_bf16<HEAD>(p, acc, mbase, TWl, tid, wave, n0, tile_m, T0, T0 + 2048);        // (no half-size residual here: conv_pp_geometry)
 #ifdef SD_PP_TRACE
     tr[5] = __builtin_readcyclecounter() - tr_end;
     tr[6] = __builtin_amdgcn_s_memrealtime();
@@ -1657,6 +1733,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) {
     }
 #endif
 }
+
+__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp(ConvArgs p) { conv3x3_bf16_pp_body<false>(p); }
+// the same convolution with the network's 1x1 head applied to its output tile in the epilogue (inference): the FPN output is never stored
+__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16_pp_head(ConvArgs p) { conv3x3_bf16_pp_body<true>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // bf16 1x1 / stride 1 convolution onto 128 output channels (the FPN laterals: 64 -> 128 on the 128 x 128 map moves 470 MB for 17 GFLOP)
@@ -4068,10 +4148,21 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
                                            PP_LDS_FLOATS * (int)sizeof(float)));
                 raised = true;
             }
-            hipLaunchKernelGGL(k_conv3x3_bf16_pp, dim3((pa.M / PP_BM) * (pa.Nn / 128)), dim3(512), PP_LDS_FLOATS * sizeof(float), st, pa);
+            if (pa.head_y) {
+                static thread_local bool raised_h = false;
+                if (!raised_h) {
+                    SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_bf16_pp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               PP_LDS_FLOATS * (int)sizeof(float)));
+                    raised_h = true;
+                }
+                hipLaunchKernelGGL(k_conv3x3_bf16_pp_head, dim3((pa.M / PP_BM) * (pa.Nn / 128)), dim3(512), PP_LDS_FLOATS * sizeof(float), st, pa);
+            } else {
+                hipLaunchKernelGGL(k_conv3x3_bf16_pp, dim3((pa.M / PP_BM) * (pa.Nn / 128)), dim3(512), PP_LDS_FLOATS * sizeof(float), st, pa);
+            }
             SD_LAUNCH_CHECK();
             return 0;
         }
+        SD_REQUIRE(!a.head_y, SD_ERR_INVALID, "sd_conv2d_fwd_bf16_head: this geometry does not take the two-group kernel (ask sd_conv2d_fwd_bf16_head_supported)");
     }
     if (!stem && !bf16) {
         RowsArgsF rf;
@@ -4294,6 +4385,60 @@ int sd_conv2d_fwd_bf16(const void* x, const void* w, void* y, const sd_conv_desc
         if (workspace && workspace_bytes >= sd_conv2d_fwd_bf16_workspace_bytes(d)) a.part = (float*)workspace;
         else a.splits = 1;
     }
+    return launch_igemm(a, false, (hipStream_t)stream, true);
+}
+
+// ---- inference: the last FPN conv with the 1x1 head in its epilogue (network.py:17-18 + 22-29) ---------------------------------
+__global__ __launch_bounds__(256) void k_head_split_bf16(const float* __restrict__ w, const float* __restrict__ bias, int co, uint16_t* __restrict__ hilo,
+                                                         float* __restrict__ bias32) {
+    for (int i = threadIdx.x; i < 32 * 128; i += 256) {
+        const int n = i >> 7;
+        const float wv = n < co ? w[i] : 0.f;
+        const uint16_t hi = f2bf(wv);
+        hilo[i] = hi;
+        hilo[32 * 128 + i] = f2bf(wv - bf2f(hi));
+    }
+    if (threadIdx.x < 32) bias32[threadIdx.x] = (int)threadIdx.x < co ? bias[threadIdx.x] : 0.f;
+}
+
+int sd_conv2d_fwd_bf16_head_supported(const sd_conv_desc* d, int head_co) {
+    if (!d || d->Cout != 128 || d->Cin % 64 || head_co < 1 || head_co > 32 || d->Wo % 4) return 0;
+    ConvArgs a{};
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / 64; a.nk = d->R * d->S * a.kchunks;
+    a.splits = fwd_splits(d, 64);
+    return (a.splits <= 1 && conv_pp_geometry(a, 0)) ? 1 : 0;
+}
+
+size_t sd_head_split_bf16_bytes(void) { return (size_t)2 * 32 * 128 * sizeof(uint16_t) + 32 * sizeof(float); }
+
+int sd_head_split_bf16(const float* head_w, const float* head_bias, int head_co, void* prepared, sd_stream_t stream) {
+    SD_REQUIRE(head_w && head_bias && prepared && head_co >= 1 && head_co <= 32, SD_ERR_INVALID, "sd_head_split_bf16: null pointer or head_co outside 1 .. 32");
+    SD_REQUIRE(aligned16(prepared), SD_ERR_ALIGN, "sd_head_split_bf16: the prepared buffer must be 16-byte aligned");
+    uint16_t* hilo = (uint16_t*)prepared;
+    hipLaunchKernelGGL(k_head_split_bf16, dim3(1), dim3(256), 0, (hipStream_t)stream, head_w, head_bias, head_co, hilo, (float*)(hilo + 2 * 32 * 128));
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+int sd_conv2d_fwd_bf16_head(const void* x, const void* w, const sd_conv_desc* d, const float* scale, const float* shift, int relu,
+                            const void* head_prepared, int head_co, float* head_y, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_fwd_bf16_head", d)) return e;
+    SD_REQUIRE(x && w && head_prepared && head_y, SD_ERR_INVALID, "sd_conv2d_fwd_bf16_head: null pointer");
+    SD_REQUIRE(sd_conv2d_fwd_bf16_head_supported(d, head_co), SD_ERR_INVALID,
+               "sd_conv2d_fwd_bf16_head: needs a 3x3 / stride 1 conv onto 128 channels that takes k_conv3x3_bf16_pp and 1 <= head_co <= 32");
+    SD_REQUIRE(aligned16(x) && aligned16(w) && aligned16(scale) && aligned16(shift) && aligned16(head_prepared) && aligned16(head_y), SD_ERR_ALIGN,
+               "sd_conv2d_fwd_bf16_head: pointers must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.y = nullptr; a.scale = scale; a.shift = shift;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ck = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Nn = d->Cout; a.R = d->R; a.S = d->S;
+    a.mul = d->stride; a.div = 1; a.off = -d->pad; a.rsign = 1;
+    a.relu = relu;
+    a.M = d->B * d->Ho * d->Wo; a.kchunks = d->Cin / 64; a.nk = d->R * d->S * a.kchunks;
+    a.splits = 1;
+    a.head_w = (const uint16_t*)head_prepared; a.head_b = (const float*)((const uint16_t*)head_prepared + 2 * 32 * 128);
+    a.head_y = head_y; a.head_co = head_co;
     return launch_igemm(a, false, (hipStream_t)stream, true);
 }
 

@@ -157,6 +157,7 @@ class _Engine:
         # removes run at HBM speed anyway.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
         self.fuse_bn_bwd = False
         self._wt_plan, self._wt_flat, self._wt_valid = None, {}, None      # transposed data-gradient weights (see _transpose_all)
+        self.fuse_head = True              # bf16 inference: the 1x1 head in the epilogue of the last FPN conv where it takes the two-group kernel (False: A/B, tests)
         self.small_batch_kernel = True     # eval forward: sd_conv2d_fwd_sb where the 128-row tile grid cannot fill the chip (False: A/B)
 
     def _kname(self, d, which):
@@ -420,6 +421,16 @@ class _Engine:
             self.net._folded[key] = w
         return w
 
+    def _head_prepared(self, hc):
+        """hi / lo bf16 halves of the fp32 head weights + the padded bias for sd_conv2d_fwd_bf16_head (cached with the folded BN affines)."""
+        key = ("head", id(hc))
+        buf = self.net._folded.get(key)
+        if buf is None:
+            buf = torch.empty(self.lib.sd_head_split_bf16_bytes(), dtype=torch.uint8, device=hc.weight.device)
+            L.check(self.lib.sd_head_split_bf16(hc.weight.data_ptr(), hc.bias.data_ptr(), hc.cout, buf.data_ptr(), L.stream()), "sd_head_split_bf16")
+            self.net._folded[key] = buf
+        return buf
+
     def conv_bf16(self, x, conv, B, Hi, Wi, scale=None, shift=None, res=None, res_up2=False, relu=False):
         d = _desc(B, Hi, Wi, conv)
         y = torch.empty((B, d.Ho, d.Wo, conv.cout), dtype=torch.bfloat16, device=x.device)
@@ -473,12 +484,19 @@ class _Engine:
             feats.append((cur, Hc, Wc))
         (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
         f, _ = self.conv_bf16(p5, net.up1, B, H5, W5, shift=net.up1.bias)
+        hc = net.head.conv
+        out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
             t, _ = self.conv_bf16(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
             sf, hf = self.bn_fold(fpn.conv[1])
+            if fpn is net.up4 and self.fuse_head:
+                # network.py:17-18 + 22-29 in one launch where the conv takes the two-group kernel: the FPN output is never stored
+                dl = _desc(B, Hs, Ws, fpn.conv[0])
+                if hc.cin == 128 and lib.sd_conv2d_fwd_bf16_head_supported(C.byref(dl), hc.cout):
+                    L.check(lib.sd_conv2d_fwd_bf16_head(t.data_ptr(), self._w_bf16(fpn.conv[0]).data_ptr(), C.byref(dl), sf.data_ptr(), hf.data_ptr(), 1,
+                                                        self._head_prepared(hc).data_ptr(), hc.cout, out.data_ptr(), L.stream()), "sd_conv2d_fwd_bf16_head")
+                    return out
             f, _ = self.conv_bf16(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True)
-        hc = net.head.conv
-        out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
         L.check(lib.sd_head_fwd_bf16(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
                                      L.stream()), "sd_head_fwd_bf16")
         return out

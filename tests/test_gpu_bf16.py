@@ -125,6 +125,43 @@ def test_network_bf16_inference_vs_oracle(B, H, W):
         close(net(x.to(DEV)).cpu(), want32, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,B,H,W", [(2, 1, 2, 128, 256), (8, 8, 1, 256, 256), (2, 1, 3, 512, 128)])
+def test_head_fused_into_the_last_fpn_conv(M, N, B, H, W):
+    """sd_conv2d_fwd_bf16_head (network.py:17-18 + 22-29 in one launch: the 1x1 head applied to every tile of `up4.conv` in the two-group
+    kernel's epilogue, the FPN output never stored) against the same network with the head as its own launch: 7 and 20 head channels, maps
+    of 32 .. 128 pixels (whole rows and column strips); then against the oracle like every other bf16 forward."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    ref, net = _pair(M, N, seed=4)
+    x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(2))
+    ref.eval(); net.eval()
+    L.check(lib.sd_set_option(b"conv_pp_min_tiles", 1))
+    L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    try:
+        d = make_desc(L, B, H // 4, W // 4, 128, 128, 3, 1, 1)
+        assert lib.sd_conv2d_fwd_bf16_head_supported(C.byref(d), M + N + 4) == 1
+        net._engine.small_batch_kernel = False        # (small batches: the plain path would take sd_conv2d_fwd_sb, another summation order)
+        with torch.no_grad():
+            net._engine.fuse_head = True
+            fused = net(x.to(DEV)).cpu()
+            net._engine.fuse_head = False
+            plain = net(x.to(DEV)).cpu()
+            want32 = ref(x)
+            with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+                want16 = ref(x).float()
+    finally:
+        net._engine.fuse_head = True
+        net._engine.small_batch_kernel = True
+        L.check(lib.sd_set_option(b"conv_pp_min_tiles", 200))
+        L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+    assert fused.shape == plain.shape == want32.shape
+    # same bf16 FPN output, same hi + lo split of the head weights; the two kernels sum the 128 products in different orders
+    scale = plain.abs().max().item()
+    assert (fused - plain).abs().max().item() <= 2e-5 * scale, ((fused - plain).abs().max().item(), scale)
+    s32 = want32.abs().max().item()
+    assert (fused - want32).abs().max().item() / s32 <= max(1.5 * (want16 - want32).abs().max().item() / s32, 2e-2)
+
+
 def test_stress_config_bf16_backbone_fp32_decode():
     """BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, >= 64 objects per image, bf16 backbone + fp32 decode.
     Decoder parity at this size is asserted against the oracle on the SAME head tensor (bit-exact indices / grouping)."""
