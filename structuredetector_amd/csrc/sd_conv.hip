@@ -2682,6 +2682,7 @@ struct WgradArgs16 {
     float* part;          // [splits][Nn][9][Ck] fp32
     int B, Hi, Wi, Ck, Ho, Wo, Nn;
     int M, splits, m_per_split;
+    int strips, chunks_total, chunks_per_split;   // k_wgrad3x3_bf16_ring: 32-pixel column strips per map row; chunk id = (image * strips + strip) * Ho + row
 };
 
 // Round 4: THREE LDS stages and explicit waits.  The first form (two stages, a __syncthreads() per 32-pixel chunk) spent two thirds of
@@ -2828,6 +2829,129 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
         for (int e = 0; e < 16; ++e) {
             const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
             if (SD_W16_ABL != 4 || acc[t][e] == 123.456f) out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wgrad3x3_bf16_ring (round 4; maps whose width is a multiple of 32): the same tile, the same MFMAs and transposed reads as
+// k_wgrad3x3_bf16<32>, but the chunks of a block walk DOWN a 32-pixel column strip (chunk = row oy of the strip) and the 3 x 34-pixel
+// input patch is a RING of five patch rows: chunk oy needs rows oy - 1 .. oy + 1, of which two are already in LDS -- ONE new row
+// (5 pieces) + the dY chunk (4 pieces) per chunk instead of 16 + 4.  The ablations of the first form showed the LDS-DMA ISSUE in the compute
+// waves as its largest single cost (no DMA in the loop: 125 -> 85 us per layer).  Pipeline as before: chunk k + 2 (its dY and its new row)
+// is issued while chunk k is multiplied, one counted vmcnt + bare s_barrier per chunk; wave 0 issues three pieces per chunk, the others
+// two (a wave-uniform branch picks the count).  A split = a contiguous range of chunk ids (image, strip, row); every (image, strip) segment
+// inside it starts with its own prologue (rows oy0 - 1, oy0 and two stages).
+// LDS: three dY stages of 4 KB + five ring rows of 40 pixels x 128 B = 37.9 KB.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
+    constexpr int DSTG = 4096, RROW = 5120, NR = 5, RING0 = 3 * DSTG;          // bytes
+    __shared__ __attribute__((aligned(16))) uint16_t W3[(3 * DSTG + NR * RROW) / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;
+    const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const uint16_t* const zero16 = reinterpret_cast<const uint16_t*>(g_zero_line);
+    const int srow = lane >> 3;
+    const int schunk = ((lane & 7) ^ ((srow & 3) << 1)) * 8;          // element offset inside the 64-channel row (source-side swizzle)
+    char* const lds_b = reinterpret_cast<char*>(W3);
+
+    // patch row iy of (image b, strip at ox0) -> ring slot: pieces of 8 pixels, piece w by wave w, piece 4 (pixels 32, 33) by wave 0
+#define WR_ROW_PIECE(pc, iy, slot)                                                                                \
+    {                                                                                                             \
+        const int px = (pc) * 8 + srow, ix = ox0 - 1 + px;                                                        \
+        const bool ok = px < 34 && (unsigned)(iy) < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;              \
+        const uint16_t* src = ok ? p.x + (((int64_t)b * p.Hi + (iy)) * p.Wi + ix) * p.Ck + tc0 + schunk : zero16; \
+        lds_dma16(src, reinterpret_cast<float*>(lds_b + RING0 + (slot) * RROW + (pc) * 1024));                    \
+    }
+#define WR_ROW(iy, slot) { WR_ROW_PIECE(wave, iy, slot) if (wave == 0) WR_ROW_PIECE(4, iy, slot) }
+    // stage j of the segment: dY of row oy0 + j (stage j % 3) and patch row oy0 + j + 1 (ring slot (j + 2) % 5); past the segment: the
+    // zero line (the counts stay fixed)
+#define WR_STAGE(j, dst, slot)                                                                                    \
+    {                                                                                                             \
+        const bool live = (j) < nseg;                                                                             \
+        const int oy = oy0 + (j);                                                                                 \
+        const uint16_t* src = live ? p.dy + ((int64_t)(b * p.Ho + oy) * p.Wo + ox0 + wave * 8 + srow) * p.Nn + tn0 + schunk : zero16; \
+        lds_dma16(src, reinterpret_cast<float*>(lds_b + (dst) * DSTG + wave * 1024));                             \
+        const int iy = live ? oy + 1 : -1;                                                                        \
+        WR_ROW(iy, slot)                                                                                          \
+    }
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int a_slot = (wn0 >> 4) + (g & 1), b_slot = (wc0 >> 4) + (g & 1);
+    const int khalf = (g >> 1) * 8 + q4;
+    const uint32_t w3 = lds_addr(W3);
+    const uint32_t ao0 = w3 + (uint32_t)(khalf * 128 + ((a_slot ^ (khalf & 3)) << 5) + pp * 8);
+    uint32_t xo0[3];                                                  // tap column s2: pixel s2 + khalf (+ 16 kb, + 4) of a ring row
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xo0[k] = w3 + RING0 + (uint32_t)((k + khalf) * 128 + ((b_slot ^ ((k + khalf) & 3)) << 5) + pp * 8);
+#define WR_MFMA(A, BP, T) acc[T] = SD_MFMA_BF16(4, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, BP), acc[T]);
+#define WR_TAP(KB, T, BP) { BP.lo = lds_tr16_async<(KB) * 16 * 128>(xa[T]); BP.hi = lds_tr16_async<(KB) * 16 * 128 + 4 * 128>(xa[T]); }
+
+    const int c_beg = split * p.chunks_per_split, c_end = min(c_beg + p.chunks_per_split, p.chunks_total);
+    for (int c = c_beg; c < c_end;) {
+        const int unit = c / p.Ho, oy0 = c - unit * p.Ho, nseg = min(c_end - c, p.Ho - oy0);
+        const int b = unit / p.strips, ox0 = (unit - b * p.strips) * 32;
+        c += nseg;
+        // the previous segment's past-the-end pieces have landed and every wave is done with its rows
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        WR_ROW(oy0 - 1, 0)
+        WR_ROW(oy0, 1)
+        WR_STAGE(0, 0, 2)
+        WR_STAGE(1, 1, 3)
+        int st = 0, s0 = 0;                                           // dY stage of chunk k; ring slot of its top row (k % 5)
+        for (int k = 0; k < nseg; ++k) {
+            if (wave == 0) wait_vmcnt<3>(); else wait_vmcnt<2>();      // chunk k's pieces of this wave (stage k + 1 may be in flight)
+            __builtin_amdgcn_s_barrier();
+            {
+                const int st2 = st == 0 ? 2 : st - 1;                 // (k + 2) % 3
+                const int sl2 = s0 >= 1 ? s0 - 1 : 4;                 // (k + 4) % 5
+                WR_STAGE(k + 2, st2, sl2)
+            }
+            const uint32_t ao = ao0 + (uint32_t)st * DSTG;
+            const int s1 = s0 + 1 >= NR ? s0 + 1 - NR : s0 + 1, s2 = s1 + 1 >= NR ? s1 + 1 - NR : s1 + 1;
+            const uint32_t r0 = (uint32_t)s0 * RROW, r1 = (uint32_t)s1 * RROW, r2 = (uint32_t)s2 * RROW;
+            const uint32_t xa[9] = {xo0[0] + r0, xo0[1] + r0, xo0[2] + r0, xo0[0] + r1, xo0[1] + r1, xo0[2] + r1, xo0[0] + r2, xo0[1] + r2, xo0[2] + r2};
+            TrPair a0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8;
+            a0.lo = lds_tr16_async<0>(ao); a0.hi = lds_tr16_async<4 * 128>(ao);
+            WR_TAP(0, 0, b0) WR_TAP(0, 1, b1) WR_TAP(0, 2, b2) WR_TAP(0, 3, b3) WR_TAP(0, 4, b4) WR_TAP(0, 5, b5) WR_TAP(0, 6, b6) WR_TAP(0, 7, b7) WR_TAP(0, 8, b8)
+            SD_W16_WAIT10(0, a0, b0, b1, b2, b3, b4, b5, b6, b7, b8);
+            a1.lo = lds_tr16_async<16 * 128>(ao); a1.hi = lds_tr16_async<20 * 128>(ao);
+            WR_MFMA(a0, b0, 0) WR_TAP(1, 0, b0)
+            WR_MFMA(a0, b1, 1) WR_TAP(1, 1, b1)
+            WR_MFMA(a0, b2, 2) WR_TAP(1, 2, b2)
+            WR_MFMA(a0, b3, 3) WR_TAP(1, 3, b3)
+            WR_MFMA(a0, b4, 4) WR_TAP(1, 4, b4)
+            WR_MFMA(a0, b5, 5) WR_TAP(1, 5, b5)
+            WR_MFMA(a0, b6, 6) WR_TAP(1, 6, b6)
+            WR_MFMA(a0, b7, 7) WR_TAP(1, 7, b7)
+            WR_MFMA(a0, b8, 8) WR_TAP(1, 8, b8)
+            SD_W16_WAIT10(0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8);
+            WR_MFMA(a1, b0, 0) WR_MFMA(a1, b1, 1) WR_MFMA(a1, b2, 2) WR_MFMA(a1, b3, 3) WR_MFMA(a1, b4, 4)
+            WR_MFMA(a1, b5, 5) WR_MFMA(a1, b6, 6) WR_MFMA(a1, b7, 7) WR_MFMA(a1, b8, 8)
+            st = st == 2 ? 0 : st + 1;
+            s0 = s1;
+        }
+    }
+    wait_vmcnt<0>();
+#undef WR_TAP
+#undef WR_MFMA
+#undef WR_STAGE
+#undef WR_ROW
+#undef WR_ROW_PIECE
+    float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
         }
 }
 
@@ -4667,6 +4791,7 @@ static bool wgrad_all_taps(const sd_conv_desc* d) {
            (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
+static thread_local int g_wgrad_bf16_ring = 1;       // sd_set_option("wgrad_bf16_ring", 0): k_wgrad3x3_bf16<32> instead of the row-ring kernel (A/B, tests)
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
         const int chunks = d->B * d->Ho * d->Wo / 32;
@@ -4799,7 +4924,10 @@ int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv
     a.splits = wgrad_splits(d, tiles);
     a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
     const int64_t n4 = (int64_t)d->Cout * 9 * d->Cin / 4;
-    if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3_bf16<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+    if (d->Wo % 32 == 0 && g_wgrad_bf16_ring) {
+        a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho; a.chunks_per_split = cdiv(a.chunks_total, a.splits);
+        hipLaunchKernelGGL(k_wgrad3x3_bf16_ring, dim3(a.splits, tiles), dim3(256), 0, st, a);
+    } else if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3_bf16<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_wgrad3x3_bf16<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
@@ -4943,6 +5071,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
+    if (name && !strcmp(name, "wgrad_bf16_ring")) { g_wgrad_bf16_ring = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
     if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }

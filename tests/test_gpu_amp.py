@@ -76,7 +76,9 @@ def test_conv_bf16_forward_statistics_and_data_gradient(case):
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1, 1), (1, 16, 16, 128, 64, 3, 1, 1), (64, 128, 128, 64, 64, 3, 1, 1), (8, 64, 64, 128, 128, 3, 1, 1),
                                   (4, 16, 16, 512, 512, 3, 1, 1), (3, 32, 64, 64, 128, 3, 1, 1), (2, 20, 12, 64, 128, 3, 2, 1), (4, 12, 12, 64, 128, 1, 2, 0),
-                                  (2, 8, 8, 128, 128, 1, 1, 0), (2, 16, 16, 256, 512, 3, 2, 1), (3, 16, 16, 512, 128, 1, 1, 0), (1, 17, 9, 128, 256, 1, 2, 0)])
+                                  (2, 8, 8, 128, 128, 1, 1, 0), (2, 16, 16, 256, 512, 3, 2, 1), (3, 16, 16, 512, 128, 1, 1, 0), (1, 17, 9, 128, 256, 1, 2, 0),
+                                  # the row-ring kernel: several (image, strip) segments per split, segments cut inside a strip, one-row maps
+                                  (20, 4, 32, 64, 64, 3, 1, 1), (5, 12, 32, 64, 128, 3, 1, 1), (3, 7, 96, 128, 64, 3, 1, 1), (9, 1, 64, 64, 64, 3, 1, 1)])
 def test_conv_bf16_weight_gradient(case):
     """sd_conv2d_wgrad_bf16: dW (fp32) from bf16 dy / x.  3x3 stride-1 layers take k_wgrad3x3_bf16 (bf16 MFMA fed by
     ds_read_b64_tr_b16 transposed reads; 32-wide rows and the two-rows-of-16 form; one and several pixel splits; image borders),
@@ -103,6 +105,14 @@ def test_conv_bf16_weight_gradient(case):
     acc = base.clone()
     L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), acc.data_ptr(), C.byref(d), 1, ws.data_ptr(), ws.numel(), L.stream()))
     close((acc - base).permute(0, 3, 1, 2).cpu(), ref, 2e-4)            # accumulate = 1 adds into dW
+    if k == 3 and stride == 1 and d.Wo % 32 == 0:                       # the first form (one 3 x 34 patch per chunk) on the same operands
+        L.check(lib.sd_set_option(b"wgrad_bf16_ring", 0))
+        try:
+            dw1 = torch.full_like(dw, float("nan"))
+            L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+        finally:
+            L.check(lib.sd_set_option(b"wgrad_bf16_ring", 1))
+        close(dw1.permute(0, 3, 1, 2).cpu(), ref, 2e-4)
 
 
 def test_bn_kernels_on_bf16_activations_equal_the_fp32_kernels_rounded():
