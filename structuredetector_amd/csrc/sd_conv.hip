@@ -2843,9 +2843,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16(WgradArgs16 p) {
 // inside it starts with its own prologue (rows oy0 - 1, oy0 and two stages).
 // LDS: three dY stages of 4 KB + five ring rows of 40 pixels x 128 B = 37.9 KB.
 // ---------------------------------------------------------------------------------------------
+template <int D>          // prefetch distance in chunks: D + 1 dY stages, D + 3 ring rows
 __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
-    constexpr int DSTG = 4096, RROW = 5120, NR = 5, RING0 = 3 * DSTG;          // bytes
-    __shared__ __attribute__((aligned(16))) uint16_t W3[(3 * DSTG + NR * RROW) / 2];
+    constexpr int DSTG = 4096, RROW = 5120, ND = D + 1, NR = D + 3, RING0 = ND * DSTG;          // bytes
+    __shared__ __attribute__((aligned(16))) uint16_t W3[(ND * DSTG + NR * RROW) / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x;
     const int c_tiles = p.Ck >> 6;
@@ -2890,7 +2891,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
     uint32_t xo0[3];                                                  // tap column s2: pixel s2 + khalf (+ 16 kb, + 4) of a ring row
 #pragma unroll
     for (int k = 0; k < 3; ++k) xo0[k] = w3 + RING0 + (uint32_t)((k + khalf) * 128 + ((b_slot ^ ((k + khalf) & 3)) << 5) + pp * 8);
-#define WR_MFMA(A, BP, T) acc[T] = SD_MFMA_BF16(4, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, BP), acc[T]);
+#define WR_MFMA(A, BP, T) if (SD_W16_ABL == 3) { asm volatile("" :: "v"(A.lo), "v"(A.hi), "v"(BP.lo), "v"(BP.hi)); } else { acc[T] = SD_MFMA_BF16(4, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, BP), acc[T]); }
 #define WR_TAP(KB, T, BP) { BP.lo = lds_tr16_async<(KB) * 16 * 128>(xa[T]); BP.hi = lds_tr16_async<(KB) * 16 * 128 + 4 * 128>(xa[T]); }
 
     const int c_beg = split * p.chunks_per_split, c_end = min(c_beg + p.chunks_per_split, p.chunks_total);
@@ -2903,16 +2904,16 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
         __builtin_amdgcn_s_barrier();
         WR_ROW(oy0 - 1, 0)
         WR_ROW(oy0, 1)
-        WR_STAGE(0, 0, 2)
-        WR_STAGE(1, 1, 3)
-        int st = 0, s0 = 0;                                           // dY stage of chunk k; ring slot of its top row (k % 5)
+#pragma unroll
+        for (int j = 0; j < D; ++j) WR_STAGE(j, j, j + 2)
+        int st = 0, s0 = 0;                                           // dY stage of chunk k (k % ND); ring slot of its top row (k % NR)
         for (int k = 0; k < nseg; ++k) {
-            if (wave == 0) wait_vmcnt<3>(); else wait_vmcnt<2>();      // chunk k's pieces of this wave (stage k + 1 may be in flight)
-            __builtin_amdgcn_s_barrier();
-            {
-                const int st2 = st == 0 ? 2 : st - 1;                 // (k + 2) % 3
-                const int sl2 = s0 >= 1 ? s0 - 1 : 4;                 // (k + 4) % 5
-                WR_STAGE(k + 2, st2, sl2)
+            if (SD_W16_ABL != 1) { if (wave == 0) wait_vmcnt<3 * (D - 1)>(); else wait_vmcnt<2 * (D - 1)>(); }     // chunk k's pieces of this wave (stages k + 1 .. k + D - 1 may be in flight)
+            if (SD_W16_ABL != 5) __builtin_amdgcn_s_barrier();
+            if (SD_W16_ABL != 1) {
+                const int st2 = st == 0 ? ND - 1 : st - 1;            // (k + D) % ND
+                const int sl2 = s0 >= 1 ? s0 - 1 : NR - 1;            // (k + D + 2) % NR
+                WR_STAGE(k + D, st2, sl2)
             }
             const uint32_t ao = ao0 + (uint32_t)st * DSTG;
             const int s1 = s0 + 1 >= NR ? s0 + 1 - NR : s0 + 1, s2 = s1 + 1 >= NR ? s1 + 1 - NR : s1 + 1;
@@ -2935,7 +2936,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
             SD_W16_WAIT10(0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8);
             WR_MFMA(a1, b0, 0) WR_MFMA(a1, b1, 1) WR_MFMA(a1, b2, 2) WR_MFMA(a1, b3, 3) WR_MFMA(a1, b4, 4)
             WR_MFMA(a1, b5, 5) WR_MFMA(a1, b6, 6) WR_MFMA(a1, b7, 7) WR_MFMA(a1, b8, 8)
-            st = st == 2 ? 0 : st + 1;
+            st = st == ND - 1 ? 0 : st + 1;
             s0 = s1;
         }
     }
@@ -2951,7 +2952,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
-            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+            if (SD_W16_ABL != 4 || acc[t][e] == 123.456f) out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
         }
 }
 
@@ -4791,7 +4792,7 @@ static bool wgrad_all_taps(const sd_conv_desc* d) {
            (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
-static thread_local int g_wgrad_bf16_ring = 1;       // sd_set_option("wgrad_bf16_ring", 0): k_wgrad3x3_bf16<32> instead of the row-ring kernel (A/B, tests)
+static thread_local int g_wgrad_bf16_ring = 3;       // sd_set_option("wgrad_bf16_ring", n): prefetch distance of the row-ring kernel (2 .. 4 chunks); 0: k_wgrad3x3_bf16<32> (A/B, tests)
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
         const int chunks = d->B * d->Ho * d->Wo / 32;
@@ -4926,7 +4927,10 @@ int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv
     const int64_t n4 = (int64_t)d->Cout * 9 * d->Cin / 4;
     if (d->Wo % 32 == 0 && g_wgrad_bf16_ring) {
         a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho; a.chunks_per_split = cdiv(a.chunks_total, a.splits);
-        hipLaunchKernelGGL(k_wgrad3x3_bf16_ring, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        if (g_wgrad_bf16_ring == 2) hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<2>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        else if (g_wgrad_bf16_ring == 3) hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<3>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        else if (g_wgrad_bf16_ring >= 4) hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<4>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<3>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     } else if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3_bf16<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_wgrad3x3_bf16<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
     SD_LAUNCH_CHECK();

@@ -111,7 +111,7 @@ def test_conv_bf16_weight_gradient(case):
             dw1 = torch.full_like(dw, float("nan"))
             L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
         finally:
-            L.check(lib.sd_set_option(b"wgrad_bf16_ring", 1))
+            L.check(lib.sd_set_option(b"wgrad_bf16_ring", 3))
         close(dw1.permute(0, 3, 1, 2).cpu(), ref, 2e-4)
 
 

@@ -27,7 +27,7 @@ plan = enc.upload(enc.plan(512, 512, *synthetic_batch(np.random.default_rng(0), 
 res = {0: [], 1: []}
 for _ in range(4):
     for v in (0, 1):
-        L.check(L.lib().sd_set_option(b"wgrad_bf16_ring", v))
+        L.check(L.lib().sd_set_option(b"wgrad_bf16_ring", 3 if v else 0))
         for _ in range(3):
             step(x, enc.render_device(plan))
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -13,6 +13,9 @@ from structuredetector_amd import _lib as L  # noqa: E402
 from tests.test_gpu_network import make_desc  # noqa: E402
 
 lib = L.lib()
+import os
+if os.environ.get('SD_RING'):
+    L.check(lib.sd_set_option(b'wgrad_bf16_ring', int(os.environ['SD_RING'])))
 dev = "cuda"
 SHAPES = [("layer1 64->64 @128", 128, 64, 64), ("layer2 128->128 @64", 64, 128, 128), ("layer3 256->256 @32", 32, 256, 256), ("layer4 512->512 @16", 16, 512, 512),
           ("up4.conv 128->128 @128", 128, 128, 128)]
