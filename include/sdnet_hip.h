@@ -327,8 +327,9 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * "conv1x1_stream_min_pixels": smallest number of output pixels for which a bf16 1x1 / stride 1 conv onto 128 channels (Cin 64 or 128, no
  *   scale, no statistics: the FPN laterals and the 128 -> 128 1x1 data-gradient) takes the stream kernel k_conv1x1_stream_bf16 (default
  *   65536; 32 = always, for tests; 1 << 30 = never).
- * "wgrad_bf16_ring": prefetch distance (2 .. 4 chunks, default 3) of the row-ring bf16 weight-gradient kernel k_wgrad3x3_bf16_ring that the 3x3 / stride 1
- *   layers with maps a multiple of 32 pixels wide take; 0 = the first form k_wgrad3x3_bf16<32> (A/B, tests).
+ * "wgrad_bf16_ring": form of the bf16 weight gradient of the 3x3 / stride 1 layers with maps a multiple of 32 pixels wide: 5 (default) =
+ *   k_wgrad3x3_bf16_ring2 (row ring, two groups of four waves half a chunk apart in one 512-thread block), 2 .. 4 = k_wgrad3x3_bf16_ring with
+ *   that prefetch distance, 0 = the first form k_wgrad3x3_bf16<32> (A/B, tests).
  * "stem_fwd_blocks": persistent blocks of the fp32 training stem forward (default 512 = two per CU; 256 = one per CU, the setting the
  *   in-kernel phase trace of tools/stem_trace_f32.py compares against). */
 int sd_set_option(const char* name, int value);

@@ -2910,11 +2910,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
         for (int k = 0; k < nseg; ++k) {
             if (SD_W16_ABL != 1) { if (wave == 0) wait_vmcnt<3 * (D - 1)>(); else wait_vmcnt<2 * (D - 1)>(); }     // chunk k's pieces of this wave (stages k + 1 .. k + D - 1 may be in flight)
             if (SD_W16_ABL != 5) __builtin_amdgcn_s_barrier();
-            if (SD_W16_ABL != 1) {
-                const int st2 = st == 0 ? ND - 1 : st - 1;            // (k + D) % ND
-                const int sl2 = s0 >= 1 ? s0 - 1 : NR - 1;            // (k + D + 2) % NR
-                WR_STAGE(k + D, st2, sl2)
-            }
             const uint32_t ao = ao0 + (uint32_t)st * DSTG;
             const int s1 = s0 + 1 >= NR ? s0 + 1 - NR : s0 + 1, s2 = s1 + 1 >= NR ? s1 + 1 - NR : s1 + 1;
             const uint32_t r0 = (uint32_t)s0 * RROW, r1 = (uint32_t)s1 * RROW, r2 = (uint32_t)s2 * RROW;
@@ -2922,6 +2917,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
             TrPair a0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8;
             a0.lo = lds_tr16_async<0>(ao); a0.hi = lds_tr16_async<4 * 128>(ao);
             WR_TAP(0, 0, b0) WR_TAP(0, 1, b1) WR_TAP(0, 2, b2) WR_TAP(0, 3, b3) WR_TAP(0, 4, b4) WR_TAP(0, 5, b5) WR_TAP(0, 6, b6) WR_TAP(0, 7, b7) WR_TAP(0, 8, b8)
+            if (SD_W16_ABL != 1) {            // (after the reads: a wave waits at an LDS-DMA instruction until the CU's queue takes it)
+                const int st2 = st == 0 ? ND - 1 : st - 1;            // (k + D) % ND
+                const int sl2 = s0 >= 1 ? s0 - 1 : NR - 1;            // (k + D + 2) % NR
+                WR_STAGE(k + D, st2, sl2)
+            }
             SD_W16_WAIT10(0, a0, b0, b1, b2, b3, b4, b5, b6, b7, b8);
             a1.lo = lds_tr16_async<16 * 128>(ao); a1.hi = lds_tr16_async<20 * 128>(ao);
             WR_MFMA(a0, b0, 0) WR_TAP(1, 0, b0)
@@ -2954,6 +2954,166 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_bf16_ring(WgradArgs16 p) {
             const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
             if (SD_W16_ABL != 4 || acc[t][e] == 123.456f) out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wgrad3x3_bf16_ring2 (round 4): the row-ring kernel as ONE 512-thread block per CU whose two groups of four waves work on the SAME
+// (n, c) tile, each on its own half of the block's chunks with its own dY stages and patch ring, HALF A CHUNK APART -- the choreography of
+// k_conv3x3_bf16_pp.  The ablations of k_wgrad3x3_bf16_ring showed that a wave's load phase (LDS-DMA issue, transposed reads) and its MFMA
+// phase do not overlap (time = no-MFMA time + MFMA time): two independent blocks per CU drift into the same phase.  Here every chunk is
+//   LOAD [the DMA of chunk k + 2, 20 transposed reads, lgkmcnt] - s_barrier - MFMA [18 MFMAs + the second k-block's 18 reads, vmcnt] - s_barrier
+// and the block-wide barrier forces one group's LOAD under the other's MFMAs on the same SIMDs.  At the end group 1's accumulators are added
+// to group 0's through LDS (three passes of three taps) and ONE partial tile is stored: half the partial-sum traffic of two blocks.
+// Every phase ends with exactly one barrier; a group executes (segment prologue + 2 phases per chunk) per segment, the group with fewer
+// phases pads with bare barriers -- the two barrier counts are equal for ANY split of the chunk range (no wave can be left waiting).
+// Prefetch distance 2: past-the-end stages are not issued (nothing is in flight when a segment ends), the vmcnt count of a wait is picked
+// by wave-uniform branches.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void k_wgrad3x3_bf16_ring2(WgradArgs16 p) {
+    constexpr int DSTG = 4096, RROW = 5120, ND = 3, NR = 5, RING0 = ND * DSTG, GRPB = ND * DSTG + NR * RROW;          // bytes: 37888 per group
+    __shared__ __attribute__((aligned(16))) uint16_t W3[2 * GRPB / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;
+    const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const uint16_t* const zero16 = reinterpret_cast<const uint16_t*>(g_zero_line);
+    const int srow = lane >> 3;
+    const int schunk = ((lane & 7) ^ ((srow & 3) << 1)) * 8;
+    char* const lds_b = reinterpret_cast<char*>(W3) + grp * GRPB;
+
+#define W2_ROW_PIECE(pc, iy, slot)                                                                                \
+    {                                                                                                             \
+        const int px = (pc) * 8 + srow, ix = ox0 - 1 + px;                                                        \
+        const bool ok = px < 34 && (unsigned)(iy) < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;              \
+        const uint16_t* src = ok ? p.x + (((int64_t)b * p.Hi + (iy)) * p.Wi + ix) * p.Ck + tc0 + schunk : zero16; \
+        lds_dma16(src, reinterpret_cast<float*>(lds_b + RING0 + (slot) * RROW + (pc) * 1024));                    \
+    }
+#define W2_ROW(iy, slot) { W2_ROW_PIECE(wave, iy, slot) if (wave == 0) W2_ROW_PIECE(4, iy, slot) }
+#define W2_STAGE(j, dst, slot)                                                                                    \
+    {                                                                                                             \
+        const int oy = oy0 + (j);                                                                                 \
+        const uint16_t* src = p.dy + ((int64_t)(b * p.Ho + oy) * p.Wo + ox0 + wave * 8 + srow) * p.Nn + tn0 + schunk; \
+        lds_dma16(src, reinterpret_cast<float*>(lds_b + (dst) * DSTG + wave * 1024));                             \
+        W2_ROW(oy + 1, slot)                                                                                      \
+    }
+    // this wave's pieces are in, except those of the `n` youngest stages (n = 0 or 1)
+#define W2_VMWAIT(n) { if ((n) == 0) wait_vmcnt<0>(); else if (wave == 0) wait_vmcnt<3>(); else wait_vmcnt<2>(); }
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int a_slot = (wn0 >> 4) + (g & 1), b_slot = (wc0 >> 4) + (g & 1);
+    const int khalf = (g >> 1) * 8 + q4;
+    const uint32_t w3 = lds_addr(W3) + (uint32_t)grp * GRPB;
+    const uint32_t ao0 = w3 + (uint32_t)(khalf * 128 + ((a_slot ^ (khalf & 3)) << 5) + pp * 8);
+    uint32_t xo0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xo0[k] = w3 + RING0 + (uint32_t)((k + khalf) * 128 + ((b_slot ^ ((k + khalf) & 3)) << 5) + pp * 8);
+#define W2_MFMA(A, BP, T) acc[T] = SD_MFMA_BF16(4, __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, BP), acc[T]);
+#define W2_TAP(KB, T, BP) { BP.lo = lds_tr16_async<(KB) * 16 * 128>(xa[T]); BP.hi = lds_tr16_async<(KB) * 16 * 128 + 4 * 128>(xa[T]); }
+
+    // the block's chunk range, cut in two; barrier phases of a range = sum over its (image, strip) segments of (1 + 2 * chunks)
+    const int c_beg = split * p.chunks_per_split, c_end = min(c_beg + p.chunks_per_split, p.chunks_total);
+    const int c_mid = c_beg + (c_end - c_beg + 1) / 2;
+    auto phases = [&](int cb, int ce) { int n = 0; for (int c = cb; c < ce;) { const int oy = c % p.Ho, ns = min(ce - c, p.Ho - oy); n += 1 + 2 * ns; c += ns; } return n; };
+    const int ph0 = phases(c_beg, c_mid), ph1 = phases(c_mid, c_end);
+    const int my_beg = grp ? c_mid : c_beg, my_end = grp ? c_end : c_mid;
+    if (grp == 1) __builtin_amdgcn_s_barrier();                       // group 1 runs one phase behind
+    for (int c = my_beg; c < my_end;) {
+        const int unit = c / p.Ho, oy0 = c - unit * p.Ho, nseg = min(my_end - c, p.Ho - oy0);
+        const int b = unit / p.strips, ox0 = (unit - b * p.strips) * 32;
+        c += nseg;
+        // ---- prologue phase (nothing of this group is in flight, every wave of the group is past its last reads)
+        W2_ROW(oy0 - 1, 0)
+        W2_ROW(oy0, 1)
+        W2_STAGE(0, 0, 2)
+        if (nseg > 1) W2_STAGE(1, 1, 3)
+        W2_VMWAIT(nseg > 1 ? 1 : 0)
+        __builtin_amdgcn_s_barrier();
+        int st = 0, s0 = 0;
+        for (int k = 0; k < nseg; ++k) {
+            // ---- LOAD phase (the reads first: a wave waits at an LDS-DMA instruction until the CU's queue takes it)
+            const uint32_t ao = ao0 + (uint32_t)st * DSTG;
+            const int s1 = s0 + 1 >= NR ? s0 + 1 - NR : s0 + 1, s2 = s1 + 1 >= NR ? s1 + 1 - NR : s1 + 1;
+            const uint32_t r0 = (uint32_t)s0 * RROW, r1 = (uint32_t)s1 * RROW, r2 = (uint32_t)s2 * RROW;
+            const uint32_t xa[9] = {xo0[0] + r0, xo0[1] + r0, xo0[2] + r0, xo0[0] + r1, xo0[1] + r1, xo0[2] + r1, xo0[0] + r2, xo0[1] + r2, xo0[2] + r2};
+            TrPair a0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8;
+            a0.lo = lds_tr16_async<0>(ao); a0.hi = lds_tr16_async<4 * 128>(ao);
+            W2_TAP(0, 0, b0) W2_TAP(0, 1, b1) W2_TAP(0, 2, b2) W2_TAP(0, 3, b3) W2_TAP(0, 4, b4) W2_TAP(0, 5, b5) W2_TAP(0, 6, b6) W2_TAP(0, 7, b7) W2_TAP(0, 8, b8)
+            if (k + 2 < nseg) {
+                const int st2 = st == 0 ? ND - 1 : st - 1, sl2 = s0 >= 1 ? s0 - 1 : NR - 1;
+                W2_STAGE(k + 2, st2, sl2)
+            }
+            SD_W16_WAIT10(0, a0, b0, b1, b2, b3, b4, b5, b6, b7, b8);
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA phase
+            __builtin_amdgcn_s_setprio(1);
+            a1.lo = lds_tr16_async<16 * 128>(ao); a1.hi = lds_tr16_async<20 * 128>(ao);
+            W2_MFMA(a0, b0, 0) W2_TAP(1, 0, b0)
+            W2_MFMA(a0, b1, 1) W2_TAP(1, 1, b1)
+            W2_MFMA(a0, b2, 2) W2_TAP(1, 2, b2)
+            W2_MFMA(a0, b3, 3) W2_TAP(1, 3, b3)
+            W2_MFMA(a0, b4, 4) W2_TAP(1, 4, b4)
+            W2_MFMA(a0, b5, 5) W2_TAP(1, 5, b5)
+            W2_MFMA(a0, b6, 6) W2_TAP(1, 6, b6)
+            W2_MFMA(a0, b7, 7) W2_TAP(1, 7, b7)
+            W2_MFMA(a0, b8, 8) W2_TAP(1, 8, b8)
+            SD_W16_WAIT10(0, a1, b0, b1, b2, b3, b4, b5, b6, b7, b8);
+            W2_MFMA(a1, b0, 0) W2_MFMA(a1, b1, 1) W2_MFMA(a1, b2, 2) W2_MFMA(a1, b3, 3) W2_MFMA(a1, b4, 4)
+            W2_MFMA(a1, b5, 5) W2_MFMA(a1, b6, 6) W2_MFMA(a1, b7, 7) W2_MFMA(a1, b8, 8)
+            __builtin_amdgcn_s_setprio(0);
+            if (k + 1 < nseg) W2_VMWAIT(k + 2 < nseg ? 1 : 0)           // chunk k + 1's pieces of this wave
+            __builtin_amdgcn_s_barrier();
+            st = st == ND - 1 ? 0 : st + 1;
+            s0 = s1;
+        }
+    }
+    {   // equal barrier counts: pad to the longer group, then group 0 takes the barrier group 1 started with
+        const int mine = grp ? ph1 : ph0, most = max(ph0, ph1);
+        for (int i = mine; i < most; ++i) __builtin_amdgcn_s_barrier();
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    }
+#undef W2_TAP
+#undef W2_MFMA
+#undef W2_VMWAIT
+#undef W2_STAGE
+#undef W2_ROW
+#undef W2_ROW_PIECE
+    // ---- group 1's sums into group 0: three taps per pass through LDS ([tap][element][thread]: conflict-free), fixed order
+    float* const red = reinterpret_cast<float*>(W3);
+    const int t4 = tid & 255;
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 256 + t4] = acc[ps * 3 + t][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ps * 3 + t][e] += red[(t * 16 + e) * 256 + t4];
+        }
+    }
+    if (grp == 0) {
+        float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+                out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4792,7 +4952,7 @@ static bool wgrad_all_taps(const sd_conv_desc* d) {
            (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
-static thread_local int g_wgrad_bf16_ring = 3;       // sd_set_option("wgrad_bf16_ring", n): prefetch distance of the row-ring kernel (2 .. 4 chunks); 0: k_wgrad3x3_bf16<32> (A/B, tests)
+static thread_local int g_wgrad_bf16_ring = 5;       // sd_set_option("wgrad_bf16_ring", n): 5 (default) = k_wgrad3x3_bf16_ring2 (two groups per 512-thread block); 2 .. 4 = k_wgrad3x3_bf16_ring with that prefetch distance; 0 = k_wgrad3x3_bf16<32> (A/B, tests)
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
         const int chunks = d->B * d->Ho * d->Wo / 32;
@@ -4925,7 +5085,14 @@ int sd_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sd_conv
     a.splits = wgrad_splits(d, tiles);
     a.m_per_split = cdiv(cdiv(a.M, a.splits), 32) * 32;
     const int64_t n4 = (int64_t)d->Cout * 9 * d->Cin / 4;
-    if (d->Wo % 32 == 0 && g_wgrad_bf16_ring) {
+    if (d->Wo % 32 == 0 && g_wgrad_bf16_ring >= 5) {
+        // one 512-thread block per CU, two groups half a chunk apart: half as many (twice as long) splits
+        a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho;
+        a.splits = std::max(1, std::min(cdiv(256, tiles), a.chunks_total / 16));
+        a.chunks_per_split = cdiv(a.chunks_total, a.splits);
+        a.splits = cdiv(a.chunks_total, a.chunks_per_split);
+        hipLaunchKernelGGL(k_wgrad3x3_bf16_ring2, dim3(a.splits, tiles), dim3(512), 0, st, a);
+    } else if (d->Wo % 32 == 0 && g_wgrad_bf16_ring) {
         a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho; a.chunks_per_split = cdiv(a.chunks_total, a.splits);
         if (g_wgrad_bf16_ring == 2) hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<2>, dim3(a.splits, tiles), dim3(256), 0, st, a);
         else if (g_wgrad_bf16_ring == 3) hipLaunchKernelGGL(k_wgrad3x3_bf16_ring<3>, dim3(a.splits, tiles), dim3(256), 0, st, a);

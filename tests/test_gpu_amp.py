@@ -105,14 +105,17 @@ def test_conv_bf16_weight_gradient(case):
     acc = base.clone()
     L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), acc.data_ptr(), C.byref(d), 1, ws.data_ptr(), ws.numel(), L.stream()))
     close((acc - base).permute(0, 3, 1, 2).cpu(), ref, 2e-4)            # accumulate = 1 adds into dW
-    if k == 3 and stride == 1 and d.Wo % 32 == 0:                       # the first form (one 3 x 34 patch per chunk) on the same operands
-        L.check(lib.sd_set_option(b"wgrad_bf16_ring", 0))
-        try:
-            dw1 = torch.full_like(dw, float("nan"))
-            L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
-        finally:
-            L.check(lib.sd_set_option(b"wgrad_bf16_ring", 3))
-        close(dw1.permute(0, 3, 1, 2).cpu(), ref, 2e-4)
+    if k == 3 and stride == 1 and d.Wo % 32 == 0:
+        # the other forms on the same operands (default 5 = two groups of four waves half a chunk apart in one 512-thread block, their sums
+        # combined through LDS): 0 = one 3 x 34 patch per chunk, 2 .. 4 = one group per block, prefetch distance 2 .. 4
+        for form in (0, 2, 3, 4):
+            L.check(lib.sd_set_option(b"wgrad_bf16_ring", form))
+            try:
+                dw1 = torch.full_like(dw, float("nan"))
+                L.check(lib.sd_conv2d_wgrad_bf16(dy16.data_ptr(), x16.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+            finally:
+                L.check(lib.sd_set_option(b"wgrad_bf16_ring", 5))
+            close(dw1.permute(0, 3, 1, 2).cpu(), ref, 2e-4)
 
 
 def test_bn_kernels_on_bf16_activations_equal_the_fp32_kernels_rounded():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Same-process A/B of sd_set_option("wgrad_bf16_ring"): the mixed-precision training step (bs = 64, 512x512) with the row-ring weight-gradient
-kernel and with the first form, interleaved."""
+"""Same-process A/B of two values of sd_set_option("wgrad_bf16_ring") on the mixed-precision training step (bs = 64, 512x512), interleaved.
+usage: ab_wgrad_ring.py [<value A> <value B>]   (default 0 3)"""
 import sys
 import time
 from pathlib import Path
@@ -24,10 +24,11 @@ step = TrainStep(net, args)
 enc = Encode(args)
 x = torch.randn(64, 3, 512, 512, device=dev)
 plan = enc.upload(enc.plan(512, 512, *synthetic_batch(np.random.default_rng(0), 64, 512, 512, 2, 1)))
-res = {0: [], 1: []}
+va, vb = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 3)      # wgrad_bf16_ring values: 0 first form, 2 .. 4 row ring, 5 two-group row ring
+res = {va: [], vb: []}
 for _ in range(4):
-    for v in (0, 1):
-        L.check(L.lib().sd_set_option(b"wgrad_bf16_ring", 3 if v else 0))
+    for v in (va, vb):
+        L.check(L.lib().sd_set_option(b"wgrad_bf16_ring", v))
         for _ in range(3):
             step(x, enc.render_device(plan))
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,5 +36,5 @@ for _ in range(4):
             step(x, enc.render_device(plan))
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / 20 * 1e3)
-print(f"mixed-precision step: first form {min(res[0]):.3f} ms, row ring {min(res[1]):.3f} ms ({min(res[1]) / min(res[0]) - 1:+.1%})   all: "
-      + " ".join(f"{a:.3f}/{b:.3f}" for a, b in zip(res[0], res[1])))
+print(f"mixed-precision step: wgrad_bf16_ring={va} {min(res[va]):.3f} ms, ={vb} {min(res[vb]):.3f} ms ({min(res[vb]) / min(res[va]) - 1:+.1%})   all: "
+      + " ".join(f"{a:.3f}/{b:.3f}" for a, b in zip(res[va], res[vb])))
