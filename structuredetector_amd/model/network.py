@@ -157,6 +157,7 @@ class _Engine:
         # removes run at HBM speed anyway.  Off by default; the path is kept and tested (tests/test_gpu_network.py).
         self.fuse_bn_bwd = False
         self._wt_plan, self._wt_flat, self._wt_valid = None, {}, None      # transposed data-gradient weights (see _transpose_all)
+        self._head_ok = {}
         self.fuse_head = True              # bf16 inference: the 1x1 head in the epilogue of the last FPN conv where it takes the two-group kernel (False: A/B, tests)
         self.small_batch_kernel = True     # eval forward: sd_conv2d_fwd_sb where the 128-row tile grid cannot fill the chip (False: A/B)
 
@@ -421,6 +422,15 @@ class _Engine:
             self.net._folded[key] = w
         return w
 
+    def _head_fusable(self, B, Hs, Ws, conv, hc):
+        """sd_conv2d_fwd_bf16_head_supported, remembered per shape (a batch-1 forward is host-bound: no descriptor + ctypes call per forward)."""
+        key = (B, Hs, Ws, hc.cout)
+        ok = self._head_ok.get(key)
+        if ok is None:
+            ok = hc.cin == 128 and bool(self.lib.sd_conv2d_fwd_bf16_head_supported(C.byref(_desc(B, Hs, Ws, conv)), hc.cout))
+            self._head_ok[key] = ok
+        return ok
+
     def _head_prepared(self, hc):
         """hi / lo bf16 halves of the fp32 head weights + the padded bias for sd_conv2d_fwd_bf16_head (cached with the folded BN affines)."""
         key = ("head", id(hc))
@@ -489,10 +499,10 @@ class _Engine:
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
             t, _ = self.conv_bf16(sc_t, fpn.lateral, B, Hs, Ws, shift=fpn.lateral.bias, res=f, res_up2=True)
             sf, hf = self.bn_fold(fpn.conv[1])
-            if fpn is net.up4 and self.fuse_head:
+            if fpn is net.up4 and self.fuse_head and self._head_fusable(B, Hs, Ws, fpn.conv[0], hc):
                 # network.py:17-18 + 22-29 in one launch where the conv takes the two-group kernel: the FPN output is never stored
                 dl = _desc(B, Hs, Ws, fpn.conv[0])
-                if hc.cin == 128 and lib.sd_conv2d_fwd_bf16_head_supported(C.byref(dl), hc.cout):
+                if True:
                     L.check(lib.sd_conv2d_fwd_bf16_head(t.data_ptr(), self._w_bf16(fpn.conv[0]).data_ptr(), C.byref(dl), sf.data_ptr(), hf.data_ptr(), 1,
                                                         self._head_prepared(hc).data_ptr(), hc.cout, out.data_ptr(), L.stream()), "sd_conv2d_fwd_bf16_head")
                     return out
