@@ -245,6 +245,29 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert name(16, 128, 64, 64) == "k_conv3x3_patch_roll<64, true>"      # 8 rows per unit < 16; 128-wide map: rolling-buffer entry point
     assert name(16, 256, 64, 64) == "k_conv3x3_c64_rows_bf16"             # stress config (1024 x 1024 inputs): two strips per row
     assert name(1, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # bs=1: split-K
+    # round 4: the FPN laterals (1x1 / stride 1 onto 128 channels from 64 / 128) stream from 65536 output pixels; the 128 -> 128 1x1
+    # data-gradient too; other widths and small maps keep the tile kernel; the option moves the threshold
+    assert name(64, 128, 64, 128, k=1, pad=0) == "k_conv1x1_stream_bf16<64, 2>"
+    assert name(64, 64, 128, 128, k=1, pad=0) == "k_conv1x1_stream_bf16<128, 1>"
+    assert name(64, 64, 128, 128, k=1, pad=0, which=17) == "k_conv1x1_stream_bf16<128, 1>"
+    assert name(64, 32, 256, 128, k=1, pad=0) == "k_conv_igemm<128, 0, true>"
+    assert name(1, 128, 64, 128, k=1, pad=0) == "k_conv_igemm<128, 0, true>"
+    assert lib.sd_set_option(b"conv1x1_stream_min_pixels", 1 << 30) == 0
+    assert name(64, 128, 64, 128, k=1, pad=0) == "k_conv_igemm<128, 0, true>"
+    assert lib.sd_set_option(b"conv1x1_stream_min_pixels", 32 * 2048) == 0
+    assert lib.sd_set_option(b"wgrad_bf16_ring", 5) == 0
+    # the head fused into the last FPN conv (inference): where that conv takes the two-group kernel, up to 32 head channels
+    def head_ok(B, H, co, cout=128):
+        e = L.ConvDesc()
+        e.B, e.Hi, e.Wi, e.Cin, e.Cout, e.R, e.S, e.stride, e.pad, e.Ho, e.Wo = B, H, H, 128, cout, 3, 3, 1, 1, H, H
+        return lib.sd_conv2d_fwd_bf16_head_supported(C.byref(e), co)
+    assert head_ok(64, 128, 7) == 1 and head_ok(16, 256, 20) == 1 and head_ok(64, 128, 32) == 1
+    assert head_ok(1, 128, 7) == 0 and head_ok(64, 128, 33) == 0 and head_ok(64, 128, 7, cout=256) == 0
+    assert lib.sd_head_split_bf16_bytes() == 2 * 32 * 128 * 2 + 32 * 4
+    assert lib.sd_head_split_bf16(16, 16, 40, 16, 0) == -1 and b"head_co" in lib.sd_last_error()
+    e = L.ConvDesc()
+    e.B, e.Hi, e.Wi, e.Cin, e.Cout, e.R, e.S, e.stride, e.pad, e.Ho, e.Wo = 1, 128, 128, 128, 128, 3, 3, 1, 1, 128, 128
+    assert lib.sd_conv2d_fwd_bf16_head(16, 16, C.byref(e), 0, 0, 1, 16, 7, 16, 0) == -1          # bs = 1: not supported -> refused before any launch
 
 
 def test_network_parameter_count_matches_published_resnet34():
