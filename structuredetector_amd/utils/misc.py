@@ -64,3 +64,28 @@ def get_unique_color_map(labels):
 def files_with_extension(folder, extension: str):
     """utils.py:327-328."""
     return [f for f in Path(folder).iterdir() if f.suffix == extension]
+
+
+class AverageMeter:
+    """Running mean of the values passed to `update` (reference: src/sdnet/utils/utils.py:311-324; same attributes `sum`, `count`, `avg`)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.sum, self.count, self.avg = 0.0, 0, 0.0
+
+    def update(self, value):
+        self.sum += value
+        self.count += 1
+        self.avg = self.sum / self.count
+        return self.avg
+
+
+def dict_grouping(iterable, key):
+    """{key(element): [elements in input order]} (reference: src/sdnet/utils/utils.py:470-474; used by its Evaluator to split by label / kind)."""
+    groups = {}
+    for element in iterable:
+        groups.setdefault(key(element), []).append(element)
+    return groups
+

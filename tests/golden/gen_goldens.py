@@ -441,7 +441,36 @@ def gen_fpn_head(rng):
     np.savez_compressed(HERE / "fpn_head.npz", **out)
 
 
+def gen_small_utils(rng):
+    """`draw_heatmaps` (visualization.py:53-91: colour of the arg-max channel times its value, truncated to uint8), `AverageMeter`
+    (utils.py:311-324) and `dict_grouping` (utils.py:470-474).  The other drawing helpers of visualization.py go through torchvision's
+    `to_pil_image`, which is absent here: they are pinned by their PIL primitives in tests/test_host_cpu.py instead."""
+    from sdnet.utils.visualization import draw_heatmaps
+    args = make_args(3, 2, 8, 8)
+    args._label_color_map = RU.get_unique_color_map(args.labels)
+    args._part_color_map = RU.get_unique_color_map(args.parts)
+    a = torch.from_numpy(rng.random((3, 12, 16)).astype(np.float32))
+    q = torch.from_numpy(rng.random((2, 12, 16)).astype(np.float32))
+    a[:, 0, 0] = torch.tensor([0.25, 0.25, 0.1])                      # a tie: the first maximal channel gives the colour
+    ca, cq = draw_heatmaps(a, q, args)
+    m = RU.AverageMeter()
+    vals = rng.random(7)
+    avgs = [m.update(float(v)) for v in vals]
+    words = ["pear", "fig", "plum", "kiwi", "lime", "date", "peach"]
+    grouped = RU.dict_grouping(words, key=len)
+    out = {"anchor_hm": a.numpy(), "part_hm": q.numpy(), "anchor_rgb": ca.numpy(), "part_rgb": cq.numpy(),
+           "label_colors": np.array([args._label_color_map[args._r_labels[i]] for i in range(3)], dtype=np.int64),
+           "part_colors": np.array([args._part_color_map[args._r_parts[i]] for i in range(2)], dtype=np.int64),
+           "meter_values": vals, "meter_avgs": np.array(avgs), "meter_sum": np.array(m.sum), "meter_count": np.array(m.count),
+           "words": np.array(words), "grouped": np.array(json.dumps({str(k): v for k, v in grouped.items()})), "meta": np.array(META)}
+    np.savez_compressed(HERE / "small_utils.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small_utils":          # one new fixture without touching the others
+        gen_small_utils(np.random.default_rng(5))
+        print("small_utils.npz written to", HERE)
+        raise SystemExit(0)
     rng = np.random.default_rng(20261003)
     gen_prims(rng)
     gen_encode_decode(rng, "scene_cfg512", 512, 2, 1, 20, 40, n_img=3, n_min=6, n_max=12, noise=0.05)
@@ -452,4 +481,5 @@ if __name__ == "__main__":
     gen_thresholds(np.random.default_rng(404))
     gen_annotation_transforms(np.random.default_rng(31))
     gen_evaluate16()
+    gen_small_utils(np.random.default_rng(5))
     print("goldens written to", HERE)

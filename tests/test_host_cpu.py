@@ -582,3 +582,61 @@ def test_pretrained_backbone_is_loaded_from_a_local_torchvision_checkpoint(tmp_p
     torch.save(bad, tmp_path / "bad.pth")
     with pytest.raises(L.SdError, match="not a torchvision ResNet-34"):
         PN.Network(ns(backbone_weights=str(tmp_path / "bad.pth")), pretrained=True)
+
+
+def test_small_utils_against_the_reference(golden_dir):
+    """`AverageMeter`, `dict_grouping` and `draw_heatmaps` (src/sdnet/utils/utils.py:311-324,470-474, visualization.py:53-91) against values
+    produced by the imported reference (tests/golden/gen_goldens.py::gen_small_utils): the last names of `sdnet.utils` this package lacked."""
+    import torch
+    from structuredetector_amd.utils import AverageMeter, dict_grouping, draw_heatmaps
+    g = np.load(golden_dir / "small_utils.npz")
+    m = AverageMeter()
+    avgs = [m.update(float(v)) for v in g["meter_values"]]
+    assert np.array_equal(np.array(avgs), g["meter_avgs"]) and m.sum == float(g["meter_sum"]) and m.count == int(g["meter_count"])
+    m.reset()
+    assert (m.sum, m.count, m.avg) == (0.0, 0, 0.0)
+    got = dict_grouping([str(w) for w in g["words"]], key=len)
+    want = json.loads(str(g["grouped"]))
+    assert {str(k): v for k, v in got.items()} == want and [str(k) for k in got] == list(want)          # groups in first-seen order too
+    labels = {f"label{i}": i for i in range(3)}; parts = {f"part{i}": i for i in range(2)}
+    args = Namespace(_r_labels={v: k for k, v in labels.items()}, _r_parts={v: k for k, v in parts.items()},
+                     _label_color_map={f"label{i}": tuple(int(c) for c in g["label_colors"][i]) for i in range(3)},
+                     _part_color_map={f"part{i}": tuple(int(c) for c in g["part_colors"][i]) for i in range(2)})
+    ca, cq = draw_heatmaps(torch.from_numpy(g["anchor_hm"]), torch.from_numpy(g["part_hm"]), args)
+    assert ca.dtype == torch.uint8 and np.array_equal(ca.numpy(), g["anchor_rgb"]) and np.array_equal(cq.numpy(), g["part_rgb"])
+    with pytest.raises(AssertionError):
+        draw_heatmaps(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 4, 4), args)
+
+
+def test_debug_drawings_place_the_reference_primitives():
+    """`draw_kp_and_emb` / `draw_embeddings` (visualization.py:94-170): discs of 1 % of the shorter side for peaks at or above the confidence
+    threshold, a segment along every drawn part's embedding, the embedding field as red segments from every fourth output pixel -- compared
+    with the same PIL primitives issued directly (the reference reaches them through torchvision's to_pil_image, absent here)."""
+    import torch
+    from PIL import Image, ImageDraw
+    from structuredetector_amd.utils import draw_embeddings, draw_kp_and_emb, un_normalize
+    args = Namespace(conf_threshold=0.5, down_ratio=4.0, _r_labels={0: "bean", 1: "maize"}, _r_parts={0: "leaf"},
+                     _label_color_map={"bean": (200, 30, 30), "maize": (30, 200, 30)}, _part_color_map={"leaf": (30, 30, 200)})
+    image = torch.zeros(3, 64, 96)
+    base = Image.fromarray((un_normalize(image).clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).numpy())
+    topk_obj = (torch.tensor([[0.9, 0.4]]), torch.tensor([[5, 9]]), torch.tensor([[1.0, 0.0]]), torch.tensor([[3.0, 10.0]]), torch.tensor([[4.0, 12.0]]))
+    topk_kp = (torch.tensor([[0.7, 0.5, 0.2]]), torch.tensor([[1, 2, 3]]), torch.zeros(1, 3), torch.tensor([[8.0, 2.0, 6.0]]), torch.tensor([[20.0, 6.0, 1.0]]))
+    emb = torch.tensor([[[-2.0, 1.5], [3.0, 0.0], [9.0, 9.0]]])
+    got = draw_kp_and_emb(image, topk_obj, topk_kp, emb, args)
+    want = base.copy(); pen = ImageDraw.Draw(want)
+    pen.ellipse([16.0, 12.0, 16.0, 12.0], fill=(30, 200, 30), outline=(30, 200, 30))                     # radius int(64 * 0.01) = 0
+    for (x, y, ex, ey) in ((80.0, 32.0, -2.0, 1.5), (24.0, 8.0, 3.0, 0.0)):                              # the 0.5 part is drawn (>= threshold), 0.2 is not
+        pen.ellipse([x, y, x, y], fill=(30, 30, 200), outline=(30, 30, 200))
+        pen.line([x, y, x + 4.0 * ex, y + 4.0 * ey], fill=(30, 30, 200), width=0)
+    assert np.array_equal(np.asarray(got), np.asarray(want))
+    field = torch.zeros(1, 2, 16, 24); field[0, 0, 4, 8] = 2.0; field[0, 1, 4, 8] = -1.0; field[0, 0, 5, 8] = 50.0   # (row 5 is not sampled)
+    got = draw_embeddings(image, field, args)
+    want = base.copy(); pen = ImageDraw.Draw(want)
+    for j in range(0, 16, 4):
+        for i in range(0, 24, 4):
+            dx, dy = float(field[0, 0, j, i]) * 4.0, float(field[0, 1, j, i]) * 4.0
+            pen.line([i * 4.0, j * 4.0, i * 4.0 + dx, j * 4.0 + dy], fill=(255, 0, 0), width=0)
+    assert np.array_equal(np.asarray(got), np.asarray(want))
+    with pytest.raises(AssertionError):
+        draw_embeddings(image, torch.zeros(2, 2, 4, 4), args)
+
