@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // A map with more than 4096 candidates (plateaus; > 6 % of all pixels) is walked a second time with the keys going to the global
 // candidate list and selected from there.  Needs w % 4 == 0 and 16-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
-constexpr int STREAM_THREADS = 512, STREAM_WAVES = STREAM_THREADS / 64, STREAM_ROWS = 16, STREAM_CAP = 4096;
+constexpr int STREAM_ROWS = 16, STREAM_CAP = 4096;       // (the block size is a template parameter NT: 512, or 1024 for maps of 16+ units of work -- 256 x 256 and larger)
 
 // lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1: one VALU move, no trip through the LDS crossbar)
 __device__ __forceinline__ float lane_from_left(float x) {
@@ -1020,10 +1020,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // cost ~100 instructions per row.  A lane with a SECOND candidate among its four pixels (ties only: 5x5 maxima are >= 3 apart) puts it
 // on the small block-wide `extra` list through an LDS atomic.  count[0] = largest fill level of a segment seen (block-wide maximum:
 // the overflow test), count[1] = entries on the extra list; the wave's fill level goes to seg_fill[wave].
-constexpr int STREAM_SEG = STREAM_CAP / STREAM_WAVES, STREAM_EXTRA = 256;
-template <bool INLINE_KEYS>
+constexpr int STREAM_EXTRA = 256;
+template <bool INLINE_KEYS, int NT>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx) {
+    constexpr int STREAM_WAVES = NT / 64, STREAM_SEG = STREAM_CAP / STREAM_WAVES;
     constexpr int R = STREAM_ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
     static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1151,6 +1152,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     }
 }
 
+template <int STREAM_THREADS>
 __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
                                                                        uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1) {
     __shared__ uint64_t stage[STREAM_CAP];                              // raw entries, then scratch of the selection (T.out)
@@ -1160,6 +1162,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     __shared__ int misc[4];
     __shared__ int alive[2];
     __shared__ int counts[3];                                           // [0] fullest segment / global keys, [1] extra entries, [2] keys
+    constexpr int STREAM_WAVES = STREAM_THREADS / 64, STREAM_SEG = STREAM_CAP / STREAM_WAVES;
     __shared__ int seg_fill[STREAM_WAVES];
     __shared__ uint64_t extra[STREAM_EXTRA];
     __shared__ float extra_mx[STREAM_EXTRA];
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     [[maybe_unused]] const int trace0 = bm == 0 ? 6400 : (bm == g0.C ? 6420 : (bm == 255 ? 6440 : -100));
     SD_TRACE(trace0 + 0);
     __syncthreads();
-    stream_map<false>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
+    stream_map<false, STREAM_THREADS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
     SD_TRACE(trace0 + 1);
     // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
     auto convert = [&](uint64_t ent, float mxv) {
@@ -1224,7 +1227,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     if (tid == 0) counts[0] = 0;
     __syncthreads();
     uint64_t* glist = cand + (int64_t)bm * hw;
-    stream_map<true>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
+    stream_map<true, STREAM_THREADS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
@@ -2056,7 +2059,11 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
                          p_sb % 4 == 0 && p_sc % 4 == 0;
         if (vec && g_map_scalar_nms == 0 && g_map_stream) {
             // tile pass + per-map selection in one kernel (candidate list `cand`: h * w slots per map, only touched by overflowing maps)
-            hipLaunchKernelGGL(k_map_stream_select, dim3(B * C), dim3(STREAM_THREADS), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            // 16 waves per map where a map has 16+ units of work (strip x 16-row band): 256 x 256 maps 40.9 -> 36.4 us per batch of 16 x 16 maps;
+            // 128 x 128 maps (8 units) stay at 8 waves (14.4 us; 14.9 with 16)
+            const int units = cdiv(w, 256) * cdiv(h, STREAM_ROWS);
+            if (units >= 16) hipLaunchKernelGGL(k_map_stream_select<1024>, dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            else hipLaunchKernelGGL(k_map_stream_select<512>, dim3(B * C), dim3(512), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
             SD_LAUNCH_CHECK();
         } else {
             const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
