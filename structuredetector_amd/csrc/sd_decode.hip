@@ -1021,11 +1021,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // on the small block-wide `extra` list through an LDS atomic.  count[0] = largest fill level of a segment seen (block-wide maximum:
 // the overflow test), count[1] = entries on the extra list; the wave's fill level goes to seg_fill[wave].
 constexpr int STREAM_EXTRA = 256;
-template <bool INLINE_KEYS, int NT>
+template <bool INLINE_KEYS, int NT, int ROWS>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx) {
     constexpr int STREAM_WAVES = NT / 64, STREAM_SEG = STREAM_CAP / STREAM_WAVES;
-    constexpr int R = STREAM_ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
+    constexpr int R = ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
     static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strips = (w + 255) >> 8, chunks = (h + R - 1) / R;
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     }
 }
 
-template <int STREAM_THREADS>
+template <int STREAM_THREADS, int ROWS>
 __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
                                                                        uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1) {
     __shared__ uint64_t stage[STREAM_CAP];                              // raw entries, then scratch of the selection (T.out)
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     [[maybe_unused]] const int trace0 = bm == 0 ? 6400 : (bm == g0.C ? 6420 : (bm == 255 ? 6440 : -100));
     SD_TRACE(trace0 + 0);
     __syncthreads();
-    stream_map<false, STREAM_THREADS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
+    stream_map<false, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
     SD_TRACE(trace0 + 1);
     // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
     auto convert = [&](uint64_t ent, float mxv) {
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     if (tid == 0) counts[0] = 0;
     __syncthreads();
     uint64_t* glist = cand + (int64_t)bm * hw;
-    stream_map<true, STREAM_THREADS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
+    stream_map<true, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
@@ -2011,6 +2011,7 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
 static thread_local int g_map_parallel_from = 2560;
 static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
+static thread_local int g_map_rows11 = 1;           // 0: 128-row maps keep 16-row bands on 8 waves (A/B)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
 static int map_tile_height(int64_t blocks16) {
     if (g_map_tile_height == 16 || g_map_tile_height == 32) return g_map_tile_height;
@@ -2061,9 +2062,13 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             // tile pass + per-map selection in one kernel (candidate list `cand`: h * w slots per map, only touched by overflowing maps)
             // 16 waves per map where a map has 16+ units of work (strip x 16-row band): 256 x 256 maps 40.9 -> 36.4 us per batch of 16 x 16 maps;
             // 128 x 128 maps (8 units) stay at 8 waves (14.4 us; 14.9 with 16)
-            const int units = cdiv(w, 256) * cdiv(h, STREAM_ROWS);
-            if (units >= 16) hipLaunchKernelGGL(k_map_stream_select<1024>, dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
-            else hipLaunchKernelGGL(k_map_stream_select<512>, dim3(B * C), dim3(512), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+const int strips = cdiv(w, 256);
+            // 16 waves per map where 16-row bands give 16+ units of work (256 x 256 maps: 40.9 -> 36.5 us per batch of 16 x 16 maps); maps of
+            // 9 .. 15 such units (128 x 128: 8) take 11-row bands on 16 waves: every wave walks 15 rows instead of 20
+            const int units16 = strips * cdiv(h, 16), units11 = strips * cdiv(h, 11);
+            if (units16 >= 16) hipLaunchKernelGGL((k_map_stream_select<1024, 16>), dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            else if (g_map_rows11 && units11 > 8 && units11 <= 16) hipLaunchKernelGGL((k_map_stream_select<1024, 11>), dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            else hipLaunchKernelGGL((k_map_stream_select<512, 16>), dim3(B * C), dim3(512), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
             SD_LAUNCH_CHECK();
         } else {
             const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
@@ -2119,6 +2124,7 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "map_parallel_from")) { g_map_parallel_from = value; return 0; }
     if (name && !strcmp(name, "map_tile_height")) { g_map_tile_height = value; return 0; }
     if (name && !strcmp(name, "map_scalar_nms")) { g_map_scalar_nms = value; return 0; }
+    if (name && !strcmp(name, "map_rows11")) { g_map_rows11 = value; return 0; }
     if (name && !strcmp(name, "map_stream")) { g_map_stream = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
