@@ -975,16 +975,18 @@ class Network(nn.Module):
         if self.training:
             raise L.SdError("graphed() captures the inference forward: call net.eval() first")
         static_in = example.detach().clone().contiguous().float()
+        # the forward `net(x)` would run: the bf16 backbone when `bf16_inference` is set (captured as it is NOW: capture again after a change)
+        fwd = self._engine.forward_bf16 if self.bf16_inference else (lambda t: self._engine.forward(t, False))
         with torch.no_grad():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):           # warm-up on the capture stream: allocations, one-time attributes
                 for _ in range(2):
-                    self._engine.forward(static_in, False)
+                    fwd(static_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                static_out = self._engine.forward(static_in, False)
+                static_out = fwd(static_in)
 
         def run(x):
             if x.data_ptr() != static_in.data_ptr():      # a caller that fills `run.static_in` itself saves the copy launch

@@ -162,6 +162,24 @@ def test_head_fused_into_the_last_fpn_conv(M, N, B, H, W):
     assert (fused - want32).abs().max().item() / s32 <= max(1.5 * (want16 - want32).abs().max().item() / s32, 2e-2)
 
 
+def test_graphed_bf16_forward_is_the_eager_bf16_forward():
+    """Network.graphed captures the forward `net(x)` runs: with `bf16_inference` the bf16 backbone (round 4: it captured the fp32 path) --
+    the replay reproduces the eager bf16 forward bit for bit, also on a second input written into the graph's static buffer."""
+    ref, net = _pair(seed=6)
+    net.eval()
+    g = torch.Generator().manual_seed(3)
+    x1, x2 = (torch.randn(1, 3, 256, 256, generator=g).to(DEV) for _ in range(2))
+    with torch.no_grad():
+        e1, e2 = net(x1).clone(), net(x2).clone()
+        run = net.graphed(x1)
+        assert torch.equal(run(x1), e1)
+        run.static_in.copy_(x2)
+        assert torch.equal(run(run.static_in), e2)
+        net.bf16_inference = False
+        f1 = net(x1)
+    assert not torch.equal(f1, e1)                    # (the fp32 forward is a different tensor: the replay above was not it)
+
+
 def test_stress_config_bf16_backbone_fp32_decode():
     """BASELINE configs[4]: 1024x1024, 8 labels / 8 parts, >= 64 objects per image, bf16 backbone + fp32 decode.
     Decoder parity at this size is asserted against the oracle on the SAME head tensor (bit-exact indices / grouping)."""

@@ -35,7 +35,10 @@ for bf16 in (False, True):
             net._engine.small_batch_kernel = sb
             eager = timed(lambda: net(x))
             if bf16:
-                print(f"B={B} bf16 sb={int(sb)}: eager {eager:.3f} ms", flush=True)
+                run = net.graphed(x)
+                run.static_in.copy_(x)
+                graph = timed(lambda: run(run.static_in))
+                print(f"B={B} bf16 sb={int(sb)}: eager {eager:.3f} ms, hipGraph {graph:.3f} ms", flush=True)
                 continue
             run = net.graphed(x)
             graph = timed(lambda: run(x))
