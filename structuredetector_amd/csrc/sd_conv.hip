@@ -2375,6 +2375,7 @@ struct WgradArgs {
     float* part;       // [splits][Nn][R*S][Ck]
     int B, Hi, Wi, Ck, Ho, Wo, Nn, R, S, stride, pad;
     int M, splits, m_per_split;
+    int strips, chunks_total, chunks_per_split;   // k_wgrad3x3_ring: 32-pixel column strips per map row; chunk id = (image * strips + strip) * Ho + row
 };
 
 template <int TN, int TC>   // tile sizes along n (Cout) and c (Cin): 128/64 and 128/64
@@ -2641,6 +2642,127 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(WgradArgs p) {
 #undef W9_MFMAS
 #undef W9_LOAD
 #undef W9_STAGE
+    float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wgrad3x3_ring (round 4; maps whose width is a multiple of 32): k_wgrad3x3<32> with the chunks of a block walking DOWN a 32-pixel
+// column strip and the 3 x 34-pixel input patch kept as a RING of four patch rows (one separate __shared__ object per row, so that
+// the compiler's wait insertion does not hold the fragment reads back for the LDS-DMA in flight into another row): chunk oy needs rows
+// oy - 1 .. oy + 1, two of which are already in LDS -- per chunk ONE new row (9 pieces of 1 KB) + the dY chunk (8 pieces) instead of
+// 26 + 8: a wave issues 4-5 LDS-DMA instructions per chunk instead of 9 (each costs the wave ~100 cycles and 6 VALU instructions of
+// address arithmetic that take fp32-MFMA time).  Same operand reads and MFMAs; a split = a contiguous range of chunk ids (image, strip,
+// row), every (image, strip) segment inside it starts with its own prologue.  LDS: 2 x 8 KB (dY) + 4 x 9 KB (rows of 36 pixels) = 52 KB.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3_ring(WgradArgs p) {
+    constexpr int RPX = 36, RFL = RPX * 64;                          // ring row: 36 pixels x 64 floats = 9 pieces of 1 KB
+    __shared__ __attribute__((aligned(16))) float Ds0[32 * 64];
+    __shared__ __attribute__((aligned(16))) float Ds1[32 * 64];
+    __shared__ __attribute__((aligned(16))) float R0[RFL];
+    __shared__ __attribute__((aligned(16))) float R1[RFL];
+    __shared__ __attribute__((aligned(16))) float R2[RFL];
+    __shared__ __attribute__((aligned(16))) float R3[RFL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;
+    const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int dpx = lane >> 4, dsl = (lane & 15) * 4;                  // DMA: lane -> (pixel within a 4-pixel piece, first of its 4 floats)
+    const int doff = dpx * p.Nn + tn0 + dsl;
+    // patch row iy of (image b, strip at ox0) -> ring row RR: piece w and w + 4 by wave w, piece 8 (pixels 32 .. 35) by wave 0
+#define G9_PIECE(pc, iy, RR)                                                                                      \
+    {                                                                                                             \
+        const int px = (pc) * 4 + dpx, ix = ox0 - 1 + px;                                                         \
+        const bool ok = px < 34 && (unsigned)(iy) < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;              \
+        lds_dma16(ok ? p.x + (((int64_t)b * p.Hi + (iy)) * p.Wi + ix) * p.Ck + tc0 + dsl : g_zero_line, (RR) + (pc) * 256); \
+    }
+#define G9_ROW(iy, RR) { G9_PIECE(wave, iy, RR) G9_PIECE(wave + 4, iy, RR) if (wave == 0) G9_PIECE(8, iy, RR) }
+#define G9_DY(j, D)                                                                                               \
+    {                                                                                                             \
+        const float* const dbase = p.dy + ((int64_t)(b * p.Ho + oy0 + (j)) * p.Wo + ox0) * p.Nn;                  \
+        lds_dma16(dbase + wave * 4 * p.Nn + doff, (D) + wave * 256);                                              \
+        lds_dma16(dbase + (wave + 4) * 4 * p.Nn + doff, (D) + (wave + 4) * 256);                                  \
+    }
+    // the operand reads and MFMAs of k_wgrad3x3<32>, the three patch rows as three objects
+#define G9_LOAD(AV, XV, bb, XT, XM, XB)                                                                           \
+    {                                                                                                             \
+        constexpr int kk0_ = 4 * (bb), pcol_ = 2 * kk0_;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AV[i] = da[(2 * (kk0_ + i)) * 64];                          \
+        _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                                           \
+            XV[0][q] = (XT)[xo + (pcol_ + q) * 64]; XV[1][q] = (XM)[xo + (pcol_ + q) * 64]; XV[2][q] = (XB)[xo + (pcol_ + q) * 64]; \
+        }                                                                                                         \
+    }
+#define G9_MFMAS(AV, XV)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                             \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i], XV[t / 3][2 * i + t % 3], acc[t], 0, 0, 0);
+#define G9_COMPUTE(D, XT, XM, XB)                                                                                 \
+    {                                                                                                             \
+        const float* da = (D) + fh * 64 + wn0 + fr;                                                               \
+        float a0[4], x0[3][9], a1[4], x1[3][9];                                                                   \
+        G9_LOAD(a0, x0, 0, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a1, x1, 1, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a0, x0, 2, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a1, x1)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a1, x1, 3, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a1, x1)                                                                                          \
+    }
+    // chunk k of the segment: its dY in DC, its rows in XT / XM / XB; chunk k + 1's dY goes to DN and its new row oy0 + k + 2 to XN
+#define G9_ITER(DC, DN, XT, XM, XB, XN)                                                                           \
+    {                                                                                                             \
+        if (k + 1 < nseg) { G9_DY(k + 1, DN) G9_ROW(oy0 + k + 2, XN) }                                            \
+        G9_COMPUTE(DC, XT, XM, XB)                                                                                \
+        __syncthreads();                                                                                          \
+        ++k;                                                                                                      \
+    }
+    const int xo = fh * 64 + wc0 + fr;
+    const int c_beg = split * p.chunks_per_split, c_end = min(c_beg + p.chunks_per_split, p.chunks_total);
+    for (int c = c_beg; c < c_end;) {
+        const int unit = c / p.Ho, oy0 = c - unit * p.Ho, nseg = min(c_end - c, p.Ho - oy0);
+        const int b = unit / p.strips, ox0 = (unit - b * p.strips) * 32;
+        c += nseg;
+        G9_ROW(oy0 - 1, R0)
+        G9_ROW(oy0, R1)
+        G9_ROW(oy0 + 1, R2)
+        G9_DY(0, Ds0)
+        __syncthreads();
+        int k = 0;
+        while (k < nseg) {
+            G9_ITER(Ds0, Ds1, R0, R1, R2, R3)
+            if (k < nseg) G9_ITER(Ds1, Ds0, R1, R2, R3, R0)
+            if (k < nseg) G9_ITER(Ds0, Ds1, R2, R3, R0, R1)
+            if (k < nseg) G9_ITER(Ds1, Ds0, R3, R0, R1, R2)
+        }
+    }
+#undef G9_ITER
+#undef G9_COMPUTE
+#undef G9_MFMAS
+#undef G9_LOAD
+#undef G9_DY
+#undef G9_ROW
+#undef G9_PIECE
     float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -4952,6 +5074,7 @@ static bool wgrad_all_taps(const sd_conv_desc* d) {
            (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
+static thread_local int g_wgrad_f32_ring = 1;        // sd_set_option("wgrad_f32_ring", 0): k_wgrad3x3<32> instead of the row-ring kernel k_wgrad3x3_ring (A/B, tests)
 static thread_local int g_wgrad_bf16_ring = 5;       // sd_set_option("wgrad_bf16_ring", n): 5 (default) = k_wgrad3x3_bf16_ring2 (two groups per 512-thread block); 2 .. 4 = k_wgrad3x3_bf16_ring with that prefetch distance; 0 = k_wgrad3x3_bf16<32> (A/B, tests)
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
@@ -5000,7 +5123,10 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
     if (wgrad_all_taps(d)) {
-        if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        if (d->Wo % 32 == 0 && g_wgrad_f32_ring) {
+            a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho; a.chunks_per_split = cdiv(a.chunks_total, a.splits);
+            hipLaunchKernelGGL(k_wgrad3x3_ring, dim3(a.splits, tiles), dim3(256), 0, st, a);
+        } else if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_wgrad3x3<16>, dim3(a.splits, tiles), dim3(256), 0, st, a);
         SD_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, a.splits, accumulate);
@@ -5243,6 +5369,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
     if (name && !strcmp(name, "wgrad_bf16_ring")) { g_wgrad_bf16_ring = value; return 0; }
+    if (name && !strcmp(name, "wgrad_f32_ring")) { g_wgrad_f32_ring = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
     if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
@@ -5257,7 +5384,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     static thread_local char name[64];
     if (!d || d->Cin <= 0 || d->Cout <= 0) return "";
     if (pass == 2) {
-        if (wgrad_all_taps(d)) return d->Wo % 32 == 0 ? "k_wgrad3x3<32>" : "k_wgrad3x3<16>";
+        if (wgrad_all_taps(d)) return d->Wo % 32 == 0 ? (g_wgrad_f32_ring ? "k_wgrad3x3_ring" : "k_wgrad3x3<32>") : "k_wgrad3x3<16>";
         snprintf(name, sizeof(name), "k_conv_wgrad<%d, %d>", d->Cout % 128 == 0 ? 128 : 64, d->Cin % 128 == 0 ? 128 : 64);
         return name;
     }

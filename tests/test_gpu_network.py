@@ -67,6 +67,10 @@ CONV_CASES = [  # B, H, W, cin, cout, k, stride, pad
     (1, 5, 64, 192, 64, 3, 1, 1),      # 3 c-tiles x 1 n-tile
     (3, 16, 16, 128, 64, 3, 1, 1),     # 16-wide maps: a chunk is two whole rows (layer4 shape class)
     (2, 6, 16, 64, 64, 3, 1, 1),
+    # the row-ring weight gradient (k_wgrad3x3_ring): several (image, strip) segments per split, segments cut inside a strip, one-row maps
+    (20, 4, 32, 64, 64, 3, 1, 1),
+    (5, 12, 32, 64, 128, 3, 1, 1),
+    (9, 1, 64, 64, 64, 3, 1, 1),
 ]
 
 
@@ -108,6 +112,16 @@ def test_conv_fwd_dgrad_wgrad(case):
     dw = torch.empty(cout, k, k, cin, device=DEV)
     L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
     close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
+    if k == 3 and stride == 1 and d.Wo % 32 == 0:          # the first form (one 3 x 34 patch per chunk, chunks in memory order) on the same operands
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3_ring"
+        L.check(lib.sd_set_option(b"wgrad_f32_ring", 0))
+        try:
+            assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
+            dw1 = torch.full_like(dw, float("nan"))
+            L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+        finally:
+            L.check(lib.sd_set_option(b"wgrad_f32_ring", 1))
+        close(dw1.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 3, 1, 1), (2, 9, 7, 256, 256, 3, 1, 1), (16, 64, 64, 64, 128, 3, 2, 1), (1, 16, 16, 512, 512, 3, 1, 1),
