@@ -328,8 +328,9 @@ int sd_bn_bwd_apply(const float* dy, const float* x, const float* y, int relu, i
  * "conv1x1_stream_min_pixels": smallest number of output pixels for which a bf16 1x1 / stride 1 conv onto 128 channels (Cin 64 or 128, no
  *   scale, no statistics: the FPN laterals and the 128 -> 128 1x1 data-gradient) takes the stream kernel k_conv1x1_stream_bf16 (default
  *   65536; 32 = always, for tests; 1 << 30 = never).
- * "wgrad_f32_ring": 1 (default) = the fp32 weight gradient of the 3x3 / stride 1 layers with maps a multiple of 32 pixels wide takes the
- *   row-ring kernel k_wgrad3x3_ring (one new patch row per chunk); 0 = the first form k_wgrad3x3<32> (A/B, tests).
+ * "wgrad_f32_ring": form of the fp32 weight gradient of the 3x3 / stride 1 layers with maps a multiple of 32 pixels wide: 2 (default) =
+ *   k_wgrad3x3_ring2 (row ring: one new patch row per chunk; two groups of four waves per 512-thread block share a tile and store ONE partial),
+ *   1 = k_wgrad3x3_ring (one group per block), 0 = the first form k_wgrad3x3<32> (A/B, tests).
  * "wgrad_bf16_ring": form of the bf16 weight gradient of the 3x3 / stride 1 layers with maps a multiple of 32 pixels wide: 5 (default) =
  *   k_wgrad3x3_bf16_ring2 (row ring, two groups of four waves half a chunk apart in one 512-thread block), 2 .. 4 = k_wgrad3x3_bf16_ring with
  *   that prefetch distance, 0 = the first form k_wgrad3x3_bf16<32> (A/B, tests).

@@ -2773,6 +2773,160 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_ring(WgradArgs p) {
         }
 }
 
+// k_wgrad3x3_ring2: ONE 512-thread block per CU, two groups of four waves on the SAME (n, c) tile, each on its own half of the block's chunks
+// with its own dY stages and ring rows; at the end group 1's accumulators are added to group 0's through LDS (three passes of three taps)
+// and ONE partial tile is stored: half the partial-sum traffic (75 -> 37 MB per launch) and half the reduce pass.  Both groups run the
+// same chunk loop; the group with fewer barrier phases (1 per segment + 1 per chunk) pads with bare barriers.
+__global__ __launch_bounds__(512, 1) void k_wgrad3x3_ring2(WgradArgs p) {
+    constexpr int RPX = 36, RFL = RPX * 64;                          // ring row: 36 pixels x 64 floats = 9 pieces of 1 KB
+    __shared__ __attribute__((aligned(16))) float Ds0a[32 * 64];
+    __shared__ __attribute__((aligned(16))) float Ds1a[32 * 64];
+    __shared__ __attribute__((aligned(16))) float R0a[RFL];
+    __shared__ __attribute__((aligned(16))) float R1a[RFL];
+    __shared__ __attribute__((aligned(16))) float R2a[RFL];
+    __shared__ __attribute__((aligned(16))) float R3a[RFL];
+    __shared__ __attribute__((aligned(16))) float Ds0b[32 * 64];
+    __shared__ __attribute__((aligned(16))) float Ds1b[32 * 64];
+    __shared__ __attribute__((aligned(16))) float R0b[RFL];
+    __shared__ __attribute__((aligned(16))) float R1b[RFL];
+    __shared__ __attribute__((aligned(16))) float R2b[RFL];
+    __shared__ __attribute__((aligned(16))) float R3b[RFL];
+    __shared__ float red_buf[3 * 16 * 256];              // 48 KB: group 1 -> group 0 (104 + 48 = 152 KB: one block per CU)
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    const int split = blockIdx.x;
+    const int c_tiles = p.Ck >> 6;
+    const int tn0 = ((int)blockIdx.y / c_tiles) * 64, tc0 = ((int)blockIdx.y % c_tiles) * 64;
+    const int wn0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int dpx = lane >> 4, dsl = (lane & 15) * 4;                  // DMA: lane -> (pixel within a 4-pixel piece, first of its 4 floats)
+    const int doff = dpx * p.Nn + tn0 + dsl;
+    // patch row iy of (image b, strip at ox0) -> ring row RR: piece w and w + 4 by wave w, piece 8 (pixels 32 .. 35) by wave 0
+#define G9_PIECE(pc, iy, RR)                                                                                      \
+    {                                                                                                             \
+        const int px = (pc) * 4 + dpx, ix = ox0 - 1 + px;                                                         \
+        const bool ok = px < 34 && (unsigned)(iy) < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;              \
+        lds_dma16(ok ? p.x + (((int64_t)b * p.Hi + (iy)) * p.Wi + ix) * p.Ck + tc0 + dsl : g_zero_line, (RR) + (pc) * 256); \
+    }
+#define G9_ROW(iy, RR) { G9_PIECE(wave, iy, RR) G9_PIECE(wave + 4, iy, RR) if (wave == 0) G9_PIECE(8, iy, RR) }
+#define G9_DY(j, D)                                                                                               \
+    {                                                                                                             \
+        const float* const dbase = p.dy + ((int64_t)(b * p.Ho + oy0 + (j)) * p.Wo + ox0) * p.Nn;                  \
+        lds_dma16(dbase + wave * 4 * p.Nn + doff, (D) + wave * 256);                                              \
+        lds_dma16(dbase + (wave + 4) * 4 * p.Nn + doff, (D) + (wave + 4) * 256);                                  \
+    }
+    // the operand reads and MFMAs of k_wgrad3x3<32>, the three patch rows as three objects
+#define G9_LOAD(AV, XV, bb, XT, XM, XB)                                                                           \
+    {                                                                                                             \
+        constexpr int kk0_ = 4 * (bb), pcol_ = 2 * kk0_;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AV[i] = da[(2 * (kk0_ + i)) * 64];                          \
+        _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                                           \
+            XV[0][q] = (XT)[xo + (pcol_ + q) * 64]; XV[1][q] = (XM)[xo + (pcol_ + q) * 64]; XV[2][q] = (XB)[xo + (pcol_ + q) * 64]; \
+        }                                                                                                         \
+    }
+#define G9_MFMAS(AV, XV)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                             \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i], XV[t / 3][2 * i + t % 3], acc[t], 0, 0, 0);
+#define G9_COMPUTE(D, XT, XM, XB)                                                                                 \
+    {                                                                                                             \
+        const float* da = (D) + fh * 64 + wn0 + fr;                                                               \
+        float a0[4], x0[3][9], a1[4], x1[3][9];                                                                   \
+        G9_LOAD(a0, x0, 0, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a1, x1, 1, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a0, x0, 2, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a1, x1)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_LOAD(a1, x1, 3, XT, XM, XB)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a0, x0)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        G9_MFMAS(a1, x1)                                                                                          \
+    }
+    // chunk k of the segment: its dY in DC, its rows in XT / XM / XB; chunk k + 1's dY goes to DN and its new row oy0 + k + 2 to XN
+#define G9_ITER(DC, DN, XT, XM, XB, XN)                                                                           \
+    {                                                                                                             \
+        if (k + 1 < nseg) { G9_DY(k + 1, DN) G9_ROW(oy0 + k + 2, XN) }                                            \
+        G9_COMPUTE(DC, XT, XM, XB)                                                                                \
+        __syncthreads();                                                                                          \
+        ++k;                                                                                                      \
+    }
+    const int xo = fh * 64 + wc0 + fr;
+    const int c_beg = split * p.chunks_per_split, c_end = min(c_beg + p.chunks_per_split, p.chunks_total);
+    const int c_mid = c_beg + (c_end - c_beg + 1) / 2;
+    auto phases = [&](int cb, int ce) { int n = 0; for (int c = cb; c < ce;) { const int oy = c % p.Ho, ns = min(ce - c, p.Ho - oy); n += 1 + ns; c += ns; } return n; };
+    const int ph0 = phases(c_beg, c_mid), ph1 = phases(c_mid, c_end);
+#define G9_WALK(CB, CE, D0, D1, RA, RB, RC, RD)                                                                   \
+    for (int c = (CB); c < (CE);) {                                                                               \
+        const int unit = c / p.Ho, oy0 = c - unit * p.Ho, nseg = min((CE) - c, p.Ho - oy0);                       \
+        const int b = unit / p.strips, ox0 = (unit - b * p.strips) * 32;                                          \
+        c += nseg;                                                                                                \
+        G9_ROW(oy0 - 1, RA)                                                                                       \
+        G9_ROW(oy0, RB)                                                                                           \
+        G9_ROW(oy0 + 1, RC)                                                                                       \
+        G9_DY(0, D0)                                                                                              \
+        __syncthreads();                                                                                          \
+        int k = 0;                                                                                                \
+        while (k < nseg) {                                                                                        \
+            G9_ITER(D0, D1, RA, RB, RC, RD)                                                                       \
+            if (k < nseg) G9_ITER(D1, D0, RB, RC, RD, RA)                                                         \
+            if (k < nseg) G9_ITER(D0, D1, RC, RD, RA, RB)                                                         \
+            if (k < nseg) G9_ITER(D1, D0, RD, RA, RB, RC)                                                         \
+        }                                                                                                         \
+    }
+    if (grp == 0) { G9_WALK(c_beg, c_mid, Ds0a, Ds1a, R0a, R1a, R2a, R3a) }
+    else { G9_WALK(c_mid, c_end, Ds0b, Ds1b, R0b, R1b, R2b, R3b) }
+    for (int i = grp ? ph1 : ph0; i < max(ph0, ph1); ++i) __syncthreads();          // equal barrier counts for any split of the range
+#undef G9_WALK
+    // ---- group 1's sums into group 0: three taps per pass through LDS ([tap][element][thread]: conflict-free), fixed order
+    {
+        const int t4 = tid & 255;
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+            __syncthreads();
+            if (grp == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red_buf[(t * 16 + e) * 256 + t4] = acc[ps * 3 + t][e];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ps * 3 + t][e] += red_buf[(t * 16 + e) * 256 + t4];
+            }
+        }
+    }
+#undef G9_ITER
+#undef G9_COMPUTE
+#undef G9_MFMAS
+#undef G9_LOAD
+#undef G9_DY
+#undef G9_ROW
+#undef G9_PIECE
+    if (grp != 0) return;
+    float* out = p.part + (int64_t)split * p.Nn * 9 * p.Ck;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = tn0 + wn0 + (e & 3) + 8 * (e >> 2) + 4 * fh, c = tc0 + wc0 + fr;
+            out[((int64_t)n * 9 + t) * p.Ck + c] = acc[t][e];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 weight gradient of a 3x3 / stride 1 / pad 1 conv (mixed-precision training): the all-taps tiling of k_wgrad3x3 on the
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 partial sums).  The reduction index is the PIXEL, but both
@@ -5074,7 +5228,7 @@ static bool wgrad_all_taps(const sd_conv_desc* d) {
            (d->Wo % 32 == 0 || (d->Wo == 16 && d->Ho % 2 == 0));
 }
 
-static thread_local int g_wgrad_f32_ring = 1;        // sd_set_option("wgrad_f32_ring", 0): k_wgrad3x3<32> instead of the row-ring kernel k_wgrad3x3_ring (A/B, tests)
+static thread_local int g_wgrad_f32_ring = 2;        // sd_set_option("wgrad_f32_ring", n): 2 = k_wgrad3x3_ring2 (two groups per 512-thread block), 1 = k_wgrad3x3_ring, 0 = k_wgrad3x3<32> (A/B, tests)
 static thread_local int g_wgrad_bf16_ring = 5;       // sd_set_option("wgrad_bf16_ring", n): 5 (default) = k_wgrad3x3_bf16_ring2 (two groups per 512-thread block); 2 .. 4 = k_wgrad3x3_bf16_ring with that prefetch distance; 0 = k_wgrad3x3_bf16<32> (A/B, tests)
 static int wgrad_splits(const sd_conv_desc* d, int tiles) {
     if (wgrad_all_taps(d)) {
@@ -5123,7 +5277,13 @@ int sd_conv2d_wgrad(const float* dy, const float* x, float* dw, const sd_conv_de
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = (int64_t)d->Cout * d->R * d->S * d->Cin / 4;
     if (wgrad_all_taps(d)) {
-        if (d->Wo % 32 == 0 && g_wgrad_f32_ring) {
+        if (d->Wo % 32 == 0 && g_wgrad_f32_ring >= 2) {
+            a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho;
+            a.splits = std::max(1, std::min(cdiv(256, tiles), a.chunks_total / 16));
+            a.chunks_per_split = cdiv(a.chunks_total, a.splits);
+            a.splits = cdiv(a.chunks_total, a.chunks_per_split);
+            hipLaunchKernelGGL(k_wgrad3x3_ring2, dim3(a.splits, tiles), dim3(512), 0, st, a);
+        } else if (d->Wo % 32 == 0 && g_wgrad_f32_ring) {
             a.strips = d->Wo / 32; a.chunks_total = d->B * a.strips * d->Ho; a.chunks_per_split = cdiv(a.chunks_total, a.splits);
             hipLaunchKernelGGL(k_wgrad3x3_ring, dim3(a.splits, tiles), dim3(256), 0, st, a);
         } else if (d->Wo % 32 == 0) hipLaunchKernelGGL(k_wgrad3x3<32>, dim3(a.splits, tiles), dim3(256), 0, st, a);
@@ -5384,7 +5544,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     static thread_local char name[64];
     if (!d || d->Cin <= 0 || d->Cout <= 0) return "";
     if (pass == 2) {
-        if (wgrad_all_taps(d)) return d->Wo % 32 == 0 ? (g_wgrad_f32_ring ? "k_wgrad3x3_ring" : "k_wgrad3x3<32>") : "k_wgrad3x3<16>";
+        if (wgrad_all_taps(d)) return d->Wo % 32 == 0 ? (g_wgrad_f32_ring >= 2 ? "k_wgrad3x3_ring2" : g_wgrad_f32_ring ? "k_wgrad3x3_ring" : "k_wgrad3x3<32>") : "k_wgrad3x3<16>";
         snprintf(name, sizeof(name), "k_conv_wgrad<%d, %d>", d->Cout % 128 == 0 ? 128 : 64, d->Cin % 128 == 0 ? 128 : 64);
         return name;
     }

@@ -113,15 +113,17 @@ def test_conv_fwd_dgrad_wgrad(case):
     L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
     close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
     if k == 3 and stride == 1 and d.Wo % 32 == 0:          # the first form (one 3 x 34 patch per chunk, chunks in memory order) on the same operands
-        assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3_ring"
-        L.check(lib.sd_set_option(b"wgrad_f32_ring", 0))
-        try:
-            assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
-            dw1 = torch.full_like(dw, float("nan"))
-            L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
-        finally:
-            L.check(lib.sd_set_option(b"wgrad_f32_ring", 1))
-        close(dw1.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
+        default = lib.sd_conv2d_kernel_name(C.byref(d), 2)
+        assert default in (b"k_wgrad3x3_ring", b"k_wgrad3x3_ring2")
+        for form, name in ((0, b"k_wgrad3x3<32>"), (1, b"k_wgrad3x3_ring"), (2, b"k_wgrad3x3_ring2")):       # (2: two groups per 512-thread block)
+            L.check(lib.sd_set_option(b"wgrad_f32_ring", form))
+            try:
+                assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == name
+                dw1 = torch.full_like(dw, float("nan"))
+                L.check(lib.sd_conv2d_wgrad(nhwc(dy).data_ptr(), xd.data_ptr(), dw1.data_ptr(), C.byref(d), 0, ws.data_ptr(), ws.numel(), L.stream()))
+            finally:
+                L.check(lib.sd_set_option(b"wgrad_f32_ring", 2 if default.endswith(b"ring2") else 1))
+            close(dw1.permute(0, 3, 1, 2).cpu(), wr.grad, 1e-5)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 3, 1, 1), (2, 9, 7, 256, 256, 3, 1, 1), (16, 64, 64, 64, 128, 3, 2, 1), (1, 16, 16, 512, 512, 3, 1, 1),

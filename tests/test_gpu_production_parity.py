@@ -42,13 +42,13 @@ def _names(lib, d):
 
 # the device kernels the production batch must engage ("What's weak" 1): layer -> (forward, data-gradient, weight-gradient)
 EXPECTED_KERNELS = {
-    "down1.0.conv1": ("k_conv3x3_c64_rows_f32", "k_conv3x3_c64_rows_f32", "k_wgrad3x3_ring"),
-    "down1.2.conv2": ("k_conv3x3_c64_rows_f32", "k_conv3x3_c64_rows_f32", "k_wgrad3x3_ring"),
-    "down2.1.conv1": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3_ring"),
-    "down3.2.conv2": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3_ring"),
+    "down1.0.conv1": ("k_conv3x3_c64_rows_f32", "k_conv3x3_c64_rows_f32", "k_wgrad3x3_ring2"),
+    "down1.2.conv2": ("k_conv3x3_c64_rows_f32", "k_conv3x3_c64_rows_f32", "k_wgrad3x3_ring2"),
+    "down2.1.conv1": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3_ring2"),
+    "down3.2.conv2": ("k_conv3x3_patch<128, false>", "k_conv3x3_patch<128, false>", "k_wgrad3x3_ring2"),
     "down4.1.conv1": ("k_conv3x3_patch<64, false>", "k_conv3x3_patch<64, false>", "k_wgrad3x3<16>"),
-    "up2.conv.0": ("k_conv3x3_patch<64, false>", "k_conv3x3_patch<64, false>", "k_wgrad3x3_ring"),
-    "up4.conv.0": ("k_conv3x3_patch_roll<128, false>", "k_conv3x3_patch_roll<128, false>", "k_wgrad3x3_ring"),    # 128-wide map: rolling-buffer entry point
+    "up2.conv.0": ("k_conv3x3_patch<64, false>", "k_conv3x3_patch<64, false>", "k_wgrad3x3_ring2"),
+    "up4.conv.0": ("k_conv3x3_patch_roll<128, false>", "k_conv3x3_patch_roll<128, false>", "k_wgrad3x3_ring2"),    # 128-wide map: rolling-buffer entry point
 }
 
 
@@ -227,7 +227,7 @@ def test_train_step_bs64_512_vs_oracle_per_kernel_family():
         assert max(errs) <= 2e-4, ("wgrad", kname, max(errs))
     for must in ("k_conv3x3_c64_rows_f32", "k_conv3x3_patch<128, false>", "k_conv3x3_patch<64, false>"):
         assert must in fam["fwd"] and must in fam["dgrad"], must
-    assert "k_wgrad3x3_ring" in fam["wgrad"]
+    assert "k_wgrad3x3_ring2" in fam["wgrad"]
 
     # ---- chain, parameter gradients of the real step.  Yardstick: an fp64 run of the oracle (a random-init network amplifies fp32
     # rounding through 44 BatchNorm-coupled layers; what can be asked is that the HIP gradients are as close to the fp64 truth as

@@ -200,9 +200,10 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     import ctypes as C
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_patch<128, false>"
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv3x3_patch<128, false>"
-    assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3_ring"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3_ring2"
     assert lib.sd_set_option(b"wgrad_f32_ring", 0) == 0 and lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3<32>"
-    assert lib.sd_set_option(b"wgrad_f32_ring", 1) == 0
+    assert lib.sd_set_option(b"wgrad_f32_ring", 1) == 0 and lib.sd_conv2d_kernel_name(C.byref(d), 2) == b"k_wgrad3x3_ring"
+    assert lib.sd_set_option(b"wgrad_f32_ring", 2) == 0
     # layer1 at bs=64 (128x128 maps, 64 channels): the fp32 row stream (256 units of 64 rows); small batches keep the tile kernel
     d.Hi = d.Wi = d.Ho = d.Wo = 128; d.Cin = d.Cout = 64
     assert lib.sd_conv2d_kernel_name(C.byref(d), 0) == b"k_conv3x3_c64_rows_f32"
