@@ -155,7 +155,9 @@ def cpu_baseline(M, N, K, P, img, budget_s=24.0):
             "sample": f"oracle ReferenceNetwork + loss, train fwd+bwd, bs=8 {img}x{img} fp32, 3 warm-ups + median of "
                       f"{counts['train_fwd_bwd_bs8']} iterations on {cores} threads (1-thread figure: bs=1); stages timed separately; "
                       f"torch {torch.__version__} CPU; {round(time.perf_counter() - t_start, 1)} s of CPU work",
-            "stages": stages, "iterations": counts}
+            "stages": stages, "iterations": counts,
+            "stages_are": "timings of THIS repository's CPU oracle (oracle/sdnet_oracle.py: numpy index work, torch-CPU fp32 maps), not of the "
+                          "reference's torch + .item() code (BASELINE.md: 5.8 ms decode / 11.4 ms encode per image on another box)"}
 
 
 PROFILES = Path(__file__).resolve().parent / "profiles"
