@@ -1240,7 +1240,9 @@ __global__ __launch_bounds__(256) void k_head_fwd_bf16_c128(const uint16_t* __re
 // access width differs: 8-byte accesses left these HBM-bound passes at ~60 % of the rate of their fp32 (16-byte) versions.
 struct F8 { float4 a, b; };
 __device__ __forceinline__ F8 ld8(const uint16_t* p, int64_t i) {
-    const uint4 r = reinterpret_cast<const uint4*>(p)[i];
+    typedef unsigned sd_u32x4_nt __attribute__((ext_vector_type(4)));               // (read once: non-temporal, see ld4 in sd_common.h)
+    const sd_u32x4_nt r_ = __builtin_nontemporal_load(reinterpret_cast<const sd_u32x4_nt*>(p) + i);
+    const uint4 r = make_uint4(r_[0], r_[1], r_[2], r_[3]);
     F8 v;
     v.a = make_float4(bf16_to_f32((uint16_t)(r.x & 0xffff)), bf16_to_f32((uint16_t)(r.x >> 16)), bf16_to_f32((uint16_t)(r.y & 0xffff)), bf16_to_f32((uint16_t)(r.y >> 16)));
     v.b = make_float4(bf16_to_f32((uint16_t)(r.z & 0xffff)), bf16_to_f32((uint16_t)(r.z >> 16)), bf16_to_f32((uint16_t)(r.w & 0xffff)), bf16_to_f32((uint16_t)(r.w >> 16)));
