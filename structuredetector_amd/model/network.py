@@ -145,7 +145,8 @@ class _Engine:
         self.prof_shapes = None   # list -> the geometry of every labelled launch, in the order of `prof` (tools/step_layers.py)
         self._nbt = []        # num_batches_tracked counters touched by the running forward (bumped with one launch)
         # Optional: weight-gradient GEMMs on a side stream (they only depend on the layer's output gradient), free-running
-        # beside the data-gradient chain.  Measured +3.5 % images/s at bs=64; OFF by default because concurrent kernels
+        # beside the data-gradient chain.  Measured +3.5 % images/s at bs=64 in round 3 and -3 % in round 4 (the row-ring weight gradient's
+        # 512-thread block owns 152 KB of LDS: no conv block fits beside it); OFF by default because concurrent kernels
         # stretch each other's durations and the per-kernel roofline numbers of bench.py / rocprofv3 stop describing a
         # kernel running alone.  (Chaining dgrad -> wgrad -> dgrad across the streams so that only the BatchNorm passes
         # overlap was measured too: slower than no overlap, the HBM-bound passes slow the wgrad they run under.)
