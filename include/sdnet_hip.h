@@ -382,6 +382,11 @@ int sd_bn_relu_maxpool_fwd_bf16(const void* x_bf16, int B, int Hi, int Wi, int C
 int sd_maxpool_bn_relu_bwd_bf16(const void* dpool_bf16, const uint8_t* idx, const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean,
                                 const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
                                 void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* ... and with the input gradient stored as bf16 (what autocast hands the stem conv's backward: trainer.py:116-121 runs conv1 in bf16):
+ * half the bytes written here and read by sd_conv2d_stem_wgrad_bf16.  dgamma / dbeta as above (fp32 sums of the fp32 values). */
+int sd_maxpool_bn_relu_bwd_bf16_dx16(const void* dpool_bf16, const uint8_t* idx, const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, void* dx_bf16, float* dgamma, float* dbeta,
+                                     int accumulate, void* workspace, size_t workspace_bytes, sd_stream_t stream);
 /* [Cout][taps][Cin] fp32 -> [Cin][taps][Cout] bf16 in one pass (the data-gradient's weights under --amp). */
 int sd_conv2d_transpose_weights_bf16(const float* w, void* w_t_bf16, int Cout, int taps, int Cin, sd_stream_t stream);
 
@@ -448,6 +453,10 @@ int sd_conv2d_stem_wgrad(const float* dy_nhwc, const float* x_nchw, float* dw_kr
  * the sums and dw stay fp32.  Same workspace. */
 int sd_conv2d_stem_wgrad_bf16mm(const float* dy, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
                                 size_t workspace_bytes, sd_stream_t stream);
+/* ... from a bf16 dy [M][64] (16-byte aligned): the mixed-precision step's stem (row-ring kernel: a block walks down a 128-pixel column
+ * strip and fetches two new image rows per tile; dy by LDS-DMA, transposed by ds_read_b64_tr_b16).  Same workspace, fp32 sums and dw. */
+int sd_conv2d_stem_wgrad_bf16(const void* dy_bf16, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                              size_t workspace_bytes, sd_stream_t stream);
 
 /* BatchNorm2d over [M][C] (M = B*H*W): training statistics (biased var for normalisation,
  * running stats with momentum and the unbiased var, torch semantics), apply (+residual, +ReLU),

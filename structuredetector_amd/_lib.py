@@ -119,6 +119,7 @@ _SIGNATURES = {
     "sd_conv2d_stem_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "sd_conv2d_stem_wgrad": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
     "sd_conv2d_stem_wgrad_bf16mm": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
+    "sd_conv2d_stem_wgrad_bf16": (c_int, [c_vp, c_vp, c_vp, C.POINTER(ConvDesc), c_int, c_vp, c_size, c_vp]),
     "sd_col_reduce_workspace_bytes": (c_size, [c_i64, c_int]),
     "sd_bn_train_stats": (c_int, [c_vp, c_i64, c_int, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_bn_apply": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -145,6 +146,7 @@ _SIGNATURES = {
     "sd_bn_relu_maxpool_fwd_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7),
     "sd_maxpool_bn_relu_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_vp, c_size, c_vp]),
     "sd_maxpool_bn_relu_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_vp, c_size, c_vp]),
+    "sd_maxpool_bn_relu_bwd_bf16_dx16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_vp, c_size, c_vp]),
     "sd_conv2d_fwd_bn_stats_workspace_bytes": (c_size, [c_vp]),
     "sd_conv2d_fwd_bn_stats": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_size, c_vp]),
     "sd_conv2d_dgrad_bn_reduce_workspace_bytes": (c_size, [c_vp]),

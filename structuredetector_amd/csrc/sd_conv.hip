@@ -56,7 +56,7 @@ namespace sd {
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP) || defined(SD_W16_ABL)
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP) || defined(SD_W16_ABL) || defined(SD_SR_ABL)
 #define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
 #else
 #define SD_EXPERIMENT_FLAG 0
@@ -3542,6 +3542,7 @@ struct StemArgs {
     const float* wt;      // [147][64] transposed weights (forward)
     const float* w;       // [64][147] weights as stored (forward on the bf16 MFMA)
     const float* dy;      // [M][64] (weight gradient)
+    const uint16_t* dy16; // [M][64] bf16 (k_stem_wgrad_bf16_ring)
     float* y;             // [M][64] forward output / partial dW [blocks][64][147]
     const float* scale;
     const float* shift;
@@ -3549,6 +3550,7 @@ struct StemArgs {
     int out_bf16;         // forward: store the NHWC output as bf16 (bf16 backbone)
     float* stat;          // forward: per-tile partial column sums [ntiles][2][64] of the raw output for the BatchNorm statistics (nullable)
     int B, H, W, Ho, Wo, tiles_x, ntiles;
+    int rg;               // k_stem_wgrad_bf16_ring: output rows per unit
 };
 
 __device__ __forceinline__ int stem_koff(int k) {      // patch offset of reduction index k (without the pixel term)
@@ -4410,6 +4412,266 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_bf16(StemArgs p) {
         }
     }
     __syncthreads();
+    float* out = p.y + (int64_t)blockIdx.x * 64 * STEM_K;
+    for (int i = tid; i < 64 * STEM_K; i += 256) {
+        const int n = i / STEM_K, k = i - n * STEM_K;
+        out[i] = R[n * 160 + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same gradient from a bf16 dy (mixed-precision step: the stem's BatchNorm backward stores bf16, as autocast does), row ring form.
+// k_stem_wgrad_bf16 spent a 128-pixel tile's time (~9500 cycles per tile and CU for 640 cycles of MFMA) fetching and spreading its whole
+// 21-row image patch (22 scalar loads and 88 two-byte LDS stores per thread) and transposing an fp32 dy tile through registers, with one
+// exposed global round trip per tile.  Here
+//   * a block walks DOWN a 128-pixel column strip (units of SR_RG output rows): consecutive tiles share five of their seven image rows
+//     per channel, so a step brings only two new rows (x 3 channels); the plane copies are a ring of 8 image rows per channel (row iy
+//     lives in slot iy & 7; the B operand offsets are recomputed per tile: 10 adds).  The three row pairs a unit's first tile needs
+//     besides its own are three steps without a dy tile and without MFMAs;
+//   * everything arrives by LDS-DMA, SR_D steps ahead, with counted waits (six instructions per wave and step, dummies included):
+//     dy bf16 as stored ([pixel][64], transposed by ds_read_b64_tr_b16 on its way into the A operand) and the raw fp32 image rows
+//     (aligned groups of four columns; converted and spread into the plane copies LDS -> LDS, 7 reads / 25 two-byte stores per thread).
+//     One block per CU: 72 KB in flight, which is what ~2.5 us of latency needs at 5 TB/s (two blocks with two stages each: 231 us);
+//   * v_mfma_f32_16x16x32_bf16: wave w owns channels 16 w .. 16 w + 15 and all ten 16-wide k tiles (40 accumulator registers, every wave
+//     the same 40 MFMAs per tile; the 32x32 shape dealt ten tiles to four waves as 3 / 3 / 2 / 2).
+// dy tile in LDS: pixel row i (128 B) keeps its 32-byte channel slot t at slot t ^ (i & 3) ^ ((i >> 3) & 1): the two 16-lane groups of a
+// half-wave read the same slot of rows 8 apart, and the four rows of a transposed read are consecutive -- all on disjoint banks.
+// ---------------------------------------------------------------------------------------------
+#ifndef SD_SR_ABL
+#define SD_SR_ABL 0            // timing experiments (WRONG RESULTS): 1 no ring commit, 2 no MFMA phase, 3 no DMA in the loop
+#else
+#define SD_SR_ABL_BUILD 1
+#endif
+constexpr int SR_RLB = 272;                                   // bytes per plane-copy row: 136 bf16 (131 used + shift pads), 17 16-byte chunks
+constexpr int SR_CSTRIDE = (25 * 17 + 2) * 16;                // bytes between the copies of s and s + 1: 25 rows + 2 chunks, = 3 chunks mod 8 (see below)
+constexpr int SR_PLANES0 = 16;                                // the first copy starts one chunk into LDS (stores of the first columns land up to 6 B in front of a row)
+constexpr int SR_PLANES_B = SR_PLANES0 + 8 * SR_CSTRIDE;      // one copy per tap column s = 0 .. 6 (plane s & 1 shifted by s >> 1 elements) + a dummy eighth: 54672 B
+constexpr int SR_NST = 4, SR_D = SR_NST - 1;                  // LDS stages; steps in flight
+constexpr int SR_GPR = 66, SR_IMGROW = 4 * SR_GPR;            // 16-byte groups / floats per staged image row: columns 2 ox0 - 4 .. 2 ox0 + 259
+constexpr int SR_STAGE = 128 * 64 * 2 + 8 * 64 * 16;          // bytes per stage: dy tile (16 KB) + 8 image DMA instructions (6 x 66 groups used)
+constexpr size_t SR_LDS_BYTES = (size_t)SR_PLANES_B + (size_t)SR_NST * SR_STAGE;        // 54672 + 4 x 24576 = 152976 B: one block per CU
+constexpr int SR_NDMA = 6;                                    // LDS-DMA instructions per wave and step
+
+// Where the strip's steps are: (unit, step of the unit) -> image, strip, row pair; advanced incrementally (block-uniform scalars, the
+// divisions once per unit).  A unit = p.rg output rows of one strip = p.rg + 3 steps (three row pairs without a tile first).
+struct SrCursor {
+    int sv, unit, b, ox0, oy_a, oy_b;
+    __device__ __forceinline__ void decode(const StemArgs& p, int groups, int units) {
+        if (unit < units) {
+            const int rg = unit % groups, t2 = unit / groups, tx = t2 % p.tiles_x;
+            b = t2 / p.tiles_x; ox0 = tx * 128; oy_a = rg * p.rg; oy_b = min(oy_a + p.rg, p.Ho);
+        } else {
+            b = 0; ox0 = 0; oy_a = 0; oy_b = -1000;            // past the end: neither rows nor a tile (dummy DMAs keep the counts)
+        }
+    }
+    __device__ __forceinline__ void advance(const StemArgs& p, int groups, int units) {
+        if (++sv == p.rg + 3) { sv = 0; unit += (int)gridDim.x; decode(p, groups, units); }
+    }
+    __device__ __forceinline__ int v() const { return oy_a - 3 + sv; }
+    __device__ __forceinline__ bool has_rows() const { return v() < oy_b; }
+    __device__ __forceinline__ bool has_tile() const { return v() < oy_b && v() >= oy_a; }
+};
+
+// Plane copies, bank layout: the B operand read of k tile kt is a ds_read_b128 whose 8-lane groups hold 8 CONSECUTIVE k = 3 (7 r + s) + ci
+// (one 16-byte chunk each, same pixel offset).  Copy s starts 3 s chunks (mod 8) into the banks, and inside a copy the row of
+// (channel ci, ring slot sigma) is 3 ((8 - sigma) & 7) + ci (17 chunks per row = 1 mod 8); with sigma = (iy0 + r) & 7 the chunk class
+// of lane k is 3 (s - r) + ci + const = k + const (mod 8): eight consecutive classes, no bank conflict.  (First layout: rows ci * 8 + sigma,
+// copies 25 rows apart -- the three channels of a tap fell on the same banks: the MFMA phase took 2740 cycles per tile for 640 of MFMA.)
+// Waves split the tile's PIXELS: wave w multiplies pixels 32 w .. 32 w + 31 against all 64 x 160 outputs (8 transposed reads + 10 B reads =
+// 14 KB of LDS per wave and tile for 40 MFMAs; a split of the outputs -- 2 x 5 tiles per wave -- read 28 KB and was LDS-bound), 160
+// accumulator registers, the four partial dW tiles are summed once, at the end.
+__global__ __launch_bounds__(256, 1) void k_stem_wgrad_bf16_ring(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const stages = reinterpret_cast<char*>(lds) + SR_PLANES_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)(SR_LDS_BYTES / 4); i += 256) reinterpret_cast<uint32_t*>(lds)[i] = 0;               // zero row, pads
+    const uint16_t* const zero16 = reinterpret_cast<const uint16_t*>(g_zero_line);
+    const int kcol = lane & 15, kq = lane >> 4;
+    int bbase[10], brow[10];                                  // bytes (without the ring row); tap row r, or -1: the zero row (k >= 147)
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+        const int k = kt * 16 + kcol;
+        if (k < STEM_K) {
+            const int ci = k % 3, tap = k / 3, r = tap / 7, sx = tap - r * 7;
+            bbase[kt] = SR_PLANES0 + sx * SR_CSTRIDE + ci * SR_RLB + 16 * kq + 64 * wave;
+            brow[kt] = r;
+        } else {
+            bbase[kt] = SR_PLANES0 + 24 * SR_RLB + 16 * kq;   // row 24 of copy 0 is never written
+            brow[kt] = -1;
+        }
+    }
+    // A operand (transposed read): 16-lane group kq addresses pixel rows 8 kq + q4 (+ 4 for the second read) of the wave's 32 pixels,
+    // lane (q4, pp) the columns 4 pp .. 4 pp + 3 of 16-channel slot t (slot t of row i lives at t ^ (i & 3) ^ ((i >> 3) & 1))
+    const int q4 = (lane >> 2) & 3, pp = lane & 3;
+    int aoff[4];                                              // bytes
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aoff[t] = (32 * wave + 8 * kq + q4) * 128 + ((t ^ q4 ^ (kq & 1)) << 5) + pp * 8;
+    const int srow = lane >> 3;                               // dy DMA: this lane's row inside an 8-row piece
+    // image DMA: instruction q = wave + 4 j covers the 16-byte groups g = 64 q + lane of the step's six rows (row6 = g / 66: channel row6 >> 1,
+    // image row 2 v + 2 + (row6 & 1); column group g % 66)
+    int irow[2], icol[2], ichan[2], dyoff[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = 64 * (wave + 4 * j) + lane;
+        irow[j] = g < 6 * SR_GPR ? g / SR_GPR : 0;             // (the last instruction's spare lanes re-read row 0: their LDS slots are never read)
+        icol[j] = 4 * (g % SR_GPR);
+        ichan[j] = (irow[j] >> 1) * p.H * p.W;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                              // element offset of this lane's 16 bytes inside the dy tile (source side of the slot swizzle)
+        const int q = wave + 4 * j;
+        dyoff[j] = (8 * q + srow) * 64 + ((lane & 7) ^ (((srow & 3) ^ (q & 1)) << 1)) * 8;
+    }
+    // commit: thread t converts column t of the six rows (+ one of the 30 elements of columns 256 .. 260 for t < 30)
+    const int xrow = min(tid, 29) / 5, xcol = 256 + min(tid, 29) % 5;
+    f32x4 acc[4][10];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kt = 0; kt < 10; ++kt) acc[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int groups = (p.Ho + p.rg - 1) / p.rg;
+    const int units = p.B * p.tiles_x * groups;
+    const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nsteps = my_units * (p.rg + 3);
+    // the step at cursor C_ -> stage ST_: exactly SR_NDMA instructions per wave, dummies where a step has no tile / no rows.  The image rows are
+    // fetched from CLAMPED coordinates (always a valid address: scalar base + one 32-bit lane offset) and zeroed when they are committed.
+#define SR_PREP(C_, ST_)                                                                                          \
+    const int iv_ = C_.v(), ib_ = C_.b, iox0_ = C_.ox0;                                                           \
+    const bool itile_ = C_.has_tile();                                                                            \
+    char* const ist_ = stages + (ST_) * SR_STAGE;                                                                 \
+    const uint16_t* const idy_ = p.dy16 + (((int64_t)ib_ * p.Ho + iv_) * p.Wo + iox0_) * 64;                      \
+    const float* const iimg_ = p.x + (int64_t)ib_ * 3 * p.H * p.W;                                                \
+    const int iy0_ = min(max(2 * iv_ + 2, 0), p.H - 1) * p.W, iy1_ = min(max(2 * iv_ + 3, 0), p.H - 1) * p.W;
+#define SR_DMA_DY(j)                                                                                              \
+    {                                                                                                             \
+        const int q = wave + 4 * (j), px = 8 * q + srow;                                                          \
+        const uint16_t* src = (itile_ && iox0_ + px < p.Wo) ? idy_ + dyoff[j] : zero16;                           \
+        lds_dma16(src, reinterpret_cast<float*>(ist_ + q * 1024));                                                \
+    }
+#define SR_DMA_IMG(j)                                                                                             \
+    {                                                                                                             \
+        const int off = ichan[j] + ((irow[j] & 1) ? iy1_ : iy0_) + min(max(2 * iox0_ - 4 + icol[j], 0), p.W - 4); \
+        lds_dma16(iimg_ + off, reinterpret_cast<float*>(ist_ + 16384 + (wave + 4 * (j)) * 1024));                 \
+    }
+#define SR_MFMA(T, KT) acc[T][KT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, at[T]), __builtin_bit_cast(bf16x8, bb[KT]), acc[T][KT], 0, 0, 0);
+#define SR_MFMA_ROW(KT) SR_MFMA(0, KT) SR_MFMA(1, KT) SR_MFMA(2, KT) SR_MFMA(3, KT)
+
+    const uint32_t lds_a = lds_addr(lds), stages_a = lds_addr(stages);
+    SrCursor ci_{0, (int)blockIdx.x, 0, 0, 0, 0}, cc_{0, (int)blockIdx.x, 0, 0, 0, 0};
+    ci_.decode(p, groups, units); cc_.decode(p, groups, units);
+    __syncthreads();                                           // LDS zeroed
+    for (int s = 0; s < SR_D; ++s) { SR_PREP(ci_, s) SR_DMA_DY(0) SR_DMA_DY(1) SR_DMA_DY(2) SR_DMA_DY(3) SR_DMA_IMG(0) SR_DMA_IMG(1) ci_.advance(p, groups, units); }
+    int stc = 0;                                               // stage of step s
+#ifdef SD_PP_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int s = 0; s < nsteps; ++s) {
+        PP_T(t0_)
+        // Every LDS access of the loop is inline asm: the compiler's wait insertion takes the LDS-DMAs in flight for possible aliases of
+        // any LDS load or store it knows about and would drain them (s_waitcnt vmcnt(0)) once per step.
+        wait_vmcnt_and_lds<(SR_D - 1) * SR_NDMA>();            // this wave's pieces of step s have landed (steps s + 1 .. s + SR_D - 1 stay in flight)
+        __builtin_amdgcn_s_barrier();                          // (A) step s is complete; every wave is done with tile s - 1 (its stage, its two oldest ring rows)
+        PP_T(t1_)
+        SR_PREP(ci_, (stc + SR_D) & (SR_NST - 1))              // step s + SR_D goes into the stage of step s - 1 (between MFMAs it was slower: 240 vs 227 us)
+        ci_.advance(p, groups, units);
+        const int v = cc_.v(), cox0 = cc_.ox0;
+        const bool has_rows = cc_.has_rows();
+        cc_.advance(p, groups, units);
+        const uint32_t st_a = stages_a + (uint32_t)stc * SR_STAGE;
+        stc = (stc + 1) & (SR_NST - 1);
+        // the raw image rows of this step (their LDS round trip runs under the DMA issue that follows)
+        const uint32_t ra = st_a + 16384 + (uint32_t)(tid + 1) * 4, rx = st_a + 16384 + (uint32_t)(xrow * SR_IMGROW + xcol + 1) * 4;
+        uint32_t raw[7];
+        if (has_rows && SD_SR_ABL != 1) {
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[0]) : "v"(ra), "n"(0 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[1]) : "v"(ra), "n"(1 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[2]) : "v"(ra), "n"(2 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[3]) : "v"(ra), "n"(3 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[4]) : "v"(ra), "n"(4 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(raw[5]) : "v"(ra), "n"(5 * SR_IMGROW * 4) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(raw[6]) : "v"(rx) : "memory");
+        }
+        if (SD_SR_ABL != 3) { SR_DMA_DY(0) SR_DMA_DY(1) SR_DMA_DY(2) SR_DMA_DY(3) SR_DMA_IMG(0) SR_DMA_IMG(1) }
+        PP_T(t2_)
+        if (has_rows && SD_SR_ABL != 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]) :: "memory");
+            // ring rows of this step: image rows 2 v + 2 (slot sg0) and 2 v + 3; element (row, col) -> plane o = col & 1, index col >> 1, written to
+            // the copies s = o, o + 2, o + 4, o + 6 at position index - (s >> 1): immediates n * (2 * SR_CSTRIDE - 2) from the copy of s = o.  No
+            // predicates: the first columns' shifted stores fall into the pad at the end of the row in front, odd columns' fourth into the dummy copy
+            const int sg0 = (2 * v + 2 + 8) & 7;
+#pragma unroll
+            for (int r6 = 0; r6 < 7; ++r6) {
+                const int row6 = r6 < 6 ? r6 : xrow, col = r6 < 6 ? tid : xcol;
+                if (r6 < 6 || tid < 30) {
+                    const bool in_img = (unsigned)(2 * v + 2 + (row6 & 1)) < (unsigned)p.H && (unsigned)(2 * cox0 - 3 + col) < (unsigned)p.W;
+                    const uint32_t h = in_img ? f2bf(__builtin_bit_cast(float, raw[r6])) : 0u;
+                    const int sg = (sg0 + (row6 & 1)) & 7, o = col & 1, ix = col >> 1;
+                    const uint32_t dst = lds_a + (uint32_t)(SR_PLANES0 + o * SR_CSTRIDE + (3 * ((8 - sg) & 7) + (row6 >> 1)) * SR_RLB + ix * 2);
+                    asm volatile("ds_write_b16 %0, %1" :: "v"(dst), "v"(h) : "memory");
+                    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(dst), "v"(h), "n"(1 * (2 * SR_CSTRIDE - 2)) : "memory");
+                    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(dst), "v"(h), "n"(2 * (2 * SR_CSTRIDE - 2)) : "memory");
+                    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(dst), "v"(h), "n"(3 * (2 * SR_CSTRIDE - 2)) : "memory");
+                }
+            }
+        }
+        PP_T(t3_)
+        wait_vmcnt_and_lds<SR_D * SR_NDMA>();                  // this wave's ring stores are done (nothing of the DMA queue is waited for)
+        __builtin_amdgcn_s_barrier();                          // (B) the ring holds rows 2 v - 3 .. 2 v + 3
+        PP_T(t4_)
+        // every step multiplies: a step without a tile has the zero line in its dy stage (0 x finite ring rows), and accumulators that are
+        // touched on every path stay in the accumulation registers (inside `if (has_tile)` the compiler kept 48 of them in VGPRs and copied
+        // them in and out around the MFMAs: 340 moves per step)
+        if (SD_SR_ABL != 2) {
+            TrPair at[4];
+            f32x4 bb[10];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t aa = st_a + (uint32_t)aoff[t];
+                at[t].lo = lds_tr16_async<0>(aa); at[t].hi = lds_tr16_async<512>(aa);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 10; ++kt)
+                bb[kt] = lds_read128_async<0>(lds_a + (uint32_t)(bbase[kt] + (brow[kt] >= 0 ? 3 * ((3 - 2 * v - brow[kt]) & 7) * SR_RLB : 0)));
+            PP_T(t5_)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(at[0].lo), "+v"(at[0].hi), "+v"(at[1].lo), "+v"(at[1].hi), "+v"(at[2].lo), "+v"(at[2].hi),
+                         "+v"(at[3].lo), "+v"(at[3].hi), "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]) :: "memory");
+            SR_MFMA_ROW(0) SR_MFMA_ROW(1) SR_MFMA_ROW(2) SR_MFMA_ROW(3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[4]), "+v"(bb[5]), "+v"(bb[6]), "+v"(bb[7]), "+v"(bb[8]), "+v"(bb[9]) :: "memory");
+            SR_MFMA_ROW(4) SR_MFMA_ROW(5) SR_MFMA_ROW(6) SR_MFMA_ROW(7) SR_MFMA_ROW(8) SR_MFMA_ROW(9)
+            PP_T(t6_)
+            PP_ACC(0, t0_, t1_) PP_ACC(1, t1_, t2_) PP_ACC(2, t2_, t3_) PP_ACC(3, t3_, t4_) PP_ACC(4, t4_, t5_) PP_ACC(5, t5_, t6_)
+#ifdef SD_PP_TRACE
+            tr[7] += 1;
+#endif
+        }
+    }
+#ifdef SD_PP_TRACE
+    if (blockIdx.x == 8 && lane == 0) { for (int k = 0; k < 8; ++k) g_pp_trace[wave][k] = tr[k]; }
+#endif
+#undef SR_MFMA_ROW
+#undef SR_MFMA
+#undef SR_DMA_IMG
+#undef SR_DMA_DY
+#undef SR_PREP
+    // the four waves' partial tiles are summed in wave order into R[n][160]
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* R = lds;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 10; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* r = R + (16 * t + 4 * kq + e) * 160 + kt * 16 + kcol;
+                        *r = (w == 0 ? 0.f : *r) + acc[t][kt][e];
+                    }
+        }
+        __syncthreads();
+    }
     float* out = p.y + (int64_t)blockIdx.x * 64 * STEM_K;
     for (int i = tid; i < 64 * STEM_K; i += 256) {
         const int n = i / STEM_K, k = i - n * STEM_K;
@@ -5468,6 +5730,34 @@ int sd_conv2d_stem_wgrad_bf16mm(const float* dy, const float* x_nchw, float* dw,
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SW_LDS_BYTES);
     (void)attr_once;
     hipLaunchKernelGGL(k_stem_wgrad_bf16, dim3(blocks), dim3(256), SW_LDS_BYTES, st, a);
+    SD_LAUNCH_CHECK();
+    const int64_t n4 = 64 * STEM_K / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);
+    SD_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same gradient from a bf16 dy (the mixed-precision step's stem: sd_maxpool_bn_relu_bwd_bf16_dx16 stores it): row-ring kernel
+int sd_conv2d_stem_wgrad_bf16(const void* dy_bf16, const float* x_nchw, float* dw, const sd_conv_desc* d, int accumulate, void* workspace,
+                              size_t workspace_bytes, sd_stream_t stream) {
+    if (int e = check_conv("sd_conv2d_stem_wgrad_bf16", d)) return e;
+    SD_REQUIRE(dy_bf16 && x_nchw && dw && workspace, SD_ERR_INVALID, "sd_conv2d_stem_wgrad_bf16: null pointer");
+    SD_REQUIRE(stem_is_7x7s2(d), SD_ERR_INVALID, "sd_conv2d_stem_wgrad_bf16: the stem is 7x7 / stride 2 / pad 3, 3 -> 64");
+    SD_REQUIRE(aligned16(dy_bf16) && aligned16(x_nchw) && d->Wi % 4 == 0, SD_ERR_INVALID,
+               "sd_conv2d_stem_wgrad_bf16: dy and the image must be 16-byte aligned and the image width a multiple of 4 (LDS-DMA in 16-byte groups)");
+    SD_REQUIRE(workspace_bytes >= sd_conv2d_stem_wgrad_workspace_bytes(d), SD_ERR_WORKSPACE, "sd_conv2d_stem_wgrad_bf16: workspace too small");
+    StemArgs a{};
+    a.x = x_nchw; a.dy16 = (const uint16_t*)dy_bf16; a.y = (float*)workspace;
+    stem_args(a, d);
+    // rows per unit: the longest strips (3 extra row pairs per unit) that still give every CU two units
+    a.rg = 64;
+    while (a.rg > 8 && d->B * a.tiles_x * cdiv(d->Ho, a.rg) < 512) a.rg >>= 1;
+    const int units = d->B * a.tiles_x * cdiv(d->Ho, a.rg);
+    const int blocks = std::max(1, std::min(std::min(256, stem_blocks(d)), units));      // one persistent block per CU
+    hipStream_t st = (hipStream_t)stream;
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad_bf16_ring), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SR_LDS_BYTES);
+    (void)attr_once;
+    hipLaunchKernelGGL(k_stem_wgrad_bf16_ring, dim3(blocks), dim3(256), SR_LDS_BYTES, st, a);
     SD_LAUNCH_CHECK();
     const int64_t n4 = 64 * STEM_K / 4;
     hipLaunchKernelGGL(k_wgrad_reduce_par, dim3(cdiv(n4, 8)), dim3(256), 0, st, (const float*)workspace, dw, n4, blocks, accumulate);

@@ -487,13 +487,13 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_reduce_quad(const PT* __res
     }
 }
 
-template <typename XT, typename PT>
+template <typename XT, typename PT, typename DT = float>
 __global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const PT* __restrict__ dpool, const uint8_t* __restrict__ idx,
                                                                  const XT* __restrict__ x, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ mg,
                                                                  const float* __restrict__ mgx, int Hi, int Wi, int Ho, int Wo, int64_t nq4,
-                                                                 int C, float* __restrict__ dx) {
+                                                                 int C, DT* __restrict__ dx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq4) return;
     const int cols = C >> 2;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_pool_bn_bwd_apply_quad(const PT* __rest
         o.y = ga.y * is.y * (g[u].y - a.y - (xv[u].y - mu.y) * is.y * bb.y);
         o.z = ga.z * is.z * (g[u].z - a.z - (xv[u].z - mu.z) * is.z * bb.z);
         o.w = ga.w * is.w * (g[u].w - a.w - (xv[u].w - mu.w) * is.w * bb.w);
-        reinterpret_cast<float4*>(dx)[off[u]] = o;
+        st4(dx, off[u], o);
     }
 }
 #undef SD_ADD4
@@ -1640,9 +1640,9 @@ int sd_bn_relu_maxpool_fwd_bf16(const void* x_bf16, int B, int Hi, int Wi, int C
 }
 
 extern "C++" {
-template <typename XT, typename PT>
+template <typename XT, typename PT, typename DT = float>
 static int maxpool_bn_relu_bwd_any(const char* what, const PT* dpool, const uint8_t* idx, const XT* x, int B, int Hi, int Wi, int C, const float* mean,
-                                   const float* invstd, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                   const float* invstd, const float* gamma, const float* beta, DT* dx, float* dgamma, float* dbeta, int accumulate,
                                    void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     const int64_t M = (int64_t)B * Hi * Wi;
     if (int e = check_mc(what, M, C)) return e;
@@ -1655,7 +1655,7 @@ static int maxpool_bn_relu_bwd_any(const char* what, const PT* dpool, const uint
     float* mg = partial + (size_t)nb * 2 * C;
     float* mgx = mg + C;
     const bool quad = Hi % 2 == 0 && Wi % 2 == 0;        // even maps: 2x2 quads share their four windows
-    constexpr bool F32 = std::is_same<XT, float>::value && std::is_same<PT, float>::value;
+    constexpr bool F32 = std::is_same<XT, float>::value && std::is_same<PT, float>::value && std::is_same<DT, float>::value;
     SD_REQUIRE(quad || F32, SD_ERR_INVALID, "%s: the bf16 form needs even Hi, Wi", what);
     if (quad) hipLaunchKernelGGL((k_pool_bn_bwd_reduce_quad<XT, PT>), dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M / 4, C, partial);
     else if constexpr (F32) hipLaunchKernelGGL(k_pool_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, Hi, Wi, Ho, Wo, M, C, partial);
@@ -1666,7 +1666,7 @@ static int maxpool_bn_relu_bwd_any(const char* what, const PT* dpool, const uint
                        (float*)nullptr, (float*)nullptr, mg, mgx, accumulate);
     SD_LAUNCH_CHECK();
     const int64_t n4 = M * C / 4;
-    if (quad) hipLaunchKernelGGL((k_pool_bn_bwd_apply_quad<XT, PT>), dim3(cdiv(n4 / 4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta,
+    if (quad) hipLaunchKernelGGL((k_pool_bn_bwd_apply_quad<XT, PT, DT>), dim3(cdiv(n4 / 4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta,
                                  (const float*)mg, (const float*)mgx, Hi, Wi, Ho, Wo, n4 / 4, C, dx);
     else if constexpr (F32) hipLaunchKernelGGL(k_pool_bn_bwd_apply, dim3(cdiv(n4, 256)), dim3(256), 0, st, dpool, idx, x, mean, invstd, gamma, beta, (const float*)mg,
                                                (const float*)mgx, Hi, Wi, Ho, Wo, n4, C, dx);
@@ -1687,6 +1687,15 @@ int sd_maxpool_bn_relu_bwd_bf16(const void* dpool_bf16, const uint8_t* idx, cons
                                 void* workspace, size_t workspace_bytes, sd_stream_t stream) {
     return maxpool_bn_relu_bwd_any<uint16_t, uint16_t>("sd_maxpool_bn_relu_bwd_bf16", (const uint16_t*)dpool_bf16, idx, (const uint16_t*)x_bf16, B, Hi, Wi, C,
                                                        mean, invstd, gamma, beta, dx, dgamma, dbeta, accumulate, workspace, workspace_bytes, stream);
+}
+
+// the same with a bf16 input gradient out (what sd_conv2d_stem_wgrad_bf16 reads: under autocast the stem conv's output gradient is bf16)
+int sd_maxpool_bn_relu_bwd_bf16_dx16(const void* dpool_bf16, const uint8_t* idx, const void* x_bf16, int B, int Hi, int Wi, int C, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
+                                     void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+    return maxpool_bn_relu_bwd_any<uint16_t, uint16_t, uint16_t>("sd_maxpool_bn_relu_bwd_bf16_dx16", (const uint16_t*)dpool_bf16, idx, (const uint16_t*)x_bf16,
+                                                                 B, Hi, Wi, C, mean, invstd, gamma, beta, (uint16_t*)dx_bf16, dgamma, dbeta, accumulate,
+                                                                 workspace, workspace_bytes, stream);
 }
 
 int sd_upsample2x_bwd(const float* dy, const float* add, float* dx, int B, int H, int W, int C, sd_stream_t stream) {

@@ -159,6 +159,7 @@ class _Engine:
         self.fuse_bn_bwd = False
         self._wt_plan, self._wt_flat, self._wt_valid = None, {}, None      # transposed data-gradient weights (see _transpose_all)
         self._head_ok = {}
+        self.stem_ring = True              # mixed-precision step: bf16 stem gradient + the row-ring stem weight gradient (False: fp32 gradient + k_stem_wgrad_bf16; A/B)
         self.fuse_head = True              # bf16 inference: the 1x1 head in the epilogue of the last FPN conv where it takes the two-group kernel (False: A/B, tests)
         self.small_batch_kernel = True     # eval forward: sd_conv2d_fwd_sb where the 128-row tile grid cannot fill the chip (False: A/B)
 
@@ -756,18 +757,20 @@ class _Engine:
         # stem
         d0, s0, m0, i0, pidx = tape["stem"]
         bn0 = net.adpater[1]
-        amp_stem = s0.dtype == torch.bfloat16       # bf16 conv output / pooled gradient in, fp32 gradient out (the 7x7 weight gradient is the fp32 one)
+        amp_stem = s0.dtype == torch.bfloat16       # bf16 conv output / pooled gradient in, bf16 gradient out (as autocast's conv1 backward sees it)
         if amp and not amp_stem:
             dcur = self._to_f32(dcur)
-        ds0 = torch.empty(s0.shape, dtype=torch.float32, device=s0.device)
+        ring = amp_stem and self.stem_ring and d0.Wi % 4 == 0          # the row-ring weight gradient fetches the image in aligned groups of four columns
+        ds0 = torch.empty(s0.shape, dtype=torch.bfloat16 if ring else torch.float32, device=s0.device)
         ws = self._ws(lib.sd_col_reduce_workspace_bytes(B * d0.Ho * d0.Wo, 64), s0.device)
-        pool_bwd = lib.sd_maxpool_bn_relu_bwd_bf16 if amp_stem else lib.sd_maxpool_bn_relu_bwd
+        pool_bwd = lib.sd_maxpool_bn_relu_bwd_bf16_dx16 if ring else (lib.sd_maxpool_bn_relu_bwd_bf16 if amp_stem else lib.sd_maxpool_bn_relu_bwd)
         L.check(pool_bwd(dcur.data_ptr(), pidx.data_ptr(), s0.data_ptr(), B, d0.Ho, d0.Wo, 64, m0.data_ptr(), i0.data_ptr(),
                          bn0.weight.data_ptr(), bn0.bias.data_ptr(), ds0.data_ptr(), net.grad_of(bn0.weight).data_ptr(),
                          net.grad_of(bn0.bias).data_ptr(), 0, ws.data_ptr(), ws.numel(), L.stream()), "sd_maxpool_bn_relu_bwd")
         stem = net.adpater[0]
         ws = self._ws(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), ds0.device)
-        stem_wgrad = lib.sd_conv2d_stem_wgrad_bf16mm if amp else lib.sd_conv2d_stem_wgrad      # amp: product on the bf16 MFMA (autocast: conv1 in bf16)
+        # amp: product on the bf16 MFMA (autocast: conv1 in bf16); a bf16 stem gives a bf16 gradient (row-ring kernel)
+        stem_wgrad = lib.sd_conv2d_stem_wgrad_bf16 if ring else (lib.sd_conv2d_stem_wgrad_bf16mm if amp else lib.sd_conv2d_stem_wgrad)
         L.check(stem_wgrad(ds0.data_ptr(), tape["x"].data_ptr(), net.grad_of(stem.weight).data_ptr(), C.byref(d0), 0,
                            ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
         self._join_side()

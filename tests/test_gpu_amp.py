@@ -532,6 +532,12 @@ def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
         out[tag] = (dx, dg, db)
     for a, b in zip(out["f32"], out["bf16"]):
         assert torch.equal(a, b)
+    # bf16 input gradient (what the step uses): the same values rounded once, the same dgamma / dbeta
+    dx16 = torch.empty(B, H, W, Cc, dtype=torch.bfloat16, device=DEV); dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+    L.check(lib.sd_maxpool_bn_relu_bwd_bf16_dx16(dp16.data_ptr(), i32.data_ptr(), x16.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(),
+                                                 gamma.data_ptr(), beta.data_ptr(), dx16.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
+                                                 ws.numel(), L.stream()))
+    assert torch.equal(dx16, out["f32"][0].bfloat16()) and torch.equal(dg, out["f32"][1]) and torch.equal(db, out["f32"][2])
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32)])
@@ -558,4 +564,31 @@ def test_stem_weight_gradient_on_the_bf16_mfma(shape):
     close(dw16.permute(0, 3, 1, 2).cpu(), w.grad, 2e-5)
     # accumulate = 1
     L.check(lib.sd_conv2d_stem_wgrad_bf16mm(dy_d.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 1, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw16.permute(0, 3, 1, 2).cpu(), 2 * w.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 136, 520), (1, 1024, 256)])
+def test_stem_weight_gradient_from_a_bf16_gradient_row_ring(shape):
+    """sd_conv2d_stem_wgrad_bf16 (bf16 dy by LDS-DMA + transposed reads, a block walks down a 128-pixel column strip and keeps a ring of 8
+    image rows per channel in its plane copies) against the fp32 kernel on the same bf16-representable operands and against autograd.
+    Shapes: partial last 128-pixel tile, several row groups of 32 with a partial last one (Ho = 68, 80, 512), a map smaller than a tile."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 5 + W)
+    img = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    d0 = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+    dy = torch.randn(B, 64, d0.Ho, d0.Wo, generator=g).bfloat16().float()
+    img_d = img.to(DEV)
+    dy32 = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dy16 = dy32.bfloat16()
+    ws = torch.empty(max(lib.sd_conv2d_stem_wgrad_workspace_bytes(C.byref(d0)), 256), dtype=torch.uint8, device=DEV)
+    dw32 = torch.empty(64, 7, 7, 3, device=DEV); dw16 = torch.empty_like(dw32)
+    L.check(lib.sd_conv2d_stem_wgrad(dy32.data_ptr(), img_d.data_ptr(), dw32.data_ptr(), C.byref(d0), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    L.check(lib.sd_conv2d_stem_wgrad_bf16(dy16.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 0, ws.data_ptr(), ws.numel(), L.stream()))
+    close(dw16.cpu(), dw32.cpu(), 2e-5)
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(img, w, None, 2, 3).backward(dy)
+    close(dw16.permute(0, 3, 1, 2).cpu(), w.grad, 2e-5)
+    L.check(lib.sd_conv2d_stem_wgrad_bf16(dy16.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 1, ws.data_ptr(), ws.numel(), L.stream()))
     close(dw16.permute(0, 3, 1, 2).cpu(), 2 * w.grad, 2e-5)
