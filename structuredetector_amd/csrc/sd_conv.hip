@@ -856,14 +856,20 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 constexpr int BMB = 256, BKB = 16;
 
 
-template <int BN, int MODE>
+// BF16 (round 4, opt-in: sd_set_option("igemm_big_bf16", 1)): the same tiles and pipeline on bf16 operands (64-byte LDS rows = 32 channels per chunk,
+// one v_mfma_f32_32x32x16_bf16 per tile and k-group) for the stride-2 3x3 convs of the mixed-precision step / bf16 forward.  Not faster than
+// k_conv_igemm<.., true> there (see g_igemm_big_bf16).
+template <int BN, int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
+    using T = typename std::conditional<BF16, uint16_t, float>::type;
+    constexpr int EPS = BF16 ? 8 : 4;                                    // elements per 16-byte slot
+    constexpr int KC = BF16 ? 32 : BKB;                                  // channels per chunk
     constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;       // wave grid
     constexpr int MT = BMB / WM / 32, NTW = BN / WN / 32;                // 32x32 MFMA tiles per wave
     constexpr int PAW = BMB / 16 / 4, PBW = BN / 16 / 4;                 // 1 KB pieces (16 rows x 64 B) per wave and chunk
     constexpr int PW = PAW + PBW;
     constexpr int A_ST = BMB * BKB, B_ST = BN * BKB;
-    constexpr int KSCALE = BK / BKB;                                     // ConvArgs counts 32-wide chunks
+    constexpr int KSCALE = BK / BKB;                                     // ConvArgs counts 32-wide chunks (bf16: 64-wide, of 32 here)
     static_assert(MODE == 0 || MODE == 2, "unit-div coordinate maps only");
     static_assert(NTW == 2 && (MT == 4 || MT == 2), "wave tile 128x64 or 64x64");
     __shared__ __attribute__((aligned(16))) float As0[A_ST];
@@ -874,8 +880,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float Bs2[B_ST];
     __shared__ int orow[BMB];
     __shared__ int rrow[BMB];              // row in a half-size residual map (res_up2), -1 = none
-    const float* const px_ = reinterpret_cast<const float*>(p.x);
-    const float* const pw_ = reinterpret_cast<const float*>(p.w);
+    const T* const px_ = reinterpret_cast<const T*>(p.x);
+    const T* const pw_ = reinterpret_cast<const T*>(p.w);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tiles = p.Nn / BN;
@@ -920,9 +926,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     // Per row: pointer to the pixel of the FIRST tap at channel 0 (+ the lane's swizzled slot); per chunk a wave-uniform
     // offset (tap step, channel chunk) is added and the coordinates are range-checked; padding reads the zero line.
     const int prow = lane >> 2, pslot = lane & 3;
-    const int qe = (pslot ^ ((prow >> 2) & 3)) * 4;          // (row >> 2) & 3 == (prow >> 2) & 3: pieces start at multiples of 16
-    const float* const zsrc = g_zero_line + qe;
-    const float* abase[PAW];
+    const int qe = (pslot ^ ((prow >> 2) & 3)) * EPS;        // (row >> 2) & 3 == (prow >> 2) & 3: pieces start at multiples of 16
+    const T* const zsrc = reinterpret_cast<const T*>(g_zero_line) + qe;
+    const T* abase[PAW];
     int aty[PAW], atx[PAW];
 #pragma unroll
     for (int j = 0; j < PAW; ++j) {
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     }
 #undef SD_BIG_PIXEL
     const int wk = p.R * p.S * p.Ck;
-    const float* bbase[PBW];
+    const T* bbase[PBW];
 #pragma unroll
     for (int j = 0; j < PBW; ++j) bbase[j] = pw_ + (int64_t)(n0 + (wave * PBW + j) * 16 + prow) * wk + qe;
     const int tdiv = MODE == 2 ? 2 : 1;                       // taps advance by tstep, input coordinates by rsign * tstep / tdiv
@@ -954,7 +960,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
             const int woff = (ld_r * p.S + ld_s) * p.Ck + ld_c0;                                   \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(bbase[j] + woff, (BD) + (wave * PBW + j) * 256); \
             ld_s += tstep;         /* taps innermost (K order note above k_conv_igemm) */           \
-            if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; if (ld_r >= p.R) { ld_r = r0; ld_c0 += BKB; } } \
+            if (ld_s >= p.S) { ld_s = s0; ld_r += tstep; if (ld_r >= p.R) { ld_r = r0; ld_c0 += KC; } } \
         } else {                                                                                   \
             _Pragma("unroll") for (int j = 0; j < PAW; ++j) lds_dma16(zsrc, (AD) + (wave * PAW + j) * 256); \
             _Pragma("unroll") for (int j = 0; j < PBW; ++j) lds_dma16(zsrc, (BD) + (wave * PBW + j) * 256); \
@@ -982,6 +988,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     const uint32_t a_k0 = ((wm0 + fr) * BKB + (((0 * 2 + fh) ^ rd_swz) << 2)) * 4, a_k1 = ((wm0 + fr) * BKB + (((1 * 2 + fh) ^ rd_swz) << 2)) * 4;
     const uint32_t b_k0 = ((wn0 + fr) * BKB + (((0 * 2 + fh) ^ rd_swz) << 2)) * 4, b_k1 = ((wn0 + fr) * BKB + (((1 * 2 + fh) ^ rd_swz) << 2)) * 4;
     constexpr int TSTR = 32 * BKB * 4;                        // bytes between consecutive 32-row MFMA tiles
+#define SD_BIG_MFMA16(FA, FB, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FA), __builtin_bit_cast(bf16x8, FB), acc[mi][ni], 0, 0, 0);
 #define SD_BIG_MFMA(FA, FB, mi, ni)                                                                \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[t], FB[t], acc[mi][ni], 0, 0, 0);
     // one chunk: all fragment reads of both k-groups are issued, then each group's MFMAs wait only for their own reads
@@ -997,6 +1004,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
         if (MT == 4) { a12 = lds_read128_async<2 * TSTR>(ab + a_k1); a13 = lds_read128_async<3 * TSTR>(ab + a_k1); } \
         f32x4 b10 = lds_read128_async<0>(bb + b_k1), b11 = lds_read128_async<TSTR>(bb + b_k1);     \
         if (MT == 4) { SD_LDS_WAIT6(6, a00, a01, a02, a03, b00, b01); } else { SD_LDS_WAIT4(4, a00, a01, b00, b01); } \
+        if constexpr (BF16) {                                                                      \
+            SD_BIG_MFMA16(a00, b00, 0, 0) SD_BIG_MFMA16(a01, b00, 1, 0)                            \
+            if (MT == 4) { SD_BIG_MFMA16(a02, b00, MT - 2, 0) SD_BIG_MFMA16(a03, b00, MT - 1, 0) } \
+            SD_BIG_MFMA16(a00, b01, 0, 1) SD_BIG_MFMA16(a01, b01, 1, 1)                            \
+            if (MT == 4) { SD_BIG_MFMA16(a02, b01, MT - 2, 1) SD_BIG_MFMA16(a03, b01, MT - 1, 1) } \
+        } else                                                                                     \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00[t], b00[t], acc[0][0], 0, 0, 0);  \
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01[t], b00[t], acc[1][0], 0, 0, 0);  \
@@ -1012,6 +1025,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
             }                                                                                      \
         }                                                                                          \
         if (MT == 4) { SD_LDS_WAIT6(0, a10, a11, a12, a13, b10, b11); } else { SD_LDS_WAIT4(0, a10, a11, b10, b11); } \
+        if constexpr (BF16) {                                                                      \
+            SD_BIG_MFMA16(a10, b10, 0, 0) SD_BIG_MFMA16(a11, b10, 1, 0)                            \
+            if (MT == 4) { SD_BIG_MFMA16(a12, b10, MT - 2, 0) SD_BIG_MFMA16(a13, b10, MT - 1, 0) } \
+            SD_BIG_MFMA16(a10, b11, 0, 1) SD_BIG_MFMA16(a11, b11, 1, 1)                            \
+            if (MT == 4) { SD_BIG_MFMA16(a12, b11, MT - 2, 1) SD_BIG_MFMA16(a13, b11, MT - 1, 1) } \
+        } else                                                                                     \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                            \
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[t], b10[t], acc[0][0], 0, 0, 0);  \
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11[t], b10[t], acc[1][0], 0, 0, 0);  \
@@ -1047,6 +1066,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
 #undef SD_BIG_ITER
 #undef SD_BIG_COMPUTE
 #undef SD_BIG_MFMA
+#undef SD_BIG_MFMA16
 #undef SD_BIG_ISSUE
 
     // 16-byte epilogue through the idle stage buffers (BN = 128: three 16 KB A stages for waves 0..2, two 8 KB B stages for wave 3);
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm_big(ConvArgs p) {
     __syncthreads();
     float* T0 = wave == 0 ? As0 : wave == 1 ? As1 : wave == 2 ? As2 : Bs0;
     float* T1 = wave == 3 ? Bs1 : T0 + 32 * 64;
-    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0, false, BN == 128>(p, acc, [&](int row) { return orow[row]; }, [&](int row, int) { return rrow[row]; },
+    tile_epilogue<BN, WM, WN, MT, NTW, MODE == 0, BF16, BN == 128>(p, acc, [&](int row) { return orow[row]; }, [&](int row, int) { return rrow[row]; },
                                                                    tid, wave, fr, fh, wm0, wn0, n0, tile_m, T0, T1);
 }
 // ---------------------------------------------------------------------------------------------
@@ -4917,6 +4937,9 @@ static bool conv_pp_geometry(ConvArgs& a, int mode) {
     return ok && !a.pt_rolling;
 }
 
+static thread_local int g_igemm_big_bf16 = 0;        // sd_set_option("igemm_big_bf16", 1): bf16 MODE 0 / 2 layers on the 256-row tiles too.  Measured neutral (bf16 forward
+                                                     // +0.3 %, mixed-precision step +0.15 %): both kernels stage A once per TAP and are bound by the LDS-DMA path (24-32 KB per 512
+                                                     // MFMA cycles = 48-64 B/clk of the CU's 64), not by how the chunks are pipelined
 // two resident blocks per CU: take the 256-row tile when it still fills the chip once (512 blocks); measured: 256x64 tiles
 // lose 4 % on the 64-channel layers, so only BN = 128
 static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
@@ -4931,9 +4954,9 @@ static int igemm_big_tiles(const ConvArgs& a, int BN, int mode) {
 template <int BN, int MODE, bool BF16 = false>
 static void launch_one(const ConvArgs& a, int tiles, size_t lds, hipStream_t st) {
     (void)lds;                             // the tiles are static __shared__ objects (65 KB for BN = 128, 49 KB for BN = 64)
-    if constexpr (!BF16 && (BN == 128 || SD_IGEMM_BIG64 || (SD_IGEMM_BIG64_S2 && MODE == 2)) && (MODE == 0 || MODE == 2)) {
-        if (const int big_tiles = igemm_big_tiles(a, BN, MODE)) {
-            hipLaunchKernelGGL((k_conv_igemm_big<BN, MODE>), dim3(big_tiles), dim3(256), 0, st, a);
+    if constexpr ((BN == 128 || (!BF16 && (SD_IGEMM_BIG64 || (SD_IGEMM_BIG64_S2 && MODE == 2)))) && (MODE == 0 || MODE == 2)) {
+        if (const int big_tiles = (!BF16 || g_igemm_big_bf16) ? igemm_big_tiles(a, BN, MODE) : 0) {
+            hipLaunchKernelGGL((k_conv_igemm_big<BN, MODE, BF16>), dim3(big_tiles), dim3(256), 0, st, a);
             return;
         }
     }
@@ -5818,6 +5841,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_bn64")) { g_patch_bn64 = value; return 0; }
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
+    if (name && !strcmp(name, "igemm_big_bf16")) { g_igemm_big_bf16 = value; return 0; }
     if (name && !strcmp(name, "wgrad_bf16_ring")) { g_wgrad_bf16_ring = value; return 0; }
     if (name && !strcmp(name, "wgrad_f32_ring")) { g_wgrad_f32_ring = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }
@@ -5855,6 +5879,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
         t = a;
         if (const int PBN = patch_tile_bn(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch%s<%d, true>", t.pt_rolling ? "_roll" : "", PBN);
+        else if (g_igemm_big_bf16 && BN == 128 && igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d, true>", BN, mode);
         else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, true>", BN, mode);
         return name;
     }

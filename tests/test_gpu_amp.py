@@ -496,6 +496,53 @@ def test_conv_bf16_row_stream_kernel_64_channels(case):
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
 
 
+def test_stride2_convs_on_the_256_row_bf16_tiles():
+    """k_conv_igemm_big<128, 0 / 2, true> (opt-in, sd_set_option("igemm_big_bf16", 1): the 3x3 / stride 2 convs of the mixed-precision step on 512+
+    tiles of 256 rows, three LDS stages, counted waits) against k_conv_igemm<.., true> on the same operands (bf16 products, fp32 sums, another summation order) and,
+    on one image, against torch: forward with bias + ReLU and with fused BatchNorm statistics, data-gradient with a residual."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W, cin, cout = 16, 128, 128, 128, 256
+    d = make_desc(L, B, H, W, cin, cout, 3, 2, 1)
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(B, cin, H, W, generator=g)).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV); wd = w.permute(0, 2, 3, 1).contiguous().to(DEV); bias_d = bias.to(DEV)
+    dy = torch.randn(B, cout, H // 2, W // 2, generator=g).bfloat16()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wt = w.permute(1, 2, 3, 0).contiguous().to(DEV)
+    prev = torch.randn(B, H, W, cin, generator=g).bfloat16().to(DEV)
+    ws = torch.empty(max(lib.sd_conv2d_fwd_bf16_bn_stats_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device=DEV)
+    out = {}
+    try:
+        for big in (1, 0):
+            L.check(lib.sd_set_option(b"igemm_big_bf16", big))
+            names = [lib.sd_conv2d_kernel_name(C.byref(d), p).decode() for p in (16, 17)]
+            assert names == (["k_conv_igemm_big<128, 0, true>", "k_conv_igemm_big<128, 2, true>"] if big else
+                             ["k_conv_igemm<128, 0, true>", "k_conv_igemm<128, 2, true>"]), names
+            y = torch.full((B, H // 2, W // 2, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L.check(lib.sd_conv2d_fwd_bf16(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), C.byref(d), 0, bias_d.data_ptr(), 0, 0, 1, 0, 0, L.stream()))
+            ys = torch.full_like(y, float("nan"))
+            mean = torch.empty(cout, device=DEV); invstd = torch.empty(cout, device=DEV)
+            L.check(lib.sd_conv2d_fwd_bf16_bn_stats(xd.data_ptr(), wd.data_ptr(), ys.data_ptr(), C.byref(d), 1e-5, 0.1, 0, 0, mean.data_ptr(), invstd.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), L.stream()))
+            dx = torch.full((B, H, W, cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L.check(lib.sd_conv2d_dgrad_bf16(dyd.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), prev.data_ptr(), 1, L.stream()))
+            out[big] = (y.float(), ys.float(), mean.clone(), invstd.clone(), dx.float())
+    finally:
+        L.check(lib.sd_set_option(b"igemm_big_bf16", 0))
+    for a, b in zip(out[1], out[0]):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max() + 1e-6, float((a - b).abs().max())
+    # one image against torch (fp32 on the bf16-representable operands)
+    ref = torch.relu(F.conv2d(x[:1].float(), w.float(), bias, 2, 1))
+    close(out[1][0][:1].permute(0, 3, 1, 2).cpu(), ref, 8e-3)
+    xg = x[:1].float().requires_grad_(True)
+    F.conv2d(xg, w.float(), None, 2, 1).backward(dy[:1].float())
+    close(out[1][4][:1].permute(0, 3, 1, 2).cpu(), xg.grad + prev[:1].float().permute(0, 3, 1, 2).cpu(), 8e-3)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 24), (3, 64, 32), (1, 256, 256)])
 def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
     """sd_bn_relu_maxpool_fwd_bf16 / sd_maxpool_bn_relu_bwd_bf16 (mixed-precision stem tail: bf16 conv output, pooled map and pooled
