@@ -5897,7 +5897,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
     RowsArgsF rf;
     if (conv_rowsf32_geometry(a, mode, rf)) return "k_conv3x3_c64_rows_f32";
     if (const int PBN = patch_tile_bn(t, BN, mode, false)) snprintf(name, sizeof(name), "k_conv3x3_patch%s<%d, false>", t.pt_rolling ? "_roll" : "", PBN);
-    else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d>", BN, mode);
+    else if (igemm_big_tiles(a, BN, mode)) snprintf(name, sizeof(name), "k_conv_igemm_big<%d, %d, false>", BN, mode);
     else snprintf(name, sizeof(name), "k_conv_igemm<%d, %d, false>", BN, mode);
     return name;
 }

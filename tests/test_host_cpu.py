@@ -220,7 +220,7 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert lib.sd_set_option(b"conv_patch_narrow", 2) == 0
     d.Hi = d.Wi = d.Ho = d.Wo = 64; d.Cin = d.Cout = 128
     d.stride, d.Ho, d.Wo = 2, 32, 32
-    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2>"
+    assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm_big<128, 2, false>"
     d.B, d.stride, d.Ho, d.Wo = 1, 1, 64, 64
     assert lib.sd_conv2d_kernel_name(C.byref(d), 1) == b"k_conv_igemm<128, 0, false>"
     # the bf16 dispatch (passes 16 / 17 = sd_conv2d_fwd_bf16 / sd_conv2d_dgrad_bf16) at bs=64, 512x512: layer2 / layer3 3x3 convs take the
