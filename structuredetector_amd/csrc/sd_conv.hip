@@ -4699,6 +4699,264 @@ __global__ __launch_bounds__(256, 1) void k_stem_wgrad_bf16_ring(StemArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem FORWARD of the mixed-precision step (bf16 NHWC output + BatchNorm statistics) on the same row ring: k_stem_fwd<true> re-staged the
+// whole 21-row patch of every 128-pixel tile and built each MFMA operand from eight 4-byte LDS reads + conversions (376 us at bs = 64 for
+// 79 us of MFMA work and a 140 us HBM floor).  Here the reduction index is ordered (ci, r, j) with j = tap column + 1 in 0 .. 7 (j = 0: zero
+// weight), so the eight k of a lane are EIGHT CONSECUTIVE IMAGE COLUMNS 2 px .. 2 px + 7 of one (ci, r) row: one aligned ds_read_b128 from
+// the copy px & 3 of the row, where copy c holds the bf16 row shifted by 2 c columns (copies start 2 c chunks (mod 8) into the banks: the
+// eight lanes of a read group -- eight consecutive pixels -- hit eight chunk classes).  K = 24 rows x 8 (21 real rows) = 6 MFMA steps.
+//   * D^T = W x patch^T: A = the weights (all in registers: 6 steps x 4 channel tiles), B = the patch; a lane then holds 16 consecutive
+//     channels of ONE pixel (rows of channel tile t are channels 16 (n >> 2) + 4 t + (n & 3)): two 16-byte stores per lane and tile;
+//   * steps, units, the image DMA and its staging as in k_stem_wgrad_bf16_ring (three stages, two steps in flight); the rows are committed
+//     as packed pairs (even shifts: four ds_write_b32 per pair of columns);
+//   * TWO WAVE GROUPS (512 threads, one block per CU): loads and stores share vmcnt and may retire out of order with each other, so a wave
+//     that both prefetches by LDS-DMA with counted waits and stores its outputs has to wait for the stores' acknowledgement every step
+//     (measured: 334 us; 659 with two blocks per CU, whose 256 registers spill).  Waves 0-3 issue the DMA, multiply and leave the tile's
+//     packed bf16 rows in LDS (chunks swizzled by pixel & 7); waves 4-7 store the previous tile from there (64 contiguous bytes per thread),
+//     sum the statistics of the rounded values (one partial row per block) and never wait for a store; both groups commit the new rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int SF_ROWB = 528;                                  // bytes per row copy: 256 bf16 + 8 (overflow of the shifted stores)
+constexpr int SF_CSTRIDE = 24 * SF_ROWB + 32;                 // 3 channels x ring of 8 rows + 2 chunks: = 2 chunks mod 8
+constexpr int SF_P0 = 16;
+constexpr int SF_PLANES_B = SF_P0 + 4 * SF_CSTRIDE;           // 50832 B
+constexpr int SF_NST = 3, SF_D = SF_NST - 1;
+constexpr int SF_STAGE = 8 * 1024;                            // 8 image DMA instructions (6 rows x 66 groups of four columns used)
+constexpr int SF_OBUF = 128 * 128;                            // a tile's bf16 outputs: 128 pixels x 64 channels
+constexpr size_t SF_LDS_BYTES = (size_t)SF_PLANES_B + (size_t)SF_NST * SF_STAGE + 2 * SF_OBUF;       // 108176 B: one block of 8 waves per CU
+constexpr int SF_NDMA = 2;
+constexpr int SF_PAIRS = 6 * 132, SF_NPAIR = (SF_PAIRS + 511) / 512;      // column pairs of a step's six rows; per thread
+
+__global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const stages = reinterpret_cast<char*>(lds) + SF_PLANES_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, cw = wave & 3;                 // group 0: DMA + MFMA waves; group 1: output / statistics waves
+    for (int i = tid; i < (int)(SF_LDS_BYTES / 4); i += 512) reinterpret_cast<uint32_t*>(lds)[i] = 0;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const uint32_t lds_a = lds_addr(lds), stages_a = lds_addr(stages), obuf_a = stages_a + SF_NST * SF_STAGE;
+    // commit: pair q = tid + 512 j of the step's 6 x 132 column pairs (both groups)
+    int prow6[SF_NPAIR], pcol[SF_NPAIR];
+#pragma unroll
+    for (int j = 0; j < SF_NPAIR; ++j) {
+        const int q = tid + 512 * j;
+        prow6[j] = q < SF_PAIRS ? q / 132 : -1;
+        pcol[j] = 2 * (q % 132);
+    }
+    const int groups = (p.Ho + p.rg - 1) / p.rg;
+    const int units = p.B * p.tiles_x * groups;
+    const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nsteps = my_units * (p.rg + 3);
+    SrCursor ci_{0, (int)blockIdx.x, 0, 0, 0, 0}, cc_{0, (int)blockIdx.x, 0, 0, 0, 0};
+    ci_.decode(p, groups, units); cc_.decode(p, groups, units);
+    // the rows of step (v, strip cox0) from stage st_a into the ring: packed pairs, copy c at position col - 2 c (immediates c * (SF_CSTRIDE - 4);
+    // the first columns fall into the pad in front of the row)
+#define SF_COMMIT(st_a, v, cox0)                                                                                  \
+    {                                                                                                             \
+        uint2 raw[SF_NPAIR];                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < SF_NPAIR; ++j)                                                      \
+            if (prow6[j] >= 0) asm volatile("ds_read_b64 %0, %1" : "=v"(raw[j]) : "v"((st_a) + (uint32_t)(prow6[j] * SR_IMGROW + pcol[j]) * 4) : "memory"); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+        const int sg0 = (2 * (v) + 2 + 8) & 7;                                                                    \
+        _Pragma("unroll") for (int j = 0; j < SF_NPAIR; ++j) {                                                    \
+            if (prow6[j] >= 0) {                                                                                  \
+                asm volatile("" : "+v"(raw[j]));                                                                  \
+                const int row6 = prow6[j], col = pcol[j], ix = 2 * (cox0) - 4 + col;                              \
+                const bool rowok = (unsigned)(2 * (v) + 2 + (row6 & 1)) < (unsigned)p.H;                          \
+                const uint32_t h0 = (rowok && (unsigned)ix < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].x)) : 0u;       \
+                const uint32_t h1 = (rowok && (unsigned)(ix + 1) < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].y)) : 0u; \
+                const uint32_t pk = h0 | (h1 << 16);                                                              \
+                const uint32_t dst = lds_a + (uint32_t)(SF_P0 + ((row6 >> 1) * 8 + ((sg0 + (row6 & 1)) & 7)) * SF_ROWB + col * 2);  \
+                asm volatile("ds_write_b32 %0, %1" :: "v"(dst), "v"(pk) : "memory");                              \
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(1 * (SF_CSTRIDE - 4)) : "memory"); \
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(2 * (SF_CSTRIDE - 4)) : "memory"); \
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(3 * (SF_CSTRIDE - 4)) : "memory"); \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    __syncthreads();                                           // LDS zeroed
+    if (grp == 0) {
+        // ================= DMA + MFMA waves =================
+        // A operand: weights of (k step ks, channel tile t): row n16 <-> channel 16 (n16 >> 2) + 4 t + (n16 & 3); k = row (4 ks + kq) = (ci, r), j = s + 1
+        bf16x8 wreg[6][4];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const int krow = 4 * ks + kq, ci = krow / 7, r = krow - ci * 7;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ch = 16 * (n16 >> 2) + 4 * t + (n16 & 3);
+                uint16_t h[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = (krow < 21 && j >= 1) ? f2bf(p.w[((ch * 7 + r) * 7 + (j - 1)) * 3 + ci]) : (uint16_t)0;
+                const uint4 pk = make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16), h[6] | ((uint32_t)h[7] << 16));
+                wreg[ks][t] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+        // B operand: pixel px = 32 cw + 16 u + n16 of the tile -> copy px & 3 at byte 16 (px >> 2); row of k step ks = (ci, ring slot of r)
+        uint32_t bpix[2], opix[2], opix1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int px = 32 * cw + 16 * u + n16;
+            bpix[u] = lds_a + SF_P0 + (px & 3) * SF_CSTRIDE + 16 * (px >> 2);
+            opix[u] = obuf_a + px * 128 + (((2 * kq) ^ (px & 7)) << 4);        // this lane's 32 bytes: chunks 2 kq, 2 kq + 1, swizzled by px & 7
+            opix1[u] = obuf_a + px * 128 + (((2 * kq + 1) ^ (px & 7)) << 4);
+        }
+        int kci[6], kr[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const int krow = min(4 * ks + kq, 20);             // rows 21 .. 23: zero weights, any row
+            kci[ks] = (krow / 7) * 8 * SF_ROWB; kr[ks] = krow % 7;
+        }
+        int irow[2], icol[2], ichan[2];                        // image DMA (as k_stem_wgrad_bf16_ring)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = 64 * (cw + 4 * j) + lane;
+            irow[j] = g < 6 * SR_GPR ? g / SR_GPR : 0;
+            icol[j] = 4 * (g % SR_GPR);
+            ichan[j] = (irow[j] >> 1) * p.H * p.W;
+        }
+#define SF_ISSUE(C_, ST_)                                                                                         \
+        {                                                                                                         \
+            const int iv_ = C_.v();                                                                               \
+            const float* const iimg_ = p.x + (int64_t)C_.b * 3 * p.H * p.W;                                       \
+            const int iy0_ = min(max(2 * iv_ + 2, 0), p.H - 1) * p.W, iy1_ = min(max(2 * iv_ + 3, 0), p.H - 1) * p.W; \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+                const int off = ichan[j] + ((irow[j] & 1) ? iy1_ : iy0_) + min(max(2 * C_.ox0 - 4 + icol[j], 0), p.W - 4); \
+                lds_dma16(iimg_ + off, reinterpret_cast<float*>(stages + (ST_) * SF_STAGE + (cw + 4 * j) * 1024)); \
+            }                                                                                                     \
+        }
+        for (int s = 0; s < SF_D; ++s) { SF_ISSUE(ci_, s) ci_.advance(p, groups, units); }
+        int stc = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            wait_vmcnt_and_lds<(SF_D - 1) * SF_NDMA>();        // step s has landed; this wave's obuf stores of tile s - 1 are done
+            __builtin_amdgcn_s_barrier();                      // (A)
+            SF_ISSUE(ci_, (stc + SF_D) % SF_NST)
+            ci_.advance(p, groups, units);
+            const int v = cc_.v(), cox0 = cc_.ox0;
+            const bool has_rows = cc_.has_rows(), has_tile = cc_.has_tile();
+            cc_.advance(p, groups, units);
+            const uint32_t st_a = stages_a + (uint32_t)stc * SF_STAGE;
+            stc = stc + 1 == SF_NST ? 0 : stc + 1;
+            if (has_rows) SF_COMMIT(st_a, v, cox0)
+            wait_vmcnt_and_lds<63>();                          // this wave's ring stores are done (lgkmcnt(0); the DMA queue is not waited for)
+            __builtin_amdgcn_s_barrier();                      // (B) the ring holds rows 2 v - 3 .. 2 v + 3
+            if (has_tile) {
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // operand reads two k steps ahead of their MFMAs, three rotating register pairs
+                f32x4 b0[3], b1[3];
+#define SF_READ(ks)                                                                                               \
+                {                                                                                                 \
+                    const uint32_t ro = (uint32_t)(kci[ks] + ((2 * v - 3 + kr[ks] + 8) & 7) * SF_ROWB);          \
+                    b0[(ks) % 3] = lds_read128_async<0>(bpix[0] + ro);                                            \
+                    b1[(ks) % 3] = lds_read128_async<0>(bpix[1] + ro);                                            \
+                }
+#define SF_KSTEP(ks, N)                                                                                           \
+                asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b0[(ks) % 3]), "+v"(b1[(ks) % 3]) :: "memory");    \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][t], __builtin_bit_cast(bf16x8, b0[(ks) % 3]), acc[0][t], 0, 0, 0); \
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][t], __builtin_bit_cast(bf16x8, b1[(ks) % 3]), acc[1][t], 0, 0, 0); \
+                }
+                SF_READ(0) SF_READ(1)
+                SF_KSTEP(0, 2) SF_READ(2)
+                SF_KSTEP(1, 2) SF_READ(3)
+                SF_KSTEP(2, 2) SF_READ(4)
+                SF_KSTEP(3, 2) SF_READ(5)
+                SF_KSTEP(4, 2)
+                SF_KSTEP(5, 0)
+#undef SF_KSTEP
+#undef SF_READ
+                // bf16 outputs -> obuf[s & 1] (the other group stores them and sums the statistics during the next step)
+                const uint32_t ob = (uint32_t)(s & 1) * SF_OBUF;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint32_t pk[8];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        pk[2 * t] = f2bf(acc[u][t][0]) | ((uint32_t)f2bf(acc[u][t][1]) << 16);
+                        pk[2 * t + 1] = f2bf(acc[u][t][2]) | ((uint32_t)f2bf(acc[u][t][3]) << 16);
+                    }
+                    const f32x4 lo = __builtin_bit_cast(f32x4, make_uint4(pk[0], pk[1], pk[2], pk[3])), hi = __builtin_bit_cast(f32x4, make_uint4(pk[4], pk[5], pk[6], pk[7]));
+                    const uint32_t oa = opix[u] + ob, oa2 = opix1[u] + ob;
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(oa), "v"(lo) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(oa2), "v"(hi) : "memory");
+                }
+            }
+        }
+        wait_vmcnt_and_lds<0>();
+        __builtin_amdgcn_s_barrier();                          // (A) of the drain step: the last tile's outputs are in obuf
+        __builtin_amdgcn_s_barrier();                          // (B)
+#undef SF_ISSUE
+    } else {
+        // ================= output / statistics waves =================
+        // thread t2 of the group: pixel t2 >> 1, channels 32 (t2 & 1) .. + 31 = chunks 4 (t2 & 1) .. + 3 of the pixel's row (swizzled by px & 7)
+        const int t2 = tid - 256, opx = t2 >> 1, half = t2 & 1;
+        float ssum[32], ssq[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) ssum[i] = ssq[i] = 0.f;
+        int pv = 0, pcox0 = 0, pb = 0;
+        bool ptile = false;                                    // the previous step's tile (its outputs are in obuf[(s - 1) & 1])
+        for (int s = 0; s <= nsteps; ++s) {
+            wait_vmcnt_and_lds<63>();                          // (this wave's LDS reads of the previous step are done; its stores keep flying)
+            __builtin_amdgcn_s_barrier();                      // (A)
+            int v = 0, cox0 = 0, cb = 0;
+            bool has_rows = false, has_tile = false;
+            if (s < nsteps) {
+                ci_.advance(p, groups, units);                 // (unused cursor: keeps both groups' scalar work alike)
+                v = cc_.v(); cox0 = cc_.ox0; cb = cc_.b; has_rows = cc_.has_rows(); has_tile = cc_.has_tile();
+                cc_.advance(p, groups, units);
+            }
+            const uint32_t st_a = stages_a + (uint32_t)(s % SF_NST) * SF_STAGE;
+            if (has_rows) SF_COMMIT(st_a, v, cox0)
+            wait_vmcnt_and_lds<63>();
+            __builtin_amdgcn_s_barrier();                      // (B)
+            if (ptile) {
+                const uint32_t ob = obuf_a + (uint32_t)((s - 1) & 1) * SF_OBUF + opx * 128;
+                f32x4 qf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qf[i] = lds_read128_async<0>(ob + ((((4 * half + i) ^ (opx & 7))) << 4));
+                SD_LDS_WAIT4(0, qf[0], qf[1], qf[2], qf[3]);
+                uint4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = __builtin_bit_cast(uint4, qf[i]);
+                if (pcox0 + opx < p.Wo) {
+                    uint4* yp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + ((((int64_t)pb * p.Ho + pv) * p.Wo + pcox0 + opx) * 64 + 32 * half));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        yp[i] = q[i];
+                        const uint32_t wd[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float f0 = bf2f((uint16_t)(wd[k] & 0xffff)), f1 = bf2f((uint16_t)(wd[k] >> 16));
+                            ssum[8 * i + 2 * k] += f0; ssq[8 * i + 2 * k] += f0 * f0;
+                            ssum[8 * i + 2 * k + 1] += f1; ssq[8 * i + 2 * k + 1] += f1 * f1;
+                        }
+                    }
+                }
+            }
+            ptile = has_tile; pv = v; pcox0 = cox0; pb = cb;
+        }
+        // statistics: the 32 pixel lanes of a wave that share a channel half (lane parity), then the four waves -- fixed order.
+        // Channel of a register: 32 half + 16 (i >> 1 ... see the compute group's packing: chunk c = 2 kq + h holds channels 16 kq + 8 h .. + 7
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+#pragma unroll
+            for (int o = 2; o < 64; o <<= 1) { ssum[i] += __shfl_xor(ssum[i], o); ssq[i] += __shfl_xor(ssq[i], o); }
+        float* R = lds;                                        // [wave][2][64] (the ring is dead: every wave is past its last read)
+        if (lane < 2) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { R[cw * 128 + 32 * half + i] = ssum[i]; R[cw * 128 + 64 + 32 * half + i] = ssq[i]; }
+        }
+    }
+#undef SF_COMMIT
+    __syncthreads();
+    const float* R = lds;
+    if (tid < 128 && p.stat) p.stat[(int64_t)blockIdx.x * 128 + tid] = ((R[tid] + R[128 + tid]) + R[256 + tid]) + R[384 + tid];
+}
+
 // parallel split reduction: 32 float4 outputs (512 contiguous bytes of every partial copy) x 8 lanes over the copies per block, eight loads in
 // flight per lane; fixed order (lane l adds copies l, l + 8, ... in turn, lane 0 adds the eight lane sums in turn): deterministic.
 // (First form: 8 outputs x 32 lanes, two loads per lane at 64 splits: 11.5 us for 38 MB.)
@@ -4948,6 +5206,7 @@ static bool conv_pp_geometry(ConvArgs& a, int mode) {
     return ok && !a.pt_rolling;
 }
 
+static thread_local int g_stem_fwd_ring = 1;         // sd_set_option("stem_fwd_ring", 0): the mixed-precision stem forward on k_stem_fwd<true> (A/B)
 static thread_local int g_igemm_big_bf16 = 0;        // sd_set_option("igemm_big_bf16", 1): bf16 MODE 0 / 2 layers on the 256-row tiles too.  Measured neutral (bf16 forward
                                                      // +0.3 %, mixed-precision step +0.15 %): both kernels stage A once per TAP and are bound by the LDS-DMA path (24-32 KB per 512
                                                      // MFMA cycles = 48-64 B/clk of the CU's 64), not by how the chunks are pipelined
@@ -5460,6 +5719,18 @@ int sd_conv2d_stem_fwd_bn_stats_bf16(const float* x_nchw, const float* w, void* 
     StemArgs a{};
     a.x = x_nchw; a.w = w; a.y = (float*)y_bf16; a.stat = partial; a.out_bf16 = 1;
     stem_args(a, d);
+    if (g_stem_fwd_ring && d->Wi % 4 == 0 && aligned16(x_nchw) && aligned16(y_bf16)) {        // row-ring kernel: image rows by LDS-DMA in groups of four columns
+        a.rg = 64;
+        while (a.rg > 8 && d->B * a.tiles_x * cdiv(d->Ho, a.rg) < 512) a.rg >>= 1;             // one block per CU, two units each
+        const int units = d->B * a.tiles_x * cdiv(d->Ho, a.rg);
+        const int blocks = std::max(1, std::min(std::min(256, a.ntiles), units));
+        static const hipError_t attr_ring = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd_bf16_ring), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_LDS_BYTES);
+        (void)attr_ring;
+        hipLaunchKernelGGL(k_stem_fwd_bf16_ring, dim3(blocks), dim3(512), SF_LDS_BYTES, st, a);
+        SD_LAUNCH_CHECK();
+        return sd_bn_finalize_stats(partial, blocks, (int64_t)d->B * d->Ho * d->Wo, 64, eps, momentum, running_mean, running_var, mean, invstd,
+                                    partial + (size_t)a.ntiles * 128, stream);
+    }
     const size_t lds = STEM_FWD_LDS_BYTES;
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr_once;
@@ -5853,6 +6124,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_pp_min_tiles")) { g_pp_min_tiles = value; return 0; }
     if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
     if (name && !strcmp(name, "igemm_big_bf16")) { g_igemm_big_bf16 = value; return 0; }
+    if (name && !strcmp(name, "stem_fwd_ring")) { g_stem_fwd_ring = value; return 0; }
     if (name && !strcmp(name, "wgrad_bf16_ring")) { g_wgrad_bf16_ring = value; return 0; }
     if (name && !strcmp(name, "wgrad_f32_ring")) { g_wgrad_f32_ring = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }

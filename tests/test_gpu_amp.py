@@ -616,6 +616,42 @@ def test_stem_weight_gradient_on_the_bf16_mfma(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 136, 520), (1, 1024, 256)])
+def test_stem_forward_row_ring(shape):
+    """k_stem_fwd_bf16_ring (mixed-precision stem forward: bf16 NHWC output + BatchNorm statistics; image rows by LDS-DMA into a ring of
+    shifted bf16 copies, weights in registers, reduction ordered (channel, row, column)) against k_stem_fwd<true> on the same operands
+    (another summation order: equal to one bf16 ulp) and against torch on the bf16-rounded operands."""
+    from structuredetector_amd import _lib as L
+    lib = L.lib()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    d0 = make_desc(L, B, H, W, 3, 64, 7, 2, 3)
+    img_d = img.to(DEV); w_d = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = torch.empty(max(lib.sd_conv2d_stem_fwd_bn_stats_workspace_bytes(C.byref(d0)), 256), dtype=torch.uint8, device=DEV)
+    out = {}
+    try:
+        for ring in (1, 0):
+            L.check(lib.sd_set_option(b"stem_fwd_ring", ring))
+            y = torch.full((B, d0.Ho, d0.Wo, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+            mean = torch.empty(64, device=DEV); invstd = torch.empty(64, device=DEV)
+            rm = torch.zeros(64, device=DEV); rv = torch.ones(64, device=DEV)
+            ws.fill_(0xFF)
+            L.check(lib.sd_conv2d_stem_fwd_bn_stats_bf16(img_d.data_ptr(), w_d.data_ptr(), y.data_ptr(), C.byref(d0), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                                                         mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), L.stream()))
+            out[ring] = (y.float(), mean, invstd, rm, rv)
+    finally:
+        L.check(lib.sd_set_option(b"stem_fwd_ring", 1))
+    ya, yb = out[1][0], out[0][0]
+    assert torch.isfinite(ya).all()
+    assert (ya - yb).abs().max() <= 2.0 ** -7 * yb.abs().max() and (ya != yb).float().mean() < 0.05
+    for a, b in zip(out[1][1:], out[0][1:]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    ref = F.conv2d(img.bfloat16().float(), w.bfloat16().float(), None, 2, 3)
+    close(ya.permute(0, 3, 1, 2).cpu(), ref, 8e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 512, 512), (3, 160, 288), (5, 32, 32), (2, 136, 520), (1, 1024, 256)])
 def test_stem_weight_gradient_from_a_bf16_gradient_row_ring(shape):
     """sd_conv2d_stem_wgrad_bf16 (bf16 dy by LDS-DMA + transposed reads, a block walks down a 128-pixel column strip and keeps a ring of 8
     image rows per channel in its plane copies) against the fp32 kernel on the same bf16-representable operands and against autograd.
