@@ -61,6 +61,7 @@ namespace sd {
 #else
 #define SD_EXPERIMENT_FLAG 0
 #endif
+void sd_nn_set_pool_pair(int v);      // sd_nn.hip
 extern "C" int sd_build_flags(void) { return (SD_ABLATE_HOT ? 1 : 0) | (SD_ABLATE_STORE ? 2 : 0) | (SD_ABLATE_PATCH ? 4 : 0) | SD_TRACE_FLAG | SD_EXPERIMENT_FLAG; }
 
 // Timing experiment (WRONG RESULTS; make SUFFIX=_shape EXTRA=-DSD_SHAPE_EXP=<mask>): the 32x32x16 bf16 MFMAs of the selected kernels are replaced
@@ -6125,6 +6126,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv1x1_stream_min_pixels")) { g_conv1x1_stream_min_px = value; return 0; }
     if (name && !strcmp(name, "igemm_big_bf16")) { g_igemm_big_bf16 = value; return 0; }
     if (name && !strcmp(name, "stem_fwd_ring")) { g_stem_fwd_ring = value; return 0; }
+    if (name && !strcmp(name, "pool_fwd_pair")) { sd_nn_set_pool_pair(value); return 0; }
     if (name && !strcmp(name, "wgrad_bf16_ring")) { g_wgrad_bf16_ring = value; return 0; }
     if (name && !strcmp(name, "wgrad_f32_ring")) { g_wgrad_f32_ring = value; return 0; }
     if (name && !strcmp(name, "conv_pp_strips")) { g_pp_strips = value; return 0; }

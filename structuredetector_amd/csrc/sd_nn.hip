@@ -369,6 +369,77 @@ __global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd(const XT* __restric
     reinterpret_cast<uchar4*>(idx)[i] = w;
 }
 
+// The same pass, two horizontally adjacent windows per thread (Wo even) and 16 bytes per load for both element types (fp32: 4 channels,
+// bf16: 8): the windows (oy, 2 j) and (oy, 2 j + 1) share the input column 4 j + 1, so 15 loads serve two outputs (7.5 per output; the
+// one-window form needs 9, of 8 bytes for bf16: 258 us at bs = 64 for a 140 us floor).  Same affine expression, same scan order
+// (row-major, strict >): the same winning taps.  Plain loads: every input element is read by two or four threads.
+template <int VEC> struct PoolVec { float v[VEC]; };
+__device__ __forceinline__ PoolVec<4> pool_ld(const float* p, int64_t e) {
+    const float4 r = *reinterpret_cast<const float4*>(p + e);
+    return PoolVec<4>{{r.x, r.y, r.z, r.w}};
+}
+__device__ __forceinline__ PoolVec<8> pool_ld(const uint16_t* p, int64_t e) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p + e);
+    return PoolVec<8>{{bf16_to_f32((uint16_t)(r.x & 0xffff)), bf16_to_f32((uint16_t)(r.x >> 16)), bf16_to_f32((uint16_t)(r.y & 0xffff)), bf16_to_f32((uint16_t)(r.y >> 16)),
+                       bf16_to_f32((uint16_t)(r.z & 0xffff)), bf16_to_f32((uint16_t)(r.z >> 16)), bf16_to_f32((uint16_t)(r.w & 0xffff)), bf16_to_f32((uint16_t)(r.w >> 16))}};
+}
+__device__ __forceinline__ void pool_st(float* p, int64_t e, const PoolVec<4>& m) { *reinterpret_cast<float4*>(p + e) = make_float4(m.v[0], m.v[1], m.v[2], m.v[3]); }
+__device__ __forceinline__ void pool_st(uint16_t* p, int64_t e, const PoolVec<8>& m) {
+    uint4 r;
+    r.x = (uint32_t)f32_to_bf16(m.v[0]) | ((uint32_t)f32_to_bf16(m.v[1]) << 16); r.y = (uint32_t)f32_to_bf16(m.v[2]) | ((uint32_t)f32_to_bf16(m.v[3]) << 16);
+    r.z = (uint32_t)f32_to_bf16(m.v[4]) | ((uint32_t)f32_to_bf16(m.v[5]) << 16); r.w = (uint32_t)f32_to_bf16(m.v[6]) | ((uint32_t)f32_to_bf16(m.v[7]) << 16);
+    *reinterpret_cast<uint4*>(p + e) = r;
+}
+template <typename XT, typename PT, int VEC>
+__global__ __launch_bounds__(256) void k_bn_relu_maxpool_fwd_pair(const XT* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, PT* __restrict__ y,
+                                                                   uint8_t* __restrict__ idx, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int cols = C / VEC, Wp = Wo >> 1;
+    const int64_t n = (int64_t)B * Ho * Wp * cols;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % cols);
+    int64_t t = i / cols;
+    const int oxp = (int)(t % Wp); t /= Wp;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float mu[VEC], is[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { mu[k] = mean[col * VEC + k]; is[k] = invstd[col * VEC + k]; ga[k] = gamma[col * VEC + k]; be[k] = beta[col * VEC + k]; }
+    PoolVec<VEC> m0, m1;
+    uint8_t w0[VEC], w1[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { m0.v[k] = m1.v[k] = -INFINITY; w0[k] = w1[k] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int iy = oy * 2 - 1 + r;
+        if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int ix = oxp * 4 - 1 + c;
+            if (ix < 0 || ix >= Wi) continue;
+            const PoolVec<VEC> xv = pool_ld(x, (((int64_t)b * Hi + iy) * Wi + ix) * C + col * VEC);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float v = fmaxf((xv.v[k] - mu[k]) * is[k] * ga[k] + be[k], 0.f);
+                if (c <= 2 && v > m0.v[k]) { m0.v[k] = v; w0[k] = (uint8_t)(r * 3 + c); }
+                if (c >= 2 && v > m1.v[k]) { m1.v[k] = v; w1[k] = (uint8_t)(r * 3 + c - 2); }
+            }
+        }
+    }
+    const int64_t o = (((int64_t)b * Ho + oy) * Wo + 2 * oxp) * C + col * VEC;
+    pool_st(y, o, m0); pool_st(y, o + C, m1);
+    uint32_t p0[VEC / 4], p1[VEC / 4];
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) {
+        p0[k] = w0[4 * k] | ((uint32_t)w0[4 * k + 1] << 8) | ((uint32_t)w0[4 * k + 2] << 16) | ((uint32_t)w0[4 * k + 3] << 24);
+        p1[k] = w1[4 * k] | ((uint32_t)w1[4 * k + 1] << 8) | ((uint32_t)w1[4 * k + 2] << 16) | ((uint32_t)w1[4 * k + 3] << 24);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC / 4; ++k) { reinterpret_cast<uint32_t*>(idx + o)[k] = p0[k]; reinterpret_cast<uint32_t*>(idx + o + C)[k] = p1[k]; }
+}
+
 // gradient w.r.t. the (never stored) BatchNorm+ReLU output at input pixel (b, iy, ix): gather form of the max-pool backward
 // (k_maxpool_bwd) followed by the ReLU mask recomputed from x
 __device__ __forceinline__ float4 pool_relu_grad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int iy, int ix,
@@ -1417,6 +1488,9 @@ static inline int ew_grid(int64_t n4) { return (int)std::min<int64_t>(cdiv(n4, 2
 
 using namespace sd;
 
+static thread_local int g_pool_pair = 1;              // sd_set_option("pool_fwd_pair", 0): one window per thread in sd_bn_relu_maxpool_fwd[_bf16] (A/B)
+namespace sd { void sd_nn_set_pool_pair(int v) { g_pool_pair = v; } }  // (called by sd_set_option in sd_conv.hip)
+
 extern "C" {
 
 // rows per reduction block: 256 for the big maps, fewer for the deep layers so that the pass still spreads over >= 1024 blocks
@@ -1621,6 +1695,10 @@ int sd_bn_relu_maxpool_fwd(const float* x, int B, int Hi, int Wi, int C, const f
                "sd_bn_relu_maxpool_fwd: bad arguments");
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    if (g_pool_pair && Wo % 2 == 0 && aligned16(x) && aligned16(y_pool) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0)
+        hipLaunchKernelGGL((k_bn_relu_maxpool_fwd_pair<float, float, 4>), dim3(cdiv(n4 / 2, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                           y_pool, idx, B, Hi, Wi, Ho, Wo, C);
+    else
     hipLaunchKernelGGL((k_bn_relu_maxpool_fwd<float, float>), dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y_pool, idx,
                        B, Hi, Wi, Ho, Wo, C);
     SD_LAUNCH_CHECK();
@@ -1633,6 +1711,10 @@ int sd_bn_relu_maxpool_fwd_bf16(const void* x_bf16, int B, int Hi, int Wi, int C
                "sd_bn_relu_maxpool_fwd_bf16: bad arguments");
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const int64_t n4 = (int64_t)B * Ho * Wo * C / 4;
+    if (g_pool_pair && Wo % 2 == 0 && C % 8 == 0 && aligned16(x_bf16) && aligned16(y_pool_bf16) && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0)
+        hipLaunchKernelGGL((k_bn_relu_maxpool_fwd_pair<uint16_t, uint16_t, 8>), dim3(cdiv(n4 / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16,
+                           mean, invstd, gamma, beta, (uint16_t*)y_pool_bf16, idx, B, Hi, Wi, Ho, Wo, C);
+    else
     hipLaunchKernelGGL((k_bn_relu_maxpool_fwd<uint16_t, uint16_t>), dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, mean,
                        invstd, gamma, beta, (uint16_t*)y_pool_bf16, idx, B, Hi, Wi, Ho, Wo, C);
     SD_LAUNCH_CHECK();

@@ -544,7 +544,7 @@ def test_stride2_convs_on_the_256_row_bf16_tiles():
     close(out[1][4][:1].permute(0, 3, 1, 2).cpu(), xg.grad + prev[:1].float().permute(0, 3, 1, 2).cpu(), 8e-3)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 24), (3, 64, 32), (1, 256, 256)])
+@pytest.mark.parametrize("shape", [(2, 16, 24), (3, 64, 32), (1, 256, 256), (2, 36, 44), (1, 18, 22)])
 def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
     """sd_bn_relu_maxpool_fwd_bf16 / sd_maxpool_bn_relu_bwd_bf16 (mixed-precision stem tail: bf16 conv output, pooled map and pooled
     gradient; fp32 arithmetic) against the fp32 kernels on the widened tensors: same winning taps, pooled map = the fp32 result rounded
@@ -569,6 +569,17 @@ def test_stem_tail_on_bf16_activations_equals_fp32_kernels(shape):
                                             y16.data_ptr(), i16.data_ptr(), L.stream()))
     assert torch.equal(i16, i32)
     assert torch.equal(y16, y32.bfloat16())
+    # one window per thread (sd_set_option("pool_fwd_pair", 0)) = two windows per thread, bit for bit
+    L.check(lib.sd_set_option(b"pool_fwd_pair", 0))
+    try:
+        y32b = torch.empty_like(y32); i32b = torch.empty_like(i32); y16b = torch.empty_like(y16); i16b = torch.empty_like(i16)
+        L.check(lib.sd_bn_relu_maxpool_fwd(x32.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           y32b.data_ptr(), i32b.data_ptr(), L.stream()))
+        L.check(lib.sd_bn_relu_maxpool_fwd_bf16(x16.data_ptr(), B, H, W, Cc, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                y16b.data_ptr(), i16b.data_ptr(), L.stream()))
+    finally:
+        L.check(lib.sd_set_option(b"pool_fwd_pair", 1))
+    assert torch.equal(y32b, y32) and torch.equal(i32b, i32) and torch.equal(y16b, y16) and torch.equal(i16b, i16)
     dp16 = torch.randn(B, Hp, Wp, Cc, generator=g).bfloat16().to(DEV)
     dp32 = dp16.float()
     ws = torch.empty(max(lib.sd_col_reduce_workspace_bytes(B * H * W, Cc), 256), dtype=torch.uint8, device=DEV)

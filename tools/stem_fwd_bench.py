@@ -39,7 +39,41 @@ def timed(n=10, reps=5):
     return best
 
 
+pool16 = torch.empty(B, H // 4, W // 4, 64, dtype=torch.bfloat16, device=dev); idx = torch.empty(B, H // 4, W // 4, 64, dtype=torch.uint8, device=dev)
+x32 = torch.randn(B, H // 2, W // 2, 64, device=dev); pool32 = torch.empty(B, H // 4, W // 4, 64, device=dev)
+gamma = torch.ones(64, device=dev); beta = torch.zeros(64, device=dev)
+
+
+def pool(bf16):
+    def f():
+        if bf16:
+            L.check(lib.sd_bn_relu_maxpool_fwd_bf16(y.data_ptr(), B, H // 2, W // 2, 64, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    pool16.data_ptr(), idx.data_ptr(), L.stream()))
+        else:
+            L.check(lib.sd_bn_relu_maxpool_fwd(x32.data_ptr(), B, H // 2, W // 2, 64, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               pool32.data_ptr(), idx.data_ptr(), L.stream()))
+    return f
+
+
+def timed_fn(fn, n=10, reps=5):
+    for _ in range(3):
+        fn()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n * 1e3)
+    return best
+
+
 with torch.cuda.stream(torch.cuda.Stream()):
+    run()
+    for pair in (0, 1, 0, 1):
+        L.check(lib.sd_set_option(b"pool_fwd_pair", pair))
+        print(f"sd_bn_relu_maxpool_fwd, pool_fwd_pair={pair}: fp32 {timed_fn(pool(False)):8.1f} us, bf16 {timed_fn(pool(True)):8.1f} us")
     for ring in (0, 1, 0, 1):
         L.check(lib.sd_set_option(b"stem_fwd_ring", ring))
         print(f"sd_conv2d_stem_fwd_bn_stats_bf16, stem_fwd_ring={ring}: {timed():8.1f} us")
