@@ -56,7 +56,7 @@ namespace sd {
 #undef SD_TRACE_FLAG
 #define SD_TRACE_FLAG 8
 #endif
-#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP) || defined(SD_W16_ABL) || defined(SD_SR_ABL)
+#if defined(SD_PP_ABL) || defined(SD_RS_ABL) || defined(SD_SB_ABL) || defined(SD_SHAPE_EXP) || defined(SD_W16_ABL) || defined(SD_SR_ABL) || defined(SD_SF_ABL)
 #define SD_EXPERIMENT_FLAG 16  // timing-only ablations of the bf16 two-group / row-stream kernels (WRONG RESULTS)
 #else
 #define SD_EXPERIMENT_FLAG 0
@@ -4717,64 +4717,41 @@ __global__ __launch_bounds__(256, 1) void k_stem_wgrad_bf16_ring(StemArgs p) {
 //     packed bf16 rows in LDS (chunks swizzled by pixel & 7); waves 4-7 store the previous tile from there (64 contiguous bytes per thread),
 //     sum the statistics of the rounded values (one partial row per block) and never wait for a store; both groups commit the new rows.
 // ---------------------------------------------------------------------------------------------
+#ifndef SD_SF_ABL
+#define SD_SF_ABL 0            // timing experiment (WRONG RESULTS): 1 no global stores of the outputs
+#else
+#define SD_SF_ABL_BUILD 1
+#endif
 constexpr int SF_ROWB = 528;                                  // bytes per row copy: 256 bf16 + 8 (overflow of the shifted stores)
-constexpr int SF_CSTRIDE = 24 * SF_ROWB + 32;                 // 3 channels x ring of 8 rows + 2 chunks: = 2 chunks mod 8
+constexpr int SF_RING = 9;                                    // image rows per channel: the seven of a tile + the two the next step brings
+constexpr int SF_CSTRIDE = 3 * SF_RING * SF_ROWB + 112;       // 3 channels x ring + 7 chunks: = 2 chunks mod 8
 constexpr int SF_P0 = 16;
-constexpr int SF_PLANES_B = SF_P0 + 4 * SF_CSTRIDE;           // 50832 B
-constexpr int SF_NST = 3, SF_D = SF_NST - 1;
+constexpr int SF_PLANES_B = SF_P0 + 4 * SF_CSTRIDE;           // 57488 B
+constexpr int SF_NST = 3;                                    // stages of 8 KB (seven stages = six steps in flight: the same 232 us)
 constexpr int SF_STAGE = 8 * 1024;                            // 8 image DMA instructions (6 rows x 66 groups of four columns used)
 constexpr int SF_OBUF = 128 * 128;                            // a tile's bf16 outputs: 128 pixels x 64 channels
-constexpr size_t SF_LDS_BYTES = (size_t)SF_PLANES_B + (size_t)SF_NST * SF_STAGE + 2 * SF_OBUF;       // 108176 B: one block of 8 waves per CU
+constexpr size_t SF_LDS_BYTES = (size_t)SF_PLANES_B + (size_t)SF_NST * SF_STAGE + 2 * SF_OBUF;       // 114832 B: one block of 8 waves per CU
 constexpr int SF_NDMA = 2;
-constexpr int SF_PAIRS = 6 * 132, SF_NPAIR = (SF_PAIRS + 511) / 512;      // column pairs of a step's six rows; per thread
+constexpr int SF_PAIRS = 6 * 132, SF_NPAIR = (SF_PAIRS + 255) / 256;      // column pairs of a step's six rows; per thread of the second group
+static_assert((SF_CSTRIDE / 16) % 8 == 2, "copy c starts 2 c chunks (mod 8) into the banks");
 
+// Schedule (one barrier per step; step s = tile row v of a strip, or one of the three row pairs in front of a unit's first tile):
+//   waves 0-3 : DMA of step s + 3 -> stage (s mod 3) | operand reads + 48 MFMAs of tile s | packed bf16 rows -> obuf[s & 1]
+//   waves 4-7 : commit of step s + 1 (stage -> ring rows 2 v + 4, 2 v + 5: with NINE ring rows they are not among the seven tile s reads)
+//               | tile s - 1: obuf[(s - 1) & 1] -> global (64 contiguous bytes per thread) + statistics
+// (with eight ring rows the commit had to sit between two barriers of its own step: 232 us)
 __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* const stages = reinterpret_cast<char*>(lds) + SF_PLANES_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, cw = wave & 3;                 // group 0: DMA + MFMA waves; group 1: output / statistics waves
+    const int grp = wave >> 2, cw = wave & 3;                 // group 0: DMA + MFMA waves; group 1: commit / output / statistics waves
     for (int i = tid; i < (int)(SF_LDS_BYTES / 4); i += 512) reinterpret_cast<uint32_t*>(lds)[i] = 0;
     const int n16 = lane & 15, kq = lane >> 4;
     const uint32_t lds_a = lds_addr(lds), stages_a = lds_addr(stages), obuf_a = stages_a + SF_NST * SF_STAGE;
-    // commit: pair q = tid + 512 j of the step's 6 x 132 column pairs (both groups)
-    int prow6[SF_NPAIR], pcol[SF_NPAIR];
-#pragma unroll
-    for (int j = 0; j < SF_NPAIR; ++j) {
-        const int q = tid + 512 * j;
-        prow6[j] = q < SF_PAIRS ? q / 132 : -1;
-        pcol[j] = 2 * (q % 132);
-    }
     const int groups = (p.Ho + p.rg - 1) / p.rg;
     const int units = p.B * p.tiles_x * groups;
     const int my_units = (int)blockIdx.x < units ? (units - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int nsteps = my_units * (p.rg + 3);
-    SrCursor ci_{0, (int)blockIdx.x, 0, 0, 0, 0}, cc_{0, (int)blockIdx.x, 0, 0, 0, 0};
-    ci_.decode(p, groups, units); cc_.decode(p, groups, units);
-    // the rows of step (v, strip cox0) from stage st_a into the ring: packed pairs, copy c at position col - 2 c (immediates c * (SF_CSTRIDE - 4);
-    // the first columns fall into the pad in front of the row)
-#define SF_COMMIT(st_a, v, cox0)                                                                                  \
-    {                                                                                                             \
-        uint2 raw[SF_NPAIR];                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < SF_NPAIR; ++j)                                                      \
-            if (prow6[j] >= 0) asm volatile("ds_read_b64 %0, %1" : "=v"(raw[j]) : "v"((st_a) + (uint32_t)(prow6[j] * SR_IMGROW + pcol[j]) * 4) : "memory"); \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-        const int sg0 = (2 * (v) + 2 + 8) & 7;                                                                    \
-        _Pragma("unroll") for (int j = 0; j < SF_NPAIR; ++j) {                                                    \
-            if (prow6[j] >= 0) {                                                                                  \
-                asm volatile("" : "+v"(raw[j]));                                                                  \
-                const int row6 = prow6[j], col = pcol[j], ix = 2 * (cox0) - 4 + col;                              \
-                const bool rowok = (unsigned)(2 * (v) + 2 + (row6 & 1)) < (unsigned)p.H;                          \
-                const uint32_t h0 = (rowok && (unsigned)ix < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].x)) : 0u;       \
-                const uint32_t h1 = (rowok && (unsigned)(ix + 1) < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].y)) : 0u; \
-                const uint32_t pk = h0 | (h1 << 16);                                                              \
-                const uint32_t dst = lds_a + (uint32_t)(SF_P0 + ((row6 >> 1) * 8 + ((sg0 + (row6 & 1)) & 7)) * SF_ROWB + col * 2);  \
-                asm volatile("ds_write_b32 %0, %1" :: "v"(dst), "v"(pk) : "memory");                              \
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(1 * (SF_CSTRIDE - 4)) : "memory"); \
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(2 * (SF_CSTRIDE - 4)) : "memory"); \
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(3 * (SF_CSTRIDE - 4)) : "memory"); \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
     __syncthreads();                                           // LDS zeroed
     if (grp == 0) {
         // ================= DMA + MFMA waves =================
@@ -4806,7 +4783,7 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             const int krow = min(4 * ks + kq, 20);             // rows 21 .. 23: zero weights, any row
-            kci[ks] = (krow / 7) * 8 * SF_ROWB; kr[ks] = krow % 7;
+            kci[ks] = (krow / 7) * SF_RING * SF_ROWB; kr[ks] = krow % 7;
         }
         int irow[2], icol[2], ichan[2];                        // image DMA (as k_stem_wgrad_bf16_ring)
 #pragma unroll
@@ -4816,6 +4793,8 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
             icol[j] = 4 * (g % SR_GPR);
             ichan[j] = (irow[j] >> 1) * p.H * p.W;
         }
+        SrCursor ci_{0, (int)blockIdx.x, 0, 0, 0, 0}, cc_{0, (int)blockIdx.x, 0, 0, 0, 0};
+        ci_.decode(p, groups, units); cc_.decode(p, groups, units);
 #define SF_ISSUE(C_, ST_)                                                                                         \
         {                                                                                                         \
             const int iv_ = C_.v();                                                                               \
@@ -4826,32 +4805,31 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
                 lds_dma16(iimg_ + off, reinterpret_cast<float*>(stages + (ST_) * SF_STAGE + (cw + 4 * j) * 1024)); \
             }                                                                                                     \
         }
-        for (int s = 0; s < SF_D; ++s) { SF_ISSUE(ci_, s) ci_.advance(p, groups, units); }
-        int stc = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            wait_vmcnt_and_lds<(SF_D - 1) * SF_NDMA>();        // step s has landed; this wave's obuf stores of tile s - 1 are done
-            __builtin_amdgcn_s_barrier();                      // (A)
-            SF_ISSUE(ci_, (stc + SF_D) % SF_NST)
+        // steps 0, 1, 2 are in flight before the first barrier; at the barrier of iteration s (s = -1 .. nsteps) step s + 1 must have landed
+        for (int s = 0; s < SF_NST; ++s) { SF_ISSUE(ci_, s) ci_.advance(p, groups, units); }
+        for (int s = -1; s <= nsteps; ++s) {
+            wait_vmcnt_and_lds<(SF_NST - 2) * SF_NDMA>();      // steps .. s + 1 have landed (s + 2 may be in flight); this wave's obuf stores are done
+            __builtin_amdgcn_s_barrier();
+            if (s < 0 || s >= nsteps) continue;
+            SF_ISSUE(ci_, s % SF_NST)                          // step s + 3 into the stage of step s (committed during iteration s - 1)
             ci_.advance(p, groups, units);
-            const int v = cc_.v(), cox0 = cc_.ox0;
-            const bool has_rows = cc_.has_rows(), has_tile = cc_.has_tile();
+            const int v = cc_.v();
+            const bool has_tile = cc_.has_tile();
             cc_.advance(p, groups, units);
-            const uint32_t st_a = stages_a + (uint32_t)stc * SF_STAGE;
-            stc = stc + 1 == SF_NST ? 0 : stc + 1;
-            if (has_rows) SF_COMMIT(st_a, v, cox0)
-            wait_vmcnt_and_lds<63>();                          // this wave's ring stores are done (lgkmcnt(0); the DMA queue is not waited for)
-            __builtin_amdgcn_s_barrier();                      // (B) the ring holds rows 2 v - 3 .. 2 v + 3
             if (has_tile) {
                 f32x4 acc[2][4];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int slot0 = (2 * v - 3 + 2 * SF_RING) % SF_RING;         // ring slot of image row 2 v - 3
                 // operand reads two k steps ahead of their MFMAs, three rotating register pairs
                 f32x4 b0[3], b1[3];
 #define SF_READ(ks)                                                                                               \
                 {                                                                                                 \
-                    const uint32_t ro = (uint32_t)(kci[ks] + ((2 * v - 3 + kr[ks] + 8) & 7) * SF_ROWB);          \
+                    int sl_ = slot0 + kr[ks];                                                                     \
+                    sl_ = sl_ >= SF_RING ? sl_ - SF_RING : sl_;                                                   \
+                    const uint32_t ro = (uint32_t)(kci[ks] + sl_ * SF_ROWB);                                      \
                     b0[(ks) % 3] = lds_read128_async<0>(bpix[0] + ro);                                            \
                     b1[(ks) % 3] = lds_read128_async<0>(bpix[1] + ro);                                            \
                 }
@@ -4887,48 +4865,76 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
                 }
             }
         }
-        wait_vmcnt_and_lds<0>();
-        __builtin_amdgcn_s_barrier();                          // (A) of the drain step: the last tile's outputs are in obuf
-        __builtin_amdgcn_s_barrier();                          // (B)
 #undef SF_ISSUE
+        wait_vmcnt<0>();
     } else {
-        // ================= output / statistics waves =================
-        // thread t2 of the group: pixel t2 >> 1, channels 32 (t2 & 1) .. + 31 = chunks 4 (t2 & 1) .. + 3 of the pixel's row (swizzled by px & 7)
-        const int t2 = tid - 256, opx = t2 >> 1, half = t2 & 1;
+        // ================= commit / output / statistics waves =================
+        const int t2 = tid - 256, opx = t2 >> 1, half = t2 & 1;   // outputs: pixel t2 >> 1, channels 32 (t2 & 1) .. + 31 = chunks 4 (t2 & 1) .. + 3 of its row
+        int prow6[SF_NPAIR], pcol[SF_NPAIR];                      // commit: pair q = t2 + 256 j of the step's 6 x 132 column pairs
+#pragma unroll
+        for (int j = 0; j < SF_NPAIR; ++j) {
+            const int q = t2 + 256 * j;
+            prow6[j] = q < SF_PAIRS ? q / 132 : -1;
+            pcol[j] = 2 * (q % 132);
+        }
         float ssum[32], ssq[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) ssum[i] = ssq[i] = 0.f;
-        int pv = 0, pcox0 = 0, pb = 0;
-        bool ptile = false;                                    // the previous step's tile (its outputs are in obuf[(s - 1) & 1])
-        for (int s = 0; s <= nsteps; ++s) {
-            wait_vmcnt_and_lds<63>();                          // (this wave's LDS reads of the previous step are done; its stores keep flying)
-            __builtin_amdgcn_s_barrier();                      // (A)
-            int v = 0, cox0 = 0, cb = 0;
-            bool has_rows = false, has_tile = false;
-            if (s < nsteps) {
-                ci_.advance(p, groups, units);                 // (unused cursor: keeps both groups' scalar work alike)
-                v = cc_.v(); cox0 = cc_.ox0; cb = cc_.b; has_rows = cc_.has_rows(); has_tile = cc_.has_tile();
-                cc_.advance(p, groups, units);
+        SrCursor cn_{0, (int)blockIdx.x, 0, 0, 0, 0};             // the step being committed (s + 1)
+        cn_.decode(p, groups, units);
+        // tiles of step s (a*) and of step s - 1 (p*: its outputs are in obuf[(s - 1) & 1]) at the top of iteration s
+        bool atile = false, ptile = false;
+        int av = 0, aox = 0, ab = 0, pv = 0, pox = 0, pb = 0;
+        for (int s = -1; s <= nsteps; ++s) {
+            wait_vmcnt_and_lds<63>();                              // this wave's LDS traffic of the previous iteration is done; its global stores keep flying
+            __builtin_amdgcn_s_barrier();
+            bool ntile = false;
+            int nv = 0, nox = 0, nb = 0;
+            if (s + 1 < nsteps) {
+                // rows of step s + 1 (tile row nv of strip nox) from their stage into the ring: packed pairs, copy c at position col - 2 c
+                // (immediates c * (SF_CSTRIDE - 4); the first columns fall into the pad in front of the row)
+                nv = cn_.v(); nox = cn_.ox0; nb = cn_.b; ntile = cn_.has_tile();
+                const bool rows1 = cn_.has_rows();
+                cn_.advance(p, groups, units);
+                if (rows1) {
+                    const uint32_t st_a = stages_a + (uint32_t)((s + 1) % SF_NST) * SF_STAGE;
+                    uint2 raw[SF_NPAIR];
+#pragma unroll
+                    for (int j = 0; j < SF_NPAIR; ++j)
+                        if (prow6[j] >= 0) asm volatile("ds_read_b64 %0, %1" : "=v"(raw[j]) : "v"(st_a + (uint32_t)(prow6[j] * SR_IMGROW + pcol[j]) * 4) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int sg0 = (2 * nv + 2 + 2 * SF_RING) % SF_RING, sg1 = sg0 + 1 == SF_RING ? 0 : sg0 + 1;
+#pragma unroll
+                    for (int j = 0; j < SF_NPAIR; ++j) {
+                        if (prow6[j] >= 0) {
+                            asm volatile("" : "+v"(raw[j]));
+                            const int row6 = prow6[j], col = pcol[j], ix = 2 * nox - 4 + col;
+                            const bool rowok = (unsigned)(2 * nv + 2 + (row6 & 1)) < (unsigned)p.H;
+                            const uint32_t h0 = (rowok && (unsigned)ix < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].x)) : 0u;
+                            const uint32_t h1 = (rowok && (unsigned)(ix + 1) < (unsigned)p.W) ? f2bf(__builtin_bit_cast(float, raw[j].y)) : 0u;
+                            const uint32_t pk = h0 | (h1 << 16);
+                            const uint32_t dst = lds_a + (uint32_t)(SF_P0 + ((row6 >> 1) * SF_RING + ((row6 & 1) ? sg1 : sg0)) * SF_ROWB + col * 2);
+                            asm volatile("ds_write_b32 %0, %1" :: "v"(dst), "v"(pk) : "memory");
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(1 * (SF_CSTRIDE - 4)) : "memory");
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(2 * (SF_CSTRIDE - 4)) : "memory");
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(dst), "v"(pk), "n"(3 * (SF_CSTRIDE - 4)) : "memory");
+                        }
+                    }
+                }
             }
-            const uint32_t st_a = stages_a + (uint32_t)(s % SF_NST) * SF_STAGE;
-            if (has_rows) SF_COMMIT(st_a, v, cox0)
-            wait_vmcnt_and_lds<63>();
-            __builtin_amdgcn_s_barrier();                      // (B)
             if (ptile) {
                 const uint32_t ob = obuf_a + (uint32_t)((s - 1) & 1) * SF_OBUF + opx * 128;
                 f32x4 qf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) qf[i] = lds_read128_async<0>(ob + ((((4 * half + i) ^ (opx & 7))) << 4));
                 SD_LDS_WAIT4(0, qf[0], qf[1], qf[2], qf[3]);
-                uint4 q[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q[i] = __builtin_bit_cast(uint4, qf[i]);
-                if (pcox0 + opx < p.Wo) {
-                    uint4* yp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + ((((int64_t)pb * p.Ho + pv) * p.Wo + pcox0 + opx) * 64 + 32 * half));
+                if (pox + opx < p.Wo) {
+                    uint4* yp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + ((((int64_t)pb * p.Ho + pv) * p.Wo + pox + opx) * 64 + 32 * half));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        yp[i] = q[i];
-                        const uint32_t wd[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+                        const uint4 q = __builtin_bit_cast(uint4, qf[i]);
+                        if (SD_SF_ABL != 1) yp[i] = q;
+                        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float f0 = bf2f((uint16_t)(wd[k] & 0xffff)), f1 = bf2f((uint16_t)(wd[k] >> 16));
@@ -4938,21 +4944,20 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
                     }
                 }
             }
-            ptile = has_tile; pv = v; pcox0 = cox0; pb = cb;
+            ptile = atile; pv = av; pox = aox; pb = ab;
+            atile = ntile; av = nv; aox = nox; ab = nb;
         }
-        // statistics: the 32 pixel lanes of a wave that share a channel half (lane parity), then the four waves -- fixed order.
-        // Channel of a register: 32 half + 16 (i >> 1 ... see the compute group's packing: chunk c = 2 kq + h holds channels 16 kq + 8 h .. + 7
+        // statistics: the 32 pixel lanes of a wave that share a channel half (lane parity), then the four waves -- fixed order
 #pragma unroll
         for (int i = 0; i < 32; ++i)
 #pragma unroll
             for (int o = 2; o < 64; o <<= 1) { ssum[i] += __shfl_xor(ssum[i], o); ssq[i] += __shfl_xor(ssq[i], o); }
-        float* R = lds;                                        // [wave][2][64] (the ring is dead: every wave is past its last read)
+        float* R = lds;                                            // [wave][2][64] (the ring is dead: every wave is past its last read)
         if (lane < 2) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) { R[cw * 128 + 32 * half + i] = ssum[i]; R[cw * 128 + 64 + 32 * half + i] = ssq[i]; }
         }
     }
-#undef SF_COMMIT
     __syncthreads();
     const float* R = lds;
     if (tid < 128 && p.stat) p.stat[(int64_t)blockIdx.x * 128 + tid] = ((R[tid] + R[128 + tid]) + R[256 + tid]) + R[384 + tid];
