@@ -4869,7 +4869,9 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
         wait_vmcnt<0>();
     } else {
         // ================= commit / output / statistics waves =================
-        const int t2 = tid - 256, opx = t2 >> 1, half = t2 & 1;   // outputs: pixel t2 >> 1, channels 32 (t2 & 1) .. + 31 = chunks 4 (t2 & 1) .. + 3 of its row
+        // outputs: store i of a tile covers its bytes 4096 i .. + 4095, thread t2 the 16 bytes at 16 t2 of them (whole 128-byte lines per store
+        // instruction; four 16-byte stores of ONE pixel per thread -- lines completed over four instructions -- ran at 2.3 TB/s): pixel 32 i + (t2 >> 3), channels 8 (t2 & 7) .. + 7
+        const int t2 = tid - 256, opx0 = t2 >> 3, och = t2 & 7;
         int prow6[SF_NPAIR], pcol[SF_NPAIR];                      // commit: pair q = t2 + 256 j of the step's 6 x 132 column pairs
 #pragma unroll
         for (int j = 0; j < SF_NPAIR; ++j) {
@@ -4877,9 +4879,9 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
             prow6[j] = q < SF_PAIRS ? q / 132 : -1;
             pcol[j] = 2 * (q % 132);
         }
-        float ssum[32], ssq[32];
+        float ssum[8], ssq[8];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) ssum[i] = ssq[i] = 0.f;
+        for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
         SrCursor cn_{0, (int)blockIdx.x, 0, 0, 0, 0};             // the step being committed (s + 1)
         cn_.decode(p, groups, units);
         // tiles of step s (a*) and of step s - 1 (p*: its outputs are in obuf[(s - 1) & 1]) at the top of iteration s
@@ -4923,23 +4925,26 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
                 }
             }
             if (ptile) {
-                const uint32_t ob = obuf_a + (uint32_t)((s - 1) & 1) * SF_OBUF + opx * 128;
+                const uint32_t ob = obuf_a + (uint32_t)((s - 1) & 1) * SF_OBUF;
                 f32x4 qf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qf[i] = lds_read128_async<0>(ob + ((((4 * half + i) ^ (opx & 7))) << 4));
+                for (int i = 0; i < 4; ++i) {
+                    const int px = 32 * i + opx0;
+                    qf[i] = lds_read128_async<0>(ob + (uint32_t)(px * 128 + ((och ^ (px & 7)) << 4)));
+                }
                 SD_LDS_WAIT4(0, qf[0], qf[1], qf[2], qf[3]);
-                if (pox + opx < p.Wo) {
-                    uint4* yp = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + ((((int64_t)pb * p.Ho + pv) * p.Wo + pox + opx) * 64 + 32 * half));
+                uint4* const yrow = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + (((int64_t)pb * p.Ho + pv) * p.Wo + pox) * 64) + t2;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) {
+                    if (pox + 32 * i + opx0 < p.Wo) {
                         const uint4 q = __builtin_bit_cast(uint4, qf[i]);
-                        if (SD_SF_ABL != 1) yp[i] = q;
+                        if (SD_SF_ABL != 1) yrow[256 * i] = q;
                         const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float f0 = bf2f((uint16_t)(wd[k] & 0xffff)), f1 = bf2f((uint16_t)(wd[k] >> 16));
-                            ssum[8 * i + 2 * k] += f0; ssq[8 * i + 2 * k] += f0 * f0;
-                            ssum[8 * i + 2 * k + 1] += f1; ssq[8 * i + 2 * k + 1] += f1 * f1;
+                            ssum[2 * k] += f0; ssq[2 * k] += f0 * f0;
+                            ssum[2 * k + 1] += f1; ssq[2 * k + 1] += f1 * f1;
                         }
                     }
                 }
@@ -4947,15 +4952,15 @@ __global__ __launch_bounds__(512, 1) void k_stem_fwd_bf16_ring(StemArgs p) {
             ptile = atile; pv = av; pox = aox; pb = ab;
             atile = ntile; av = nv; aox = nox; ab = nb;
         }
-        // statistics: the 32 pixel lanes of a wave that share a channel half (lane parity), then the four waves -- fixed order
+        // statistics: the 8 lanes of a wave that share a channel group (lane & 7), then the four waves -- fixed order
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int o = 2; o < 64; o <<= 1) { ssum[i] += __shfl_xor(ssum[i], o); ssq[i] += __shfl_xor(ssq[i], o); }
+            for (int o = 8; o < 64; o <<= 1) { ssum[i] += __shfl_xor(ssum[i], o); ssq[i] += __shfl_xor(ssq[i], o); }
         float* R = lds;                                            // [wave][2][64] (the ring is dead: every wave is past its last read)
-        if (lane < 2) {
+        if (lane < 8) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { R[cw * 128 + 32 * half + i] = ssum[i]; R[cw * 128 + 64 + 32 * half + i] = ssq[i]; }
+            for (int i = 0; i < 8; ++i) { R[cw * 128 + 8 * och + i] = ssum[i]; R[cw * 128 + 64 + 8 * och + i] = ssq[i]; }
         }
     }
     __syncthreads();
