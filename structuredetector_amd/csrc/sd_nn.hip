@@ -120,20 +120,22 @@ __global__ __launch_bounds__(256) void k_col_finalize(const float* __restrict__ 
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
         double t0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int b = lr;
-        for (; b + 64 * 7 < nblocks; b += 64 * 8) {
+        // eight rows in flight per lane and trip, the last trip's missing rows read row 0 and add nothing (no serial tail: with 128-512 partial
+        // rows -- most layers -- the pass used to be two to seven dependent round trips)
+        for (int b = lr; b < nblocks; b += 64 * 8) {
             float v0[8], v1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                v0[u] = partial[(int64_t)(b + 64 * u) * 2 * C + c];
-                v1[u] = partial[(int64_t)(b + 64 * u) * 2 * C + C + c];
+                const int row = b + 64 * u;
+                const int64_t o = (int64_t)(row < nblocks ? row : 0) * 2 * C + c;
+                v0[u] = partial[o];
+                v1[u] = partial[o + C];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { t0[u] += (double)v0[u]; t1[u] += (double)v1[u]; }
-        }
-        for (; b < nblocks; b += 64) {
-            t0[0] += (double)partial[(int64_t)b * 2 * C + c];
-            t1[0] += (double)partial[(int64_t)b * 2 * C + C + c];
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = b + 64 * u < nblocks;
+                t0[u] += ok ? (double)v0[u] : 0.0; t1[u] += ok ? (double)v1[u] : 0.0;
+            }
         }
         s0 = ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t0[4] + t0[5]) + (t0[6] + t0[7]));
         s1 = ((t1[0] + t1[1]) + (t1[2] + t1[3])) + ((t1[4] + t1[5]) + (t1[6] + t1[7]));
