@@ -26,3 +26,9 @@ t = timed(lambda: a.fill_(1.0)); print(f"fill (write only)   {t * 1e3:8.1f} us  
 t = timed(lambda: a.sum());     print(f"sum (read only)     {t * 1e3:8.1f} us  {gb / t:6.2f} TB/s read")
 t = timed(lambda: b.copy_(a));  print(f"copy (read + write) {t * 1e3:8.1f} us  {2 * gb / t:6.2f} TB/s total")
 t = timed(lambda: torch.add(a, 1.0, out=b)); print(f"add scalar (r + w)  {t * 1e3:8.1f} us  {2 * gb / t:6.2f} TB/s total")
+# three streams, bf16 (the shape of a BatchNorm backward apply pass: two reads, one write, 16 bytes per lane)
+n2 = 1 << 28
+x16 = torch.empty(n2, device=dev, dtype=torch.bfloat16); y16 = torch.empty_like(x16); z16 = torch.empty_like(x16)
+t = timed(lambda: torch.mul(x16, y16, out=z16)); print(f"mul bf16 (2 r + 1 w) {t * 1e3:8.1f} us  {3 * n2 * 2 / 1e9 / t:6.2f} TB/s total")
+x32 = torch.empty(n2 // 2, device=dev); y32 = torch.empty_like(x32); z32 = torch.empty_like(x32)
+t = timed(lambda: torch.mul(x32, y32, out=z32)); print(f"mul fp32 (2 r + 1 w) {t * 1e3:8.1f} us  {3 * (n2 // 2) * 4 / 1e9 / t:6.2f} TB/s total")
