@@ -12,6 +12,7 @@ expected outputs, data only).  Version skew: reference pins torch 2.5.1, this
 container runs the torch recorded in each file's ``meta``.
 """
 import json
+import re
 import sys
 import types
 from argparse import Namespace
@@ -466,10 +467,84 @@ def gen_small_utils(rng):
     np.savez_compressed(HERE / "small_utils.npz", **out)
 
 
+def hf_to_oracle_key(k):
+    """HF `ResNetModel` state_dict key -> the key of the same tensor in the reference's `Network` (`network.py:43-50`: `adpater` =
+    conv1 / bn1 / relu / maxpool, `down1..4` = layer1..4 of torchvision's resnet34)."""
+    part = {"convolution": None, "normalization": None}
+    if k.startswith("embedder.embedder."):
+        kind, leaf = k[len("embedder.embedder."):].split(".", 1)
+        return f"adpater.{0 if kind == 'convolution' else 1}.{leaf}"
+    s, l, rest = re.match(r"encoder\.stages\.(\d+)\.layers\.(\d+)\.(.*)", k).groups()
+    base = f"down{int(s) + 1}.{l}."
+    if rest.startswith("shortcut."):
+        kind, leaf = rest[len("shortcut."):].split(".", 1)
+        return base + f"downsample.{0 if kind == 'convolution' else 1}.{leaf}"
+    i, kind, leaf = re.match(r"layer\.(\d)\.(\w+)\.(.*)", rest).groups()
+    return base + (f"conv{int(i) + 1}." if kind == "convolution" else f"bn{int(i) + 1}.") + leaf
+
+
+def gen_resnet34_second_source():
+    """An INDEPENDENT published port of torchvision's ResNet-34 as the second source for the trunk the reference takes from torchvision
+    (`network.py:3,41,43-50`; torchvision itself is absent from this container): Hugging Face `transformers`' `ResNetModel` with
+    `layer_type="basic"`, depths [3,4,6,3], widths [64,128,256,512] -- 21 284 672 parameters, torchvision's count without the fc layer.
+    Weights come from `oracle.build_reference_network(seed)` (so the test can rebuild them from the seed) plus non-trivial running
+    statistics, loaded INTO the HF model through `hf_to_oracle_key`; the fixture holds what the HF model computes."""
+    import hashlib
+    stubs = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] == "torchvision"}   # transformers probes for torchvision
+    try:
+        import transformers
+        from transformers import ResNetConfig, ResNetModel
+    finally:
+        sys.modules.update(stubs)
+    seed = 34
+    onet = O.build_reference_network(2, 1, seed=seed)
+    osd = onet.state_dict()
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sorted(osd):
+        if k.endswith("running_mean"):
+            osd[k].copy_(0.2 * torch.randn(osd[k].shape, generator=g))
+        elif k.endswith("running_var"):
+            osd[k].copy_(0.5 + torch.rand(osd[k].shape, generator=g))
+    hf = ResNetModel(ResNetConfig(layer_type="basic", depths=[3, 4, 6, 3], hidden_sizes=[64, 128, 256, 512], embedding_size=64))
+    assert sum(p.numel() for p in hf.parameters()) == 21_284_672
+    hsd = hf.state_dict()
+    mapped = {k: osd[hf_to_oracle_key(k)].clone() for k in hsd}
+    trunk = {k for k in osd if k.startswith(("adpater.", "down"))}
+    assert {hf_to_oracle_key(k) for k in hsd} == trunk, "the HF trunk and the reference's trunk keys are not in bijection"
+    assert all(hsd[k].shape == mapped[k].shape for k in hsd)
+    hf.load_state_dict(mapped, strict=True)
+    h = hashlib.sha256()
+    for k in sorted(trunk):
+        h.update(k.encode()); h.update(osd[k].numpy().tobytes())
+    x = torch.randn(2, 3, 96, 128, generator=torch.Generator().manual_seed(seed + 2))
+    out = {"meta": np.array(json.dumps({"torch": torch.__version__, "transformers": transformers.__version__, "seed": seed,
+                                        "source": "transformers.ResNetModel(layer_type=basic, depths=[3,4,6,3])"})),
+           "seed": np.array(seed), "x": x.numpy(), "trunk_sha256": np.array(h.hexdigest())}
+    hf.eval()
+    with torch.no_grad():
+        hs = hf(x, output_hidden_states=True).hidden_states
+    assert len(hs) == 5
+    for i, t in enumerate(hs):
+        out[f"eval_stage{i}"] = t.numpy()                              # 0 = stem + max-pool, 1..4 = layer1..4
+    hf.train()
+    with torch.no_grad():
+        hs = hf(x, output_hidden_states=True).hidden_states
+    for i, t in enumerate(hs):
+        out[f"train_stage{i}"] = t.numpy()
+    for k, v in hf.state_dict().items():                               # running statistics after ONE training-mode forward
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            out["after." + hf_to_oracle_key(k)] = v.numpy()
+    np.savez_compressed(HERE / "resnet34_second_source.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "small_utils":          # one new fixture without touching the others
         gen_small_utils(np.random.default_rng(5))
         print("small_utils.npz written to", HERE)
+        raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet34_second_source":
+        gen_resnet34_second_source()
+        print("resnet34_second_source.npz written to", HERE)
         raise SystemExit(0)
     rng = np.random.default_rng(20261003)
     gen_prims(rng)
@@ -482,4 +557,5 @@ if __name__ == "__main__":
     gen_annotation_transforms(np.random.default_rng(31))
     gen_evaluate16()
     gen_small_utils(np.random.default_rng(5))
+    gen_resnet34_second_source()
     print("goldens written to", HERE)

@@ -242,6 +242,54 @@ def test_torchvision_boundary_structural_pin():
             cin = c
 
 
+def test_resnet34_trunk_against_independent_published_port(golden_dir):
+    """a4 second source (src/sdnet/model/network.py:3,41,43-50): torchvision is absent, but Hugging Face `transformers`' `ResNetModel`
+    (`layer_type="basic"`, depths [3,4,6,3], 21 284 672 parameters = torchvision's resnet34 without fc) is an independent published port
+    of the same network.  `tests/golden/gen_goldens.py::gen_resnet34_second_source` loaded the seeded oracle weights INTO that model and
+    recorded what IT computes: the stem + max-pool output and the four stage outputs in eval and in training mode, and every running
+    statistic after one training-mode forward.  The oracle's restated trunk must reproduce them: unpinned at torchvision itself,
+    cross-checked against an independent port."""
+    import hashlib
+    g = np.load(golden_dir / "resnet34_second_source.npz")
+    seed = int(g["seed"])
+    net = O.build_reference_network(2, 1, seed=seed)
+    sd = net.state_dict()
+    gen = torch.Generator().manual_seed(seed + 1)
+    for k in sorted(sd):                                                 # the generator's non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k].copy_(0.2 * torch.randn(sd[k].shape, generator=gen))
+        elif k.endswith("running_var"):
+            sd[k].copy_(0.5 + torch.rand(sd[k].shape, generator=gen))
+    h = hashlib.sha256()
+    for k in sorted(k for k in sd if k.startswith(("adpater.", "down"))):
+        h.update(k.encode()); h.update(sd[k].numpy().tobytes())
+    assert h.hexdigest() == str(g["trunk_sha256"]), "seeded weights differ from the ones the fixture was generated with"
+    x = torch.from_numpy(g["x"])
+
+    def stages(n):
+        out = [n.adpater(x)]
+        for layer in (n.down1, n.down2, n.down3, n.down4):
+            out.append(layer(out[-1]))
+        return out
+
+    for mode in ("eval", "train"):                                       # eval first: the training-mode pass updates the statistics
+        net.train(mode == "train")
+        with torch.no_grad():
+            got = stages(net)
+        for i, t in enumerate(got):
+            want = g[f"{mode}_stage{i}"]
+            assert t.shape == want.shape
+            scale = np.abs(want).max()
+            np.testing.assert_allclose(t.numpy(), want, rtol=0, atol=1e-5 * scale, err_msg=f"{mode} stage {i}")
+    n_stats = 0
+    for k, v in net.state_dict().items():
+        if k.startswith(("adpater.", "down")) and k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            want = g["after." + k]
+            np.testing.assert_allclose(v.numpy(), want, rtol=1e-5, atol=1e-6, err_msg=k)
+            n_stats += 1
+    assert n_stats == 36 * 3                                             # 1 stem + 32 block + 3 downsample BatchNorms
+
+
 SCHEMA_SHA256 = "df09e4ae27bca73d31fff2e2feb03c3a78219894d27e89d6d351cedad0b717cc"   # 244 entries, M=2, N=1, fpn_depth=128
 
 
