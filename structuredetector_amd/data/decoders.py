@@ -30,10 +30,13 @@ class Decoder:
         self.selector_timeouts = 0       # sd_decode_fused calls that were redone by the two-launch decoder (a tile block was delayed)
 
     # ------------------------------------------------------------------ device stage
-    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None):
+    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None, state_out=None):
         """Run the device stage; returns (packed int32 device buffer, (B, K, P, h, w)).
         exact_topk=False drops peaks with score < fp32(conf) before the selection: same annotations, fewer candidates.
-        fused: None = one-launch sd_decode_fused whenever K, P allow it; False = the two-launch sd_decode (bit-identical)."""
+        fused: None = one-launch sd_decode_fused whenever K, P allow it; False = the two-launch sd_decode (bit-identical).
+        state_out: a list; when given and the one-launch kernel runs, it runs on a hand-off state buffer of ITS OWN taken from this
+        decoder's free list and appended to the list (the caller gives it back with `_release_state`): a decode whose status has not
+        been read yet must not share its records with the next launch (`submit`)."""
         a, a_p, a_sb, a_sc = L.map_view(outputs["anchor_hm"])
         p, p_p, p_sb, p_sc = L.map_view(outputs["part_hm"])
         o, o_p, o_sb, o_sc = L.map_view(outputs["offsets"])
@@ -53,7 +56,12 @@ class Decoder:
             fused = bool(lib.sd_decode_fused_recommended(B, M, N, h, w, K, P, int(exact_topk)))
         if fused:
             ws = L.workspace(lib.sd_decode_fused_workspace_bytes(B, M, N, h, w, K, P), a.device)
-            state = self._fused_state(a.device, lib.sd_decode_state_bytes(B, M, N, h, w))
+            need = lib.sd_decode_state_bytes(B, M, N, h, w)
+            if state_out is None:
+                state = self._fused_state(a.device, need)
+            else:
+                state = self._acquire_state(a.device, need)
+                state_out.append(state)
             try:
                 L.check(lib.sd_decode_fused(a_p, a_sb, a_sc, p_p, p_sb, p_sc, o_p, o_sb, o_sc, e_p, e_sb, e_sc, B, M, N, h, w, K, P,
                                             conf32, dist32, int(bool(exact_topk)) | force, packed.data_ptr(), state.data_ptr(), state.numel(),
@@ -75,6 +83,24 @@ class Decoder:
             buf = torch.zeros(max(need, 1 << 14), dtype=torch.uint8, device=device)
             self._state[key] = buf
         return buf
+
+    def _acquire_state(self, device, need):
+        """A zeroed hand-off state buffer owned by ONE in-flight `submit` (ring of as many buffers as there are submissions in flight):
+        sd_decode_fused leaves its state zero only when every selector met its tiles; a timed-out call leaves a late tile's record
+        behind, and that record is self-validating -- the NEXT launch on the same buffer would accept it.  The synchronous `__call__`
+        reads the status and re-zeroes before its next launch; a queued submission cannot, so it gets its own buffer."""
+        key = (device.index if device.index is not None else torch.cuda.current_device(), L.stream())
+        free = self.__dict__.setdefault("_state_free", {}).setdefault(key, [])
+        for i, buf in enumerate(free):
+            if buf.numel() >= need:
+                return free.pop(i)
+        return torch.zeros(max(need, 1 << 14), dtype=torch.uint8, device=device)
+
+    def _release_state(self, state, key, failed):
+        """Back to the free list; after a failed call (caller has synchronised the stream) the buffer is re-zeroed first."""
+        if failed:
+            state.zero_()
+        self.__dict__.setdefault("_state_free", {}).setdefault(key, []).append(state)
 
     @staticmethod
     def split_packed(packed, B, K, P):
@@ -225,12 +251,16 @@ class Decoder:
         batched caller (`evaluate`, validation, `detect`) queue the next batch's forward + decode before it assembles this one."""
         conf_thresh = conf_thresh if conf_thresh is not None else self.args.conf_threshold
         dist_thresh = dist_thresh if dist_thresh is not None else self.args.decoder_dist_thresh
-        packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=with_raw_parts)
+        states = []
+        packed, (B, K, P, out_h, out_w) = self.decode_packed(outputs, conf_thresh, dist_thresh, exact_topk=with_raw_parts, state_out=states)
         buf = self._pinned(packed.numel(), packed.dtype)
         buf.copy_(packed, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(packed.device))
-        return PendingDecode(self, outputs, packed, buf, done, (B, K, P, out_h, out_w), conf_thresh, dist_thresh, with_raw_parts)
+        dev = packed.device
+        state_key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream())
+        return PendingDecode(self, outputs, packed, buf, done, (B, K, P, out_h, out_w), conf_thresh, dist_thresh, with_raw_parts,
+                             states[0] if states else None, state_key)
 
     def __call__(self, outputs, conf_thresh=None, dist_thresh=None, return_metadata=False, metadata_fields=None):
         """decoders.py:29-179.  `metadata_fields` (extension, default None = the reference's full metadata dict): the keys a caller of
@@ -274,17 +304,23 @@ class Decoder:
 class PendingDecode:
     """A decode in flight (`Decoder.submit`): device buffer, pinned host copy, the event after which the copy is complete."""
 
-    def __init__(self, decoder, outputs, packed, host, done, dims, conf_thresh, dist_thresh, want_raw):
+    def __init__(self, decoder, outputs, packed, host, done, dims, conf_thresh, dist_thresh, want_raw, state=None, state_key=None):
         self.decoder, self.outputs, self.packed, self.host, self.done = decoder, outputs, packed, host, done
         self.dims, self.conf_thresh, self.dist_thresh, self.want_raw = dims, conf_thresh, dist_thresh, want_raw
+        self.state, self.state_key = state, state_key      # the one-launch kernel's hand-off records: this submission's own buffer
 
     def result(self):
         dec = self.decoder
         B, K, P, out_h, out_w = self.dims
         self.done.synchronize()
         host = dec.split_packed(self.host.numpy(), B, K, P)
-        if host["status"].any():
+        failed = bool(host["status"].any())
+        if failed:
             torch.cuda.current_stream(self.packed.device).synchronize()
+        if self.state is not None:
+            dec._release_state(self.state, self.state_key, failed)       # a late tile's record may still sit in it: re-zeroed
+            self.state = None
+        if failed:
             _, host = dec._redo_two_launch(self.outputs, self.conf_thresh, self.dist_thresh, self.want_raw, self.packed.device)
         out = dec._assemble(host, B, out_h, out_w, self.conf_thresh, self.want_raw)
         dec._host_pool[(self.host.numel(), self.host.dtype)].append(self.host)        # values were copied into Python objects
@@ -322,7 +358,7 @@ class FusedOutputDecoder(Decoder):
     src/sdnet/data/decoders.py:182-342): top-k directly on the already suppressed heatmaps (`sd_topk`), then the same gather +
     association kernel (`sd_decode_group`) and the same host assembly as `Decoder`."""
 
-    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None):
+    def decode_packed(self, outputs, conf_thresh, dist_thresh, exact_topk=True, fused=None, state_out=None):
         from ..utils.ops import topk
         a_s, a_i, a_c, _, _ = topk(outputs["anchor_hm"], self.max_objects)
         p_s, p_i, p_c, _, _ = topk(outputs["part_hm"], self.max_parts)

@@ -504,10 +504,16 @@ class _Engine:
             if fpn is net.up4 and self.fuse_head and self._head_fusable(B, Hs, Ws, fpn.conv[0], hc):
                 # network.py:17-18 + 22-29 in one launch where the conv takes the two-group kernel: the FPN output is never stored
                 dl = _desc(B, Hs, Ws, fpn.conv[0])
-                if True:
-                    L.check(lib.sd_conv2d_fwd_bf16_head(t.data_ptr(), self._w_bf16(fpn.conv[0]).data_ptr(), C.byref(dl), sf.data_ptr(), hf.data_ptr(), 1,
-                                                        self._head_prepared(hc).data_ptr(), hc.cout, out.data_ptr(), L.stream()), "sd_conv2d_fwd_bf16_head")
+                rc = lib.sd_conv2d_fwd_bf16_head(t.data_ptr(), self._w_bf16(fpn.conv[0]).data_ptr(), C.byref(dl), sf.data_ptr(), hf.data_ptr(), 1,
+                                                 self._head_prepared(hc).data_ptr(), hc.cout, out.data_ptr(), L.stream())
+                if rc == 0:
                     return out
+                if rc > 0:
+                    L.check(rc, "sd_conv2d_fwd_bf16_head")
+                # rc < 0 = "geometry not served" BEFORE any launch: the remembered answer was taken under other thread-local dispatch
+                # options (`conv_pp_min_tiles`, `conv_pp_strips`, `conv_fwd_split_k` change what the two-group kernel takes).  Forget
+                # it and run conv + head as two launches.
+                self._head_ok.pop((B, Hs, Ws, hc.cout), None)
             f, _ = self.conv_bf16(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True)
         L.check(lib.sd_head_fwd_bf16(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
                                      L.stream()), "sd_head_fwd_bf16")

@@ -75,8 +75,9 @@ class Predictor(torch.nn.Module):
         from ..data import Decoder
         from .network import Network
         self.args = args
+        assert getattr(args, "pretrained_model", None), "No pretrained model specified. Use the option '--load_model <model_path>'."   # cli/evaluate.py:14-16
         self.model = Network(args, pretrained=False, init_weights=False)          # every tensor comes from the checkpoint (predictor.py:13-16)
-        self.model.load_state_dict(torch.load(args.pretrained_model, map_location="cpu", weights_only=True))
+        self.model.load_state_dict(torch.load(args.pretrained_model, map_location="cpu", weights_only=True), strict=True)
         self.model.eval().to(args.device)
         self.decoder = Decoder(args)
 

@@ -399,6 +399,14 @@ class Trainer:
         return self._writer
 
     def train(self):
+        try:
+            self._train()
+        finally:                                                       # the TensorBoard event file and scalars.jsonl are closed with the run
+            if self._writer is not None:
+                self._writer.close()
+                self._writer = None
+
+    def _train(self):
         steps = 0
         for epoch in range(self.start_epoch, self.args.epochs):
             self.epoch = epoch

@@ -572,6 +572,46 @@ def test_fused_decoder_limits_and_fallback():
         dec.decode_packed(head_views(head, 1, 1), 0.5, 0.1, fused=True)
 
 
+def test_queued_decodes_own_their_hand_off_state():
+    """`Decoder.submit` keeps decodes in flight whose status nobody has read yet.  sd_decode_fused's hand-off records are self-validating, so a
+    record left behind by a timed-out call would be accepted by the NEXT launch on the same state buffer: every queued submission therefore
+    runs on a state buffer of its own, and a failed one is re-zeroed before it is reused.  Checked: two submissions in flight hold distinct
+    buffers; a submission whose status word is made non-zero (the GPU cannot be made to time out on demand) goes through the two-launch
+    redo, its -- deliberately dirtied -- buffer comes back ZERO, the other submission's result is untouched, and both results equal the
+    synchronous call's."""
+    from structuredetector_amd.data import Decoder
+    M, N, K, P = 2, 1, 20, 40
+    rng = np.random.default_rng(3)
+    args = make_args(M, N, K, P, device=torch.device(DEV))
+    scenes = [O.synthetic_scene(rng, 512, 512, M, N, 4, 9) for _ in range(8)]
+    enc = [O.encode(512, 512, s, M, N, K, P, 4.0, 0.1) for s in scenes]
+    heads = [dev(np.stack([O.head_from_targets(rng, e, M, N, noise=0.05) for e in enc[i:i + 4]])) for i in (0, 4)]
+    dec = Decoder(args)
+    want = [dec(head_views(h, M, N)) for h in heads]
+    first = dec.submit(head_views(heads[0], M, N))
+    second = dec.submit(head_views(heads[1], M, N))
+    assert first.state is not None and second.state is not None, "bs = 4 at the cfg shape is served by the one-launch kernel"
+    assert first.state.data_ptr() != second.state.data_ptr()
+    second_ptr = second.state.data_ptr()
+    torch.cuda.synchronize()
+    assert int(first.state.count_nonzero()) == 0 and int(second.state.count_nonzero()) == 0      # left zero by a successful call
+    first.state[100:164] = 0xA5                                         # what a late tile block of a timed-out call leaves behind
+    first.host.numpy()[-4] = 1                                          # status word of image 0: "selector gave up"
+    dirty = first.state
+    got0, _ = first.result()
+    assert dec.selector_timeouts == 1
+    assert int(dirty.count_nonzero()) == 0, "the failed submission's state buffer must be re-zeroed before it is reused"
+    got1, _ = second.result()
+    assert dec.selector_timeouts == 1
+    for got, exp in ((got0, want[0]), (got1, want[1])):
+        assert [repr(a) for a in got] == [repr(a) for a in exp]
+    third = dec.submit(head_views(heads[0], M, N))                      # the ring is reused, not grown
+    assert third.state.data_ptr() in (dirty.data_ptr(), second_ptr)
+    got2, _ = third.result()
+    assert [repr(a) for a in got2] == [repr(a) for a in want[0]]
+    assert sum(len(v) for v in dec._state_free.values()) == 2
+
+
 # ------------------------------------------------------------------------------------------ empty and ragged inputs
 @pytest.mark.parametrize("hm_fn", ["mse", "focal"])
 def test_empty_and_ragged_batch_encode_loss_decode_vs_oracle(hm_fn):
