@@ -530,6 +530,18 @@ int sd_allreduce_init(const void* id, int rank, int world, void** comm_out);
 int sd_allreduce_run(void* comm, float* buf, int64_t count, sd_stream_t stream);
 int sd_allreduce_destroy(void* comm);
 
+/* ---- profiler ranges (no reference counterpart: SURVEY.md section 5 lists tracing as absent from the reference) ----
+ * roctx ranges on the calling thread, for `rocprofv3 --marker-trace`.  Active only when the environment holds SDNET_ROCTX=1 at the
+ * first call AND a marker library (librocprofiler-sdk-roctx / libroctx64) can be dlopen'ed; otherwise every call is a no-op returning 0.
+ * sd_range_enabled: 1 when ranges are recorded.  sd_range_library: the soname that was loaded ("" when disabled).
+ * The host mirror (structuredetector_amd/utils/trace.py) brackets target rendering, the forward stages, the loss, the backward stages,
+ * every gradient bucket and the Adam launch of `TrainStep` with them. */
+int         sd_range_enabled(void);
+const char* sd_range_library(void);
+int         sd_range_push(const char* name);
+int         sd_range_pop(void);
+int         sd_range_mark(const char* name);
+
 #ifdef __cplusplus
 }
 #endif

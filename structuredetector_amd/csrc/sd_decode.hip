@@ -1878,7 +1878,7 @@ struct PeaksWs {
 };
 static PeaksWs carve(void* ws, int B, int C0, int C1, int h, int w) {
     PeaksWs r;
-    char* p = reinterpret_cast<char*>(ws);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(ws);   // integer arithmetic: the size queries carve a null base (pointer + offset on null is UB)
     size_t off = 0;
     r.counters = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * 2 * CNT_STRIDE * sizeof(int), 256);
     r.cand0 = reinterpret_cast<uint64_t*>(p + off);    off += align_up((size_t)B * C0 * h * w * 8, 256);
@@ -1994,7 +1994,7 @@ struct MapWs {
 };
 static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int P) {
     MapWs r;
-    char* p = reinterpret_cast<char*>(ws);
+    const uintptr_t p = reinterpret_cast<uintptr_t>(ws);   // integer arithmetic: size queries carve a null base
     const size_t tiles = (size_t)cdiv(w, TW) * cdiv(h, th);
     size_t off = 0;
     r.cand = reinterpret_cast<uint64_t*>(p + off);     off += align_up((size_t)B * C * tiles * TW * th * 8, 256);

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from ..utils import trace as T
 from ..utils.misc import clip_annotation
 
 
@@ -130,7 +131,8 @@ class Encode:
         }
 
     def render(self, plan, device=None):
-        return self.render_device(self.upload(plan, device))
+        with T.span("render_targets"):
+            return self.render_device(self.upload(plan, device))
 
     def batch(self, img_size, annotations, device=None):
         """Collated targets (the dict CropDataset.collate_fn would build, dataset.py:58-87) for a list of

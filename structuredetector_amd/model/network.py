@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ..utils import trace as T
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -316,6 +317,7 @@ class _Engine:
         rec = tape is not None
 
         # stem: conv7x7/2 + BN + ReLU + maxpool3x3/2 (network.py:43-45)
+        T.push("fwd:stem")
         stem, bn0 = net.adpater[0], net.adpater[1]
         d0 = _desc(B, H, W, stem)
         # mixed precision: the stem's conv output and pooled map are bf16 too (even maps: the quad form of the tail's backward); BatchNorm
@@ -352,10 +354,12 @@ class _Engine:
         if amp and not amp_stem:
             p1 = self._to_bf16(p1)          # (odd maps: fp32 stem tail) everything behind the max-pool is bf16
 
+        T.pop()
         # trunk (network.py:47-50)
         feats, cur, Hc, Wc = [], p1, Hp, Wp
         blocks_tape = []
-        for layer in (net.down1, net.down2, net.down3, net.down4):
+        for li, layer in enumerate((net.down1, net.down2, net.down3, net.down4), start=1):
+            T.push(f"fwd:down{li}")
             for blk in layer:
                 if training:
                     c1, d1, st1 = self.conv_stats(cur, blk.conv1, B, Hc, Wc, blk.bn1, amp=amp)
@@ -382,9 +386,11 @@ class _Engine:
                     out, _ = self.conv(a1, blk.conv2, B, d1.Ho, d1.Wo, scale=s2, shift=h2, res=idt, relu=True, sb=True)
                 cur, Hc, Wc = out, d1.Ho, d1.Wo
             feats.append((cur, Hc, Wc))
+            T.pop()
         (p2, H2, W2), (p3, H3, W3), (p4, H4, W4), (p5, H5, W5) = feats
 
         # FPN (network.py:52-55,6-19): lateral 1x1 (+bias) with the x2-upsampled coarser map added in the epilogue
+        T.push("fwd:fpn")
         f, _ = self.conv(p5, net.up1, B, H5, W5, shift=net.up1.bias, amp=amp, sb=not training)
         fpn_tape = []
         for fpn, (sc_t, Hs, Ws) in ((net.up2, (p4, H4, W4)), (net.up3, (p3, H3, W3)), (net.up4, (p2, H2, W2))):
@@ -398,13 +404,16 @@ class _Engine:
                 sf, hf = self.bn_fold(fpn.conv[1])
                 fn, _ = self.conv(t, fpn.conv[0], B, Hs, Ws, scale=sf, shift=hf, relu=True, sb=True)
             f = fn
+        T.pop()
 
         # head (network.py:57): NHWC -> NCHW
+        T.push("fwd:head")
         hc = net.head.conv
         out = torch.empty((B, hc.cout, H2, W2), dtype=torch.float32, device=x.device)
         head_fwd = lib.sd_head_fwd_bf16 if amp else lib.sd_head_fwd       # (the head's output and the loss stay fp32)
         L.check(head_fwd(f.data_ptr(), hc.weight.data_ptr(), hc.bias.data_ptr(), out.data_ptr(), B, H2 * W2, hc.cin, hc.cout,
                          L.stream()), "sd_head_fwd")
+        T.pop()
         if rec:
             tape.update(blocks=blocks_tape, fpn=fpn_tape, p5=(p5, H5, W5), f1=f, B=B, hw=(H2, W2))
         if self._nbt:
@@ -663,6 +672,7 @@ class _Engine:
         amp = bool(tape.get("amp"))
         if amp and self.fuse_bn_bwd:
             raise L.SdError("fuse_bn_bwd is an fp32-path experiment; switch it off for mixed-precision training")
+        T.push("bwd:fpn_head")
         self._transpose_all(amp)
         ws = self._ws(lib.sd_head_bwd_workspace_bytes(B, H2 * W2, hc.cin, hc.cout), dhead.device)
         if amp and hc.cin in (64, 128) and hc.cout <= 8:
@@ -714,12 +724,14 @@ class _Engine:
         nxt = None if has_lateral else bn2_of(last)
         r = self._dgrad(df, net.up1, d5, bn_next=nxt)
         dcur, mcur = r if nxt is not None else (r, None)
+        T.pop()
         if on_stage:
             self._join_side()
             on_stage("fpn_head")
 
         # trunk, last block first
         first_of = {id(net.down4[0]): "down4", id(net.down3[0]): "down3", id(net.down2[0]): "down2"}
+        T.push("bwd:down4")
         for bi in range(last, -1, -1):
             (blk, xin, (Hc, Wc), d1, c1, a1, m1, i1, d2, c2, m2, i2, out, dd, cd, md, idd, msk) = blocks[bi]
             extra = lateral_grad.pop(out.data_ptr(), None)
@@ -756,9 +768,12 @@ class _Engine:
             r = self._dgrad(dc1, blk.conv1, d1, res=skip, bn_next=nxt, res_half=half)
             dcur, mcur = r if nxt is not None else (r, None)
             self._wgrad(dc1, xin, blk.conv1, d1)
-            if on_stage and id(blk) in first_of:
-                self._join_side()
-                on_stage(first_of[id(blk)])
+            if id(blk) in first_of:                                         # the first block of a layer closes that layer's range
+                T.pop()
+                if on_stage:
+                    self._join_side()
+                    on_stage(first_of[id(blk)])
+                T.push("bwd:" + {"down4": "down3", "down3": "down2", "down2": "down1_stem"}[first_of[id(blk)]])
 
         # stem
         d0, s0, m0, i0, pidx = tape["stem"]
@@ -781,6 +796,7 @@ class _Engine:
                            ws.data_ptr(), ws.numel(), L.stream()), "sd_conv2d_stem_wgrad")
         self._join_side()
         self._wt_valid = None                               # the optimizer step that follows changes the weights
+        T.pop()
         if on_stage:
             on_stage("down1_stem")
 

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib as L
+from ..utils import trace as T
 from .loss import LossStats, loss_backward, loss_config, loss_forward
 
 
@@ -182,18 +183,37 @@ class TrainStep:
     def __call__(self, images, targets):
         """One optimizer step; returns the loss vector [total, hm, offset, embedding] as a device tensor."""
         net = self.net
+        T.push("step")
+        T.push("forward")
         head, tape = net.forward_train(images, amp=self.amp)
+        T.pop()
+        T.push("loss")
         M, N = net.label_count, net.part_count
         cfg = loss_config(self.args, M, N, targets["anchor_inds"].shape[1], targets["part_inds"].shape[1])
         desc, keep, out8 = loss_forward(head, targets, cfg)
         dhead = loss_backward(desc, out8, self.one, tuple(head.shape))
+        T.pop()
         on_stage, finish = self._exchange_hooks()
+        if on_stage is not None and T.enabled():
+            launch = on_stage
+
+            def on_stage(name):                                    # every gradient bucket as its own range
+                T.push("bucket:" + name)
+                launch(name)
+                T.pop()
+        T.push("backward")
         net.backward_from(tape, dhead, on_stage)
+        T.pop()
+        T.push("exchange:join")
         finish()
+        T.pop()
         self.step_count += 1
+        T.push("adam")
         L.check(L.lib().sd_adam_step(net.flat_params.data_ptr(), net.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), net.flat_params.numel(), self.step_count, self.lr, self.betas[0],
                                      self.betas[1], self.eps, 1.0 / self.world, L.stream()), "sd_adam_step")
+        T.pop()
+        T.pop()
         self.stats.update(out8[1], out8[2], out8[3])
         return out8[:4]
 

@@ -2,7 +2,10 @@
 (value types, Encode's float64 slot planner, LossStats, flag table) behaves like the reference.
 No GPU compute is issued here."""
 import json
+import os
 import re
+import subprocess
+import sys
 from argparse import Namespace
 from pathlib import Path
 
@@ -643,3 +646,59 @@ def test_debug_drawings_place_the_reference_primitives():
     with pytest.raises(AssertionError):
         draw_embeddings(image, torch.zeros(2, 2, 4, 4), args)
 
+
+
+SAN_RUNTIME = Path("/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so")
+SAN_TESTS = ["test_library_exports_every_declared_symbol", "test_c_abi_rejects_bad_arguments_without_touching_the_gpu",
+             "test_set_option_is_host_only_and_rejects_unknown_names", "test_dispatch_options_are_thread_local",
+             "test_roctx_ranges_behind_the_c_abi"]
+
+
+def test_host_half_under_asan_ubsan():
+    """SURVEY.md section 5 ("Race detection / sanitizers": none in the reference): `make SAN=1` builds libsdnet_hip_san.so with
+    AddressSanitizer + UndefinedBehaviorSanitizer on the HOST half (-fno-sanitize-recover: the first finding aborts); a child python
+    with the shared ASan runtime preloaded runs the tests that drive the validating entry points, every size query, the thread-local
+    option tables and the roctx loader through it.  CPU container only (GPU sanitizers are unavailable on the pool)."""
+    import glob
+    runtime = SAN_RUNTIME if SAN_RUNTIME.exists() else next((Path(p) for p in glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")), None)
+    if runtime is None:
+        pytest.skip("no shared ASan runtime in this image")
+    if os.environ.get("SDNET_UNDER_SAN") == "1":
+        pytest.skip("already inside the sanitizer child")
+    csrc = ROOT / "structuredetector_amd" / "csrc"
+    subprocess.run(["make", "-C", str(csrc), "SAN=1", "-j6"], check=True, capture_output=True, timeout=900)
+    san = csrc / "libsdnet_hip_san.so"
+    assert san.exists()
+    env = dict(os.environ, LD_PRELOAD=str(runtime), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", SDNET_HIP_LIB=str(san), SDNET_UNDER_SAN="1", SDNET_ROCTX="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", str(ROOT / "tests" / "test_host_cpu.py"), "-k",
+                        " or ".join(SAN_TESTS)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert f"{len(SAN_TESTS)} passed" in r.stdout, tail
+    assert "AddressSanitizer" not in tail and "runtime error" not in tail, tail
+
+
+def test_roctx_ranges_behind_the_c_abi():
+    """sd_range_* (include/sdnet_hip.h; no reference counterpart): with SDNET_ROCTX=1 in the environment of the FIRST call the marker
+    library is resolved and ranges nest; without it every call is a no-op.  Each case runs in its own child (the switch is read once)."""
+    code = ("from structuredetector_amd import _lib as L\n"
+            "from structuredetector_amd.utils import trace as T\n"
+            "lib = L.lib()\n"
+            "print(int(T.enabled()), lib.sd_range_library().decode())\n"
+            "with T.span('step'):\n"
+            "    with T.span('forward'):\n"
+            "        T.mark('m')\n"
+            "assert lib.sd_range_push(None) == (-1 if T.enabled() else 0)\n"
+            "assert lib.sd_range_pop() == 0\n")
+    for on in ("1", "0"):
+        env = {k: v for k, v in os.environ.items() if k != "SDNET_ROCTX"}
+        if on == "1":
+            env["SDNET_ROCTX"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        flag, name = (r.stdout.split() + [""])[:2]
+        if on == "1":
+            assert flag == "1" and "roctx" in name, r.stdout           # the image ships librocprofiler-sdk-roctx / libroctx64
+        else:
+            assert flag == "0" and name == ""
