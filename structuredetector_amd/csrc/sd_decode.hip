@@ -996,7 +996,14 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // A map with more than 4096 candidates (plateaus; > 6 % of all pixels) is walked a second time with the keys going to the global
 // candidate list and selected from there.  Needs w % 4 == 0 and 16-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
-constexpr int STREAM_ROWS = 16, STREAM_CAP = 4096;       // (the block size is a template parameter NT: 512, or 1024 for maps of 16+ units of work -- 256 x 256 and larger)
+// entries of a WAVE's segment of the stage: 4096 entries over the waves of a block of 8 or 16 waves; 256 per wave in smaller blocks
+// (a wave of those walks one band of a split map: 256 entries = 9 % of an 11-row band of 256 columns)
+__host__ __device__ constexpr int stream_seg(int waves) { return waves >= 8 ? 4096 / waves : 256; }
+// Round 5: a map may be SPLIT over `splits` blocks (blockIdx.x = (image * maps + map) * splits + part): a block walks the row bands
+// [part * bands / splits, (part + 1) * bands / splits) of its map (the halo rows of a band are read from the map, whoever owns them) and
+// stores ITS sorted top-k as one more stage-1 list -- k_rank_maps / k_rank_group merge the lists of a group by rank whatever map or
+// part of a map they come from (the class travels in the key).  At BASELINE configs[2] (bs = 64, 3 maps of 128 x 128) one block per map
+// was 192 blocks of 12 busy waves on 256 CUs; three parts per map are 576 blocks of 4 waves, every wave with one 11-row band.
 
 // lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1: one VALU move, no trip through the LDS crossbar)
 __device__ __forceinline__ float lane_from_left(float x) {
@@ -1023,18 +1030,19 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 constexpr int STREAM_EXTRA = 256;
 template <bool INLINE_KEYS, int NT, int ROWS>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
-                                           float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx) {
-    constexpr int STREAM_WAVES = NT / 64, STREAM_SEG = STREAM_CAP / STREAM_WAVES;
+                                           float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx,
+                                           int band_lo, int band_hi) {
+    constexpr int STREAM_WAVES = NT / 64, STREAM_SEG = stream_seg(STREAM_WAVES);
     constexpr int R = ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
     static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int strips = (w + 255) >> 8, chunks = (h + R - 1) / R;
+    const int strips = (w + 255) >> 8;
     const float NEG = -INFINITY;
     int fill = 0;                                               // (wave-uniform) entries in this wave's segment
     uint64_t* seg = stage + wave * STREAM_SEG;
     float* seg_mx = mxs + wave * STREAM_SEG;
-    for (int unit = wave; unit < strips * chunks; unit += STREAM_WAVES) {
-        const int sy = unit / strips, sx = unit - sy * strips;
+    for (int unit = wave; unit < strips * (band_hi - band_lo); unit += STREAM_WAVES) {
+        const int sy = band_lo + unit / strips, sx = unit % strips;
         const int x0 = sx * 256 + lane * 4;
         const bool col_in = x0 < w;
         const bool narrow = sx * 256 + 256 > w;                 // (wave-uniform) the strip has lanes beyond the map's right edge
@@ -1154,21 +1162,24 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
 
 template <int STREAM_THREADS, int ROWS>
 __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
-                                                                       uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1) {
-    __shared__ uint64_t stage[STREAM_CAP];                              // raw entries, then scratch of the selection (T.out)
-    __shared__ uint64_t buf[STREAM_CAP + STREAM_EXTRA];                 // keys (segments + extra list)
+                                                                       uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1, int splits) {
+    constexpr int STREAM_WAVES = STREAM_THREADS / 64, STREAM_SEG = stream_seg(STREAM_WAVES), STREAM_CAP = STREAM_WAVES * STREAM_SEG;
+    constexpr int OUT_CAP = STREAM_CAP > SD_MAX_TOPK ? STREAM_CAP : SD_MAX_TOPK;    // `stage` is also the selection's output scratch (np2k keys)
+    __shared__ uint64_t stage[OUT_CAP];                                 // raw entries, then scratch of the selection (T.out)
+    __shared__ uint64_t buf[OUT_CAP + STREAM_EXTRA];                    // keys (segments + extra list)
     __shared__ float mxs[STREAM_CAP];
     __shared__ int hist[2 * 256];
     __shared__ int misc[4];
     __shared__ int alive[2];
     __shared__ int counts[3];                                           // [0] fullest segment / global keys, [1] extra entries, [2] keys
-    constexpr int STREAM_WAVES = STREAM_THREADS / 64, STREAM_SEG = STREAM_CAP / STREAM_WAVES;
     __shared__ int seg_fill[STREAM_WAVES];
     __shared__ uint64_t extra[STREAM_EXTRA];
     __shared__ float extra_mx[STREAM_EXTRA];
     const int tid = threadIdx.x;
     const int C = g0.C + g1.C;
-    const int bm = blockIdx.x, b = bm / C, m = bm - b * C;
+    const int part = blockIdx.x % splits, bm = blockIdx.x / splits, b = bm / C, m = bm - b * C;
+    const int bands = (h + ROWS - 1) / ROWS;
+    const int band_lo = part * bands / splits, band_hi = (part + 1) * bands / splits;
     const int grp = (m >= g0.C) ? 1 : 0;
     const Group g = grp ? g1 : g0;
     const int c = grp ? m - g0.C : m;
@@ -1177,10 +1188,11 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     const float* plane = g.p + (int64_t)b * g.sb + (int64_t)c * g.sc;
     if (tid < 3) counts[tid] = 0;
     if (tid < 2) alive[tid] = 0;
-    [[maybe_unused]] const int trace0 = bm == 0 ? 6400 : (bm == g0.C ? 6420 : (bm == 255 ? 6440 : -100));
+    [[maybe_unused]] const int trace0 = blockIdx.x == 0 ? 6400 : ((int)blockIdx.x == g0.C * splits ? 6420 : (blockIdx.x == gridDim.x - 1 ? 6440 : -100));
     SD_TRACE(trace0 + 0);
+    SD_TRACE(blockIdx.x < 592 ? 7000 + (int)blockIdx.x : -1);          // (trace builds: start / end of every block of the first 592)
     __syncthreads();
-    stream_map<false, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx);
+    stream_map<false, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx, band_lo, band_hi);
     SD_TRACE(trace0 + 1);
     // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
     auto convert = [&](uint64_t ent, float mxv) {
@@ -1200,7 +1212,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     SD_TRACE(trace0 + 2);
     const Team T{tid, buf, hist, misc, nullptr, stage, 0, alive};
     const int np2k = max(next_pow2(k), 2);
-    uint64_t* out = stage1 + (int64_t)bm * kmax;
+    uint64_t* out = stage1 + (int64_t)blockIdx.x * kmax;
     if (counts[0] <= STREAM_SEG && counts[1] <= STREAM_EXTRA) {         // (block-uniform) nothing overflowed
         for (int i = tid; i < counts[1]; i += STREAM_THREADS) convert(extra[i], extra_mx[i]);
         __syncthreads();
@@ -1220,14 +1232,15 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
             for (int i = tid; i < k; i += STREAM_THREADS) out[i] = stage[i];
         }
         SD_TRACE(trace0 + 5);
+        SD_TRACE(blockIdx.x < 592 ? 7600 + (int)blockIdx.x : -1);
         return;
     }
     // more candidates than the stage holds: second walk, keys straight to the map's global list, selection from there
     __syncthreads();
     if (tid == 0) counts[0] = 0;
     __syncthreads();
-    uint64_t* glist = cand + (int64_t)bm * hw;
-    stream_map<true, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr);
+    uint64_t* glist = cand + (int64_t)bm * hw + (int64_t)band_lo * ROWS * w;      // this part's rows of the map's h * w slots
+    stream_map<true, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr, band_lo, band_hi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
@@ -1368,7 +1381,9 @@ constexpr int GROUP_PARTS = 64, GROUP_THREADS = 256;
 // keys[npos..k) := the zero slots of the reference's top-k on a map whose suppressed pixels are exactly 0 (utils.py:451): the lowest
 // class-major flat indices that are not peaks, ascending (same rule as fill_zero_slots).  Block-wide, GROUP_THREADS threads; `flags` has
 // k ints.  Only works when the list has fewer than k peaks; always executes the same four barriers.
+template <int NT = GROUP_THREADS>
 __device__ void fill_zero_keys(uint64_t* keys, int npos, int k, int* flags, int* wave_tot) {
+    constexpr int GROUP_THREADS = NT;                             // (shadows the namespace constant: the body is written against it)
     const int tid = threadIdx.x;
     const bool need = npos < k;
     if (need)
@@ -1539,6 +1554,279 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     }
     SD_TRACE(trace0 + 3);
     if (chunk == 0 && tid == 0) L.status[b] = 0;
+}
+
+// stages 2 + 3 in ONE launch (round 5), one block per image: the stage-1 lists of both groups (maps x parts-of-a-map lists of k sorted,
+// zero padded keys) are loaded into LDS once, every key finds its final rank like in k_rank_maps (its position in its own list + the
+// number of keys that beat it in every other list of its group: branch-free binary searches) and drops into the group's final list in
+// LDS; zero slots are filled like fill_zero_slots does and block_group runs the gathers + the K x P association (decoders.py:49-100) --
+// the same device functions, the same values as k_rank_maps + k_group_wide, without the launch between them and without the trip of the
+// final lists through global memory (two dependent round trips less on a chain that is nothing but dependent round trips).  The
+// round-3 one-block-per-image selector was slow because it SELECTED per image; here the per-map selection is already done and an image
+// is a few thousand keys at most.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_rank_group(const uint64_t* __restrict__ stage1, int LM, int LN, int h, int w, int K, int P, float conf,
+                                                    float dist_px, RegMaps rm, void* packed, int B) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                  // [LM * K] anchors' lists, then [LN * P] parts' lists
+    const int na_keys = LM * K, np_keys = LN * P, n_keys = na_keys + np_keys;
+    uint64_t* fin = keys + n_keys;                                        // [K] final anchor keys, [P] final part keys
+    __shared__ float as_[SD_MAX_TOPK], ps_[SD_MAX_TOPK], posx[SD_MAX_TOPK], posy[SD_MAX_TOPK];
+    __shared__ int ai_[SD_MAX_TOPK], ac_[SD_MAX_TOPK], pi_[SD_MAX_TOPK], pc_[SD_MAX_TOPK];
+    __shared__ int flags[SD_MAX_TOPK];
+    __shared__ int wave_tot[NT / 64];
+    __shared__ int cnt_s[2];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int hw = h * w, kmax = max(K, P);
+    const uint64_t* src = stage1 + (int64_t)b * (LM + LN) * kmax;
+    [[maybe_unused]] const int trace0 = b == 0 ? 6700 : (b == (int)gridDim.x - 1 ? 6710 : -100);
+    SD_TRACE(trace0 + 0);
+    if (tid < 2) cnt_s[tid] = 0;
+    for (int base = tid; base < n_keys; base += 4 * NT) {               // every load of the thread in flight together
+        uint64_t kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * NT;
+            const bool part = i >= na_keys;
+            const int j = part ? i - na_keys : i, k = part ? P : K;
+            const int l = j / k;
+            kv[u] = i < n_keys ? src[(int64_t)((part ? LM : 0) + l) * kmax + (j - l * k)] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * NT < n_keys) keys[base + u * NT] = kv[u];
+    }
+    for (int i = tid; i < K + P; i += NT) fin[i] = 0ull;
+    __syncthreads();
+    SD_TRACE(trace0 + 1);
+    int nz[2] = {0, 0};
+    for (int idx = tid; idx < n_keys; idx += NT) {
+        const uint64_t key = keys[idx];
+        if (key == 0ull) continue;
+        const int grp = idx >= na_keys ? 1 : 0;
+        const int k = grp ? P : K, nl = grp ? LN : LM;
+        const uint64_t* lists = keys + (grp ? na_keys : 0);
+        const int j = idx - (grp ? na_keys : 0);
+        const int own = j / k;
+        int rank = j - own * k;
+        int top = 1;                                            // largest power of two <= k: first probe of the branch-free search
+        while (top * 2 <= k) top *= 2;
+        for (int l = 0; l < nl; ++l) {
+            if (l == own) continue;
+            const uint64_t* lst = lists + l * k;                // descending, zero padded: count of keys greater than `key`
+            int pos = 0;
+            for (int step = top; step > 0; step >>= 1) {
+                const uint64_t probe = lst[min(pos + step, k) - 1];
+                pos += (pos + step <= k && probe > key) ? step : 0;
+            }
+            rank += pos;
+        }
+        ++nz[grp];
+        if (rank < k) fin[(grp ? K : 0) + rank] = key;
+    }
+    if (nz[0]) atomicAdd(&cnt_s[0], nz[0]);
+    if (nz[1]) atomicAdd(&cnt_s[1], nz[1]);
+    __syncthreads();
+    SD_TRACE(trace0 + 2);
+    const int na = min(cnt_s[0], K), np = min(cnt_s[1], P);     // the ranks are dense: the first min(candidates, k) slots are taken
+    fill_zero_keys<NT>(fin, na, K, flags, wave_tot);
+    fill_zero_keys<NT>(fin + K, np, P, flags, wave_tot);
+    for (int i = tid; i < K + P; i += NT) {
+        const uint64_t key = fin[i];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw;
+        const bool part = i >= K;
+        const int o = part ? i - K : i;
+        (part ? ps_ : as_)[o] = ord2f((uint32_t)(key >> 32));
+        (part ? pi_ : ai_)[o] = flat - cls * hw;
+        (part ? pc_ : ac_)[o] = cls;
+    }
+    __syncthreads();
+    SD_TRACE(trace0 + 3);
+    const PackedLayout L = packed_layout(packed, B, K, P);
+    block_group(b, K, P, w, conf, dist_px, rm, as_, ai_, ac_, ps_, pi_, pc_, posx, posy, L);
+    SD_TRACE(trace0 + 4);
+}
+
+// k_rank_group for SMALL selections (K, P <= 64, <= 512 stage-1 keys per group: the cfg shape, 2 + 1 maps, K = 20, P = 40, maps split in
+// three): the chain of an image is nothing but dependent round trips, so every one that can be taken off it is:
+//   * a thread that owns a stage-1 key issues that key's gathers (offset x / y, and embedding x / y for a part) the moment the key has
+//     arrived -- BEFORE the ranks exist: the gathers travel with the key to its final slot (4 floats through LDS) instead of being a second
+//     round trip behind the ranking;
+//   * the zero slots of a short list (utils.py:451: the lowest class-major flat indices that are not peaks; always < k <= 64, class 0) read
+//     their gathers from the first 64 pixels of the four regression planes, fetched at kernel start;
+//   * the rank of a key = its position in its own list + the number of GREATER keys in the other lists of its group, counted over the
+//     group's keys with independent 16-byte LDS reads (two keys each; every lane reads the same address: a broadcast) -- a binary search
+//     is ~6 dependent LDS round trips per list (traced: 4.1 us for nine lists);
+//   * zero slots by one wave per group with a ballot (fill_zero_slots' rule), both groups side by side.
+// Same values as k_rank_maps + k_group_wide / block_group: the arithmetic of decoders.py:49-100 is restated operation by operation.
+constexpr int RGS_THREADS = 256, RGS_KPT = 4, RGS_KEYS = 512, RGS_K = 64;
+__global__ __launch_bounds__(RGS_THREADS) void k_rank_group_small(const uint64_t* __restrict__ stage1, int LM, int LN, int h, int w, int K, int P,
+                                                                   float conf, float dist_px, RegMaps rm, void* packed, int B) {
+    __shared__ __align__(16) uint64_t keys[2][RGS_KEYS + 2];             // the group's lists, padded with a zero key to an even count
+    __shared__ float zpre[4][RGS_K];                                      // offsets x / y, embeddings x / y of the pixels 0 .. 63
+    __shared__ uint64_t fkey[2][RGS_K];                                   // final keys by rank
+    __shared__ float fg[2][4][RGS_K];                                     // their gathers by rank
+    __shared__ float posx[RGS_K], posy[RGS_K];
+    __shared__ int cnt_s[2], n_live_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int hw = h * w, kmax = max(K, P);
+    const int na_keys = LM * K, np_keys = LN * P, n_keys = na_keys + np_keys;
+    const uint64_t* src = stage1 + (int64_t)b * (LM + LN) * kmax;
+    const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
+    const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
+    [[maybe_unused]] const int trace0 = b == 0 ? 6700 : (b == (int)gridDim.x - 1 ? 6710 : -100);
+    SD_TRACE(trace0 + 0);
+    // ---- round trip 1: this thread's keys, and the regression values of the pixels a zero slot can name
+    uint64_t kv[RGS_KPT];
+#pragma unroll
+    for (int u = 0; u < RGS_KPT; ++u) {
+        const int i = tid + u * RGS_THREADS;
+        const bool part = i >= na_keys;
+        const int j = part ? i - na_keys : i, k = part ? P : K;
+        const int l = j / k;
+        kv[u] = i < n_keys ? src[(int64_t)((part ? LM : 0) + l) * kmax + (j - l * k)] : 0ull;
+    }
+    {
+        const int plane = tid >> 6, f = min(lane, hw - 1);               // wave q fetches plane q
+        const float* pl = plane == 0 ? off_b : (plane == 1 ? off_b + rm.o_sc : (plane == 2 ? emb_b : emb_b + rm.e_sc));
+        zpre[plane][lane] = pl[f];
+    }
+    if (tid < 2) cnt_s[tid] = 0;
+    if (tid == 2) n_live_s = 0;
+    for (int i = tid; i < 2 * RGS_K; i += RGS_THREADS) fkey[i / RGS_K][i % RGS_K] = 0ull;
+    // ---- round trip 2 (in flight while the ranks are counted): the gathers of every key this thread owns
+    float gv[RGS_KPT][4];
+    int nz[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < RGS_KPT; ++u) {
+        const int i = tid + u * RGS_THREADS;
+        const bool part = i >= na_keys;
+        gv[u][0] = gv[u][1] = gv[u][2] = gv[u][3] = 0.f;
+        if (i < n_keys) {
+            keys[part ? 1 : 0][part ? i - na_keys : i] = kv[u];
+            if (kv[u] != 0ull) {
+                const uint32_t flat = ~(uint32_t)kv[u];
+                const int ind = (int)(flat % (uint32_t)hw);
+                gv[u][0] = off_b[ind]; gv[u][1] = off_b[rm.o_sc + ind];
+                if (part) { gv[u][2] = emb_b[ind]; gv[u][3] = emb_b[rm.e_sc + ind]; }
+                ++nz[part ? 1 : 0];
+            }
+        }
+    }
+    if (tid < 2) { const int n = tid ? np_keys : na_keys; keys[tid][n] = 0ull; keys[tid][n + 1] = 0ull; }      // pad to whole pairs
+    if (nz[0]) atomicAdd(&cnt_s[0], nz[0]);
+    if (nz[1]) atomicAdd(&cnt_s[1], nz[1]);
+    __syncthreads();
+    SD_TRACE(trace0 + 1);
+    // ---- ranks by counting
+#pragma unroll
+    for (int u = 0; u < RGS_KPT; ++u) {
+        const int i = tid + u * RGS_THREADS;
+        const uint64_t key = kv[u];
+        if (i >= n_keys || key == 0ull) continue;
+        const int grp = i >= na_keys ? 1 : 0;
+        const int n = grp ? np_keys : na_keys, k = grp ? P : K;
+        const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(keys[grp]);
+        int rank = 0;                                                    // keys are unique: `>` counts exactly the keys ahead of this one
+        for (int q = 0; q < (n + 1) / 2; ++q) {                          // (kept rolled: a one-shot kernel runs from a cold instruction cache --
+            const ulonglong2 two = pairs[q];                             //  unrolled by eight it took 4.4 instead of 2.5 us on 120 keys)
+            rank += (two.x > key ? 1 : 0) + (two.y > key ? 1 : 0);
+        }
+        if (rank < k) {
+            fkey[grp][rank] = key;
+            fg[grp][0][rank] = gv[u][0]; fg[grp][1][rank] = gv[u][1]; fg[grp][2][rank] = gv[u][2]; fg[grp][3][rank] = gv[u][3];
+        }
+    }
+    __syncthreads();
+    SD_TRACE(trace0 + 2);
+    // ---- zero slots (fill_zero_slots' one-wave rule), wave 0: anchors, wave 1: parts
+    if (wave < 2) {
+        const int k = wave ? P : K, npos = min(cnt_s[wave], k);
+        if (npos < k) {
+            int used = 0;
+            for (int j = 0; j < npos; ++j) used |= ((uint32_t)(~fkey[wave][j]) == (uint32_t)lane);
+            const bool flag = lane < k && !used;
+            const unsigned long long m = __ballot(flag);
+            const int slot = npos + __popcll(m & ((1ull << lane) - 1ull));
+            if (flag && slot < k) {
+                fkey[wave][slot] = make_key(0.0f, (uint32_t)lane);
+                fg[wave][0][slot] = zpre[0][lane]; fg[wave][1][slot] = zpre[1][lane];
+                fg[wave][2][slot] = zpre[2][lane]; fg[wave][3][slot] = zpre[3][lane];
+            }
+        }
+    }
+    __syncthreads();
+    SD_TRACE(trace0 + 3);
+    // ---- decoders.py:49-100 (block_group's arithmetic): anchors on wave 0, then every part on its own thread
+    const PackedLayout L = packed_layout(packed, B, K, P);
+    if (tid < K) {
+        const int a = tid;
+        const uint64_t key = fkey[0][a];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw, ind = flat - cls * hw;
+        const int y = ind / w, x = ind - y * w;
+        const float score = ord2f((uint32_t)(key >> 32));
+        const float ax = (float)x + fg[0][0][a];                // decoders.py:52
+        const float ay = (float)y + fg[0][1][a];                // decoders.py:53
+        const bool mk = score > conf;                           // decoders.py:83
+        posx[a] = mk ? ax : 1e6f;                               // decoders.py:85-86
+        posy[a] = mk ? ay : 1e6f;
+        if (mk) atomicMax(&n_live_s, a + 1);
+        float* ao = L.anchor_out + ((int64_t)b * K + a) * 4;
+        ao[0] = ax; ao[1] = ay; ao[2] = score; ao[3] = (float)cls;
+        L.anchor_smask[(int64_t)b * K + a] = mk ? score : -1.0f; // decoders.py:84
+        L.anchor_ind[(int64_t)b * K + a] = ind;
+    }
+    __syncthreads();
+    const int n_live = n_live_s;
+    if (tid >= 64 && tid - 64 < P) {                            // (waves 1 ..: the anchors' stores of wave 0 are not in their way)
+        const int p = tid - 64;
+        const uint64_t key = fkey[1][p];
+        const uint32_t flat = ~(uint32_t)key;
+        const int cls = flat / hw, ind = flat - cls * hw;
+        const int y = ind / w, x = ind - y * w;
+        const float score = ord2f((uint32_t)(key >> 32));
+        const float ex = fg[1][2][p], ey = fg[1][3][p];         // decoders.py:66
+        const float px = (float)x + fg[1][0][p];                // decoders.py:67
+        const float py = (float)y + fg[1][1][p];                // decoders.py:68
+        const float ox = px + ex, oy = py + ey;                 // decoders.py:69-70
+        const bool mk = score > conf;                           // decoders.py:78
+        const float orx = mk ? ox : -1e6f, ory = mk ? oy : -1e6f; // decoders.py:80-81
+        float best = INFINITY, best_s = INFINITY;               // (see block_group: masked anchors are a suffix and never within dist_px)
+        int best_a = 0;
+        if (mk && dist_px < 1e5f) {
+            for (int a = 0; a < n_live; ++a) {
+                const float dx = orx - posx[a], dy = ory - posy[a];
+                const float sx = dx * dx, sy = dy * dy;
+                const float ss = sx + sy;
+                if (ss < best_s) {
+                    const float d = sqrtf(ss);
+                    best_s = ss;
+                    if (d < best) { best = d; best_a = a; }     // strict <: lowest anchor rank wins ties
+                }
+            }
+        } else {
+            for (int a = 0; a < K; ++a) {                       // (absurd thresholds: the reference's full scan)
+                const float dx = orx - posx[a], dy = ory - posy[a];
+                const float sx = dx * dx, sy = dy * dy;
+                const float d = sqrtf(sx + sy);
+                if (d < best) { best = d; best_a = a; }
+            }
+        }
+        float* po = L.part_out + ((int64_t)b * P + p) * 6;
+        po[0] = px; po[1] = py; po[2] = score; po[3] = (float)cls; po[4] = ox; po[5] = oy;
+        L.part_emb[((int64_t)b * P + p) * 2 + 0] = ex;
+        L.part_emb[((int64_t)b * P + p) * 2 + 1] = ey;
+        L.part_smask[(int64_t)b * P + p] = mk ? score : -1.0f;   // decoders.py:79
+        L.part_ind[(int64_t)b * P + p] = ind;
+        L.assign[(int64_t)b * P + p] = (best < dist_px) ? best_a : -1;   // decoders.py:100
+    }
+    if (tid == 0) L.status[b] = 0;
+#ifdef SD_DECODE_TRACE
+    __syncthreads();                                            // (trace builds: the parts' threads are done too)
+#endif
+    SD_TRACE(trace0 + 4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1992,6 +2280,7 @@ struct MapWs {
     int* final_cnt;       // B * 2
     size_t bytes;
 };
+constexpr int MAP_SPLIT_MAX = 4;            // parts a map is split into at most (k_map_stream_select)
 static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int P) {
     MapWs r;
     const uintptr_t p = reinterpret_cast<uintptr_t>(ws);   // integer arithmetic: size queries carve a null base
@@ -1999,7 +2288,7 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
     size_t off = 0;
     r.cand = reinterpret_cast<uint64_t*>(p + off);     off += align_up((size_t)B * C * tiles * TW * th * 8, 256);
     r.tile_cnt = reinterpret_cast<int*>(p + off);      off += align_up((size_t)B * C * tiles * sizeof(int), 256);
-    r.stage1 = reinterpret_cast<uint64_t*>(p + off);   off += align_up((size_t)B * C * std::max(K, P) * 8, 256);
+    r.stage1 = reinterpret_cast<uint64_t*>(p + off);   off += align_up((size_t)B * C * MAP_SPLIT_MAX * std::max(K, P) * 8, 256);   // one list per part of a split map
     r.stage1_cnt = reinterpret_cast<int*>(p + off);    off += align_up((size_t)B * C * sizeof(int), 256);
     r.final_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up((size_t)B * 2 * std::max(K, P) * 8, 256);
     r.final_cnt = reinterpret_cast<int*>(p + off);     off += align_up((size_t)B * 2 * sizeof(int), 256);
@@ -2013,6 +2302,9 @@ static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
 static thread_local int g_map_rows11 = 1;           // 0: 128-row maps keep 16-row bands on 8 waves (A/B)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
+static thread_local int g_map_split = 0;            // parts per map in k_map_stream_select: 0 = by geometry, 1 .. MAP_SPLIT_MAX = forced (A/B, tests)
+static thread_local int g_map_rank_group = 1;       // 0: k_rank_maps + k_group_wide instead of the one-launch k_rank_group (A/B, tests)
+constexpr size_t RANK_GROUP_LDS_MAX = 96 * 1024;    // dynamic LDS of k_rank_group (beside its 37 KB of static arrays)
 static int map_tile_height(int64_t blocks16) {
     if (g_map_tile_height == 16 || g_map_tile_height == 32) return g_map_tile_height;
     return blocks16 >= 8192 ? 32 : 16;
@@ -2058,17 +2350,39 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
         const float min_score = exact_topk ? 0.f : conf;
         const bool vec = g_map_scalar_nms == 0 && w % 4 == 0 && aligned16(anchor_hm) && aligned16(part_hm) && a_sb % 4 == 0 && a_sc % 4 == 0 &&
                          p_sb % 4 == 0 && p_sc % 4 == 0;
+        int splits = 1;                                              // stage-1 lists per map (parts of a split map)
         if (vec && g_map_scalar_nms == 0 && g_map_stream) {
             // tile pass + per-map selection in one kernel (candidate list `cand`: h * w slots per map, only touched by overflowing maps)
             // 16 waves per map where a map has 16+ units of work (strip x 16-row band): 256 x 256 maps 40.9 -> 36.4 us per batch of 16 x 16 maps;
             // 128 x 128 maps (8 units) stay at 8 waves (14.4 us; 14.9 with 16)
-const int strips = cdiv(w, 256);
+            const int strips = cdiv(w, 256);
             // 16 waves per map where 16-row bands give 16+ units of work (256 x 256 maps: 40.9 -> 36.5 us per batch of 16 x 16 maps); maps of
-            // 9 .. 15 such units (128 x 128: 8) take 11-row bands on 16 waves: every wave walks 15 rows instead of 20
+            // 9 .. 15 such units (128 x 128: 8) take 11-row bands: every wave walks 15 rows instead of 20 -- and, round 5, such a map is SPLIT
+            // over ceil(bands / 4) blocks of four waves, one band per wave (bs = 64, 3 maps of 128 x 128: 576 blocks of 4 waves on every CU of
+            // the chip instead of 192 blocks with 12 busy waves of 16)
             const int units16 = strips * cdiv(h, 16), units11 = strips * cdiv(h, 11);
-            if (units16 >= 16) hipLaunchKernelGGL((k_map_stream_select<1024, 16>), dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
-            else if (g_map_rows11 && units11 > 8 && units11 <= 16) hipLaunchKernelGGL((k_map_stream_select<1024, 11>), dim3(B * C), dim3(1024), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
-            else hipLaunchKernelGGL((k_map_stream_select<512, 16>), dim3(B * C), dim3(512), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1);
+            const int rows = units16 >= 16 ? 16 : ((g_map_rows11 && units11 > 8 && units11 <= 16) ? 11 : 16);
+            const int bands = cdiv(h, rows);
+            int want = g_map_split;
+            // (measured, `profiles/r05_decode_split_sweep.txt`: at bs = 64 -- 192 maps -- one block per map and three parts per map stream in the
+            // same 14 us, the kernel is bound by the start-up spread of its ~2500 waves and their first round trips, and the rank kernel pays for
+            // three times the lists; at bs = 512 the parts stream in 53 instead of 74 us: five 27 KB blocks per CU instead of one of 86 KB)
+            if (want <= 0) want = (rows == 11 && strips == 1 && (int64_t)B * C >= 384) ? cdiv(bands, 4) : 1;
+            splits = std::max(1, std::min({want, MAP_SPLIT_MAX, bands}));
+            if ((int64_t)M * splits * K > RANK_KEYS_MAX || (int64_t)N * splits * P > RANK_KEYS_MAX) splits = 1;
+            const int per_block = strips * cdiv(bands, splits);            // units of work of the largest part
+            const unsigned grid = (unsigned)(B * C * splits);
+#define SD_STREAM(NT_, ROWS_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1, splits)
+            if (rows == 16) {
+                if (splits == 1 && units16 >= 16) SD_STREAM(1024, 16);
+                else if (per_block > 4 || splits == 1) SD_STREAM(512, 16);
+                else SD_STREAM(256, 16);
+            } else {
+                if (per_block > 8 || splits == 1) SD_STREAM(1024, 11);
+                else if (per_block > 4) SD_STREAM(512, 11);
+                else SD_STREAM(256, 11);
+            }
+#undef SD_STREAM
             SD_LAUNCH_CHECK();
         } else {
             const dim3 tgrid((unsigned)((int64_t)B * C * tiles));
@@ -2080,7 +2394,35 @@ const int strips = cdiv(w, 256);
             hipLaunchKernelGGL(k_select_map, dim3(B * C), dim3(SEL_THREADS), 0, st, mw.cand, mw.tile_cnt, tiles, TW * th, M, N, K, P, mw.stage1);
             SD_LAUNCH_CHECK();
         }
-        const size_t rank_lds = (size_t)std::max((int64_t)M * K, (int64_t)N * P) * 8;
+        RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
+        const int LM = M * splits, LN = N * splits;                  // lists per group
+        const size_t rg_lds = ((size_t)LM * K + (size_t)LN * P + K + P) * 8;
+        // ranks + gathers + association of an image in ONE block (two dependent launches less) where an image's lists are short: the
+        // ranking is serial per image there (stress, 16 lists of 128 / 512 keys in one 1024-thread block: 75 us against 8.6 + 7.4 for
+        // k_rank_maps + k_group_wide -- `profiles/r05_decode_split_sweep.txt`), so large selections keep the map-parallel pair.
+        // map_rank_group: 0 never, 1 by size (default), 2 the generic one-block kernel wherever its lists fit LDS (tests)
+        const int64_t n_keys = (int64_t)LM * K + (int64_t)LN * P;
+        const bool small = K <= RGS_K && P <= RGS_K && LM * K <= RGS_KEYS && LN * P <= RGS_KEYS && n_keys <= RGS_THREADS * RGS_KPT && h * w >= RGS_K;
+        if (g_map_rank_group == 1 && small) {
+            hipLaunchKernelGGL(k_rank_group_small, dim3(B), dim3(RGS_THREADS), 0, st, mw.stage1, LM, LN, h, w, K, P, conf, dist_px, rm, packed, B);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
+        if (rg_lds <= RANK_GROUP_LDS_MAX && (g_map_rank_group == 2 || (g_map_rank_group == 1 && n_keys <= 1024 && K <= 256 && P <= 256))) {
+            static thread_local bool raised_rg = false;             // per host thread: cheap, idempotent
+            if (!raised_rg) {
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_group<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANK_GROUP_LDS_MAX));
+                SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_group<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANK_GROUP_LDS_MAX));
+                raised_rg = true;
+            }
+            if (n_keys <= 1024 && K <= 256 && P <= 256)
+                hipLaunchKernelGGL(k_rank_group<256>, dim3(B), dim3(256), rg_lds, st, mw.stage1, LM, LN, h, w, K, P, conf, dist_px, rm, packed, B);
+            else
+                hipLaunchKernelGGL(k_rank_group<1024>, dim3(B), dim3(1024), rg_lds, st, mw.stage1, LM, LN, h, w, K, P, conf, dist_px, rm, packed, B);
+            SD_LAUNCH_CHECK();
+            return 0;
+        }
+        const size_t rank_lds = (size_t)std::max((int64_t)LM * K, (int64_t)LN * P) * 8;
         if (rank_lds > 48 * 1024) {
             static thread_local bool raised = false;               // per host thread: cheap, idempotent
             if (!raised) {
@@ -2088,9 +2430,9 @@ const int strips = cdiv(w, 256);
                 raised = true;
             }
         }
-        hipLaunchKernelGGL(k_rank_maps, dim3(B * C), dim3(SEL_THREADS), rank_lds, st, mw.stage1, M, N, K, P, mw.final_keys);
+        // (a part of a split map is one more sorted list of its group: k_rank_maps sees M * splits and N * splits lists)
+        hipLaunchKernelGGL(k_rank_maps, dim3(B * C * splits), dim3(SEL_THREADS), rank_lds, st, mw.stage1, LM, LN, K, P, mw.final_keys);
         SD_LAUNCH_CHECK();
-        RegMaps rm{offsets, o_sb, o_sc, embeddings, e_sb, e_sc};
         const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)((K + 3) & ~3) * 8 + (size_t)std::max(K, P) * 4;
         hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, h, w, K, P,
                            conf, dist_px, rm, packed, B);
@@ -2126,6 +2468,8 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "map_scalar_nms")) { g_map_scalar_nms = value; return 0; }
     if (name && !strcmp(name, "map_rows11")) { g_map_rows11 = value; return 0; }
     if (name && !strcmp(name, "map_stream")) { g_map_stream = value; return 0; }
+    if (name && !strcmp(name, "map_split")) { g_map_split = value; return 0; }
+    if (name && !strcmp(name, "map_rank_group")) { g_map_rank_group = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
 }

@@ -497,18 +497,29 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
             want, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
             L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
             # streaming kernel (tile pass + per-map selection in one) / logit-domain tile kernel / per-pixel-sigmoid tile kernel + k_select_map
-            for th, scalar, stream in ((0, 0, 1), (16, 0, 0), (32, 0, 0), (16, 1, 0), (32, 1, 0)):
+            # round 5: every map split over 1 .. 4 blocks of the streaming kernel (split 0 = the rule by geometry), and ranks + association in
+            # ONE launch (k_rank_group, rank_group = 1) or as k_rank_maps + k_group_wide (0)
+            # (rank_group 1 = by size: k_rank_group_small for K, P <= 64, the generic one-block kernel up to 1024 keys, the pair beyond; 2 = the
+            # generic one-block kernel wherever its lists fit LDS)
+            variants = [(0, 0, 1, 0, 1), (0, 0, 1, 0, 0), (0, 0, 1, 0, 2), (0, 0, 1, 1, 1), (0, 0, 1, 2, 1), (0, 0, 1, 3, 0), (0, 0, 1, 3, 2), (0, 0, 1, 4, 1),
+                        (16, 0, 0, 0, 1), (32, 0, 0, 0, 0), (16, 1, 0, 0, 2), (32, 1, 0, 0, 0)]
+            for th, scalar, stream, split, rank_group in variants:
                 L.check(lib.sd_decode_set_option(b"map_tile_height", th))
                 L.check(lib.sd_decode_set_option(b"map_scalar_nms", scalar))
                 L.check(lib.sd_decode_set_option(b"map_stream", stream))
+                L.check(lib.sd_decode_set_option(b"map_split", split))
+                L.check(lib.sd_decode_set_option(b"map_rank_group", rank_group))
                 for _ in range(2):                                                                # (back to back: no state left behind)
                     got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-                    assert torch.equal(got, want), f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream}"
+                    assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} "
+                                                    f"map_split={split} map_rank_group={rank_group}")
     finally:
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
         L.check(lib.sd_decode_set_option(b"map_scalar_nms", 0))
         L.check(lib.sd_decode_set_option(b"map_stream", 1))
+        L.check(lib.sd_decode_set_option(b"map_split", 0))
+        L.check(lib.sd_decode_set_option(b"map_rank_group", 1))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
