@@ -2181,6 +2181,290 @@ __global__ __launch_bounds__(256) void k_conv3x3_c64_rows_bf16(RowsArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv3x3_c64_rows16_bf16 (round 5): the row stream of k_conv3x3_c64_rows_bf16 with the MFMA operands SWAPPED and the epilogue in
+// registers.  The 32x32x16 form traced at 4935 cycles per row for 2304 cycles of MFMA (`profiles/r05_rows_bf16_ablations.txt`): 2950 in the
+// MFMA stream even with nothing between the MFMAs, +350 for the LDS-DMA issue, +900 for the row form of the previous row (scratch reads,
+// residual, rounding, statistics, stores), +640 for the accumulators' trip into the LDS scratch while the matrix pipe idles, +80 barrier.
+// Here:
+//   * D = W x X^T on `v_mfma_f32_16x16x32_bf16`: the weights are the A operand (72 fragments of 16 channels x 32 k in registers, as before),
+//     the pixels the B operand (one `ds_read_b128` per 16 pixels x 32 k from the same ring; 36 reads per row as before), so a lane ends up
+//     with the channels of ONE pixel: rows 4 g + e of a 16-channel tile, g = lane >> 4.  The weight ROWS are permuted at load time (tile
+//     ct, row m <-> channel 32 (ct >> 1) + 8 (m >> 2) + 4 (ct & 1) + (m & 3)), which makes the eight values a lane holds in tiles 2 j and
+//     2 j + 1 eight CONSECUTIVE channels 32 j + 8 g ... of its pixel: affine, residual, ReLU, rounding and the BatchNorm sums happen in
+//     registers and the 16-byte store goes straight out (the four lane groups of a pixel write 64 contiguous bytes per instruction).  No
+//     scratch, no transposition, no row form: ~35 vector instructions per item instead of ~75 + 16 LDS operations;
+//   * TWO accumulator sets (64 AGPRs; 48 of the 72 weight fragments in AGPRs, 24 in VGPRs): row y accumulates into one set while the
+//     epilogue of row y - 1 reads the other, cut into eight pieces between the MFMAs of steps 3 .. 10 -- the matrix pipe never waits for an
+//     epilogue; per row one counted `vmcnt`, one `s_barrier`;
+//   * 16x16x32 is also the shape the chip holds a higher clock on under its power limit (`tools/micro/mfma_bf16_shape.hip`).
+// Same ring, LDS-DMA pieces, units and statistics layout as k_conv3x3_c64_rows_bf16; one instantiation per epilogue kind (plain / affine /
+// statistics, with or without a residual: the 32 auxiliary registers of the affine or of the sums, and the residual's 16, only where used).  sd_set_option("conv_rows16", 0) = the 32x32x16 kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int R16_LDS_BYTES = RS_NR * RS_ROW_BYTES + 4 * 128 * 4;
+constexpr int R16_W_AGPR = 48;
+template <bool W_IN_AGPR, bool ZERO>
+__device__ __forceinline__ void r16_mfma(f32x4& acc, const bf16x8& w, const f32x4& px) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ZERO) {
+        if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(px));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(px));
+    } else {
+        if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(px));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(px));
+    }
+#else
+    (void)acc; (void)w; (void)px;
+#endif
+}
+
+// KIND 0: plain (data-gradient), 1: affine epilogue (inference), 2: BatchNorm statistics (training forward); RES: a residual tensor is added
+template <int KIND, bool RES>
+__global__ __launch_bounds__(256) void k_conv3x3_c64_rows16_bf16(RowsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    char* const ring = reinterpret_cast<char*>(rs_lds);
+    float* const sred = reinterpret_cast<float*>(ring + RS_NR * RS_ROW_BYTES);                     // [4][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const uint16_t* const zero_ = reinterpret_cast<const uint16_t*>(g_zero_line);
+    const int H = p.H, W = p.W;
+    constexpr bool has_res = RES, has_stat = KIND == 2, has_affine = KIND == 1;
+    const bool relu = p.relu != 0;
+    const uint16_t* const xg = p.x;
+    const uint16_t* const resg = p.res;
+    uint16_t* const yg = p.y;
+
+    // ---- every weight fragment of the layer: lane (row m = n, k group g) of tile ct holds w[chan(ct, n)][tap][32 ks + 8 g .. + 7]
+    bf16x8 Wf[72];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int ch = 32 * (ct >> 1) + 8 * (n >> 2) + 4 * (ct & 1) + (n & 3);
+                Wf[(t * 2 + ks) * 4 + ct] = *reinterpret_cast<const bf16x8*>(p.w + (ch * 9 + (p.flip ? 8 - t : t)) * 64 + ks * 32 + g * 8);
+            }
+    // aux: scale / shift of the lane's 16 channels (32 j + 8 g + i at [8 j + i]) -- or, in a statistics launch, their running sums
+    float aux[KIND == 0 ? 1 : 32];
+#pragma unroll
+    for (int k = 0; k < (KIND == 0 ? 1 : 32); ++k) aux[k] = (k < 16 && has_affine) ? 1.f : 0.f;
+    if constexpr (has_affine) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (p.scale) aux[8 * j + i] = p.scale[32 * j + 8 * g + i];
+                if (p.shift) aux[16 + 8 * j + i] = p.shift[32 * j + 8 * g + i];
+            }
+    }
+    // pixel fragment offsets inside a ring row: output pixel 32 wave + 16 pt + n, tap column s -> ring pixel + s (ring pixel 0 = image column x0 - 1)
+    // (k half ks = 1: slot (4 + g) ^ swizzle = the ks = 0 offset with bit 6 flipped -- one v_xor per read instead of six more registers)
+    uint32_t poff[3][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int pxr = wave * 32 + 16 * pt + n + s_;
+            poff[s_][pt] = (uint32_t)pxr * 128u + (uint32_t)((g ^ ((pxr >> 1) & 7)) << 4);
+        }
+    const uint32_t ring_base = lds_addr(ring);
+    const int dpx = lane >> 3, dslot = lane & 7;          // LDS-DMA: lane -> (pixel within an 8-pixel piece, physical 16-byte slot)
+    const int rows_per_unit = p.rows, units_per_col = p.units_per_col, segs = p.segs, nunits = p.nunits;
+
+    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        const int col = unit / units_per_col, yu = unit - col * units_per_col;
+        const int b = col / segs, x0 = (col - b * segs) * 128;
+        const int y0 = yu * rows_per_unit, y1 = min(y0 + rows_per_unit, H);
+        const uint16_t* const img = xg + (int64_t)b * H * W * 64;
+        // this lane's 16 bytes of an output / residual row: pixel 32 wave + 16 pt + n, channels 32 j + 8 g
+        const int lane_off32 = (wave * 32 + n) * 64 + 8 * g;
+        auto issue_row = [&](int iy) {
+            const int slot = (iy - y0 + 1) % RS_NR;
+            float* const dst = reinterpret_cast<float*>(ring + slot * RS_ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pc = wave + 4 * j;
+                if (pc < 17) {
+                    const int pxr = pc * 8 + dpx, ix = x0 - 1 + pxr;
+                    const bool ok = pxr < 130 && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+                    const uint16_t* src = ok ? img + ((int64_t)iy * W + ix) * 64 + ((dslot ^ ((pxr >> 1) & 7)) << 3) : zero_ + (dslot << 3);
+                    lds_dma16(src, dst + pc * 256);
+                }
+            }
+        };
+        if constexpr (has_stat) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) aux[k] = 0.f;
+        }
+        uint4 resv[RES ? 4 : 1];
+        f32x4 acc[2][2][4];                                                   // [set][pixel tile][channel tile]: AGPRs
+        float f[8];
+        uint4 o = make_uint4(0, 0, 0, 0);
+        // epilogue item (pt, j) of output row yy from accumulator set `S_`, in two halves (A: values, B: rounding + statistics + store)
+#define R16_ITEM_A(S_, pt_, j_)                                                                                                        \
+        {                                                                                                                              \
+            const f32x4 a0_ = acc[S_][pt_][2 * (j_)], a1_ = acc[S_][pt_][2 * (j_) + 1];                                                \
+            f[0] = a0_[0]; f[1] = a0_[1]; f[2] = a0_[2]; f[3] = a0_[3]; f[4] = a1_[0]; f[5] = a1_[1]; f[6] = a1_[2]; f[7] = a1_[3];    \
+            if constexpr (has_affine) {                                                                                                \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) f[i] = f[i] * aux[8 * (j_) + i] + aux[16 + 8 * (j_) + i];                \
+            }                                                                                                                          \
+            if constexpr (has_res) {                                                                                                   \
+                const uint4 r = resv[2 * (pt_) + (j_)];                                                                                \
+                f[0] += __uint_as_float(r.x << 16); f[1] += __uint_as_float(r.x & 0xffff0000u); f[2] += __uint_as_float(r.y << 16); f[3] += __uint_as_float(r.y & 0xffff0000u); \
+                f[4] += __uint_as_float(r.z << 16); f[5] += __uint_as_float(r.z & 0xffff0000u); f[6] += __uint_as_float(r.w << 16); f[7] += __uint_as_float(r.w & 0xffff0000u); \
+            }                                                                                                                          \
+        }
+#define R16_ITEM_B(yy_, pt_, j_)                                                                                                       \
+        {                                                                                                                              \
+            o.x = rs_pack2(f[0], f[1]); o.y = rs_pack2(f[2], f[3]); o.z = rs_pack2(f[4], f[5]); o.w = rs_pack2(f[6], f[7]);            \
+            if (relu) { o.x = rs_relu2(o.x); o.y = rs_relu2(o.y); o.z = rs_relu2(o.z); o.w = rs_relu2(o.w); }                          \
+            if constexpr (has_stat) {                                                                                                  \
+                const uint32_t od[4] = {o.x, o.y, o.z, o.w};                                                                           \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                        \
+                    const float a0 = __uint_as_float(od[k] << 16), a1 = __uint_as_float(od[k] & 0xffff0000u);                          \
+                    aux[8 * (j_) + 2 * k] += a0; aux[16 + 8 * (j_) + 2 * k] += a0 * a0;                                                \
+                    aux[8 * (j_) + 2 * k + 1] += a1; aux[16 + 8 * (j_) + 2 * k + 1] += a1 * a1;                                        \
+                }                                                                                                                      \
+            }                                                                                                                          \
+            int lo_ = lane_off32;                                                                                                      \
+            asm volatile("" : "+v"(lo_));                                                                                              \
+            *reinterpret_cast<uint4*>(yg + (((int64_t)b * H + (yy_)) * W + x0) * 64 + lo_ + (pt_) * 1024 + (j_) * 32) = o;             \
+        }
+        for (int iy = y0 - 1; iy <= min(y0 + 2, y1); ++iy) issue_row(iy);
+        wait_vmcnt<0>();
+        __syncthreads();
+
+        // one output row: 18 steps (tap t = q / 2, k half ks = q % 2) of 2 pixel-fragment reads + 8 MFMAs; the epilogue of the previous row
+        // (other accumulator set), the LDS-DMA of row y + 3 and the residual loads of this row sit between the steps
+#define R16_ADDR(q_, pt_) (sb[((q_) / 2) / 3] + (poff[((q_) / 2) % 3][pt_] ^ (((q_) % 2) ? 64u : 0u)))
+#define R16_MF(S_, q_, ct_)                                                                                                            \
+            r16_mfma<((q_) * 4 + (ct_) < R16_W_AGPR), (q_) == 0>(acc[S_][0][ct_], Wf[(q_) * 4 + (ct_)], Bp[((q_) % 2) * 2 + 0]);       \
+            r16_mfma<((q_) * 4 + (ct_) < R16_W_AGPR), (q_) == 0>(acc[S_][1][ct_], Wf[(q_) * 4 + (ct_)], Bp[((q_) % 2) * 2 + 1]);
+#define R16_STEP(S_, q_)                                                                                                               \
+        {                                                                                                                              \
+            /* window of two steps: the fragments of step q + 1 go into the registers step q - 1 read (its MFMAs are issued) */         \
+            if ((q_) + 1 < 18) {                                                                                                       \
+                Bp[(((q_) + 1) % 2) * 2 + 0] = lds_read128_async<0>(R16_ADDR((q_) + 1 < 18 ? (q_) + 1 : 0, 0));                        \
+                Bp[(((q_) + 1) % 2) * 2 + 1] = lds_read128_async<0>(R16_ADDR((q_) + 1 < 18 ? (q_) + 1 : 0, 1));                        \
+            }                                                                                                                          \
+            if ((q_) + 1 < 18) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Bp[((q_) % 2) * 2]), "+v"(Bp[((q_) % 2) * 2 + 1]) :: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bp[((q_) % 2) * 2]), "+v"(Bp[((q_) % 2) * 2 + 1]) :: "memory");            \
+            R16_MF(S_, q_, 0) R16_MF(S_, q_, 1) R16_MF(S_, q_, 2) R16_MF(S_, q_, 3)                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        }
+#define R16_DMA_PIECE(pc_expr, chk)                                                                                                    \
+        {                                                                                                                              \
+            int dpx_ = dpx;                                                                                                            \
+            asm volatile("" : "+v"(dpx_));       /* (opaque: the piece's lane offsets are re-formed here, not kept live across the row loop) */ \
+            const int pc = (pc_expr), pxr = pc * 8 + dpx_, ix = x0 - 1 + pxr;                                                          \
+            const bool ok = (!(chk) || pxr < 130) && (unsigned)ix < (unsigned)W && (unsigned)(y + 3) < (unsigned)H;                    \
+            lds_dma16(ok ? img + ((int64_t)(y + 3) * W + ix) * 64 + ((dslot ^ ((pxr >> 1) & 7)) << 3) : zero_ + (dslot << 3), ddst + pc * 256); \
+        }
+#define R16_RES_LOAD(pt_, j_) { int lo_ = lane_off32; asm volatile("" : "+v"(lo_)); \
+            resv[2 * (pt_) + (j_)] = *reinterpret_cast<const uint4*>(resg + (((int64_t)b * H + y) * W + x0) * 64 + lo_ + (pt_) * 1024 + (j_) * 32); }
+#define R16_ROW(S_)                                                                                                                    \
+        {                                                                                                                              \
+            const bool prev = y > y0;                                                                                                  \
+            const bool more = y + 3 <= y1;                                                                                             \
+            float* const ddst = reinterpret_cast<float*>(ring + ((y + 3 - y0 + 1) % RS_NR) * RS_ROW_BYTES);                            \
+            uint32_t sb[3];                                                                                                            \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r) sb[r] = ring_base + (uint32_t)((y - 1 + r - y0 + 1) % RS_NR) * RS_ROW_BYTES; \
+            f32x4 Bp[4];                                                                                                               \
+            Bp[0] = lds_read128_async<0>(R16_ADDR(0, 0)); Bp[1] = lds_read128_async<0>(R16_ADDR(0, 1));                                \
+            R16_STEP(S_, 0)                                                                                                            \
+            if (more) { R16_DMA_PIECE(wave, 0) R16_DMA_PIECE(wave + 4, 0) }                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 1)                                                                                                            \
+            if (more) { R16_DMA_PIECE(wave + 8, 0) R16_DMA_PIECE(wave + 12, 0) }                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 2)                                                                                                            \
+            if (more && wave == 0) R16_DMA_PIECE(16, 1)                                                                                \
+            if (prev) R16_ITEM_A(1 - (S_), 0, 0)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 3)                                                                                                            \
+            if (prev) R16_ITEM_B(y - 1, 0, 0)                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 4)                                                                                                            \
+            if (prev) R16_ITEM_A(1 - (S_), 0, 1)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 5)                                                                                                            \
+            if (prev) R16_ITEM_B(y - 1, 0, 1)                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 6)                                                                                                            \
+            if (prev) R16_ITEM_A(1 - (S_), 1, 0)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 7)                                                                                                            \
+            if (prev) R16_ITEM_B(y - 1, 1, 0)                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 8)                                                                                                            \
+            if (prev) R16_ITEM_A(1 - (S_), 1, 1)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 9)                                                                                                            \
+            if (prev) R16_ITEM_B(y - 1, 1, 1)                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 10)                                                                                                           \
+            if constexpr (has_res) { R16_RES_LOAD(0, 0) }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 11)                                                                                                           \
+            if constexpr (has_res) { R16_RES_LOAD(0, 1) }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 12)                                                                                                           \
+            if constexpr (has_res) { R16_RES_LOAD(1, 0) }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 13)                                                                                                           \
+            if constexpr (has_res) { R16_RES_LOAD(1, 1) }                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                         \
+            R16_STEP(S_, 14) R16_STEP(S_, 15) R16_STEP(S_, 16) R16_STEP(S_, 17)                                                        \
+            /* the LDS-DMA pieces of row y + 3 (steps 0 .. 2) and the previous row's stores (steps 3 .. 9) are older than the four residual \
+               loads (steps 10 .. 13): loads return in order, so "all but the four youngest" covers every DMA piece */                  \
+            if constexpr (has_res) wait_vmcnt<4>(); else wait_vmcnt<0>();                                                                        \
+            __builtin_amdgcn_s_barrier();      /* every wave is done with input row y - 1 and has published its pieces of row y + 3 */ \
+        }
+        int y = y0;
+        for (; y + 1 < y1; y += 2) {
+            R16_ROW(0)
+            ++y;
+            R16_ROW(1)
+            --y;
+        }
+        int last_set = 1;
+        if (y < y1) { R16_ROW(0) last_set = 0; ++y; }
+        // the last row's epilogue: nothing to hide it under.  (The asm MFMAs are invisible to the hazard recogniser: their results must
+        // not be read for 18 wait states.)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        wait_vmcnt<0>();
+        if (last_set == 0) {
+            R16_ITEM_A(0, 0, 0) R16_ITEM_B(y1 - 1, 0, 0) R16_ITEM_A(0, 0, 1) R16_ITEM_B(y1 - 1, 0, 1)
+            R16_ITEM_A(0, 1, 0) R16_ITEM_B(y1 - 1, 1, 0) R16_ITEM_A(0, 1, 1) R16_ITEM_B(y1 - 1, 1, 1)
+        } else {
+            R16_ITEM_A(1, 0, 0) R16_ITEM_B(y1 - 1, 0, 0) R16_ITEM_A(1, 0, 1) R16_ITEM_B(y1 - 1, 0, 1)
+            R16_ITEM_A(1, 1, 0) R16_ITEM_B(y1 - 1, 1, 0) R16_ITEM_A(1, 1, 1) R16_ITEM_B(y1 - 1, 1, 1)
+        }
+#undef R16_ROW
+#undef R16_RES_LOAD
+#undef R16_DMA_PIECE
+#undef R16_STEP
+#undef R16_MF
+#undef R16_ADDR
+#undef R16_ITEM_A
+#undef R16_ITEM_B
+        if constexpr (has_stat) {
+            // the 16 lanes n of a lane group hold the same channels of different pixels
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                float a = aux[k];
+                for (int o_ = 1; o_ < 16; o_ <<= 1) a += __shfl_xor(a, o_);
+                if (n == 0) sred[wave * 128 + (k >> 4) * 64 + 32 * ((k & 15) >> 3) + 8 * g + (k & 7)] = a;
+            }
+            __syncthreads();
+            if (tid < 128) p.stat[(int64_t)unit * 128 + tid] = (sred[tid] + sred[128 + tid]) + (sred[256 + tid] + sred[384 + tid]);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();                     // the ring and sred are reused by the next unit
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 3x3 / stride 1 / pad 1 convolution of the 64 -> 64 channel layers (layer1; forward and flipped-tap data-gradient) as a ROW
 // STREAM with the weights in registers -- the fp32 twin of k_conv3x3_c64_rows_bf16.  K is only 576: a tile kernel re-stages the
 // 147 KB of weights for every 128-pixel tile and spends 10 % of a tile in prologue + epilogue (k_conv_igemm<64, 0>: 115 TFLOP/s).
@@ -5171,6 +5455,11 @@ static bool conv_rows64_geometry(const ConvArgs& a, int mode, RowsArgs& r) {
     return true;
 }
 
+// the swapped-operand form k_conv3x3_c64_rows16_bf16 takes every launch of the row stream except one that asks for statistics AND an
+// affine epilogue at once (its 32 auxiliary registers hold one or the other; no caller does).  sd_set_option("conv_rows16", 0): off.
+static thread_local int g_rows16 = 1;
+static bool conv_rows16_args(const RowsArgs& r) { return g_rows16 && !(r.stat && (r.scale || r.shift || r.res)); }
+
 // k_conv3x3_c64_rows_f32 applies: fp32, 64 -> 64 channels, unit-stride 3x3 with pad 1 (forward or flipped data-gradient), map width a
 // multiple of 64, plain or same-size residual, no fused BatchNorm-backward reduction, no split-K, and enough units to fill the chip.
 static thread_local int g_rowsf32_min_units = 192;   // sd_set_option("conv_rows_f32_min_units", n) (tests: 1; off: 1 << 30)
@@ -5263,7 +5552,19 @@ static int launch_igemm(const ConvArgs& a, bool stem, hipStream_t st, bool bf16 
                 SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_rows_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES));
                 raised64 = true;
             }
-            hipLaunchKernelGGL(k_conv3x3_c64_rows_bf16, dim3(std::min(ra.nunits, 256)), dim3(256), RS_LDS_BYTES, st, ra);
+            if (conv_rows16_args(ra)) {
+                const dim3 grid(std::min(ra.nunits, 256));
+#define SD_R16(KIND_, RES_) { static thread_local bool up = false;                                                                          \
+                if (!up) { SD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64_rows16_bf16<KIND_, RES_>), hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES)); up = true; } \
+                hipLaunchKernelGGL((k_conv3x3_c64_rows16_bf16<KIND_, RES_>), grid, dim3(256), R16_LDS_BYTES, st, ra); }
+                const bool affine = ra.scale || ra.shift;
+                if (ra.stat) SD_R16(2, false)
+                else if (affine && ra.res) SD_R16(1, true)
+                else if (affine) SD_R16(1, false)
+                else if (ra.res) SD_R16(0, true)
+                else SD_R16(0, false)
+#undef SD_R16
+            } else hipLaunchKernelGGL(k_conv3x3_c64_rows_bf16, dim3(std::min(ra.nunits, 256)), dim3(256), RS_LDS_BYTES, st, ra);
             SD_LAUNCH_CHECK();
             return 0;
         }
@@ -6143,6 +6444,7 @@ int sd_set_option(const char* name, int value) {
     if (name && !strcmp(name, "conv_patch_narrow")) { g_patch_narrow = value; return 0; }
     if (name && !strcmp(name, "conv_fwd_split_k")) { g_fwd_split_k = value; return 0; }
     if (name && !strcmp(name, "conv_rows64_min_units")) { g_rows64_min_units = value; return 0; }
+    if (name && !strcmp(name, "conv_rows16")) { g_rows16 = value; return 0; }
     if (name && !strcmp(name, "conv_rows_f32_min_units")) { g_rowsf32_min_units = value; return 0; }
     if (name && !strcmp(name, "stem_fwd_blocks")) { g_stem_fwd_blocks = value; return 0; }
     sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
@@ -6170,7 +6472,7 @@ const char* sd_conv2d_kernel_name(const sd_conv_desc* d, int pass) {
         t = a;
         if (conv1x1_stream_geometry(a, mode)) return a.Ck == 64 ? "k_conv1x1_stream_bf16<64, 2>" : "k_conv1x1_stream_bf16<128, 1>";   // (launches with a scale or statistics: k_conv_igemm)
         RowsArgs ra;
-        if (conv_rows64_geometry(a, mode, ra)) return "k_conv3x3_c64_rows_bf16";
+        if (conv_rows64_geometry(a, mode, ra)) return conv_rows16_args(ra) ? "k_conv3x3_c64_rows16_bf16" : "k_conv3x3_c64_rows_bf16";
         if (conv_pp_geometry(t, mode)) return "k_conv3x3_bf16_pp";
         t = a;
         if (const int PBN = patch_tile_bn(t, BN, mode, true)) snprintf(name, sizeof(name), "k_conv3x3_patch%s<%d, true>", t.pt_rolling ? "_roll" : "", PBN);

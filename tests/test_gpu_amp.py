@@ -461,21 +461,28 @@ def test_head_backward_on_bf16_activations(case):
     close(dw.cpu(), 2 * w.grad.reshape(Co, Cc), 2e-5)
 
 
-@pytest.mark.parametrize("case", [(2, 16, 128, 64, 64, 3, 1, 1), (1, 24, 256, 64, 64, 3, 1, 1), (3, 9, 128, 64, 64, 3, 1, 1), (8, 40, 128, 64, 64, 3, 1, 1)])
-def test_conv_bf16_row_stream_kernel_64_channels(case):
-    """k_conv3x3_c64_rows_bf16 (layer1's 64 -> 64 convs: persistent blocks stream the rows of a 128-pixel strip, weights in registers,
-    output stored one row late with the residual / ReLU / BatchNorm column sums): forced onto small problems with sd_set_option, then
-    the checks of the other bf16 conv kernels (forward + fused statistics, data-gradient plain / + residual) plus the forward epilogue.
-    Shapes: two strips per row (W = 256), row counts that are not a multiple of the unit, several units per strip."""
+@pytest.mark.parametrize("rows16", [1, 0])
+@pytest.mark.parametrize("case", [(2, 16, 128, 64, 64, 3, 1, 1), (1, 24, 256, 64, 64, 3, 1, 1), (3, 9, 128, 64, 64, 3, 1, 1), (8, 40, 128, 64, 64, 3, 1, 1),
+                                  (2, 1, 128, 64, 64, 3, 1, 1), (1, 2, 128, 64, 64, 3, 1, 1)])
+def test_conv_bf16_row_stream_kernel_64_channels(case, rows16):
+    """layer1's 64 -> 64 convs as a row stream (persistent blocks walk the rows of a 128-pixel strip, weights in registers): forced onto small
+    problems with sd_set_option, then the checks of the other bf16 conv kernels (forward + fused statistics, data-gradient plain / + residual)
+    plus the forward epilogue (affine, + residual, ReLU).  rows16 = 1: k_conv3x3_c64_rows16_bf16 (round 5: swapped MFMA operands on
+    16x16x32, epilogue of the previous row in registers out of a second accumulator set, one instantiation per epilogue kind);
+    rows16 = 0: k_conv3x3_c64_rows_bf16 (32x32x16, output stored one row late through an LDS scratch).
+    Shapes: two strips per row (W = 256), row counts that are not a multiple of the unit, several units per strip, one- and two-row maps
+    (a unit whose first row is its last / whose second accumulator set is the last one read)."""
     from structuredetector_amd import _lib as L
     lib = L.lib()
     B, H, W, cin, cout, k, stride, pad = case
     d = make_desc(L, B, H, W, cin, cout, k, stride, pad)
     L.check(lib.sd_set_option(b"conv_rows64_min_units", 1))
     L.check(lib.sd_set_option(b"conv_fwd_split_k", 0))
+    L.check(lib.sd_set_option(b"conv_rows16", rows16))
+    name = "k_conv3x3_c64_rows16_bf16" if rows16 else "k_conv3x3_c64_rows_bf16"
     try:
-        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == "k_conv3x3_c64_rows_bf16"
-        assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode() == "k_conv3x3_c64_rows_bf16"
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == name
+        assert lib.sd_conv2d_kernel_name(C.byref(d), 17).decode() == name
         test_conv_bf16_forward_statistics_and_data_gradient(case)
         g = torch.Generator().manual_seed(sum(case) + 2)
         x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
@@ -494,6 +501,7 @@ def test_conv_bf16_row_stream_kernel_64_channels(case):
     finally:
         L.check(lib.sd_set_option(b"conv_rows64_min_units", 192))
         L.check(lib.sd_set_option(b"conv_fwd_split_k", 1))
+        L.check(lib.sd_set_option(b"conv_rows16", 1))
 
 
 def test_stride2_convs_on_the_256_row_bf16_tiles():

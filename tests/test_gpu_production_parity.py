@@ -285,7 +285,7 @@ def test_stress_geometry_bf16_forward_bs16_1024_vs_autocast_oracle():
     net.load_state_dict(ref.state_dict())
     x = torch.randn(B, 3, S, S, generator=g)
     # the kernels this geometry must engage
-    for (a, want) in (((B, 256, 256, 64, 64, 3, 1, 1), "k_conv3x3_c64_rows_bf16"), ((B, 128, 128, 128, 128, 3, 1, 1), "k_conv3x3_bf16_pp"),
+    for (a, want) in (((B, 256, 256, 64, 64, 3, 1, 1), "k_conv3x3_c64_rows16_bf16"), ((B, 128, 128, 128, 128, 3, 1, 1), "k_conv3x3_bf16_pp"),
                       ((B, 64, 64, 256, 256, 3, 1, 1), "k_conv3x3_bf16_pp"), ((B, 256, 256, 128, 128, 3, 1, 1), "k_conv3x3_bf16_pp")):
         d = make_desc(L, *a)
         assert lib.sd_conv2d_kernel_name(C.byref(d), 16).decode() == want, (a, lib.sd_conv2d_kernel_name(C.byref(d), 16).decode())

@@ -237,7 +237,7 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     for which in (16, 17):
         assert name(64, 64, 128, 128, which=which) == "k_conv3x3_bf16_pp"
         assert name(64, 32, 256, 256, which=which) == "k_conv3x3_bf16_pp"
-        assert name(64, 128, 64, 64, which=which) == "k_conv3x3_c64_rows_bf16"
+        assert name(64, 128, 64, 64, which=which) == "k_conv3x3_c64_rows16_bf16"
         assert name(64, 16, 512, 512, which=which) == "k_conv3x3_patch<64, true>"      # layer4: 128 two-group tiles, 256 patch tiles of 128 channels, 512 of 64
         assert name(64, 128, 128, 128, which=which) == "k_conv3x3_bf16_pp"          # up4.conv: 64-pixel column strips
         assert lib.sd_set_option(b"conv_pp_strips", 0) == 0
@@ -249,7 +249,7 @@ def test_set_option_is_host_only_and_rejects_unknown_names():
     assert name(8, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # ... and 256 of 64 channels < 512
     assert name(32, 64, 128, 128) == "k_conv3x3_bf16_pp"                  # 256 two-group tiles
     assert name(16, 128, 64, 64) == "k_conv3x3_patch_roll<64, true>"      # 8 rows per unit < 16; 128-wide map: rolling-buffer entry point
-    assert name(16, 256, 64, 64) == "k_conv3x3_c64_rows_bf16"             # stress config (1024 x 1024 inputs): two strips per row
+    assert name(16, 256, 64, 64) == "k_conv3x3_c64_rows16_bf16"             # stress config (1024 x 1024 inputs): two strips per row
     assert name(1, 64, 128, 128) == "k_conv_igemm<128, 0, true>"          # bs=1: split-K
     # round 4: the FPN laterals (1x1 / stride 1 onto 128 channels from 64 / 128) stream from 65536 output pixels; the 128 -> 128 1x1
     # data-gradient too; other widths and small maps keep the tile kernel; the option moves the threshold
