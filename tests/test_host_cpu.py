@@ -702,3 +702,13 @@ def test_roctx_ranges_behind_the_c_abi():
             assert flag == "1" and "roctx" in name, r.stdout           # the image ships librocprofiler-sdk-roctx / libroctx64
         else:
             assert flag == "0" and name == ""
+
+
+def test_rows16_kernel_isa_has_no_unseen_mfma_hazard():
+    """k_conv3x3_c64_rows16_bf16's MFMAs are inline asm, invisible to hipcc's hazard recogniser: safe only while the register allocator keeps
+    every weight fragment where its constraint pinned it (a parked fragment is copied into an AGPR quad in front of the MFMA without the wait
+    states in between -- seen in round 5 as wrong, run-to-run different sums).  tools/check_rows16_isa.py compiles the translation unit to ISA
+    and checks every DISPATCHED instantiation: no weight AGPR written, nothing spilled, inside the row loops."""
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_rows16_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok" in r.stdout
