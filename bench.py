@@ -215,6 +215,11 @@ def main():
                          "precision -0.3 %%: both streams are MFMA-bound and share the power budget; per-kernel durations then overlap)")
     ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
                     help="gradient all-reduce binding for --gpus > 1: torch.distributed's RCCL (default) or the C-ABI sd_allreduce_*")
+    ap.add_argument("--no-comm-sim", dest="comm_sim", action="store_false", default=True,
+                    help="skip `north_star.comm_sim` (single-GPU runs): the training step with a simulated all-reduce beside its backward")
+    ap.add_argument("--comm-sim-wgs", type=int, default=32, help="workgroups of the simulated collective (RCCL: one or two per channel)")
+    ap.add_argument("--comm-sim-gbps", type=float, default=200.0,
+                    help="modelled bus bandwidth of the 8-rank all-reduce over xGMI (7 links x ~50 GB/s per direction: 150-300 GB/s for 1-50 MB buckets)")
     ap.add_argument("--fuse-bn-bwd", dest="fuse_bn_bwd", action="store_true", default=None,
                     help="BatchNorm-backward reductions inside the data-gradient epilogues (experiment switch; default: the engine's)")
     ap.add_argument("--no-fuse-bn-bwd", dest="fuse_bn_bwd", action="store_false")
@@ -355,8 +360,12 @@ def main():
         net._engine.prof = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        rccl["ms_per_step_per_rank_min"] = round(min(float(v.item()) for v in per_rank) / a.steps * 1e3, 3)
+        rccl["ms_per_step_per_rank_max"] = round(max(float(v.item()) for v in per_rank) / a.steps * 1e3, 3)
     loss_host = [float(v) for v in loss.cpu()]
     assert all(np.isfinite(loss_host)), f"non-finite loss {loss_host}"
     if world > 1:
@@ -517,6 +526,56 @@ def main():
                     "decode_annotations_only_us_per_img": round(sd_fast / Bs * 1e6, 2),
                     "fwd_plus_decode_ms": round(sboth * 1e3, 3), "objects_per_img": "64-96", "K": Ks, "P": Ps}
 
+        def fig_comm_sim():
+            # What eight ranks will add to a step, sized on ONE GPU: a persistent copy launch of RCCL's shape (`--comm-sim-wgs` workgroups of 256
+            # threads, 8 KB LDS, link-bound at `--comm-sim-gbps`) at the five bucket trigger points of the backward, on the exchange's side stream,
+            # moving 2 x 7 / 8 x the bucket (`TrainStep.attach_sim`, csrc/sd_commsim.hip).  Same-process alternating A/B; `stretched` = the conv
+            # kernels whose launches grew most per step (stream events around every conv launch, with and without the simulated exchange).
+            def per_kernel(n_steps=2):
+                ev = []
+                net._engine.prof = ev
+                for i in range(n_steps):
+                    run_step(i)
+                torch.cuda.synchronize()
+                net._engine.prof = None
+                agg = {}
+                for kind, _fl, e0, e1, _ph in ev:
+                    d = agg.setdefault(kind, [0, 0.0])
+                    d[0] += 1; d[1] += e0.elapsed_time(e1)
+                return {k: (v[0] / n_steps, v[1] / n_steps) for k, v in agg.items()}          # launches per step, ms per step
+
+            out = {"ranks_modelled": 8, "workgroups": a.comm_sim_wgs, "bus_GBps_modelled": a.comm_sim_gbps,
+                   "bytes_moved_per_step": int(2 * 7 / 8 * net.flat_grads.numel() * 4)}
+            for label, amp in (("fp32", False), ("amp_bf16", True)):
+                step.amp = amp
+                try:
+                    base, with_sim = [], []
+                    for _ in range(3):
+                        step.detach_sim()
+                        base.append(timed(lambda: run_step(0), 4, warm=1))
+                        step.attach_sim(ranks=8, workgroups=a.comm_sim_wgs, gbps=a.comm_sim_gbps)
+                        with_sim.append(timed(lambda: run_step(0), 4, warm=1))
+                    k_sim = per_kernel()
+                    sim = step.sim
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(); e0.record(sim.side)
+                    for name in step.STAGES:
+                        sim.all_reduce(net.flat_grads, *step.ranges[name])
+                    e1.record(sim.side); e1.synchronize()
+                    isolated = e0.elapsed_time(e1)
+                    step.detach_sim()
+                    k_base = per_kernel()
+                    grown = sorted(((k_sim[k][1] - k_base[k][1], k) for k in k_base if k in k_sim), reverse=True)[:3]
+                    t0_, t1_ = min(base), min(with_sim)
+                    out[label] = {"ms_per_step": round(t0_ * 1e3, 3), "ms_per_step_with_sim": round(t1_ * 1e3, 3),
+                                  "exposed_ms": round((t1_ - t0_) * 1e3, 3), "exposed_pct": round(100 * (t1_ / t0_ - 1), 2),
+                                  "sim_launches_isolated_ms": round(isolated, 3),
+                                  "stretched": [{"kernel": k, "ms_per_step": round(k_base[k][1], 3), "ms_per_step_with_sim": round(k_sim[k][1], 3)} for _d, k in grown]}
+                finally:
+                    step.amp = False
+                    step.detach_sim()
+            return out
+
         net.eval()
         guarded(ns, "fwd_eval_fp32", fig_fwd_fp32)
         guarded(ns, "infer_bs1_fp32", fig_bs1)
@@ -524,6 +583,8 @@ def main():
         net.train()
         if not a.amp:
             guarded(ns, "train_step_amp_bf16", fig_amp)
+            if a.comm_sim:
+                guarded(ns, "comm_sim", fig_comm_sim)
         guarded(ns, "stress_1024_8x8_bf16", fig_stress)
 
         def fig_directory_feed():
@@ -556,7 +617,9 @@ def main():
                                "device_GBps_bs%d" % B: round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9, 1),
                                "frac_of_hbm_peak": round(B * DECODE_BYTES_PER_IMG / d_dev / 1e9 / PEAK_HBM_GBPS, 4),
                                "exact_topk_us_per_img_bs%d" % B: round(d_exact / B * 1e6, 3),
-                               "e2e_us_per_img_bs1": round(d_one * 1e6, 1), "bytes_per_img": DECODE_BYTES_PER_IMG}
+                               "e2e_us_per_img_bs1": round(d_one * 1e6, 1), "bytes_per_img": DECODE_BYTES_PER_IMG,
+                               # one-launch decodes that were redone because a selector block gave up its bounded wait (contention)
+                               "selector_timeouts": int(dec.selector_timeouts)}
             if (B, img) == (64, 512):
                 # the streaming rate at a batch that hides the fixed cost of the launches (bs = 512: 8 copies of the same head)
                 big = {k: v.repeat(8, 1, 1, 1) for k, v in outs.items()}

@@ -530,6 +530,13 @@ int sd_allreduce_init(const void* id, int rank, int world, void** comm_out);
 int sd_allreduce_run(void* comm, float* buf, int64_t count, sd_stream_t stream);
 int sd_allreduce_destroy(void* comm);
 
+/* Stand-in for ONE RCCL all-reduce launch on a single GPU (no reference counterpart; sizing tool for the data-parallel step, csrc/sd_commsim.hip):
+ * `workgroups` persistent blocks of 256 threads / 8 KB LDS copy `move_bytes` (a multiple of 16; the source of `src_bytes` wraps) from src to dst,
+ * throttled on the 100 MHz wall clock to `gbps` GB/s in total -- the launch occupies its CUs for move_bytes / gbps like a link-bound collective.
+ * `TrainStep(exchange="sim")` issues it at the five bucket trigger points of the backward on the exchange's side stream; bench.py reports the
+ * step time with and without it (`north_star.comm_sim`). */
+int sd_comm_sim_copy(const void* src, void* dst, size_t src_bytes, size_t move_bytes, int workgroups, float gbps, sd_stream_t stream);
+
 /* ---- profiler ranges (no reference counterpart: SURVEY.md section 5 lists tracing as absent from the reference) ----
  * roctx ranges on the calling thread, for `rocprofv3 --marker-trace`.  Active only when the environment holds SDNET_ROCTX=1 at the
  * first call AND a marker library (librocprofiler-sdk-roctx / libroctx64) can be dlopen'ed; otherwise every call is a no-op returning 0.

@@ -59,6 +59,33 @@ class RcclExchange:
             self._comm = None
 
 
+class SimExchange:
+    """Stand-in for the gradient all-reduce on ONE GPU (`TrainStep(..., exchange="sim")`): at every bucket trigger point of the backward a
+    persistent copy launch of RCCL's shape (`sd_comm_sim_copy`: `workgroups` blocks of 256 threads, 8 KB of LDS, link-bound at `gbps`) moves
+    2 (N - 1) / N x the bucket (N = `ranks`) on the exchange's side stream -- same ordering as `RcclExchange` (waits for the compute stream,
+    joined before Adam).  The gradients are NOT changed (the copy goes to a scratch buffer): the step computes what a single rank computes;
+    only its timing carries the collective's footprint.  bench.py: `north_star.comm_sim`."""
+
+    def __init__(self, device, largest_bucket_floats, ranks=8, workgroups=32, gbps=200.0):
+        self.ranks, self.workgroups, self.gbps = int(ranks), int(workgroups), float(gbps)
+        self.side = torch.cuda.Stream(device)
+        self.scratch = torch.empty(largest_bucket_floats, dtype=torch.float32, device=device)
+        self.moved_bytes = 0
+
+    def all_reduce(self, flat, lo, hi):
+        n = hi - lo
+        if n > self.scratch.numel():
+            raise L.SdError(f"SimExchange: bucket of {n} floats exceeds the scratch buffer ({self.scratch.numel()})")
+        move = int(2 * (self.ranks - 1) / self.ranks * n * 4) // 16 * 16
+        self.side.wait_stream(torch.cuda.current_stream())
+        L.check(L.lib().sd_comm_sim_copy(flat.data_ptr() + 4 * lo, self.scratch.data_ptr(), n * 4, move, self.workgroups, self.gbps, self.side.cuda_stream),
+                "sd_comm_sim_copy")
+        self.moved_bytes += move
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
 class TrainStep:
     def __init__(self, net, args, lr=None, betas=(0.9, 0.999), eps=1e-8, process_group=None, exchange=None):
         if net.flat_params is None:
@@ -72,10 +99,14 @@ class TrainStep:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         exchange = exchange or os.environ.get("SDNET_EXCHANGE", "torch")
-        if exchange not in ("torch", "rccl"):
-            raise ValueError(f"exchange must be 'torch' or 'rccl', got {exchange!r}")
+        want_sim = exchange == "sim"
+        if exchange not in ("torch", "rccl", "sim"):
+            raise ValueError(f"exchange must be 'torch', 'rccl' or 'sim', got {exchange!r}")
         self.rccl = RcclExchange(net.flat_params.device, process_group) if (exchange == "rccl" and self.world > 1) else None
         self.ranges = net.stage_ranges()
+        self.sim = None                  # SimExchange: the collective's footprint on one GPU (attach_sim)
+        if want_sim:
+            self.attach_sim()
         self.one = torch.ones((), dtype=torch.float32, device=net.flat_params.device)
         self.stats = LossStats()
         self.amp = bool(getattr(args, "use_amp", False))      # mixed-precision step (trainer.py:115-121)
@@ -105,19 +136,48 @@ class TrainStep:
             for b in self.net.buffers():
                 dist.broadcast(b, 0, group=self.pg)
 
+    # Bucket plans: which stages travel together.  A group is launched when its LAST stage completes; the stages of a group are adjacent in
+    # the flat buffer (parameters are laid out in registration order: stem, down1 .. down4, FPN, head -- the backward completes them from
+    # the end), so a group is ONE contiguous all-reduce.  Five launches hide best under a 73 ms fp32 step; a 15 ms mixed-precision step pays
+    # ~0.08 ms of fixed cost per launch (stream hand-offs on both sides + the launch itself: `profiles/r05_comm_sim_sweep.txt`).
+    BUCKET_PLANS = {5: (("fpn_head",), ("down4",), ("down3",), ("down2",), ("down1_stem",)),
+                    3: (("fpn_head", "down4"), ("down3",), ("down2", "down1_stem")),
+                    2: (("fpn_head", "down4", "down3"), ("down2", "down1_stem")),
+                    1: (("fpn_head", "down4", "down3", "down2", "down1_stem"),)}
+
+    def set_bucket_plan(self, launches):
+        """Number of all-reduce launches per step: 5 (default: one per parameter group), 3, 2 or 1."""
+        if launches not in self.BUCKET_PLANS:
+            raise ValueError(f"bucket plan must be one of {sorted(self.BUCKET_PLANS)}, got {launches!r}")
+        self.bucket_plan = launches
+
+    def _groups(self):
+        """{trigger stage: (lo, hi)} of the current plan: the flat range a group covers, keyed by the stage that completes it."""
+        out = {}
+        for group in self.BUCKET_PLANS[getattr(self, "bucket_plan", 5)]:
+            lo = min(self.ranges[n][0] for n in group); hi = max(self.ranges[n][1] for n in group)
+            assert hi - lo == sum(self.ranges[n][1] - self.ranges[n][0] for n in group), "the stages of a bucket group must be adjacent in the flat buffer"
+            out[group[-1]] = (lo, hi)
+        return out
+
     def _exchange_hooks(self):
-        """(on_stage, finish): on_stage(name) starts the all-reduce of one gradient bucket (called by the backward schedule as
-        soon as that parameter group's gradients are complete), finish() joins every bucket before the Adam launch."""
+        """(on_stage, finish): on_stage(name) starts the all-reduce of the gradient bucket group that stage `name` completes (called by the
+        backward schedule as soon as that parameter group's gradients are complete), finish() joins every launch before the Adam launch."""
         net = self.net
+        groups = self._groups()
+        sim = getattr(self, "sim", None)
+        if sim is not None and self.exchange_enabled:
+            return (lambda name: sim.all_reduce(net.flat_grads, *groups[name]) if name in groups else None), sim.wait
         if self.world == 1 or not self.exchange_enabled:
             return None, (lambda: None)
         if self.rccl is not None:
-            return (lambda name: self.rccl.all_reduce(net.flat_grads, *self.ranges[name])), self.rccl.wait
+            return (lambda name: self.rccl.all_reduce(net.flat_grads, *groups[name]) if name in groups else None), self.rccl.wait
         works = []
 
         def on_stage(name):
-            lo, hi = self.ranges[name]
-            works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
+            if name in groups:
+                lo, hi = groups[name]
+                works.append(dist.all_reduce(net.flat_grads[lo:hi], group=self.pg, async_op=True))
 
         def finish():
             for w in works:
@@ -125,6 +185,15 @@ class TrainStep:
         return on_stage, finish
 
     STAGES = ("fpn_head", "down4", "down3", "down2", "down1_stem")       # order in which the backward completes the buckets
+
+    def attach_sim(self, ranks=8, workgroups=32, gbps=200.0):
+        """Run every following step with the simulated exchange (`SimExchange`) beside its backward; `detach_sim()` ends it."""
+        # (scratch as large as the whole flat buffer: a bucket plan may send several parameter groups -- up to all of them -- in one launch)
+        self.sim = SimExchange(self.net.flat_params.device, int(self.net.flat_grads.numel()), ranks, workgroups, gbps)
+        return self.sim
+
+    def detach_sim(self):
+        self.sim = None
 
     def verify_exchange(self):
         """Self-check of the data-parallel exchange THROUGH THE PATH THE STEP USES (same buckets, same binding, same streams):

@@ -137,6 +137,10 @@ def _verify8_worker(rank, world, port, ranges, total, out):
         report = step.verify_exchange()
         ok = report["ranks"] == world and report["check"].startswith(f"ok: sum(rank+1) == {world * (world + 1) // 2:g}")
         ok = ok and sum(report["buckets"].values()) == total and float(step.net.flat_grads.abs().max()) == 0.0
+        for plan in (3, 2, 1):                                   # round 5: adjacent parameter groups merged into fewer, larger all-reduces
+            step.set_bucket_plan(plan)
+            ok = ok and len(step._groups()) == plan and step.verify_exchange()["check"].startswith("ok")
+        step.set_bucket_plan(5)
         # a rank that contributes nothing must be caught: rank 3 zeroes its buffer inside the exchange
         step2 = object.__new__(TrainStep)
         step2.net = Namespace(flat_grads=torch.zeros(total))

@@ -202,3 +202,61 @@ def test_two_rank_step_over_rccl_when_two_gpus_are_present():
     for exchange in ("torch", "rccl"):
         assert out[0][exchange + "_check"].startswith("ok") and out[1][exchange + "_check"].startswith("ok")
         assert torch.equal(out[0][exchange], out[1][exchange]), f"ranks diverged with exchange={exchange}"
+
+
+def test_simulated_exchange_keeps_the_step_and_takes_its_modelled_time():
+    """`TrainStep(exchange="sim")` / `attach_sim` (what eight ranks add to a step, sized on one GPU): at the five bucket
+    trigger points of the backward a persistent copy launch of RCCL's shape runs on the exchange's side stream (`sd_comm_sim_copy`:
+    workgroups x 256 threads, link-bound at `gbps`).  Checked: (1) the step computes exactly what the single-rank step computes (parameters
+    bit-identical after two steps: the copy goes to a scratch buffer, the mean over one rank is the gradient itself); (2) five launches
+    move 2 x 7 / 8 x the flat gradient buffer; (3) a launch alone lasts move_bytes / gbps (the throttle, not the HBM, sets its duration) and
+    copies what it should; (4) bad arguments are refused without a launch."""
+    import ctypes as C
+    from argparse import Namespace
+
+    import numpy as np
+    import torch
+
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.data import Encode
+    from structuredetector_amd.data.synthetic import synthetic_batch
+    from structuredetector_amd.model import Network
+    from structuredetector_amd.model.trainer import TrainStep
+    dev = torch.device("cuda")
+    labels = {"a": 0, "b": 1}; parts = {"p": 0}
+    args = Namespace(labels=labels, parts=parts, _r_labels={v: k for k, v in labels.items()}, _r_parts={v: k for k, v in parts.items()},
+                     anchor_name="stem", down_ratio=4.0, max_objects=20, max_parts=40, conf_threshold=0.5, decoder_dist_thresh=0.1, sigma_gauss=0.1,
+                     hm_loss_fn="mse", hm_weight=1.0, offset_weight=0.001, embedding_weight=0.001, fpn_depth=128, learning_rate=1e-3, device=dev)
+    enc = Encode(args)
+    x = torch.randn(2, 3, 128, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    tgt = enc.render(enc.plan(128, 128, *synthetic_batch(np.random.default_rng(1), 2, 128, 128, 2, 1)), dev)
+    finals = []
+    for sim in (False, True):
+        torch.manual_seed(11)
+        net = Network(args, pretrained=False).to(dev).train()
+        step = TrainStep(net, args)
+        if sim:
+            s = step.attach_sim(ranks=8, workgroups=16, gbps=400.0)
+        for _ in range(2):
+            step(x, tgt)
+        torch.cuda.synchronize()
+        finals.append(net.flat_params.clone())
+        if sim:
+            want = sum(int(2 * 7 / 8 * (hi - lo) * 4) // 16 * 16 for lo, hi in step.ranges.values())
+            assert s.moved_bytes == 2 * want and want >= int(2 * 7 / 8 * net.flat_grads.numel() * 4) - 16 * 5
+    assert torch.equal(finals[0], finals[1]), "the simulated exchange must not change what the step computes"
+    lib = L.lib()
+    n = 4 << 20                                                        # 16 MB at 100 GB/s: 168 us
+    src = torch.arange(n, dtype=torch.float32, device=dev); dst = torch.zeros_like(src)
+    for _ in range(2):
+        L.check(lib.sd_comm_sim_copy(src.data_ptr(), dst.data_ptr(), n * 4, n * 4, 16, 100.0, L.stream()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.sd_comm_sim_copy(src.data_ptr(), dst.data_ptr(), n * 4, n * 4, 16, 100.0, L.stream()))
+    e1.record(); e1.synchronize()
+    assert torch.equal(src, dst)
+    us = e0.elapsed_time(e1) * 1e3
+    assert 0.9 * 167.8 <= us <= 1.5 * 167.8, f"16 MB at a modelled 100 GB/s should take ~168 us, took {us:.1f}"
+    assert lib.sd_comm_sim_copy(src.data_ptr(), dst.data_ptr(), n * 4, n * 4 + 8, 16, 100.0, L.stream()) == -1       # not a multiple of 16 bytes
+    assert lib.sd_comm_sim_copy(src.data_ptr(), dst.data_ptr(), n * 4, n * 4, 0, 100.0, L.stream()) == -1           # no workgroups
+    assert lib.sd_comm_sim_copy(src.data_ptr() + 4, dst.data_ptr(), n * 4 - 16, 16, 4, 100.0, L.stream()) == -3      # misaligned
