@@ -475,6 +475,27 @@ def main():
                     "hipgraph_fwd_decode_objects_ms": round(ge2e * 1e3, 3), "bf16_fwd_ms": round(f1b * 1e3, 3),
                     "bf16_fwd_hipgraph_ms": round(g1b * 1e3, 3), "bf16_fwd_decode_objects_ms": round(e2eb * 1e3, 3)}
 
+        def measured_bf16_stream():
+            # the box's own ceiling: a bare LDS-read + MFMA loop on random bf16 operands (csrc/sd_bench.hip), ~0.4 s of warm launches, the last ones timed
+            if "tflops" not in bf16_stream:
+                L_ = __import__("structuredetector_amd._lib", fromlist=["lib"])
+                lib_ = L_.lib()
+                gen_ = torch.Generator(device=dev).manual_seed(5)
+                ops = (torch.rand(32 * 1024, device=dev, generator=gen_) * 2 - 1).to(torch.bfloat16)          # 64 KB of bf16 in [-1, 1)
+                sink = torch.empty(256 * 512, dtype=torch.float32, device=dev)
+                iters = 20000
+                for _ in range(60):
+                    L_.check(lib_.sd_mfma_bf16_stream(ops.data_ptr(), sink.data_ptr(), iters, L_.stream()))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    L_.check(lib_.sd_mfma_bf16_stream(ops.data_ptr(), sink.data_ptr(), iters, L_.stream()))
+                e1.record(); e1.synchronize()
+                bf16_stream["tflops"] = 5 * lib_.sd_mfma_bf16_stream_flops(iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            return bf16_stream["tflops"]
+
+        bf16_stream = {}
+
         def fig_fwd_bf16():
             # bf16 backbone (inference), same network object: bs=64 512x512, against the dense bf16 MFMA peak
             net.bf16_inference = True
@@ -485,8 +506,11 @@ def main():
             finally:
                 net.bf16_inference = False
                 net.invalidate_folded()
+            stream_tf = measured_bf16_stream()
             return {"batch": B, "ms": round(b16 * 1e3, 3), "tflops": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3, 1),
-                    "frac_of_bf16_mfma_peak": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4)}
+                    "frac_of_bf16_mfma_peak": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "measured_bf16_stream_tflops": round(stream_tf, 1),
+                    "frac_of_measured_bf16_stream": round(B * FWD_GFLOP_PER_IMG / b16 / 1e3 / stream_tf, 4)}
 
         def fig_amp():
             # the same training step under `--amp` (trainer.py:115-121): bf16 activations / conv weights, fp32 accumulation + master weights
@@ -521,6 +545,7 @@ def main():
                 sboth = timed(lambda: (snet(simg), sdec.decode_packed(souts, 0.5, 0.1, exact_topk=True)), 5)
             return {"batch": Bs, "fwd_ms": round(sf * 1e3, 3), "fwd_tflops": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3, 1),
                     "fwd_frac_of_bf16_mfma_peak": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "fwd_frac_of_measured_bf16_stream": round(Bs * STRESS_FWD_GFLOP_PER_IMG / sf / 1e3 / measured_bf16_stream(), 4),
                     "decode_us_per_img": round(sd_ / Bs * 1e6, 2), "decode_GBps": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9, 1),
                     "decode_frac_of_hbm_peak": round(Bs * STRESS_DECODE_BYTES_PER_IMG / sd_ / 1e9 / PEAK_HBM_GBPS, 4),
                     "decode_annotations_only_us_per_img": round(sd_fast / Bs * 1e6, 2),

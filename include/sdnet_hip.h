@@ -537,6 +537,13 @@ int sd_allreduce_destroy(void* comm);
  * step time with and without it (`north_star.comm_sim`). */
 int sd_comm_sim_copy(const void* src, void* dst, size_t src_bytes, size_t move_bytes, int workgroups, float gbps, sd_stream_t stream);
 
+/* The box's own bf16 MFMA ceiling (no reference counterpart; measurement, csrc/sd_bench.hip): 256 blocks x 512 threads run `iters` K = 32
+ * steps of a bare LDS-read + v_mfma_f32_16x16x32_bf16 loop (wave tile 128 x 64, the bf16 conv kernels' shape) on the 64 KB of bf16 operands at
+ * `operands64k`; `out` receives 256 x 512 floats (so that nothing is optimised away).  sd_mfma_bf16_stream_flops(iters) = the flop count of one
+ * launch; bench.py times warm launches with stream events and reports the bf16 forwards as a fraction of that rate beside the nominal peak. */
+double sd_mfma_bf16_stream_flops(int iters);
+int    sd_mfma_bf16_stream(const void* operands64k, float* out, int iters, sd_stream_t stream);
+
 /* ---- profiler ranges (no reference counterpart: SURVEY.md section 5 lists tracing as absent from the reference) ----
  * roctx ranges on the calling thread, for `rocprofv3 --marker-trace`.  Active only when the environment holds SDNET_ROCTX=1 at the
  * first call AND a marker library (librocprofiler-sdk-roctx / libroctx64) can be dlopen'ed; otherwise every call is a no-op returning 0.

@@ -159,6 +159,8 @@ _SIGNATURES = {
     "sd_allreduce_init": (c_int, [c_vp, c_int, c_int, C.POINTER(c_vp)]),
     "sd_allreduce_run": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "sd_allreduce_destroy": (c_int, [c_vp]),
+    "sd_mfma_bf16_stream_flops": (C.c_double, [c_int]),
+    "sd_mfma_bf16_stream": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "sd_comm_sim_copy": (c_int, [c_vp, c_vp, c_size, c_size, c_int, c_float, c_vp]),
     "sd_range_enabled": (c_int, []),
     "sd_range_library": (C.c_char_p, []),
