@@ -997,8 +997,8 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // candidate list and selected from there.  Needs w % 4 == 0 and 16-byte aligned planes.
 // ---------------------------------------------------------------------------------------------
 // entries of a WAVE's segment of the stage: 4096 entries over the waves of a block of 8 or 16 waves; 256 per wave in smaller blocks
-// (a wave of those walks one band of a split map: 256 entries = 9 % of an 11-row band of 256 columns)
-__host__ __device__ constexpr int stream_seg(int waves) { return waves >= 8 ? 4096 / waves : 256; }
+// (a wave of those walks one or two bands of a split map: 512 entries = 9 % of two 11-row bands of 256 columns)
+__host__ __device__ constexpr int stream_seg(int waves) { return waves >= 8 ? 4096 / waves : 512; }
 // Round 5: a map may be SPLIT over `splits` blocks (blockIdx.x = (image * maps + map) * splits + part): a block walks the row bands
 // [part * bands / splits, (part + 1) * bands / splits) of its map (the halo rows of a band are read from the map, whoever owns them) and
 // stores ITS sorted top-k as one more stage-1 list -- k_rank_maps / k_rank_group merge the lists of a group by rank whatever map or
@@ -1028,7 +1028,10 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // on the small block-wide `extra` list through an LDS atomic.  count[0] = largest fill level of a segment seen (block-wide maximum:
 // the overflow test), count[1] = entries on the extra list; the wave's fill level goes to seg_fill[wave].
 constexpr int STREAM_EXTRA = 256;
-template <bool INLINE_KEYS, int NT, int ROWS>
+// HALF (round 5; maps up to 128 columns wide): a strip of 128 columns is 32 lanes of one float4, so the two halves of a wave walk TWO bands
+// side by side (lanes 0-31: band u, lanes 32-63: band u + 1) -- at the cfg shape half of every wave used to idle beyond the map's right
+// edge.  Half as many waves to start (the start-up spread of a launch is ~2 ns per wave), half the vector instructions per pixel.
+template <bool INLINE_KEYS, int NT, int ROWS, bool HALF>
 __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx,
                                            int band_lo, int band_hi) {
@@ -1041,15 +1044,21 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     int fill = 0;                                               // (wave-uniform) entries in this wave's segment
     uint64_t* seg = stage + wave * STREAM_SEG;
     float* seg_mx = mxs + wave * STREAM_SEG;
-    for (int unit = wave; unit < strips * (band_hi - band_lo); unit += STREAM_WAVES) {
-        const int sy = band_lo + unit / strips, sx = unit % strips;
-        const int x0 = sx * 256 + lane * 4;
-        const bool col_in = x0 < w;
-        const bool narrow = sx * 256 + 256 > w;                 // (wave-uniform) the strip has lanes beyond the map's right edge
-        const int y0 = sy * R;
-        // the edge lanes' halo: lane 0 needs the two columns left of the strip, lane 63 the two right of it (8-byte aligned pairs)
-        const int hx = lane == 0 ? x0 - 2 : x0 + 4;
-        const bool halo_in = (lane == 0 || lane == 63) && hx >= 0 && hx < w;
+    constexpr int PER = HALF ? 2 : 1;                           // units of work a wave walks at once
+    const int sl = HALF ? (lane & 31) : lane;                   // lane within its strip
+    const bool edge_l = sl == 0, edge_r = sl == (HALF ? 31 : 63);
+    const int units = strips * (band_hi - band_lo);
+    for (int unit0 = wave * PER; unit0 < units; unit0 += STREAM_WAVES * PER) {
+        const int unit = unit0 + (HALF ? (lane >> 5) : 0);      // (HALF: strips == 1, the unit is the band)
+        const bool unit_in = !HALF || unit < units;
+        const int sy = band_lo + (HALF ? unit : unit / strips), sx = HALF ? 0 : unit % strips;
+        const int x0 = sx * 256 + sl * 4;
+        const bool col_in = x0 < w && unit_in;
+        const bool narrow = HALF || sx * 256 + 256 > w;         // (wave-uniform) the strip has lanes beyond the map's right edge / an empty half
+        const int y0 = sy * R;                                  // (HALF: differs between the two halves of the wave)
+        // the edge lanes' halo: the first lane of a strip needs the two columns left of it, the last the two right of it (8-byte aligned pairs)
+        const int hx = edge_l ? x0 - 2 : x0 + 4;
+        const bool halo_in = (edge_l || edge_r) && hx >= 0 && hx < w && unit_in;
         // row pointers advance by w per request; lanes outside the map (and the 62 inner lanes' halo) re-read the plane's first words
         const float* pv = plane + (col_in ? x0 : 0);
         const float* ph = plane + (halo_in ? hx : 0);
@@ -1072,21 +1081,25 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                 float4 cur = v[u];
                 float2 hh = hl[u];
                 if (j + RING < NR) request(j + RING, u);               // the slot is free again: row j + RING goes out
-                if (y < 0 || y >= h) {                                  // (wave-uniform)
+                if (y < 0 || y >= h) {                                  // (wave-uniform unless HALF)
                     cur = make_float4(NEG, NEG, NEG, NEG); hh = make_float2(NEG, NEG);
                 } else {
                     if (narrow && !col_in) cur = make_float4(NEG, NEG, NEG, NEG);
                     if (!halo_in) hh = make_float2(NEG, NEG);
                 }
                 float lz = lane_from_left(cur.z), lw = lane_from_left(cur.w), rx = lane_from_right(cur.x), ry = lane_from_right(cur.y);
-                if (lane == 0) { lz = hh.x; lw = hh.y; }
-                if (lane == 63) { rx = hh.x; ry = hh.y; }
+                if (edge_l) { lz = hh.x; lw = hh.y; }                  // (HALF: lane 32's left neighbour is lane 31 of the OTHER band: replaced like lane 0's)
+                if (edge_r) { rx = hh.x; ry = hh.y; }
                 const float ma = max3f(cur.x, cur.y, cur.z), mb = max3f(cur.y, cur.z, cur.w);
                 hm[u] = make_float4(max3f(ma, lz, lw), max3f(ma, lw, cur.w), max3f(mb, cur.x, rx), max3f(mb, rx, ry));
                 const float4 centre = c2;                               // row j - 2
                 c2 = c1; c1 = cur;
                 const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all RING slots), centre j - 2
-                if (j < 4 || yo >= h) continue;                         // (wave-uniform)
+                if (j < 4) continue;
+                if constexpr (!HALF) { if (yo >= h) continue; }         // (wave-uniform)
+                // HALF: an output row beyond the map in ONE half of the wave: no candidates there (a window entirely outside the map is all
+                // -inf, and inf - inf fails the `>` of the survivor rule: it must be masked, not left to the arithmetic)
+                const bool row_ok = !HALF || yo < h;
 #if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 2                         // timing experiment: loads + horizontal maxima only
                 if (hm[u].x != 12345.f) continue;
 #endif
@@ -1100,7 +1113,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                     float sc[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e])) && !(narrow && !col_in);
+                        cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e])) && !(narrow && !col_in) && row_ok;
                         sc[e] = 0.f;
                         if (cand[e]) {
                             sc[e] = clamped_sigmoid(xv[e]);
@@ -1116,9 +1129,11 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                     continue;
                 }
                 // (lanes beyond the map hold -inf: inf - inf fails `>`, they are dropped by the `narrow` term)
-                const bool c0 = !(mx[0] - xv[0] > nms_margin(mx[0])), c1e = !(mx[1] - xv[1] > nms_margin(mx[1]));
-                const bool c2e = !(mx[2] - xv[2] > nms_margin(mx[2])), c3 = !(mx[3] - xv[3] > nms_margin(mx[3]));
-                const bool any = (c0 || c1e || c2e || c3) && !(narrow && !col_in);
+                const bool c0r = !(mx[0] - xv[0] > nms_margin(mx[0])), c1r = !(mx[1] - xv[1] > nms_margin(mx[1]));
+                const bool c2r = !(mx[2] - xv[2] > nms_margin(mx[2])), c3r = !(mx[3] - xv[3] > nms_margin(mx[3]));
+                const bool live = !(narrow && !col_in) && row_ok;
+                const bool c0 = c0r && live, c1e = c1r && live, c2e = c2r && live, c3 = c3r && live;
+                const bool any = c0 || c1e || c2e || c3;
 #if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 1                         // timing experiment: no append (results wrong by design)
                 if (mx[0] != 12345.f) continue;
 #endif
@@ -1160,7 +1175,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     }
 }
 
-template <int STREAM_THREADS, int ROWS>
+template <int STREAM_THREADS, int ROWS, bool HALF = false>
 __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
                                                                        uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1, int splits) {
     constexpr int STREAM_WAVES = STREAM_THREADS / 64, STREAM_SEG = stream_seg(STREAM_WAVES), STREAM_CAP = STREAM_WAVES * STREAM_SEG;
@@ -1192,7 +1207,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     SD_TRACE(trace0 + 0);
     SD_TRACE(blockIdx.x < 592 ? 7000 + (int)blockIdx.x : -1);          // (trace builds: start / end of every block of the first 592)
     __syncthreads();
-    stream_map<false, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx, band_lo, band_hi);
+    stream_map<false, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx, band_lo, band_hi);
     SD_TRACE(trace0 + 1);
     // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
     auto convert = [&](uint64_t ent, float mxv) {
@@ -1240,7 +1255,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     if (tid == 0) counts[0] = 0;
     __syncthreads();
     uint64_t* glist = cand + (int64_t)bm * hw + (int64_t)band_lo * ROWS * w;      // this part's rows of the map's h * w slots
-    stream_map<true, STREAM_THREADS, ROWS>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr, band_lo, band_hi);
+    stream_map<true, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr, band_lo, band_hi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
@@ -2302,6 +2317,7 @@ static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
 static thread_local int g_map_rows11 = 1;           // 0: 128-row maps keep 16-row bands on 8 waves (A/B)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
+static thread_local int g_map_half = 1;             // 0: one band per wave also on maps up to 128 columns wide (A/B, tests)
 static thread_local int g_map_split = 0;            // parts per map in k_map_stream_select: 0 = by geometry, 1 .. MAP_SPLIT_MAX = forced (A/B, tests)
 static thread_local int g_map_rank_group = 1;       // 0: k_rank_maps + k_group_wide instead of the one-launch k_rank_group (A/B, tests)
 constexpr size_t RANK_GROUP_LDS_MAX = 96 * 1024;    // dynamic LDS of k_rank_group (beside its 37 KB of static arrays)
@@ -2363,24 +2379,31 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             const int units16 = strips * cdiv(h, 16), units11 = strips * cdiv(h, 11);
             const int rows = units16 >= 16 ? 16 : ((g_map_rows11 && units11 > 8 && units11 <= 16) ? 11 : 16);
             const int bands = cdiv(h, rows);
+            // maps up to 128 columns wide: two bands per wave (lanes 0-31 / 32-63), half the waves (sd_decode_set_option("map_half", 0): off)
+            const bool half = g_map_half && strips == 1 && w <= 128;
             int want = g_map_split;
             // (measured, `profiles/r05_decode_split_sweep.txt`: at bs = 64 -- 192 maps -- one block per map and three parts per map stream in the
             // same 14 us, the kernel is bound by the start-up spread of its ~2500 waves and their first round trips, and the rank kernel pays for
             // three times the lists; at bs = 512 the parts stream in 53 instead of 74 us: five 27 KB blocks per CU instead of one of 86 KB)
-            if (want <= 0) want = (rows == 11 && strips == 1 && (int64_t)B * C >= 384) ? cdiv(bands, 4) : 1;
+            //  With two bands per wave (maps up to 128 columns) two parts per map pay from ~100 maps: bs = 64 21.4 -> 20.5 us, bs = 512 72.8 -> 53.6.)
+            if (want <= 0) want = (rows == 11 && strips == 1) ? (half ? ((int64_t)B * C >= 96 ? 2 : 1) : ((int64_t)B * C >= 384 ? cdiv(bands, 4) : 1)) : 1;
             splits = std::max(1, std::min({want, MAP_SPLIT_MAX, bands}));
             if ((int64_t)M * splits * K > RANK_KEYS_MAX || (int64_t)N * splits * P > RANK_KEYS_MAX) splits = 1;
             const int per_block = strips * cdiv(bands, splits);            // units of work of the largest part
+            const int per_wave = half ? cdiv(per_block, 2) : per_block;    // wave-iterations of work of the largest part
             const unsigned grid = (unsigned)(B * C * splits);
-#define SD_STREAM(NT_, ROWS_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1, splits)
-            if (rows == 16) {
-                if (splits == 1 && units16 >= 16) SD_STREAM(1024, 16);
-                else if (per_block > 4 || splits == 1) SD_STREAM(512, 16);
-                else SD_STREAM(256, 16);
+#define SD_STREAM(NT_, ROWS_, HALF_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_, HALF_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1, splits)
+            if (half) {
+                if (rows == 16) { if (per_wave > 8) SD_STREAM(1024, 16, true); else if (per_wave > 4) SD_STREAM(512, 16, true); else SD_STREAM(256, 16, true); }
+                else            { if (per_wave > 8) SD_STREAM(1024, 11, true); else if (per_wave > 4) SD_STREAM(512, 11, true); else SD_STREAM(256, 11, true); }
+            } else if (rows == 16) {
+                if (splits == 1 && units16 >= 16) SD_STREAM(1024, 16, false);
+                else if (per_block > 4 || splits == 1) SD_STREAM(512, 16, false);
+                else SD_STREAM(256, 16, false);
             } else {
-                if (per_block > 8 || splits == 1) SD_STREAM(1024, 11);
-                else if (per_block > 4) SD_STREAM(512, 11);
-                else SD_STREAM(256, 11);
+                if (per_block > 8 || splits == 1) SD_STREAM(1024, 11, false);
+                else if (per_block > 4) SD_STREAM(512, 11, false);
+                else SD_STREAM(256, 11, false);
             }
 #undef SD_STREAM
             SD_LAUNCH_CHECK();
@@ -2469,6 +2492,7 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "map_rows11")) { g_map_rows11 = value; return 0; }
     if (name && !strcmp(name, "map_stream")) { g_map_stream = value; return 0; }
     if (name && !strcmp(name, "map_split")) { g_map_split = value; return 0; }
+    if (name && !strcmp(name, "map_half")) { g_map_half = value; return 0; }
     if (name && !strcmp(name, "map_rank_group")) { g_map_rank_group = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;
@@ -2525,6 +2549,11 @@ int sd_decode_fused_supported(int B, int M, int N, int h, int w, int K, int P) {
 // top-k only small batches (bs = 64: 39.0 vs 31.3 us, its two 2048-key sort buffers cost the tile blocks occupancy).
 static int64_t fused_image_tiles(int M, int N, int h, int w) { return (int64_t)(M + N) * fused_tiles(h, w, 16); }
 int sd_decode_fused_recommended(int B, int M, int N, int h, int w, int K, int P, int exact_topk) {
+    // round 5: from the batch where sd_decode takes its map-parallel path (2560 tile blocks per call: bs >= 54 at the cfg shape) that path is
+    // the faster one on maps up to 128 columns wide -- two bands per wave, two parts per map, ranks + association in one launch: 20.5 us per
+    // bs = 64 batch against 23.5 for the one-launch kernel (`profiles/r05_decode_split_sweep.txt`)
+    const int64_t blocks16 = (int64_t)B * (M + N) * cdiv(w, TW) * cdiv(h, 16);
+    if (blocks16 >= g_map_parallel_from && g_map_half && g_map_stream && w <= 128 && w % 4 == 0 && map_path_possible(M, N, h, w, K, P)) return 0;
     return sd_decode_fused_supported(B, M, N, h, w, K, P) && fused_image_tiles(M, N, h, w) <= 256 && (!(exact_topk & 1) || B <= 8);
 }
 

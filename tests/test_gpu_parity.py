@@ -455,7 +455,8 @@ def test_sigmoid_properties_behind_the_logit_domain_nms_hold_for_every_fp32_valu
 
 @pytest.mark.parametrize("B,img,M,N,K,P,kind", [(4, 1024, 8, 8, 128, 512, "scene"), (2, 1024, 8, 8, 128, 512, "noise"), (64, 512, 2, 1, 20, 40, "scene"),
                                                 (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise"),
-                                                (3, 512, 2, 2, 64, 200, "ties"), (2, 528, 2, 1, 20, 40, "ties"), (2, 266, 2, 1, 20, 40, "noise")])
+                                                (3, 512, 2, 2, 64, 200, "ties"), (2, 528, 2, 1, 20, 40, "ties"), (2, 266, 2, 1, 20, 40, "noise"),
+                                                (3, 208, 2, 1, 20, 40, "noise"), (2, 400, 1, 2, 30, 50, "ties"), (130, 512, 2, 1, 20, 40, "scene")])
 def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, kind):
     """sd_decode's map-parallel path (tile pass without global atomics -> one selector block per MAP = the reference's per-class top-k,
     utils.py:451 -> one merge + association block per image = its second top-k, utils.py:459) against the launch pair with one selector
@@ -501,18 +502,21 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
             # ONE launch (k_rank_group, rank_group = 1) or as k_rank_maps + k_group_wide (0)
             # (rank_group 1 = by size: k_rank_group_small for K, P <= 64, the generic one-block kernel up to 1024 keys, the pair beyond; 2 = the
             # generic one-block kernel wherever its lists fit LDS)
-            variants = [(0, 0, 1, 0, 1), (0, 0, 1, 0, 0), (0, 0, 1, 0, 2), (0, 0, 1, 1, 1), (0, 0, 1, 2, 1), (0, 0, 1, 3, 0), (0, 0, 1, 3, 2), (0, 0, 1, 4, 1),
-                        (16, 0, 0, 0, 1), (32, 0, 0, 0, 0), (16, 1, 0, 0, 2), (32, 1, 0, 0, 0)]
-            for th, scalar, stream, split, rank_group in variants:
+            # half = 1 (default): on maps up to 128 columns wide the two halves of a wave walk two bands side by side; 0: one band per wave
+            variants = [(0, 0, 1, 0, 1, 1), (0, 0, 1, 0, 0, 1), (0, 0, 1, 0, 2, 1), (0, 0, 1, 1, 1, 1), (0, 0, 1, 2, 1, 1), (0, 0, 1, 3, 0, 1), (0, 0, 1, 3, 2, 1),
+                        (0, 0, 1, 4, 1, 1), (0, 0, 1, 0, 1, 0), (0, 0, 1, 1, 0, 0), (0, 0, 1, 2, 1, 0), (0, 0, 1, 3, 2, 0), (0, 0, 1, 4, 1, 0),
+                        (16, 0, 0, 0, 1, 1), (32, 0, 0, 0, 0, 1), (16, 1, 0, 0, 2, 1), (32, 1, 0, 0, 0, 1)]
+            for th, scalar, stream, split, rank_group, half in variants:
                 L.check(lib.sd_decode_set_option(b"map_tile_height", th))
                 L.check(lib.sd_decode_set_option(b"map_scalar_nms", scalar))
                 L.check(lib.sd_decode_set_option(b"map_stream", stream))
                 L.check(lib.sd_decode_set_option(b"map_split", split))
                 L.check(lib.sd_decode_set_option(b"map_rank_group", rank_group))
+                L.check(lib.sd_decode_set_option(b"map_half", half))
                 for _ in range(2):                                                                # (back to back: no state left behind)
                     got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
                     assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} "
-                                                    f"map_split={split} map_rank_group={rank_group}")
+                                                    f"map_split={split} map_rank_group={rank_group} map_half={half}")
     finally:
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
@@ -520,6 +524,7 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
         L.check(lib.sd_decode_set_option(b"map_stream", 1))
         L.check(lib.sd_decode_set_option(b"map_split", 0))
         L.check(lib.sd_decode_set_option(b"map_rank_group", 1))
+        L.check(lib.sd_decode_set_option(b"map_half", 1))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))

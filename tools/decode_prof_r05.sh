@@ -9,15 +9,17 @@ OUT=gpurun_out/decode_split_${1:-r05}.txt
 : > $OUT
 rm -rf gpurun_out/dsplit_*
 #            B fused exact [stress] | split rank_group
-for V in "64 0 0|1 0" "64 0 0|1 1" "64 0 0|3 1" "64 0 0|4 1" "64 0 1|1 0" "64 0 1|3 1" "512 0 0|1 0" "512 0 0|3 1" \
-         "16 0 1 stress|1 0" "16 0 1 stress|1 1" "16 0 0 stress|1 0" "16 0 0 stress|1 1"; do
+#            B fused exact [stress] | split rank_group half
+for V in "64 0 0|1 0 0" "64 0 0|1 1 0" "64 0 0|1 1 1" "64 0 0|2 1 1" "64 0 1|1 0 0" "64 0 1|1 1 1" "512 0 0|1 0 0" "512 0 0|3 1 0" "512 0 0|0 1 1" "512 0 0|1 1 1" \
+         "16 0 1 stress|1 0 0" "16 0 0 stress|1 0 0"; do
   ARGS=${V%%|*}; OPT=${V##*|}
-  export SD_MAP_SPLIT=${OPT%% *} SD_MAP_RG=${OPT##* }
+  set -- $OPT
+  export SD_MAP_SPLIT=$1 SD_MAP_RG=$2 SD_MAP_HALF=$3
   TAG=$(echo "$ARGS $OPT" | tr ' ' '_')
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/dsplit_$TAG -- python3 tools/decode_prof.py $ARGS > gpurun_out/dsplit_$TAG.log 2>&1
   F=$(find gpurun_out/dsplit_$TAG -name '*kernel_stats.csv' | head -1)
   T=$(find gpurun_out/dsplit_$TAG -name '*kernel_trace.csv' | head -1)
-  echo "== B fused exact: $ARGS | map_split $SD_MAP_SPLIT map_rank_group $SD_MAP_RG" >> $OUT
+  echo "== B fused exact: $ARGS | map_split $SD_MAP_SPLIT map_rank_group $SD_MAP_RG map_half $SD_MAP_HALF" >> $OUT
   python3 - "$F" "$T" >> $OUT <<'PY'
 import csv, sys
 import numpy as np
