@@ -25,7 +25,7 @@ stats fwd_bf16 tools/prof_bf16_fwd.py 6
 stats fwd_bf16_stress tools/prof_bf16_fwd.py 6 stress
 stats fwd_bs1 tools/prof_fwd1.py 20
 # 4. decoder variants (per-kernel durations + device span per call)
-bash tools/decode_prof.sh $TAG > /dev/null 2>&1 && cp gpurun_out/decode_prof_$TAG.txt $OUT/${TAG}_decode_variants.txt
+bash tools/decode_prof_r05.sh $TAG > /dev/null 2>&1 && cp gpurun_out/decode_split_$TAG.txt $OUT/${TAG}_decode_variants.txt
 # 5. HBM traffic of the conv kernels (PMC, separate passes)
 bash tools/pmc_traffic.sh > $OUT/${TAG}_pmc_traffic.stdout 2>&1 && cp gpurun_out/pmc_traffic.json $OUT/${TAG}_pmc_hbm_traffic_conv_kernels.json
 ls -la $OUT
