@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Error maps of k_conv3x3_c64_rows16_bf16 against torch on a small problem (bs 2, 16 x 128): per row / 16-pixel group / 8-channel group /
+image for the plain forward, the residual forward, the statistics forward and the data-gradients, a run-to-run determinism check against the
+32x32x16 kernel, and the spatial map of the second launch.  The tool the AGPR-copy hazard of round 5 was bisected with
+(`profiles/r05_rows16_agpr_copy_hazard.txt`): the wrong sums showed only from the SECOND launch of a process on and moved between runs."""
 import ctypes as C, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 import torch, torch.nn.functional as F
 from structuredetector_amd import _lib as L
 lib = L.lib(); dev = "cuda"
