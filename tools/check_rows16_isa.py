@@ -5,7 +5,7 @@ Its MFMAs are inline asm (the weight fragments are pinned to AGPRs / VGPRs by co
 That is safe only while the register allocator keeps every weight fragment where it was pinned: a fragment it parks elsewhere is copied into
 an AGPR quad in front of the MFMA that takes it (`v_accvgpr_write` / `v_accvgpr_mov` inside the row loop) WITHOUT the wait states between the
 copy and the MFMA's operand read -- wrong, run-to-run different sums (seen in round 5: `profiles/r05_rows16_agpr_copy_hazard.txt`).  This tool
-compiles sd_conv.hip to ISA (device side only, ~35 s) and fails when, behind the first MFMA of a dispatched instantiation,
+compiles sd_conv_rows16.hip to ISA (device side only, a few seconds) and fails when, behind the first MFMA of a dispatched instantiation,
   * an AGPR that any MFMA reads as its weight operand is written, or
   * a scratch (spill) instruction appears.
 usage: check_rows16_isa.py [--keep file.s]"""
@@ -55,7 +55,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         out = Path(keep) if keep else Path(tmp) / "sd_conv.s"
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "--cuda-device-only", "-S",
-                        "-I", str(ROOT / "include"), str(ROOT / "structuredetector_amd" / "csrc" / "sd_conv.hip"), "-o", str(out)],
+                        "-I", str(ROOT / "include"), str(ROOT / "structuredetector_amd" / "csrc" / "sd_conv_rows16.hip"), "-o", str(out)],
                        check=True, cwd=tmp, capture_output=True)
         problems = check(out.read_text())
     for pb in problems:
