@@ -188,6 +188,9 @@ class TrainStep:
 
     def attach_sim(self, ranks=8, workgroups=32, gbps=200.0):
         """Run every following step with the simulated exchange (`SimExchange`) beside its backward; `detach_sim()` ends it."""
+        if self.world > 1:
+            raise L.SdError("attach_sim replaces the gradient exchange by a stand-in that moves no gradients: single-rank sizing runs only "
+                            f"(this step has {self.world} ranks)")
         # (scratch as large as the whole flat buffer: a bucket plan may send several parameter groups -- up to all of them -- in one launch)
         self.sim = SimExchange(self.net.flat_params.device, int(self.net.flat_grads.numel()), ranks, workgroups, gbps)
         return self.sim
