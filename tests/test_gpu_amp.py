@@ -695,3 +695,16 @@ def test_stem_weight_gradient_from_a_bf16_gradient_row_ring(shape):
     close(dw16.permute(0, 3, 1, 2).cpu(), w.grad, 2e-5)
     L.check(lib.sd_conv2d_stem_wgrad_bf16(dy16.data_ptr(), img_d.data_ptr(), dw16.data_ptr(), C.byref(d0), 1, ws.data_ptr(), ws.numel(), L.stream()))
     close(dw16.permute(0, 3, 1, 2).cpu(), 2 * w.grad, 2e-5)
+
+
+def test_rows16_kernel_is_bit_identical_to_the_32x32x16_row_stream_on_random_cases():
+    """tools/rows16_fuzz.py: 80 random (batch, height incl. 1 / 2 / odd / not a multiple of the unit, one or two strips, forward / data-gradient,
+    affine / residual / ReLU) cases; k_conv3x3_c64_rows16_bf16 must reproduce k_conv3x3_c64_rows_bf16 bit for bit (the same fp32 sums: K = 32
+    per MFMA instead of 16 does not change the order within a k step here) and itself on a second run -- the check that exposed nothing in
+    round 5's final build but would have caught the AGPR-copy hazard of its first (run-to-run different sums from the second launch on)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "rows16_fuzz.py"), "80", "5"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "80 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
