@@ -407,7 +407,10 @@ static bool sb_plan(SbArgs& a, const sd_conv_desc* d, bool bf16) {
     int s = 1;
     // about one block per CU (measured: 512 blocks of half the work are 5 % slower, the combine grows with the slices), at least two
     // chunks per slice, at most 16 slabs for the reducer
-    if (tiles < 192) s = std::max(1, std::min(std::min(16, a.nk / 2), (256 + tiles / 2) / tiles));
+#ifndef SD_SB_TARGET
+#define SD_SB_TARGET 256     // (timing experiments: blocks per launch the K split aims at)
+#endif
+    if (tiles < SD_SB_TARGET * 3 / 4) s = std::max(1, std::min(std::min(16, a.nk / 2), (SD_SB_TARGET + tiles / 2) / tiles));
     if (bf16 && tiles >= 128) s = 1;                         // bf16: the loop is a fraction of a split's combine (measured: 1.8 vs 3.4 us)
     a.cper = cdiv(kchunks, std::min(s, kchunks));            // whole channel chunks per slice: every slice starts at filter tap 0
     a.per = ntap * a.cper;

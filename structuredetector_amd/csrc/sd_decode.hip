@@ -999,18 +999,28 @@ __global__ __launch_bounds__(256) void k_selfcheck_sigmoid(unsigned long long* o
 // entries of a WAVE's segment of the stage: 4096 entries over the waves of a block of 8 or 16 waves; 256 per wave in smaller blocks
 // (a wave of those walks one or two bands of a split map: 512 entries = 9 % of two 11-row bands of 256 columns)
 __host__ __device__ constexpr int stream_seg(int waves) { return waves >= 8 ? 4096 / waves : 512; }
+#ifndef SD_STREAM_DEPTH_SMALL
+#define SD_STREAM_DEPTH_SMALL 0          // (timing experiments: 5 = the round-4 ring everywhere)
+#endif
+// rows a wave requests ahead: in blocks of up to 8 waves every row of an 11-row band (15 rows, one round trip: 6 registers per row and lane)
+// and ten of the twenty rows of a 16-row band; the five of the window in 16-wave blocks (128 registers per lane there: ten rows ahead spill,
+// measured on the 256 x 256 maps of the stress shape 36.5 -> 41.8 us)
+__host__ __device__ constexpr int stream_depth(int nt, int nr) {
+    return SD_STREAM_DEPTH_SMALL ? SD_STREAM_DEPTH_SMALL : (nt <= 512 ? (nr % 10 == 0 ? 10 : nr) : 5);
+}
 // Round 5: a map may be SPLIT over `splits` blocks (blockIdx.x = (image * maps + map) * splits + part): a block walks the row bands
 // [part * bands / splits, (part + 1) * bands / splits) of its map (the halo rows of a band are read from the map, whoever owns them) and
 // stores ITS sorted top-k as one more stage-1 list -- k_rank_maps / k_rank_group merge the lists of a group by rank whatever map or
 // part of a map they come from (the class travels in the key).  At BASELINE configs[2] (bs = 64, 3 maps of 128 x 128) one block per map
 // was 192 blocks of 12 busy waves on 256 CUs; three parts per map are 576 blocks of 4 waves, every wave with one 11-row band.
 
-// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1: one VALU move, no trip through the LDS crossbar)
+// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1: one VALU move, no trip through the LDS crossbar; bound_ctrl:
+// the lane without a source reads 0 and the destination needs no initialising move -- the callers replace that lane's value anyway)
 __device__ __forceinline__ float lane_from_left(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_from_right(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 
 // max of three in ONE instruction (fmaxf chains compile to v_max_f32 pairs plus NaN canonicalisation moves: 47 instructions for the
@@ -1020,6 +1030,15 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// sixteen bytes of -inf: what a lane outside the map, a row outside the map and the 62 inner lanes' halo read (the pointer is chosen when
+// the row is REQUESTED: no masking of the loaded values afterwards -- six selects per row and lane in the two-bands-per-wave form)
+__device__ __attribute__((aligned(16))) const float g_neg_inf4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
 // Candidates of a wave go to the wave's OWN segment of the stage (STREAM_SEG entries), the fill level lives in a scalar register: one
 // ballot per row ("this lane has a candidate") ranks the lanes, no atomic -- per-lane LDS atomics on one block-wide counter serialise
@@ -1032,12 +1051,15 @@ constexpr int STREAM_EXTRA = 256;
 // side by side (lanes 0-31: band u, lanes 32-63: band u + 1) -- at the cfg shape half of every wave used to idle beyond the map's right
 // edge.  Half as many waves to start (the start-up spread of a launch is ~2 ns per wave), half the vector instructions per pixel.
 template <bool INLINE_KEYS, int NT, int ROWS, bool HALF>
-__device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, uint64_t* stage,
+__device__ __forceinline__ void stream_map(const float* __restrict__ plane, int h, int w, int c, float min_score, float min_logit, uint64_t* stage,
                                            float* mxs, int* count, uint64_t* __restrict__ gkeys, int* seg_fill, uint64_t* extra, float* extra_mx,
                                            int band_lo, int band_hi) {
     constexpr int STREAM_WAVES = NT / 64, STREAM_SEG = stream_seg(STREAM_WAVES);
-    constexpr int R = ROWS, NR = R + 4, RING = 5;       // rows requested RING ahead; the window of horizontal maxima is RING rows
-    static_assert(NR % RING == 0, "the row loop is unrolled by the ring size");
+    // WIN = the 5-row window of horizontal maxima; DEPTH = rows requested ahead (round 5, late: the two used to be ONE ring of five, and a
+    // wave's 15 / 20 rows were three / four dependent round trips to memory -- `profiles/r05_decode_trace_cfg.txt`: 7-10 us of walking for
+    // 15 rows whose arithmetic is ~0.1 us each.  Now a wave of the small blocks asks for ALL its rows at once, one round trip)
+    constexpr int R = ROWS, NR = R + 4, WIN = 5, DEPTH = stream_depth(NT, NR);
+    static_assert(NR % DEPTH == 0 && DEPTH % WIN == 0, "the row loop is unrolled by the request depth, a multiple of the window");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strips = (w + 255) >> 8;
     const float NEG = -INFINITY;
@@ -1059,49 +1081,44 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
         // the edge lanes' halo: the first lane of a strip needs the two columns left of it, the last the two right of it (8-byte aligned pairs)
         const int hx = edge_l ? x0 - 2 : x0 + 4;
         const bool halo_in = (edge_l || edge_r) && hx >= 0 && hx < w && unit_in;
-        // row pointers advance by w per request; lanes outside the map (and the 62 inner lanes' halo) re-read the plane's first words
-        const float* pv = plane + (col_in ? x0 : 0);
-        const float* ph = plane + (halo_in ? hx : 0);
+        // row pointers advance by w per request; lanes outside the map (and the 62 inner lanes' halo) read g_neg_inf4
+        const float* const negp = g_neg_inf4;
+        const float* pv = col_in ? plane + x0 : negp;
+        const float* ph = halo_in ? plane + hx : negp;
         const int64_t vstep = col_in ? w : 0, hstep = halo_in ? w : 0;
-        float4 v[RING], hm[RING];
-        float2 hl[RING];
+        float4 v[DEPTH], hm[WIN];
+        float2 hl[DEPTH];
         float4 c1 = make_float4(NEG, NEG, NEG, NEG), c2 = c1;   // the rows one and two above the row being staged
         auto request = [&](int j, int slot) {
-            const int y = min(max(y0 + j - 2, 0), h - 1);       // rows outside the map: a valid row is read and discarded below
-            v[slot] = *reinterpret_cast<const float4*>(pv + y * vstep);
-            hl[slot] = *reinterpret_cast<const float2*>(ph + y * hstep);
+            const int y = y0 + j - 2;
+            const bool rin = (unsigned)y < (unsigned)h;         // rows outside the map read -inf (wave-uniform unless HALF)
+            v[slot] = *reinterpret_cast<const float4*>(rin ? pv + y * vstep : negp);
+            hl[slot] = *reinterpret_cast<const float2*>(rin ? ph + y * hstep : negp);
         };
 #pragma unroll
-        for (int u = 0; u < RING; ++u) request(u, u);
-        for (int jb = 0; jb < NR; jb += RING) {
+        for (int u = 0; u < DEPTH; ++u) request(u, u);
+        for (int jb = 0; jb < NR; jb += DEPTH) {
 #pragma unroll
-            for (int u = 0; u < RING; ++u) {
+            for (int u = 0; u < DEPTH; ++u) {
                 const int j = jb + u;
-                const int y = y0 + j - 2;
-                float4 cur = v[u];
-                float2 hh = hl[u];
-                if (j + RING < NR) request(j + RING, u);               // the slot is free again: row j + RING goes out
-                if (y < 0 || y >= h) {                                  // (wave-uniform unless HALF)
-                    cur = make_float4(NEG, NEG, NEG, NEG); hh = make_float2(NEG, NEG);
-                } else {
-                    if (narrow && !col_in) cur = make_float4(NEG, NEG, NEG, NEG);
-                    if (!halo_in) hh = make_float2(NEG, NEG);
-                }
+                const float4 cur = v[u];
+                const float2 hh = hl[u];
+                if (j + DEPTH < NR) request(j + DEPTH, u);             // the slot is free again: row j + DEPTH goes out
                 float lz = lane_from_left(cur.z), lw = lane_from_left(cur.w), rx = lane_from_right(cur.x), ry = lane_from_right(cur.y);
                 if (edge_l) { lz = hh.x; lw = hh.y; }                  // (HALF: lane 32's left neighbour is lane 31 of the OTHER band: replaced like lane 0's)
                 if (edge_r) { rx = hh.x; ry = hh.y; }
                 const float ma = max3f(cur.x, cur.y, cur.z), mb = max3f(cur.y, cur.z, cur.w);
-                hm[u] = make_float4(max3f(ma, lz, lw), max3f(ma, lw, cur.w), max3f(mb, cur.x, rx), max3f(mb, rx, ry));
+                hm[u % WIN] = make_float4(max3f(ma, lz, lw), max3f(ma, lw, cur.w), max3f(mb, cur.x, rx), max3f(mb, rx, ry));
                 const float4 centre = c2;                               // row j - 2
                 c2 = c1; c1 = cur;
-                const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all RING slots), centre j - 2
+                const int yo = y0 + j - 4;                              // output row: window rows j - 4 .. j (all WIN slots), centre j - 2
                 if (j < 4) continue;
                 if constexpr (!HALF) { if (yo >= h) continue; }         // (wave-uniform)
                 // HALF: an output row beyond the map in ONE half of the wave: no candidates there (a window entirely outside the map is all
                 // -inf, and inf - inf fails the `>` of the survivor rule: it must be masked, not left to the arithmetic)
                 const bool row_ok = !HALF || yo < h;
 #if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 2                         // timing experiment: loads + horizontal maxima only
-                if (hm[u].x != 12345.f) continue;
+                if (hm[u % WIN].x != 12345.f) continue;
 #endif
                 const float mx[4] = {max3f(max3f(hm[0].x, hm[1].x, hm[2].x), hm[3].x, hm[4].x), max3f(max3f(hm[0].y, hm[1].y, hm[2].y), hm[3].y, hm[4].y),
                                      max3f(max3f(hm[0].z, hm[1].z, hm[2].z), hm[3].z, hm[4].z), max3f(max3f(hm[0].w, hm[1].w, hm[2].w), hm[3].w, hm[4].w)};
@@ -1113,7 +1130,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                     float sc[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e])) && !(narrow && !col_in) && row_ok;
+                        cand[e] = !(mx[e] - xv[e] > nms_margin(mx[e])) && !(narrow && !col_in) && row_ok && xv[e] >= min_logit;
                         sc[e] = 0.f;
                         if (cand[e]) {
                             sc[e] = clamped_sigmoid(xv[e]);
@@ -1128,11 +1145,26 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                         if (cand[e]) gkeys[slot++] = make_key(sc[e], (uint32_t)(c * h * w) + pix + e);
                     continue;
                 }
+                const bool live = !(narrow && !col_in) && row_ok;
+                {   // Quiet rows leave here: with every window maximum of the lane's four pixels in (-13, 4) the margin is 1e-4 for all four, so
+                    // "no pixel within 1e-4 of its maximum" is the survivor rule's own answer, in 13 instructions instead of 24 + the flag logic
+                    // (a lane beyond the map holds -inf maxima: not quiet, dropped by `live` as below)
+                    const float dmin = min3f(min3f(mx[0] - xv[0], mx[1] - xv[1], mx[2] - xv[2]), mx[3] - xv[3], mx[3] - xv[3]);
+                    const float mhi = max3f(max3f(mx[0], mx[1], mx[2]), mx[3], mx[3]), mlo = min3f(min3f(mx[0], mx[1], mx[2]), mx[3], mx[3]);
+                    // ... and a lane whose four logits are all below min_logit has nothing the score threshold would keep (annotations-only
+                    // mode: without this every local maximum of the background -- one per ~13 pixels, some in every row -- went through
+                    // the append below to be dropped by the sigmoid pass: 3.3 of the 5.9 us a wave walked at the cfg shape)
+                    const float xhi = max3f(max3f(xv[0], xv[1], xv[2]), xv[3], xv[3]);
+                    const bool quiet = (dmin > 1e-4f && mhi < 4.0f && mlo > -13.0f) || xhi < min_logit;
+#if !defined(SD_STREAM_ABL) || SD_STREAM_ABL != 1
+                    if (__ballot(!quiet && live) == 0ull) continue;    // (wave-uniform)
+#endif
+                }
                 // (lanes beyond the map hold -inf: inf - inf fails `>`, they are dropped by the `narrow` term)
                 const bool c0r = !(mx[0] - xv[0] > nms_margin(mx[0])), c1r = !(mx[1] - xv[1] > nms_margin(mx[1]));
                 const bool c2r = !(mx[2] - xv[2] > nms_margin(mx[2])), c3r = !(mx[3] - xv[3] > nms_margin(mx[3]));
-                const bool live = !(narrow && !col_in) && row_ok;
-                const bool c0 = c0r && live, c1e = c1r && live, c2e = c2r && live, c3 = c3r && live;
+                const bool c0 = c0r && live && xv[0] >= min_logit, c1e = c1r && live && xv[1] >= min_logit;
+                const bool c2e = c2r && live && xv[2] >= min_logit, c3 = c3r && live && xv[3] >= min_logit;
                 const bool any = c0 || c1e || c2e || c3;
 #if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 1                         // timing experiment: no append (results wrong by design)
                 if (mx[0] != 12345.f) continue;
@@ -1176,7 +1208,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
 }
 
 template <int STREAM_THREADS, int ROWS, bool HALF = false>
-__global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, int K, int P,
+__global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, Group g1, int h, int w, float min_score, float min_logit, int K, int P,
                                                                        uint64_t* __restrict__ cand, uint64_t* __restrict__ stage1, int splits) {
     constexpr int STREAM_WAVES = STREAM_THREADS / 64, STREAM_SEG = stream_seg(STREAM_WAVES), STREAM_CAP = STREAM_WAVES * STREAM_SEG;
     constexpr int OUT_CAP = STREAM_CAP > SD_MAX_TOPK ? STREAM_CAP : SD_MAX_TOPK;    // `stage` is also the selection's output scratch (np2k keys)
@@ -1207,7 +1239,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     SD_TRACE(trace0 + 0);
     SD_TRACE(blockIdx.x < 592 ? 7000 + (int)blockIdx.x : -1);          // (trace builds: start / end of every block of the first 592)
     __syncthreads();
-    stream_map<false, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx, band_lo, band_hi);
+    stream_map<false, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, min_logit, stage, mxs, counts, nullptr, seg_fill, extra, extra_mx, band_lo, band_hi);
     SD_TRACE(trace0 + 1);
     // sigmoids of the compacted entries only: every wave converts its own segment as soon as it has walked its rows
     auto convert = [&](uint64_t ent, float mxv) {
@@ -1255,12 +1287,22 @@ __global__ __launch_bounds__(STREAM_THREADS) void k_map_stream_select(Group g0, 
     if (tid == 0) counts[0] = 0;
     __syncthreads();
     uint64_t* glist = cand + (int64_t)bm * hw + (int64_t)band_lo * ROWS * w;      // this part's rows of the map's h * w slots
-    stream_map<true, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr, band_lo, band_hi);
+    stream_map<true, STREAM_THREADS, ROWS, HALF>(plane, h, w, c, min_score, min_logit, nullptr, nullptr, counts, glist, nullptr, nullptr, nullptr, band_lo, band_hi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int n = counts[0];
     radix_select_sorted<STREAM_THREADS>(T, FlatSrc<STREAM_THREADS, true>{glist, n}, k, buf, np2k);
     for (int i = tid; i < k; i += STREAM_THREADS) out[i] = i < min(n, k) ? buf[i] : 0ull;
+}
+
+// A logit below which clamped_sigmoid(x) < min_score FOR SURE (host side of the streaming kernel's early score cut): the exact logit
+// of min_score lowered by 1 % (at least 0.01) -- the sigmoid moves by >= 15 ulp over that distance anywhere below 0.999 --, -inf where
+// the clamp (1e-6) or a zero threshold lets every pixel pass.  The exact `sigmoid >= min_score` test still runs on what passes.
+static float conservative_min_logit(float min_score) {
+    if (!(min_score > 1e-5f)) return -INFINITY;
+    const double m = std::min((double)min_score, 0.999);
+    const double t = std::log(m / (1.0 - m));
+    return (float)(t - 1e-2 * std::max(1.0, std::fabs(t)));
 }
 
 constexpr int MAP_TILES_MAX = 1024;          // tiles of one map the per-map selector indexes in LDS (2048 x 2048 output maps at 64 x 32 tiles)
@@ -1710,28 +1752,27 @@ __global__ __launch_bounds__(RGS_THREADS) void k_rank_group_small(const uint64_t
     if (tid < 2) cnt_s[tid] = 0;
     if (tid == 2) n_live_s = 0;
     for (int i = tid; i < 2 * RGS_K; i += RGS_THREADS) fkey[i / RGS_K][i % RGS_K] = 0ull;
+    __syncthreads();                                                     // the counters are zero before any wave allocates from them
     // ---- round trip 2 (in flight while the ranks are counted): the gathers of every key this thread owns
+    // The group's NON-ZERO keys are compacted into keys[grp] (any order: they are only counted over; slots by one LDS atomic per wave
+    // and group): the zero padding of a short list is never ahead of a peak, and in the annotations-only mode a list is mostly padding
+    // (cfg shape: ~10 of 80 keys per group) -- the counting loop below is a chain of dependent LDS reads, ~1.5 us over 80 keys.
     float gv[RGS_KPT][4];
-    int nz[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < RGS_KPT; ++u) {
         const int i = tid + u * RGS_THREADS;
         const bool part = i >= na_keys;
+        const bool live = i < n_keys && kv[u] != 0ull;
         gv[u][0] = gv[u][1] = gv[u][2] = gv[u][3] = 0.f;
-        if (i < n_keys) {
-            keys[part ? 1 : 0][part ? i - na_keys : i] = kv[u];
-            if (kv[u] != 0ull) {
-                const uint32_t flat = ~(uint32_t)kv[u];
-                const int ind = (int)(flat % (uint32_t)hw);
-                gv[u][0] = off_b[ind]; gv[u][1] = off_b[rm.o_sc + ind];
-                if (part) { gv[u][2] = emb_b[ind]; gv[u][3] = emb_b[rm.e_sc + ind]; }
-                ++nz[part ? 1 : 0];
-            }
+        if (live) {
+            const uint32_t flat = ~(uint32_t)kv[u];
+            const int ind = (int)(flat % (uint32_t)hw);
+            gv[u][0] = off_b[ind]; gv[u][1] = off_b[rm.o_sc + ind];
+            if (part) { gv[u][2] = emb_b[ind]; gv[u][3] = emb_b[rm.e_sc + ind]; }
         }
+        const int sa = alloc_slot(&cnt_s[0], live && !part), sp = alloc_slot(&cnt_s[1], live && part);
+        if (live) keys[part ? 1 : 0][part ? sp : sa] = kv[u];
     }
-    if (tid < 2) { const int n = tid ? np_keys : na_keys; keys[tid][n] = 0ull; keys[tid][n + 1] = 0ull; }      // pad to whole pairs
-    if (nz[0]) atomicAdd(&cnt_s[0], nz[0]);
-    if (nz[1]) atomicAdd(&cnt_s[1], nz[1]);
     __syncthreads();
     SD_TRACE(trace0 + 1);
     // ---- ranks by counting
@@ -1741,13 +1782,14 @@ __global__ __launch_bounds__(RGS_THREADS) void k_rank_group_small(const uint64_t
         const uint64_t key = kv[u];
         if (i >= n_keys || key == 0ull) continue;
         const int grp = i >= na_keys ? 1 : 0;
-        const int n = grp ? np_keys : na_keys, k = grp ? P : K;
+        const int n = cnt_s[grp], k = grp ? P : K;
         const ulonglong2* pairs = reinterpret_cast<const ulonglong2*>(keys[grp]);
         int rank = 0;                                                    // keys are unique: `>` counts exactly the keys ahead of this one
-        for (int q = 0; q < (n + 1) / 2; ++q) {                          // (kept rolled: a one-shot kernel runs from a cold instruction cache --
+        for (int q = 0; q < n / 2; ++q) {                                // (kept rolled: a one-shot kernel runs from a cold instruction cache --
             const ulonglong2 two = pairs[q];                             //  unrolled by eight it took 4.4 instead of 2.5 us on 120 keys)
             rank += (two.x > key ? 1 : 0) + (two.y > key ? 1 : 0);
         }
+        if (n & 1) rank += keys[grp][n - 1] > key ? 1 : 0;
         if (rank < k) {
             fkey[grp][rank] = key;
             fg[grp][0][rank] = gv[u][0]; fg[grp][1][rank] = gv[u][1]; fg[grp][2][rank] = gv[u][2]; fg[grp][3][rank] = gv[u][3];
@@ -2392,7 +2434,8 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             const int per_block = strips * cdiv(bands, splits);            // units of work of the largest part
             const int per_wave = half ? cdiv(per_block, 2) : per_block;    // wave-iterations of work of the largest part
             const unsigned grid = (unsigned)(B * C * splits);
-#define SD_STREAM(NT_, ROWS_, HALF_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_, HALF_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, K, P, mw.cand, mw.stage1, splits)
+            const float min_logit = conservative_min_logit(min_score);
+#define SD_STREAM(NT_, ROWS_, HALF_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_, HALF_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, min_logit, K, P, mw.cand, mw.stage1, splits)
             if (half) {
                 if (rows == 16) { if (per_wave > 8) SD_STREAM(1024, 16, true); else if (per_wave > 4) SD_STREAM(512, 16, true); else SD_STREAM(256, 16, true); }
                 else            { if (per_wave > 8) SD_STREAM(1024, 11, true); else if (per_wave > 4) SD_STREAM(512, 11, true); else SD_STREAM(256, 11, true); }

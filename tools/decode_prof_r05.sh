@@ -10,8 +10,9 @@ OUT=gpurun_out/decode_split_${1:-r05}.txt
 rm -rf gpurun_out/dsplit_*
 #            B fused exact [stress] | split rank_group
 #            B fused exact [stress] | split rank_group half
-for V in "64 0 0|1 0 0" "64 0 0|1 1 0" "64 0 0|1 1 1" "64 0 0|2 1 1" "64 0 1|1 0 0" "64 0 1|1 1 1" "512 0 0|1 0 0" "512 0 0|3 1 0" "512 0 0|0 1 1" "512 0 0|1 1 1" \
-         "16 0 1 stress|1 0 0" "16 0 0 stress|1 0 0"; do
+DEFAULT_VARIANTS="64 0 0|1 0 0;64 0 0|1 1 0;64 0 0|1 1 1;64 0 0|2 1 1;64 0 1|1 0 0;64 0 1|1 1 1;512 0 0|1 0 0;512 0 0|3 1 0;512 0 0|0 1 1;512 0 0|1 1 1;16 0 1 stress|1 0 0;16 0 0 stress|1 0 0"
+IFS=';' read -ra VARIANTS <<< "${SD_DECODE_VARIANTS:-$DEFAULT_VARIANTS}"      # (override: SD_DECODE_VARIANTS="16 0 1 stress|2 0 0;...")
+for V in "${VARIANTS[@]}"; do
   ARGS=${V%%|*}; OPT=${V##*|}
   set -- $OPT
   export SD_MAP_SPLIT=$1 SD_MAP_RG=$2 SD_MAP_HALF=$3

@@ -19,11 +19,12 @@ from structuredetector_amd.data.synthetic import synthetic_batch  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 exact = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
 dev = torch.device("cuda")
-M, N, K, P, img = 2, 1, 20, 40, 512
+stress = len(sys.argv) > 3          # configs[4]-like scene: 1024 x 1024, 8 + 8 maps, K = 128, P = 512 (usage: 16 1 stress)
+M, N, K, P, img = (8, 8, 128, 512, 1024) if stress else (2, 1, 20, 40, 512)
 args = make_args(dev, M, N, K, P)
 enc, dec = Encode(args), Decoder(args)
 gen = torch.Generator(device=dev).manual_seed(0)
-tgt = enc.render(enc.plan(img, img, *synthetic_batch(np.random.default_rng(B), B, img, img, M, N)), dev)
+tgt = enc.render(enc.plan(img, img, *synthetic_batch(np.random.default_rng(B), B, img, img, M, N, *((64, 96) if stress else (6, 12)))), dev)
 hm = torch.cat([tgt["anchor_hm"], tgt["part_hm"]], 1).clamp(1e-4, 0.95)
 head = torch.cat([torch.log(hm / (1 - hm)) + 0.05 * torch.randn(hm.shape, device=dev, generator=gen),
                   0.1 * torch.randn(B, 4, img // 4, img // 4, device=dev, generator=gen)], 1)
@@ -45,14 +46,14 @@ for it in range(30):
     t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
     if it >= 10:
         t0 = t[6400]
-        nb = min(B * 3 * int(os.environ.get("SD_MAP_SPLIT", "1") or 1), 592)
+        nb = min(B * (M + N) * int(os.environ.get("SD_MAP_SPLIT", "1") or 1), 592)
         st, en = t[7000:7000 + nb] - t0, t[7600:7600 + nb] - t0
         blocks.append([st.min(), np.percentile(st, 50), np.percentile(st, 90), st.max(), np.median(en - st), (en - st).max(), en.max()])
         rows.append(np.concatenate([t[6400:6406] - t0, t[6420:6426] - t0, t[6500:6503] - t0, t[6600:6604] - t0, t[6610:6614] - t0,
                                     t[6700:6705] - t0, t[6710:6715] - t0]))
 r = np.median(np.array(rows, np.float64), axis=0) * 0.01
 f = lambda v: " ".join(f"{x:7.2f}" for x in v)
-print(f"cfg decode B={B} exact={exact} split={os.environ.get('SD_MAP_SPLIT', 'auto')} rank_group={os.environ.get('SD_MAP_RG', '1')}: us since block 0 of "
+print(f"{'stress' if stress else 'cfg'} decode B={B} exact={exact} split={os.environ.get('SD_MAP_SPLIT', 'auto')} rank_group={os.environ.get('SD_MAP_RG', '1')}: us since block 0 of "
       "k_map_stream_select started (medians over 20 runs; thread 0's view)")
 print("  stream block 0      [start, streamed(wave 0), keys converted, extra, selected, stored]:", f(r[0:6]))
 print("  stream first part map block                                                      :", f(r[6:12]))
