@@ -186,11 +186,12 @@ struct Team {
 // order), only the few long-distance stages synchronise the whole block: 6 instead of 66 barriers for 2048 keys.
 template <int NT>
 __device__ void bitonic_desc(const Team& T, uint64_t* buf, int np2) {
-    constexpr int NW = NT / 64;
+    constexpr int WAVES = NT / 64;
+    constexpr int NW = WAVES >= 16 ? 16 : (WAVES >= 8 ? 8 : (WAVES >= 4 ? 4 : (WAVES >= 2 ? 2 : 1)));   // ranges: a power of two (192-thread blocks: two)
     const int lane = T.tid & 63, wave = T.tid >> 6;
     const int R = max(np2 / NW, 128);                 // elements per wave range
     const int half_pairs = min(R, np2) >> 1;          // compare-exchange pairs per range and stage
-    const bool active = wave * R < np2;
+    const bool active = wave < NW && wave * R < np2;
     bool local_dirty = false;                         // wave-local stages since the last block barrier
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -2359,6 +2360,7 @@ static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
 static thread_local int g_map_rows11 = 1;           // 0: 128-row maps keep 16-row bands on 8 waves (A/B)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
+static thread_local int g_map_waves3 = 1;           // parts of three wave-iterations on 192-thread blocks: 1 = from 1024 blocks with a score threshold, 0 never, 2 always (A/B, tests)
 static thread_local int g_map_half = 1;             // 0: one band per wave also on maps up to 128 columns wide (A/B, tests)
 static thread_local int g_map_split = 0;            // parts per map in k_map_stream_select: 0 = by geometry, 1 .. MAP_SPLIT_MAX = forced (A/B, tests)
 static thread_local int g_map_rank_group = 1;       // 0: k_rank_maps + k_group_wide instead of the one-launch k_rank_group (A/B, tests)
@@ -2435,10 +2437,15 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             const int per_wave = half ? cdiv(per_block, 2) : per_block;    // wave-iterations of work of the largest part
             const unsigned grid = (unsigned)(B * C * splits);
             const float min_logit = conservative_min_logit(min_score);
+            const bool waves3 = g_map_waves3 == 2 || (g_map_waves3 == 1 && grid >= 1024u && min_score > 0.f);
 #define SD_STREAM(NT_, ROWS_, HALF_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_, HALF_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, min_logit, K, P, mw.cand, mw.stage1, splits)
             if (half) {
                 if (rows == 16) { if (per_wave > 8) SD_STREAM(1024, 16, true); else if (per_wave > 4) SD_STREAM(512, 16, true); else SD_STREAM(256, 16, true); }
-                else            { if (per_wave > 8) SD_STREAM(1024, 11, true); else if (per_wave > 4) SD_STREAM(512, 11, true); else SD_STREAM(256, 11, true); }
+                // (three band pairs per part -- the cfg shape in two parts -- on three waves where several blocks share a CU and a score
+                //  threshold keeps the selections short: bs = 512 32.1 -> 28.7 us; at bs = 64, 384 blocks, the idle fourth wave costs nothing
+                //  -- 9.6 vs 10.1 us: the start-up spread of a launch goes by its blocks, not its waves -- and the exact top-k's radix select over
+                //  ~1000 keys wants the fourth wave: 16.3 vs 21.0 us)
+                else            { if (per_wave > 8) SD_STREAM(1024, 11, true); else if (per_wave > 4) SD_STREAM(512, 11, true); else if (per_wave == 3 && waves3) SD_STREAM(192, 11, true); else SD_STREAM(256, 11, true); }
             } else if (rows == 16) {
                 if (splits == 1 && units16 >= 16) SD_STREAM(1024, 16, false);
                 else if (per_block > 4 || splits == 1) SD_STREAM(512, 16, false);
@@ -2446,6 +2453,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             } else {
                 if (per_block > 8 || splits == 1) SD_STREAM(1024, 11, false);
                 else if (per_block > 4) SD_STREAM(512, 11, false);
+                else if (per_block == 3 && waves3) SD_STREAM(192, 11, false);
                 else SD_STREAM(256, 11, false);
             }
 #undef SD_STREAM
@@ -2536,6 +2544,7 @@ int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "map_stream")) { g_map_stream = value; return 0; }
     if (name && !strcmp(name, "map_split")) { g_map_split = value; return 0; }
     if (name && !strcmp(name, "map_half")) { g_map_half = value; return 0; }
+    if (name && !strcmp(name, "map_waves3")) { g_map_waves3 = value; return 0; }
     if (name && !strcmp(name, "map_rank_group")) { g_map_rank_group = value; return 0; }
     sd::set_error("sd_decode_set_option: unknown option '%s'", name ? name : "(null)");
     return SD_ERR_INVALID;

@@ -513,10 +513,14 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
                 L.check(lib.sd_decode_set_option(b"map_split", split))
                 L.check(lib.sd_decode_set_option(b"map_rank_group", rank_group))
                 L.check(lib.sd_decode_set_option(b"map_half", half))
-                for _ in range(2):                                                                # (back to back: no state left behind)
-                    got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-                    assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} "
-                                                    f"map_split={split} map_rank_group={rank_group} map_half={half}")
+                # parts of three wave-iterations (128-row maps in two parts with two bands per wave, in four with one) on 192-thread blocks
+                # (2 = always) and on 256-thread blocks with an idle wave (0)
+                for waves3 in ((2, 0) if split in (2, 4) else (1,)):
+                    L.check(lib.sd_decode_set_option(b"map_waves3", waves3))
+                    for _ in range(2):                                                            # (back to back: no state left behind)
+                        got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
+                        assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} "
+                                                        f"map_split={split} map_rank_group={rank_group} map_half={half} map_waves3={waves3}")
     finally:
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
@@ -525,6 +529,7 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
         L.check(lib.sd_decode_set_option(b"map_split", 0))
         L.check(lib.sd_decode_set_option(b"map_rank_group", 1))
         L.check(lib.sd_decode_set_option(b"map_half", 1))
+        L.check(lib.sd_decode_set_option(b"map_waves3", 1))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))

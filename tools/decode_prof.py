@@ -29,7 +29,7 @@ if os.environ.get("SD_MAP_FROM"):
     L.check(L.lib().sd_decode_set_option(b"map_parallel_from", int(os.environ["SD_MAP_FROM"])))
 if os.environ.get("SD_MAP_STREAM"):
     L.check(L.lib().sd_decode_set_option(b"map_stream", int(os.environ["SD_MAP_STREAM"])))
-for env, key in (("SD_MAP_SPLIT", b"map_split"), ("SD_MAP_RG", b"map_rank_group"), ("SD_MAP_ROWS11", b"map_rows11"), ("SD_MAP_HALF", b"map_half")):
+for env, key in (("SD_MAP_SPLIT", b"map_split"), ("SD_MAP_RG", b"map_rank_group"), ("SD_MAP_ROWS11", b"map_rows11"), ("SD_MAP_HALF", b"map_half"), ("SD_MAP_WAVES3", b"map_waves3")):
     if os.environ.get(env):
         L.check(L.lib().sd_decode_set_option(key, int(os.environ[env])))
 if os.environ.get("SD_MAP_TH"):
