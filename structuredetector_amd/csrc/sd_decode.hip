@@ -1479,6 +1479,58 @@ __device__ void fill_zero_keys(uint64_t* keys, int npos, int k, int* flags, int*
     __syncthreads();
 }
 
+// fill_zero_keys for the anchor list and the part list of an image in the SAME four barriers (k_group_wide: the two calls in sequence were
+// 2 us of a 9.5 us kernel at the stress shape -- eight barriers with a dependent LDS round trip between each pair).  `flags` has ka + kb ints.
+__device__ void fill_zero_keys_pair(uint64_t* keys_a, int npos_a, int ka, uint64_t* keys_b, int npos_b, int kb, int* flags, int (*wave_tot)[GROUP_THREADS / 64]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t* const keys[2] = {keys_a, keys_b};
+    const int npos[2] = {npos_a, npos_b}, k[2] = {ka, kb};
+    int* const fl[2] = {flags, flags + ka};
+    const bool need[2] = {npos_a < ka, npos_b < kb};
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (need[g])
+            for (int f = tid; f < k[g]; f += GROUP_THREADS) fl[g][f] = 1;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (need[g])
+            for (int j = tid; j < npos[g]; j += GROUP_THREADS) {      // a peak whose flat index is below k takes that index out
+                const uint32_t flat = (uint32_t)(~keys[g][j]);
+                if (flat < (uint32_t)k[g]) fl[g][flat] = 0;
+            }
+    __syncthreads();
+    int lo[2], hi[2], sum[2], incl[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int per = (k[g] + GROUP_THREADS - 1) / GROUP_THREADS;  // thread t owns flat indices [t * per, t * per + per)
+        lo[g] = min(tid * per, k[g]); hi[g] = min(lo[g] + per, k[g]);
+        sum[g] = 0;
+        if (need[g])
+            for (int f = lo[g]; f < hi[g]; ++f) sum[g] += fl[g][f];
+        incl[g] = sum[g];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v0 = __shfl_up(incl[0], o), v1 = __shfl_up(incl[1], o);
+        if (lane >= o) { incl[0] += v0; incl[1] += v1; }
+    }
+    if (lane == 63) { wave_tot[0][wave] = incl[0]; wave_tot[1][wave] = incl[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (need[g]) {
+            int run = incl[g] - sum[g];
+            for (int q = 0; q < wave; ++q) run += wave_tot[g][q];
+            for (int f = lo[g]; f < hi[g]; ++f)
+                if (fl[g][f]) {
+                    if (npos[g] + run < k[g]) keys[g][npos[g] + run] = make_key(0.0f, (uint32_t)f);
+                    ++run;
+                }
+        }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __restrict__ final_keys, int h, int w, int K, int P, float conf,
                                                                float dist_px, RegMaps rm, void* packed, int B) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1487,9 +1539,9 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     const int Kp = (K + 3) & ~3;                                          // (float4 reads of the anchor positions)
     float* posx = reinterpret_cast<float*>(pkeys + P);                    // [Kp]
     float* posy = posx + Kp;                                              // [Kp]
-    int* flags = reinterpret_cast<int*>(posy + Kp);                       // [max(K, P)]
+    int* flags = reinterpret_cast<int*>(posy + Kp);                       // [K + P]
     __shared__ int n_live_s, cnt_s[2];
-    __shared__ int wave_tot[GROUP_THREADS / 64];
+    __shared__ int wave_tot[2][GROUP_THREADS / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int hw = h * w, kmax = max(K, P);
@@ -1506,23 +1558,37 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     uint64_t ak[APT];
 #pragma unroll
     for (int u = 0; u < APT; ++u) ak[u] = (tid + u * GROUP_THREADS < K) ? fa[tid + u * GROUP_THREADS] : 0ull;
+    // (the whole part list too, speculatively: a short list needs it in LDS for its zero slots, and asking for it only once `p_last` has
+    //  arrived is one more dependent round trip -- the annotations-only mode, where lists are mostly padding, always took it)
+    uint64_t pk[APT];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) pk[u] = (tid + u * GROUP_THREADS < P) ? fp[tid + u * GROUP_THREADS] : 0ull;
     const uint64_t a_last = fa[K - 1], p_last = fp[P - 1];
     const PackedLayout L = packed_layout(packed, B, K, P);
     const float* off_b = rm.offsets + (int64_t)b * rm.o_sb;
     const float* emb_b = rm.embeddings + (int64_t)b * rm.e_sb;
     if (a_last == 0ull || p_last == 0ull) {                     // (block-uniform) fewer peaks than slots: the lists go through LDS for the zero slots
         __syncthreads();
-        int na_t = 0, np_t = 0;
+        // (the peaks are counted per wave by ballots, one LDS atomic per wave and list: 256 lanes adding to ONE counter serialise --
+        //  traced 4.7 us from the block's start to this barrier at the stress shape, 1.7 for the loads alone)
+        int na_w = 0, np_w = 0;
 #pragma unroll
-        for (int u = 0; u < APT; ++u)
-            if (tid + u * GROUP_THREADS < K) { akeys[tid + u * GROUP_THREADS] = ak[u]; na_t += ak[u] != 0ull; }
-        for (int i = tid; i < P; i += GROUP_THREADS) { const uint64_t kv = fp[i]; pkeys[i] = kv; np_t += kv != 0ull; }
-        if (na_t) atomicAdd(&cnt_s[0], na_t);
-        if (np_t) atomicAdd(&cnt_s[1], np_t);
+        for (int u = 0; u < APT; ++u) {
+            const bool ina = tid + u * GROUP_THREADS < K, inp = tid + u * GROUP_THREADS < P;
+            if (ina) akeys[tid + u * GROUP_THREADS] = ak[u];
+            if (inp) pkeys[tid + u * GROUP_THREADS] = pk[u];
+            na_w += __popcll(__ballot(ina && ak[u] != 0ull));
+            np_w += __popcll(__ballot(inp && pk[u] != 0ull));
+        }
+        if ((tid & 63) == 0) {
+            if (na_w) atomicAdd(&cnt_s[0], na_w);
+            if (np_w) atomicAdd(&cnt_s[1], np_w);
+        }
         __syncthreads();
         const int na = cnt_s[0], np = cnt_s[1];
-        fill_zero_keys(akeys, na, K, flags, wave_tot);
-        fill_zero_keys(pkeys, np, P, flags, wave_tot);
+        SD_TRACE(trace0 + 4);
+        fill_zero_keys_pair(akeys, na, K, pkeys, np, P, flags, wave_tot);
+        SD_TRACE(trace0 + 5);
 #pragma unroll
         for (int u = 0; u < APT; ++u)
             if (tid + u * GROUP_THREADS < K) ak[u] = akeys[tid + u * GROUP_THREADS];
@@ -1682,8 +1748,12 @@ __global__ __launch_bounds__(NT) void k_rank_group(const uint64_t* __restrict__ 
         ++nz[grp];
         if (rank < k) fin[(grp ? K : 0) + rank] = key;
     }
-    if (nz[0]) atomicAdd(&cnt_s[0], nz[0]);
-    if (nz[1]) atomicAdd(&cnt_s[1], nz[1]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { nz[0] += __shfl_xor(nz[0], o); nz[1] += __shfl_xor(nz[1], o); }   // one LDS atomic per wave and list
+    if ((tid & 63) == 0) {
+        if (nz[0]) atomicAdd(&cnt_s[0], nz[0]);
+        if (nz[1]) atomicAdd(&cnt_s[1], nz[1]);
+    }
     __syncthreads();
     SD_TRACE(trace0 + 2);
     const int na = min(cnt_s[0], K), np = min(cnt_s[1], P);     // the ranks are dense: the first min(candidates, k) slots are taken
@@ -2507,7 +2577,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
         // (a part of a split map is one more sorted list of its group: k_rank_maps sees M * splits and N * splits lists)
         hipLaunchKernelGGL(k_rank_maps, dim3(B * C * splits), dim3(SEL_THREADS), rank_lds, st, mw.stage1, LM, LN, K, P, mw.final_keys);
         SD_LAUNCH_CHECK();
-        const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)((K + 3) & ~3) * 8 + (size_t)std::max(K, P) * 4;
+        const size_t group_lds = (size_t)K * 8 + (size_t)P * 8 + (size_t)((K + 3) & ~3) * 8 + (size_t)(K + P) * 4;
         hipLaunchKernelGGL(k_group_wide, dim3(B, cdiv(P, GROUP_PARTS)), dim3(GROUP_THREADS), group_lds, st, mw.final_keys, h, w, K, P,
                            conf, dist_px, rm, packed, B);
         SD_LAUNCH_CHECK();

@@ -50,7 +50,7 @@ for it in range(30):
         st, en = t[7000:7000 + nb] - t0, t[7600:7600 + nb] - t0
         blocks.append([st.min(), np.percentile(st, 50), np.percentile(st, 90), st.max(), np.median(en - st), (en - st).max(), en.max()])
         rows.append(np.concatenate([t[6400:6406] - t0, t[6420:6426] - t0, t[6500:6503] - t0, t[6600:6604] - t0, t[6610:6614] - t0,
-                                    t[6700:6705] - t0, t[6710:6715] - t0]))
+                                    t[6700:6705] - t0, t[6710:6715] - t0, t[6604:6606] - t0]))
 r = np.median(np.array(rows, np.float64), axis=0) * 0.01
 f = lambda v: " ".join(f"{x:7.2f}" for x in v)
 print(f"{'stress' if stress else 'cfg'} decode B={B} exact={exact} split={os.environ.get('SD_MAP_SPLIT', 'auto')} rank_group={os.environ.get('SD_MAP_RG', '1')}: us since block 0 of "
@@ -62,5 +62,6 @@ print("  k_group_wide (0,0)  [start, anchors posted, barrier, parts done]       
 print("  k_group_wide last   [start, anchors posted, barrier, parts done]                  :", f(r[19:23]))
 print("  k_rank_group block 0 [start, lists in LDS, ranked, decoded, grouped]              :", f(r[23:28]))
 print("  k_rank_group last    [start, lists in LDS, ranked, decoded, grouped]              :", f(r[28:33]))
+print("  k_group_wide (0,0)  short lists: [lists in LDS, zero slots filled] (0 / negative = path not taken):", f(r[33:35]))
 bl = np.median(np.array(blocks, np.float64), axis=0) * 0.01
 print(f"  all blocks of k_map_stream_select: start min {bl[0]:.2f} median {bl[1]:.2f} p90 {bl[2]:.2f} max {bl[3]:.2f}; run time median {bl[4]:.2f} max {bl[5]:.2f}; last end {bl[6]:.2f}")
