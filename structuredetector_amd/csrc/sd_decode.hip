@@ -422,6 +422,19 @@ __device__ __forceinline__ int alloc_slot(int* counter, bool take) {
     return take ? base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) : -1;
 }
 
+// Block-wide sum / maximum into one LDS word with ONE atomic per wave: lanes of a wave adding to the same LDS address serialise (~20 cycles
+// each -- k_group_wide spent 3.6 us of 13.5 on two counters every lane added to).  Call from converged code (every lane of the wave).
+__device__ __forceinline__ void wave_atomic_add(int* counter, int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+}
+__device__ __forceinline__ void wave_atomic_max(int* counter, int v) {             // (v >= 0; *counter starts at 0)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(counter, v);
+}
+
 // MSB-first 8-bit radix select of the k largest of the source's n unique keys into dst[0..np2k) (zero padded), then sorted
 // descending.  Two block barriers per pass (histograms double-buffered by pass parity, bucket scan by one wave); the passes stop
 // as soon as the boundary bucket is taken whole in EVERY team of the block (unique keys: usually after the score bytes) --
@@ -673,7 +686,7 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         L.anchor_smask[(int64_t)b * K + a] = m ? score : -1.0f; // decoders.py:84
         L.anchor_ind[(int64_t)b * K + a] = ind;
     }
-    if (last_live) atomicMax(&n_live_s, last_live);
+    wave_atomic_max(&n_live_s, last_live);
     __syncthreads();
     const int n_live = n_live_s;
     for (int p = tid; p < P; p += (int)blockDim.x) {
@@ -1071,6 +1084,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     const int sl = HALF ? (lane & 31) : lane;                   // lane within its strip
     const bool edge_l = sl == 0, edge_r = sl == (HALF ? 31 : 63);
     const int units = strips * (band_hi - band_lo);
+    const bool has_cut = min_logit > -INFINITY;                 // (uniform) annotations-only mode
     for (int unit0 = wave * PER; unit0 < units; unit0 += STREAM_WAVES * PER) {
         const int unit = unit0 + (HALF ? (lane >> 5) : 0);      // (HALF: strips == 1, the unit is the band)
         const bool unit_in = !HALF || unit < units;
@@ -1121,9 +1135,14 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
 #if defined(SD_STREAM_ABL) && SD_STREAM_ABL == 2                         // timing experiment: loads + horizontal maxima only
                 if (hm[u % WIN].x != 12345.f) continue;
 #endif
+                const float xv[4] = {centre.x, centre.y, centre.z, centre.w};
+                const float xhi = max3f(max3f(xv[0], xv[1], xv[2]), xv[3], xv[3]);
+                // with a score threshold most rows have no pixel above its logit anywhere in the wave: they skip the column maxima and the
+                // survivor test altogether (pixels outside the map are -inf; the dense scenes' walk was bound by vector instruction issue:
+                // 16 waves per CU x 20 rows x ~90 instructions)
+                if (has_cut && __ballot(xhi >= min_logit) == 0ull) continue;
                 const float mx[4] = {max3f(max3f(hm[0].x, hm[1].x, hm[2].x), hm[3].x, hm[4].x), max3f(max3f(hm[0].y, hm[1].y, hm[2].y), hm[3].y, hm[4].y),
                                      max3f(max3f(hm[0].z, hm[1].z, hm[2].z), hm[3].z, hm[4].z), max3f(max3f(hm[0].w, hm[1].w, hm[2].w), hm[3].w, hm[4].w)};
-                const float xv[4] = {centre.x, centre.y, centre.z, centre.w};
                 const uint32_t pix = (uint32_t)(yo * w + x0);
                 if (INLINE_KEYS) {                                       // (second walk of an overflowing map: keys with their sigmoids at once)
                     int cnt = 0;
@@ -1155,7 +1174,6 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
                     // ... and a lane whose four logits are all below min_logit has nothing the score threshold would keep (annotations-only
                     // mode: without this every local maximum of the background -- one per ~13 pixels, some in every row -- went through
                     // the append below to be dropped by the sigmoid pass: 3.3 of the 5.9 us a wave walked at the cfg shape)
-                    const float xhi = max3f(max3f(xv[0], xv[1], xv[2]), xv[3], xv[3]);
                     const bool quiet = (dmin > 1e-4f && mhi < 4.0f && mlo > -13.0f) || xhi < min_logit;
 #if !defined(SD_STREAM_ABL) || SD_STREAM_ABL != 1
                     if (__ballot(!quiet && live) == 0ull) continue;    // (wave-uniform)
@@ -1395,7 +1413,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_rank_maps(const uint64_t* __res
         for (int u = 0; u < 8; ++u)
             if (base + u * SEL_THREADS < span) { keys[base + u * SEL_THREADS] = kv[u]; nonzero += kv[u] != 0ull; }
     }
-    if (own == 0 && nonzero) atomicAdd(&total, nonzero);
+    if (own == 0) wave_atomic_add(&total, nonzero);                          // (block-uniform condition)
     __syncthreads();
     SD_TRACE(trace0 + 1);
     int top = 1;                                                // largest power of two <= k: first probe of the branch-free search
@@ -1626,7 +1644,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
             L.anchor_ind[(int64_t)b * K + a] = ind;
         }
     }
-    if (last_live) atomicMax(&n_live_s, last_live);
+    wave_atomic_max(&n_live_s, last_live);
     SD_TRACE(trace0 + 1);
     __syncthreads();
     SD_TRACE(trace0 + 2);
@@ -1900,7 +1918,8 @@ __global__ __launch_bounds__(RGS_THREADS) void k_rank_group_small(const uint64_t
         const bool mk = score > conf;                           // decoders.py:83
         posx[a] = mk ? ax : 1e6f;                               // decoders.py:85-86
         posy[a] = mk ? ay : 1e6f;
-        if (mk) atomicMax(&n_live_s, a + 1);
+        const unsigned long long lv = __ballot(mk);              // (K <= 64: the anchors are lanes of wave 0; the ballot sees the active ones)
+        if (a == 0) n_live_s = lv ? 64 - __clzll((long long)lv) : 0;   // last live rank + 1, no atomic
         float* ao = L.anchor_out + ((int64_t)b * K + a) * 4;
         ao[0] = ax; ao[1] = ay; ao[2] = score; ao[3] = (float)cls;
         L.anchor_smask[(int64_t)b * K + a] = mk ? score : -1.0f; // decoders.py:84
