@@ -422,6 +422,16 @@ __device__ __forceinline__ int alloc_slot(int* counter, bool take) {
     return take ? base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) : -1;
 }
 
+// Block barrier that publishes LDS data only.  __syncthreads() is a workgroup-scope fence + s_barrier: it also waits for the wave's global
+// STORES in flight (s_waitcnt vmcnt(0): ~1.5 us for a store's acknowledgement), which nobody in the block reads -- where the anchors' outputs
+// are stored just before the barrier that hands their positions to the parts' threads, every thread of the block waited for those stores
+// (traced: 3.3 us from the zero slots to the end of k_rank_group_small, 2 of them behind this barrier).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Block-wide sum / maximum into one LDS word with ONE atomic per wave: lanes of a wave adding to the same LDS address serialise (~20 cycles
 // each -- k_group_wide spent 3.6 us of 13.5 on two counters every lane added to).  Call from converged code (every lane of the wave).
 __device__ __forceinline__ void wave_atomic_add(int* counter, int v) {
@@ -687,7 +697,7 @@ __device__ void block_group(int b, int K, int P, int w, float conf, float dist_p
         L.anchor_ind[(int64_t)b * K + a] = ind;
     }
     wave_atomic_max(&n_live_s, last_live);
-    __syncthreads();
+    lds_barrier();                                              // (not __syncthreads(): the anchors' stores stay in flight)
     const int n_live = n_live_s;
     for (int p = tid; p < P; p += (int)blockDim.x) {
         const int ind = pi_[p];
@@ -1646,7 +1656,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_wide(const uint64_t* __
     }
     wave_atomic_max(&n_live_s, last_live);
     SD_TRACE(trace0 + 1);
-    __syncthreads();
+    lds_barrier();                                              // (not __syncthreads(): block 0's anchor stores stay in flight)
     SD_TRACE(trace0 + 2);
     // anchors beyond the last live rank are all masked: at (1e6, 1e6) they are never within dist_px of a live part (see block_group)
     const int n_scan = dist_px < 1e5f ? n_live_s : K;
@@ -1925,7 +1935,7 @@ __global__ __launch_bounds__(RGS_THREADS) void k_rank_group_small(const uint64_t
         L.anchor_smask[(int64_t)b * K + a] = mk ? score : -1.0f; // decoders.py:84
         L.anchor_ind[(int64_t)b * K + a] = ind;
     }
-    __syncthreads();
+    lds_barrier();                                              // (not __syncthreads(): the anchors' stores stay in flight)
     const int n_live = n_live_s;
     if (tid >= 64 && tid - 64 < P) {                            // (waves 1 ..: the anchors' stores of wave 0 are not in their way)
         const int p = tid - 64;
