@@ -453,6 +453,57 @@ def test_sigmoid_properties_behind_the_logit_domain_nms_hold_for_every_fp32_valu
     assert margin == 0, f"{margin} window maxima whose margin admits a tie"
 
 
+@pytest.mark.parametrize("img,kind", [(512, "noise"), (512, "ties"), (1024, "noise"), (208, "ties"), (512, "planted"), (1024, "planted")])
+def test_early_score_cut_of_the_streaming_decoder_over_thresholds(img, kind):
+    """The streaming kernel of the map-parallel path drops a lane's pixels early when their logits are below a CONSERVATIVE logit of the score
+    threshold (sd_decode.hip, conservative_min_logit: the exact `clamped_sigmoid(x) >= fp32(conf)` test of decoders.py:78,83 / utils.py:355-361
+    still runs on what passes).  Swept over thresholds at both ends of the clamp, just around representable sigmoid values and beyond 0.999
+    (where the cut is capped): the annotations-only result must equal the launch pair's, which has no such cut, bit for bit."""
+    from structuredetector_amd import _lib as L
+    from structuredetector_amd.data import Decoder
+    B, M, N, K, P = 3, 2, 2, 24, 48
+    rng = np.random.default_rng(img + len(kind))
+    h = img // 4
+    planted = None
+    if kind == "noise":
+        head = (4 * rng.standard_normal((B, M + N + 4, h, h))).astype(np.float32)                # sigmoids from ~1e-7 to ~1 - 1e-7
+    elif kind == "planted":
+        # isolated peaks on a flat floor, fewer than the lists hold, and thresholds placed ON their scores (and one ulp either side): a cut
+        # that is not conservative -- the threshold's logit, or a hair above it -- loses exactly these (checked with such a build: this
+        # case fails with `t + 2e-3`, the noise cases do not: there the peaks next to the threshold never make the lists)
+        K, P = 64, 64
+        head = np.full((B, M + N + 4, h, h), -20.0, np.float32)
+        planted = np.concatenate([np.linspace(-13.5, 13.5, 14), rng.uniform(-14, 14, 6)]).astype(np.float32)
+        for c in range(M + N):
+            for i, v in enumerate(rng.permutation(planted)):
+                head[:, c, 6 + 8 * (i // 5), 5 + 9 * (i % 5) + c] = v
+    else:
+        head = (np.round(3 * rng.standard_normal((B, M + N + 4, h, h))) * np.float32(2.5)).astype(np.float32)
+        head[:, 0, :8, :] = 14.5; head[:, 0, 8:12, :] = np.float32(-13.9); head[:, 1, 4:6, :] = np.float32(6.9)      # clamp plateaus, sigmoid(6.9) = 0.99899
+    views = head_views(dev(head), M, N)
+    dec = Decoder(make_args(M, N, K, P))
+    lib = L.lib()
+    sig = lambda x: float(1.0 / (1.0 + np.exp(-np.float64(x))))
+    confs = [0.0, 1e-7, 1e-6, 2e-6, 9e-6, 1.1e-5, 1e-4, 0.05, 0.4, 0.5, float(np.float32(sig(2.5))), float(np.nextafter(np.float32(sig(2.5)), np.float32(1))),
+             0.9, 0.99, 0.999, 0.9990001, 0.9995, float(np.float32(sig(7.5))), 0.999999, 1.0]
+    if planted is not None:
+        for v in planted:
+            s32 = np.float32(sig(v))
+            confs += [float(s32), float(np.nextafter(s32, np.float32(0))), float(np.nextafter(s32, np.float32(1))), float(np.float32(sig(v - np.float32(1e-3))))]
+    try:
+        for conf in confs:
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 1 << 30))
+            want, _ = dec.decode_packed(views, conf, 0.1, exact_topk=False, fused=False)
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
+            for split in (0, 1, 3):
+                L.check(lib.sd_decode_set_option(b"map_split", split))
+                got, _ = dec.decode_packed(views, conf, 0.1, exact_topk=False, fused=False)
+                assert torch.equal(got, want), f"conf={conf!r} map_split={split}"
+    finally:
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
+        L.check(lib.sd_decode_set_option(b"map_split", 0))
+
+
 @pytest.mark.parametrize("B,img,M,N,K,P,kind", [(4, 1024, 8, 8, 128, 512, "scene"), (2, 1024, 8, 8, 128, 512, "noise"), (64, 512, 2, 1, 20, 40, "scene"),
                                                 (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise"),
                                                 (3, 512, 2, 2, 64, 200, "ties"), (2, 528, 2, 1, 20, 40, "ties"), (2, 266, 2, 1, 20, 40, "noise"),
