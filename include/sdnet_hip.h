@@ -133,10 +133,14 @@ int sd_decode_fused(const float* anchor_hm, int64_t a_sb, int64_t a_sc,
  * _workspace_bytes cover both.
  * Knobs of sd_decode (same rules): "map_parallel_from" = number of 64x16-pixel tile blocks of a call from which sd_decode takes its
  * map-parallel path -- tile pass without global atomics, one selector block per (image, map), one merge + association block per image;
- * bit-identical results -- instead of the launch pair with one selector block per image (default 2560, and always for images of 1024+
- * tile blocks such as 1024x1024 inputs with 8 + 8 maps; 1 = always, 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there;
+ * bit-identical results -- instead of the launch pair with one selector block per image (default, value -1: by geometry and mode -- on maps up to 128
+ * columns wide sd_decode always takes it, and the one-launch kernel is recommended below 960 tile blocks without the exact top-k only;
+ * wider maps from 2560; always for images of 1024+ tile blocks such as
+ * 1024x1024 inputs with 8 + 8 maps; sd_decode_fused_recommended follows the same rule; a value >= 0 holds for every geometry: 1 = always,
+ * 1 << 30 = never); "map_tile_height" = 16 / 32 / 0 (by size) rows per NMS tile there;
  * "map_scalar_nms" = 1 keeps the per-pixel-sigmoid tile kernel where the logit-domain one (w % 4 == 0, aligned planes) applies;
- * "map_rows11" = 0 keeps 16-row bands on 8 waves per map for 128-row maps (default 1: 11-row bands on 16 waves). */
+ * "map_rows11" = bands of 128-row maps: 1 (default) 8-row bands with two bands per wave on launches of < 1024 maps, else 11-row bands; 0 = 16-row bands;
+ * 8 / 11 = forced. */
 int sd_decode_set_option(const char* name, int value);
 
 /* Device self-check of the two properties the logit-domain NMS tile pass of sd_decode rests on, over ALL 2^32 fp32 bit patterns:

@@ -1030,7 +1030,7 @@ __host__ __device__ constexpr int stream_seg(int waves) { return waves >= 8 ? 40
 // and ten of the twenty rows of a 16-row band; the five of the window in 16-wave blocks (128 registers per lane there: ten rows ahead spill,
 // measured on the 256 x 256 maps of the stress shape 36.5 -> 41.8 us)
 __host__ __device__ constexpr int stream_depth(int nt, int nr) {
-    return SD_STREAM_DEPTH_SMALL ? SD_STREAM_DEPTH_SMALL : (nt <= 512 ? (nr % 10 == 0 ? 10 : nr) : 5);
+    return SD_STREAM_DEPTH_SMALL ? SD_STREAM_DEPTH_SMALL : (nt <= 512 ? (nr % 10 == 0 ? 10 : nr) : (nr % 5 == 0 ? 5 : nr));
 }
 // Round 5: a map may be SPLIT over `splits` blocks (blockIdx.x = (image * maps + map) * splits + part): a block walks the row bands
 // [part * bands / splits, (part + 1) * bands / splits) of its map (the halo rows of a band are read from the map, whoever owns them) and
@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void stream_map(const float* __restrict__ plane, int 
     // wave's 15 / 20 rows were three / four dependent round trips to memory -- `profiles/r05_decode_trace_cfg.txt`: 7-10 us of walking for
     // 15 rows whose arithmetic is ~0.1 us each.  Now a wave of the small blocks asks for ALL its rows at once, one round trip)
     constexpr int R = ROWS, NR = R + 4, WIN = 5, DEPTH = stream_depth(NT, NR);
-    static_assert(NR % DEPTH == 0 && DEPTH % WIN == 0, "the row loop is unrolled by the request depth, a multiple of the window");
+    static_assert(NR % DEPTH == 0 && (DEPTH == NR || DEPTH % WIN == 0), "the row loop is unrolled by the request depth: all rows, or a multiple of the window");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strips = (w + 255) >> 8;
     const float NEG = -INFINITY;
@@ -2455,12 +2455,28 @@ static MapWs carve_map(void* ws, int B, int C, int h, int w, int th, int K, int 
 // Tile blocks (at 64x16) from which sd_decode takes the map-parallel path, and its tile height (0 = by size); per host thread.
 // sd_decode_set_option("map_parallel_from" / "map_tile_height", n).
 static thread_local int g_map_parallel_from = 2560;
+static thread_local int g_map_from_user = 0;        // 1: "map_parallel_from" was set by the caller and holds for every geometry and mode (tests, A/B)
 static thread_local int g_map_tile_height = 0;
 static thread_local int g_map_stream = 1;           // 0: tile kernel + k_select_map instead of k_map_stream_select (A/B, tests)
-static thread_local int g_map_rows11 = 1;           // 0: 128-row maps keep 16-row bands on 8 waves (A/B)
+static thread_local int g_map_rows11 = 1;           // bands of maps with 9-16 units of 11 rows: 1 = 8 or 11 rows by size, 0 = 16 rows, 8 / 11 = forced (A/B, tests)
 static thread_local int g_map_scalar_nms = 0;       // 1: the per-pixel-sigmoid tile kernel also where the logit-domain one applies (A/B, tests)
 static thread_local int g_map_waves3 = 1;           // parts of three wave-iterations on 192-thread blocks: 1 = from 1024 blocks with a score threshold, 0 never, 2 always (A/B, tests)
 static thread_local int g_map_half = 1;             // 0: one band per wave also on maps up to 128 columns wide (A/B, tests)
+// 64 x 16 tile blocks per call from which sd_decode takes the map-parallel path (and the one-launch kernel is no longer recommended).  On maps
+// up to 128 columns wide -- two bands per wave, two parts per map, one rank + association launch -- measured at the cfg shape after the early
+// score cut (`profiles/r05_decode_small_batches.txt`): annotations-only 16.7 us at bs = 16 .. 20 against 16.6 .. 17.7 for k_decode_fused and
+// 19.8 for the launch pair (bs = 32: 15.7 / 19.2; bs = 8: 16.3 / 15.9 / 20.3): from 960 tile blocks (bs = 20); with the exact top-k 19.7 us
+// at bs = 1 against 26.5 for k_decode_fused: always.  Wider maps keep the round-4 threshold.
+static int64_t map_from(int w, bool exact) {
+    if (g_map_from_user) return g_map_parallel_from;
+    const bool fast = g_map_half && g_map_stream && w <= 128 && w % 4 == 0;
+    return fast ? (exact ? 1 : 960) : g_map_parallel_from;
+}
+// ... and inside sd_decode, where the alternative is the launch pair (19.8-21.6 us at bs = 1 .. 16 against 14.8-16.8): always on those maps
+static int64_t map_from_pair(int w) {
+    if (g_map_from_user) return g_map_parallel_from;
+    return (g_map_half && g_map_stream && w <= 128 && w % 4 == 0) ? 1 : g_map_parallel_from;
+}
 static thread_local int g_map_split = 0;            // parts per map in k_map_stream_select: 0 = by geometry, 1 .. MAP_SPLIT_MAX = forced (A/B, tests)
 static thread_local int g_map_rank_group = 1;       // 0: k_rank_maps + k_group_wide instead of the one-launch k_rank_group (A/B, tests)
 constexpr size_t RANK_GROUP_LDS_MAX = 96 * 1024;    // dynamic LDS of k_rank_group (beside its 37 KB of static arrays)
@@ -2500,7 +2516,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
     // maps: 64 us at bs = 1), the map-parallel chain 25-35 us + the tile pass; they cross at ~2500 tile blocks, and images of 1024 and
     // more tile blocks are better off on the map-parallel path at any batch size
     const int64_t tiles_img16 = (int64_t)(M + N) * cdiv(w, TW) * cdiv(h, 16);
-    const bool want_map = blocks16 >= g_map_parallel_from || (g_map_parallel_from < (1 << 30) && tiles_img16 >= 1024);
+    const bool want_map = blocks16 >= map_from_pair(w) || (g_map_parallel_from < (1 << 30) && tiles_img16 >= 1024);
     if (map_path_possible(M, N, h, w, K, P) && want_map && blocks16 < (1ll << 30)) {
         const int th = map_tile_height(blocks16);
         const MapWs mw = carve_map(workspace, B, M + N, h, w, th, K, P);
@@ -2520,7 +2536,13 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             // over ceil(bands / 4) blocks of four waves, one band per wave (bs = 64, 3 maps of 128 x 128: 576 blocks of 4 waves on every CU of
             // the chip instead of 192 blocks with 12 busy waves of 16)
             const int units16 = strips * cdiv(h, 16), units11 = strips * cdiv(h, 11);
-            const int rows = units16 >= 16 ? 16 : ((g_map_rows11 && units11 > 8 && units11 <= 16) ? 11 : 16);
+            // ... and 8-row bands (12 rows per wave, all requested at once) with two bands per wave while the launch is small enough for its
+            // latency to matter more than the halo rows it re-reads (measured at 128 x 128 maps, two parts per map: bs = 64 17.3 -> 16.6 us,
+            // bs = 128 19.2 -> 18.2, exact top-k 24.6 -> 23.3; bs = 512 36.5 -> 38.1: from 1024 maps the 11-row bands stay)
+            const bool half_ok = g_map_half && strips == 1 && w <= 128;
+            const bool short_ok = units11 > 8 && units11 <= 16;
+            const int rows = units16 >= 16 ? 16 : (!short_ok || g_map_rows11 == 0) ? 16
+                           : (g_map_rows11 == 8 || (g_map_rows11 == 1 && half_ok && (int64_t)B * C < 1024)) ? (half_ok ? 8 : 11) : 11;
             const int bands = cdiv(h, rows);
             // maps up to 128 columns wide: two bands per wave (lanes 0-31 / 32-63), half the waves (sd_decode_set_option("map_half", 0): off)
             const bool half = g_map_half && strips == 1 && w <= 128;
@@ -2529,7 +2551,7 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             // same 14 us, the kernel is bound by the start-up spread of its ~2500 waves and their first round trips, and the rank kernel pays for
             // three times the lists; at bs = 512 the parts stream in 53 instead of 74 us: five 27 KB blocks per CU instead of one of 86 KB)
             //  With two bands per wave (maps up to 128 columns) two parts per map pay from ~100 maps: bs = 64 21.4 -> 20.5 us, bs = 512 72.8 -> 53.6.)
-            if (want <= 0) want = (rows == 11 && strips == 1) ? (half ? ((int64_t)B * C >= 96 ? 2 : 1) : ((int64_t)B * C >= 384 ? cdiv(bands, 4) : 1)) : 1;
+            if (want <= 0) want = ((rows == 11 || rows == 8) && strips == 1) ? (half ? ((int64_t)B * C >= 96 ? 2 : 1) : ((int64_t)B * C >= 384 ? cdiv(bands, 4) : 1)) : 1;
             splits = std::max(1, std::min({want, MAP_SPLIT_MAX, bands}));
             if ((int64_t)M * splits * K > RANK_KEYS_MAX || (int64_t)N * splits * P > RANK_KEYS_MAX) splits = 1;
             const int per_block = strips * cdiv(bands, splits);            // units of work of the largest part
@@ -2539,7 +2561,8 @@ int sd_decode(const float* anchor_hm, int64_t a_sb, int64_t a_sc, const float* p
             const bool waves3 = g_map_waves3 == 2 || (g_map_waves3 == 1 && grid >= 1024u && min_score > 0.f);
 #define SD_STREAM(NT_, ROWS_, HALF_) hipLaunchKernelGGL((k_map_stream_select<NT_, ROWS_, HALF_>), dim3(grid), dim3(NT_), 0, st, g0, g1, h, w, min_score, min_logit, K, P, mw.cand, mw.stage1, splits)
             if (half) {
-                if (rows == 16) { if (per_wave > 8) SD_STREAM(1024, 16, true); else if (per_wave > 4) SD_STREAM(512, 16, true); else SD_STREAM(256, 16, true); }
+                if (rows == 8) { if (per_wave > 8) SD_STREAM(1024, 8, true); else if (per_wave > 4) SD_STREAM(512, 8, true); else SD_STREAM(256, 8, true); }
+                else if (rows == 16) { if (per_wave > 8) SD_STREAM(1024, 16, true); else if (per_wave > 4) SD_STREAM(512, 16, true); else SD_STREAM(256, 16, true); }
                 // (three band pairs per part -- the cfg shape in two parts -- on three waves where several blocks share a CU and a score
                 //  threshold keeps the selections short: bs = 512 32.1 -> 28.7 us; at bs = 64, 384 blocks, the idle fourth wave costs nothing
                 //  -- 9.6 vs 10.1 us: the start-up spread of a launch goes by its blocks, not its waves -- and the exact top-k's radix select over
@@ -2636,7 +2659,9 @@ static int next_pow2_host(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static thread_local int g_tall_tiles_from = 2688;      // per host thread, like the conv dispatch thresholds
 int sd_decode_set_option(const char* name, int value) {
     if (name && !strcmp(name, "tall_tiles_from")) { g_tall_tiles_from = value; return 0; }
-    if (name && !strcmp(name, "map_parallel_from")) { g_map_parallel_from = value; return 0; }
+    if (name && !strcmp(name, "map_parallel_from")) {            // < 0: back to the built-in rule (map_from)
+        g_map_from_user = value >= 0; g_map_parallel_from = value >= 0 ? value : 2560; return 0;
+    }
     if (name && !strcmp(name, "map_tile_height")) { g_map_tile_height = value; return 0; }
     if (name && !strcmp(name, "map_scalar_nms")) { g_map_scalar_nms = value; return 0; }
     if (name && !strcmp(name, "map_rows11")) { g_map_rows11 = value; return 0; }
@@ -2704,7 +2729,7 @@ int sd_decode_fused_recommended(int B, int M, int N, int h, int w, int K, int P,
     // the faster one on maps up to 128 columns wide -- two bands per wave, two parts per map, ranks + association in one launch: 20.5 us per
     // bs = 64 batch against 23.5 for the one-launch kernel (`profiles/r05_decode_split_sweep.txt`)
     const int64_t blocks16 = (int64_t)B * (M + N) * cdiv(w, TW) * cdiv(h, 16);
-    if (blocks16 >= g_map_parallel_from && g_map_half && g_map_stream && w <= 128 && w % 4 == 0 && map_path_possible(M, N, h, w, K, P)) return 0;
+    if (blocks16 >= map_from(w, (exact_topk & 1) != 0) && g_map_half && g_map_stream && w <= 128 && w % 4 == 0 && map_path_possible(M, N, h, w, K, P)) return 0;
     return sd_decode_fused_supported(B, M, N, h, w, K, P) && fused_image_tiles(M, N, h, w) <= 256 && (!(exact_topk & 1) || B <= 8);
 }
 

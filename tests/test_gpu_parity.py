@@ -500,7 +500,7 @@ def test_early_score_cut_of_the_streaming_decoder_over_thresholds(img, kind):
                 got, _ = dec.decode_packed(views, conf, 0.1, exact_topk=False, fused=False)
                 assert torch.equal(got, want), f"conf={conf!r} map_split={split}"
     finally:
-        L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", -1))
         L.check(lib.sd_decode_set_option(b"map_split", 0))
 
 
@@ -566,14 +566,16 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
                 L.check(lib.sd_decode_set_option(b"map_half", half))
                 # parts of three wave-iterations (128-row maps in two parts with two bands per wave, in four with one) on 192-thread blocks
                 # (2 = always) and on 256-thread blocks with an idle wave (0)
-                for waves3 in ((2, 0) if split in (2, 4) else (1,)):
+                # bands of 128-row maps: 8 rows with two bands per wave on launches of < 1024 maps (1 = by size), 11 rows forced, 16 rows (0)
+                for waves3, rows11 in (((2, 1), (0, 1), (2, 11)) if split in (2, 4) else ((1, 1), (1, 11), (1, 0)) if stream and split < 2 else ((1, 1),)):
                     L.check(lib.sd_decode_set_option(b"map_waves3", waves3))
+                    L.check(lib.sd_decode_set_option(b"map_rows11", rows11))
                     for _ in range(2):                                                            # (back to back: no state left behind)
                         got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=exact, fused=False)
-                        assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} "
-                                                        f"map_split={split} map_rank_group={rank_group} map_half={half} map_waves3={waves3}")
+                        assert torch.equal(got, want), (f"exact_topk={exact} map_tile_height={th} map_scalar_nms={scalar} map_stream={stream} map_split={split} "
+                                                        f"map_rank_group={rank_group} map_half={half} map_waves3={waves3} map_rows11={rows11}")
     finally:
-        L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
+        L.check(lib.sd_decode_set_option(b"map_parallel_from", -1))
         L.check(lib.sd_decode_set_option(b"map_tile_height", 0))
         L.check(lib.sd_decode_set_option(b"map_scalar_nms", 0))
         L.check(lib.sd_decode_set_option(b"map_stream", 1))
@@ -581,13 +583,14 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
         L.check(lib.sd_decode_set_option(b"map_rank_group", 1))
         L.check(lib.sd_decode_set_option(b"map_half", 1))
         L.check(lib.sd_decode_set_option(b"map_waves3", 1))
+        L.check(lib.sd_decode_set_option(b"map_rows11", 1))
     if kind == "scene":
         t = O.decode_tensors(head[:, :M], head[:, M:M + N], head[:, M + N:M + N + 2], head[:, M + N + 2:], K, P, 0.5, 0.1)
         L.check(lib.sd_decode_set_option(b"map_parallel_from", 1))
         try:
             got, _ = dec.decode_packed(views, 0.5, 0.1, exact_topk=True, fused=False)
         finally:
-            L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
+            L.check(lib.sd_decode_set_option(b"map_parallel_from", -1))
         assert_decode_matches_oracle(dec.split_packed(got.cpu().numpy(), B, K, P), t, 0.5, SIG_TOL)
 
 

@@ -51,4 +51,4 @@ for (M, N, K, P, img, dense) in ((8, 8, 128, 512, 1024, True), (2, 1, 20, 40, 51
             fused = f"  | one launch (fast) {(time.perf_counter() - t0) / 30 * 1e6:7.1f}"
         print(f"{img}x{img} {M}+{N} maps K={K} P={P} B={B:3d} ({B * (M + N) * (h // 64 or 1) * ((h + 15) // 16):6d} tile blocks): exact pair {row[0]:7.1f} / map {row[1]:7.1f} us"
               f"   fast pair {row[2]:7.1f} / map {row[3]:7.1f} us{fused}", flush=True)
-L.check(lib.sd_decode_set_option(b"map_parallel_from", 2560))
+L.check(lib.sd_decode_set_option(b"map_parallel_from", -1))
