@@ -507,7 +507,8 @@ def test_early_score_cut_of_the_streaming_decoder_over_thresholds(img, kind):
 @pytest.mark.parametrize("B,img,M,N,K,P,kind", [(4, 1024, 8, 8, 128, 512, "scene"), (2, 1024, 8, 8, 128, 512, "noise"), (64, 512, 2, 1, 20, 40, "scene"),
                                                 (3, 264, 3, 2, 12, 24, "noise"), (2, 132, 1, 1, 3, 2, "flat"), (2, 512, 1, 2, 900, 1000, "noise"),
                                                 (3, 512, 2, 2, 64, 200, "ties"), (2, 528, 2, 1, 20, 40, "ties"), (2, 266, 2, 1, 20, 40, "noise"),
-                                                (3, 208, 2, 1, 20, 40, "noise"), (2, 400, 1, 2, 30, 50, "ties"), (130, 512, 2, 1, 20, 40, "scene")])
+                                                (3, 208, 2, 1, 20, 40, "noise"), (2, 400, 1, 2, 30, 50, "ties"), (130, 512, 2, 1, 20, 40, "scene"),
+                                                (5, (384, 512), 2, 1, 20, 40, "noise"), (3, (512, 320), 1, 2, 20, 40, "ties"), (2, (448, 1024), 2, 2, 64, 96, "noise")])
 def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, K, P, kind):
     """sd_decode's map-parallel path (tile pass without global atomics -> one selector block per MAP = the reference's per-class top-k,
     utils.py:451 -> one merge + association block per image = its second top-k, utils.py:459) against the launch pair with one selector
@@ -515,17 +516,18 @@ def test_map_parallel_decoder_is_bit_identical_to_two_launch_path(B, img, M, N, 
     the LDS radix select, the global radix select (one plateau: 64 k candidates in one map) and K / P close to the 1024 limit."""
     from structuredetector_amd import _lib as L
     from structuredetector_amd.data import Decoder
-    rng = np.random.default_rng(B * 131 + img + K)
-    h = img // 4
+    ih, iw = img if isinstance(img, tuple) else (img, img)      # (non-square maps: bands go by the height, strips and the two-bands-per-wave form by the width)
+    rng = np.random.default_rng(B * 131 + ih + K)
+    h, w = ih // 4, iw // 4
     if kind == "noise":
-        head = (2 * rng.standard_normal((B, M + N + 4, h, h))).astype(np.float32)
+        head = (2 * rng.standard_normal((B, M + N + 4, h, w))).astype(np.float32)
     elif kind == "flat":
-        head = np.full((B, M + N + 4, h, h), -20.0, np.float32)
+        head = np.full((B, M + N + 4, h, w), -20.0, np.float32)
         head[:, :, 5, 7] = 3.0
     elif kind == "ties":
         # what the logit-domain tile pass must get right: exact ties (coarse grid), near-ties one ulp apart, both saturated ends of the
         # clamp (|x| > 13.8: plateaus where every tied pixel survives), windows whose maximum sits in each band of the margin table
-        q = np.round(3 * rng.standard_normal((B, M + N + 4, h, h))) * np.float32(2.5)             # grid of 2.5: many equal neighbours, |x| up to ~30
+        q = np.round(3 * rng.standard_normal((B, M + N + 4, h, w))) * np.float32(2.5)             # grid of 2.5: many equal neighbours, |x| up to ~30
         head = q.astype(np.float32)
         bump = rng.random(head.shape) < 0.3
         head[bump] = np.nextafter(head[bump], np.float32(np.inf))                                # one ulp above a neighbour's value
